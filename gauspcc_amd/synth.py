@@ -1,0 +1,135 @@
+"""Deterministic synthetic inputs: anchor clouds and GausPcgc weights.
+
+The reference ships neither data nor the trained checkpoint (README.md:73-77), so
+the benchmark and the parity tests run on seeded synthetic inputs.  Everything here
+is a counter-based generator (splitmix64) so that the same seed gives the same
+bytes on every box, independent of numpy's Generator stream.
+
+Cloud recipe: cluster centres uniform in a 2^16 cube,
+per-cluster sigma in U(4, 40) voxels, anisotropy (1, 1, 0.15), integer-rounded,
+de-duplicated, first N after a seeded shuffle.
+"""
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(ctr: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (ctr + np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        return z ^ (z >> np.uint64(31))
+
+
+class CounterRNG:
+    """uniform()/normal() streams addressed by (seed, stream id, index)."""
+
+    def __init__(self, seed: int):
+        self.seed = np.uint64(seed)
+
+    def bits(self, stream: int, n: int) -> np.ndarray:
+        with np.errstate(over="ignore"):
+            base = _splitmix64(np.array([self.seed ^ (np.uint64(stream) * np.uint64(0xD1342543DE82EF95))], dtype=np.uint64))[0]
+            ctr = base + np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        return _splitmix64(ctr)
+
+    def uniform(self, stream: int, n: int) -> np.ndarray:
+        """float64 in [0, 1) with 53 random bits."""
+        return (self.bits(stream, n) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+    def normal(self, stream: int, n: int) -> np.ndarray:
+        m = (n + 1) // 2
+        u1 = 1.0 - self.uniform(stream * 2 + 1, m)
+        u2 = self.uniform(stream * 2 + 2, m)
+        r = np.sqrt(-2.0 * np.log(u1))
+        out = np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)])
+        return out[:n]
+
+
+def synthetic_cloud(n_points: int, seed: int = 1234, negative: bool = False, extent_log2: int = 16) -> np.ndarray:
+    """(n_points, 3) int32, duplicate-free, 'globally sparse, locally dense'."""
+    rng = CounterRNG(seed)
+    n_clusters = max(4, n_points // 250)
+    ext = 1 << extent_log2
+    margin = ext // 32
+    centres = margin + rng.uniform(1, n_clusters * 3).reshape(n_clusters, 3) * (ext - 2 * margin)
+    sigma = 4.0 + 36.0 * rng.uniform(2, n_clusters)
+    # random axis permutation per cluster for the thin direction
+    thin = (rng.uniform(3, n_clusters) * 3).astype(np.int64)
+    pts = np.zeros((0, 3), dtype=np.int64)
+    want = n_points
+    attempt = 0
+    while pts.shape[0] < n_points:
+        m = int(want * 1.6) + 64
+        cid = (rng.uniform(10 + attempt * 4, m) * n_clusters).astype(np.int64)
+        g = rng.normal(11 + attempt * 4, m * 3).reshape(m, 3)
+        aniso = np.ones((m, 3))
+        aniso[np.arange(m), thin[cid]] = 0.15
+        p = np.rint(centres[cid] + g * sigma[cid, None] * aniso).astype(np.int64)
+        p = np.clip(p, 0, ext - 1)
+        pts = np.concatenate([pts, p], axis=0)
+        # de-duplicate keeping first occurrence
+        key = (pts[:, 2] << 42) | (pts[:, 1] << 21) | pts[:, 0]
+        _, first = np.unique(key, return_index=True)
+        pts = pts[np.sort(first)]
+        want = n_points - pts.shape[0]
+        attempt += 1
+    # seeded shuffle, first N
+    order = np.argsort(rng.bits(99, pts.shape[0]), kind="stable")
+    pts = pts[order[:n_points]]
+    if negative:
+        pts = pts - (ext // 2)
+    return np.ascontiguousarray(pts.astype(np.int32))
+
+
+# --------------------------------------------------------------------------- weights
+STAGE_M = (2, 2, 4, 16)
+
+CONV_KEYS = (
+    [f"prior_resnet.{k}" for k in ("0.kernel", "2.conv0.kernel", "2.conv1.kernel", "3.conv0.kernel", "3.conv1.kernel")]
+    + [f"target_resnet.{k}" for k in ("0.kernel", "2.conv0.kernel", "2.conv1.kernel", "3.conv0.kernel", "3.conv1.kernel")]
+    + [f"spatial_conv_s{s}.{i}.kernel" for s in range(4) for i in (0, 2)]
+)
+
+
+def synthetic_state_dict(channels: int = 32, kernel_size: int = 5, seed: int = 7, gain: float = 4.0) -> dict:
+    """Seeded weights under the upstream state-dict key names
+    (network_ue_4stage_conv.py:15-98, kit/nn.py:14-16,31,106).
+
+    Initialisers follow the reference modules: sparse conv U(+-1/sqrt(Cin*k^3)),
+    nn.Linear U(+-1/sqrt(fan_in)), nn.Embedding N(0,1).  `gain` multiplies the conv
+    kernels: a submanifold conv only sees ~10 of the k^3 taps, so the nominal
+    initialiser makes activations vanish after a few layers; gain=4 keeps them O(1)
+    so that the predicted probabilities actually vary between nodes.  It has no
+    effect on the work done.
+    """
+    rng = CounterRNG(seed)
+    C, K = channels, kernel_size ** 3
+    sd = {}
+    stream = [100]
+
+    def uni(shape, bound):
+        stream[0] += 1
+        n = int(np.prod(shape))
+        return ((rng.uniform(stream[0], n) * 2.0 - 1.0) * bound).astype(np.float32).reshape(shape)
+
+    def nrm(shape):
+        stream[0] += 1
+        n = int(np.prod(shape))
+        return rng.normal(stream[0], n).astype(np.float32).reshape(shape)
+
+    sd["prior_embedding.weight"] = nrm((256, C))
+    for key in CONV_KEYS:
+        sd[key] = uni((K, C, C), gain / np.sqrt(C * K))
+    sd["target_embedding.target_res_embedding.weight"] = nrm((8, C))
+    for s, m in enumerate(STAGE_M):
+        b = 1.0 / np.sqrt(C)
+        sd[f"pred_head_s{s}.0.weight"] = uni((C, C), b)
+        sd[f"pred_head_s{s}.0.bias"] = uni((C,), b)
+        sd[f"pred_head_s{s}.2.weight"] = uni((m, C), b)
+        sd[f"pred_head_s{s}.2.bias"] = uni((m,), b)
+        if s > 0:
+            sd[f"pred_head_s{s}_emb.weight"] = nrm((2 ** (1, 2, 4)[s - 1], C))
+    sd["fog.conv.kernel"] = np.ones((8, 1, 1), dtype=np.float32)
+    return sd

@@ -1,0 +1,41 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle
+
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def synth_model_k5(orc):
+    from gauspcc_amd.model import tensor_table
+    from gauspcc_amd.synth import synthetic_state_dict
+
+    return orc.Model(tensor_table(synthetic_state_dict(32, 5), 32, 5), 32, 5)
+
+
+@pytest.fixture(scope="session")
+def synth_model_k3(orc):
+    from gauspcc_amd.model import tensor_table
+    from gauspcc_amd.synth import synthetic_state_dict
+
+    return orc.Model(tensor_table(synthetic_state_dict(32, 3), 32, 3), 32, 3)

@@ -1,0 +1,75 @@
+"""ctypes binding of libgauspcc.so (C ABI: include/gauspcc.h).
+
+There is no CPU fallback: importing a symbol from here without the built HIP library,
+or calling it without an MI355X, raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgauspcc.so")
+
+_lib = None
+
+
+class GpccError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libgauspcc error {code}: {msg}")
+        self.code = code
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("num_points", C.c_int64),
+        ("num_bytes", C.c_int64),
+        ("num_levels", C.c_int32),
+        ("reserved", C.c_int32),
+        ("level_nodes", C.c_int64 * 24),
+        ("coded_nodes", C.c_int64),
+        ("conv_pairs", C.c_int64),
+        ("device_ms", C.c_double),
+    ]
+
+
+EXPORTS = [
+    "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_raster_order",
+    "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_sort_zyx",
+    "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C gauspcc_amd/csrc). gauspcc_amd has no CPU fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, u16 = C.c_void_p, C.c_int64, C.c_int, C.c_uint16
+    L.gpcc_last_error.restype = C.c_char_p
+    L.gpcc_ctx_create.argtypes = [i32, C.POINTER(vp)]
+    L.gpcc_ctx_destroy.argtypes = [vp]
+    L.gpcc_ctx_destroy.restype = None
+    L.gpcc_raster_order.argtypes = [vp, vp, i32, i64, vp, vp]
+    L.gpcc_model_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]
+    L.gpcc_model_destroy.argtypes = [vp]
+    L.gpcc_model_destroy.restype = None
+    L.gpcc_encode.argtypes = [vp, vp, vp, i64, i32, u16, C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats), vp]
+    L.gpcc_decode.argtypes = [vp, vp, vp, i64, C.POINTER(vp), C.POINTER(i64), C.POINTER(u16), C.POINTER(Stats), vp]
+    L.gpcc_sort_zyx.argtypes = [vp, vp, i64, vp, vp]
+    L.gpcc_build_octree.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i64), vp, vp, i64, vp]
+    L.gpcc_conv3d.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, i32, vp, C.POINTER(i64), vp]
+    L.gpcc_head_cdf.argtypes = [vp, vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.gpcc_rc_encode.argtypes = [vp, vp, i32, vp, i64, i32, C.POINTER(vp), C.POINTER(i64), vp]
+    L.gpcc_rc_decode.argtypes = [vp, vp, i32, vp, i64, i64, i32, vp, vp]
+    L.gpcc_memcpy_d2d.argtypes = [vp, vp, vp, i64, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise GpccError(rc, lib().gpcc_last_error().decode(errors="replace"))

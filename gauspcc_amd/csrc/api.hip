@@ -1,0 +1,473 @@
+// api.hip -- context / model management, calculate_morton_order, and the stage-level C-ABI entry
+// points used by the parity tests (include/gauspcc.h).
+#include <algorithm>
+
+#include "network.hpp"
+#include "octree.hpp"
+#include "primitives.hpp"
+#include "rangecoder.hpp"
+
+using namespace gpcc;
+
+namespace gpcc {
+thread_local char g_err[512] = "";
+}
+
+extern "C" const char *gpcc_last_error(void) { return gpcc::g_err; }
+extern "C" int gpcc_version(void) { return 100; }
+
+extern "C" int gpcc_ctx_create(int device, gpcc_ctx **out)
+{
+    if (!out) return fail(GPCC_ERR_ARG, "null argument");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(GPCC_ERR_ARG, "device %d not present (%d visible)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(GPCC_ERR_ARG, "libgauspcc is built for gfx950 (MI355X); device %d is %s", device, prop.gcnArchName);
+    gpcc_ctx *c = new gpcc_ctx();
+    c->device = device;
+    *out = c;
+    return GPCC_OK;
+}
+
+extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
+    if (c->hstage.p) (void)hipHostFree(c->hstage.p);
+    delete c;
+}
+
+extern "C" int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst, const void *src, int64_t nbytes, void *stream)
+{
+    if (!ctx || !dst || !src || nbytes < 0) return fail(GPCC_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ model
+extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, const float *const *t, gpcc_model **out)
+{
+    if (!ctx || !t || !out) return fail(GPCC_ERR_ARG, "null argument");
+    if (channels != CH) return fail(GPCC_ERR_ARG, "the gfx950 kernels are specialised for channels = 32 (got %d)", channels);
+    if (kernel_size != 3 && kernel_size != 5 && kernel_size != 7) return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+    for (int i = 0; i < GPCC_T_COUNT; ++i) if (!t[i]) return fail(GPCC_ERR_ARG, "tensor %d is null", i);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int C = CH, K = kernel_size * kernel_size * kernel_size;
+    std::vector<float> h;
+    std::vector<size_t> off;
+    auto push_rows_phys = [&](const float *src, int rows) {  // (rows, C) logical -> physical channel order
+        off.push_back(h.size());
+        size_t b = h.size();
+        h.resize(b + (size_t)rows * C);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < C; ++c) h[b + (size_t)r * C + phys_of(c)] = src[(size_t)r * C + c];
+    };
+    auto push_raw = [&](const float *src, size_t count) {
+        off.push_back(h.size());
+        h.insert(h.end(), src, src + count);
+        while (h.size() % 64) h.push_back(0.0f);
+    };
+    push_rows_phys(t[GPCC_T_PRIOR_EMB], 256);
+    for (int ci = 0; ci < 18; ++ci) {  // (K, C, C) -> per offset the B fragments of 16 MFMAs: [lane][kk] = W[o][2kk + lane/32][lane%32]
+        off.push_back(h.size());
+        size_t b = h.size();
+        h.resize(b + (size_t)K * C * C);
+        const float *W = t[GPCC_T_CONV0 + ci];
+        for (int o = 0; o < K; ++o)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int kk = 0; kk < 16; ++kk)
+                    h[b + ((size_t)o * 64 + lane) * 16 + kk] = W[((size_t)o * C + (2 * kk + (lane >> 5))) * C + (lane & 31)];
+    }
+    push_rows_phys(t[GPCC_T_TEMB], 8);
+    for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW1 + s], (size_t)C * C);
+    for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB1 + s], (size_t)C);
+    for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW2 + s], (size_t)STAGE_M[s] * C);
+    for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB2 + s], (size_t)STAGE_M[s]);
+    static const int semb_rows[3] = {2, 4, 16};
+    for (int s = 0; s < 3; ++s) push_rows_phys(t[GPCC_T_SEMB + s], semb_rows[s]);
+    gpcc_model *m = new gpcc_model();
+    m->C = C; m->k = kernel_size; m->K = K;
+    if (hipMalloc((void **)&m->slab, h.size() * sizeof(float)) != hipSuccess) { delete m; return fail(GPCC_ERR_NOMEM, "hipMalloc of the model slab failed"); }
+    if (hipMemcpy(m->slab, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(m->slab); delete m; return fail(GPCC_ERR_HIP, "model upload failed"); }
+    size_t i = 0;
+    m->prior_emb = m->slab + off[i++];
+    for (int ci = 0; ci < 18; ++ci) m->conv[ci] = m->slab + off[i++];
+    m->temb = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hw1[s] = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hb1[s] = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hw2[s] = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hb2[s] = m->slab + off[i++];
+    for (int s = 0; s < 3; ++s) m->semb[s] = m->slab + off[i++];
+    *out = m;
+    return GPCC_OK;
+}
+
+extern "C" void gpcc_model_destroy(gpcc_model *m)
+{
+    if (!m) return;
+    if (m->slab) (void)hipFree(m->slab);
+    delete m;
+}
+
+// ------------------------------------------------------------------ calculate_morton_order
+namespace {
+
+constexpr int TB = 256;
+
+template <typename T>
+__global__ __launch_bounds__(TB) void k_minmax(const T *__restrict__ x, int64_t n, double *__restrict__ part /* [grid][6] */)
+{
+    __shared__ double sm[4][6];
+    T mn[3], mx[3];
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            T v = x[3 * i + a];
+            if (!any) { mn[a] = v; mx[a] = v; }
+            else { mn[a] = v < mn[a] ? v : mn[a]; mx[a] = v > mx[a] ? v : mx[a]; }
+        }
+        any = true;
+    }
+    double dmn[3], dmx[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { dmn[a] = any ? (double)mn[a] : 1e300; dmx[a] = any ? (double)mx[a] : -1e300; }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            dmn[a] = fmin(dmn[a], __shfl_xor(dmn[a], d, 64));
+            dmx[a] = fmax(dmx[a], __shfl_xor(dmx[a], d, 64));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+        for (int a = 0; a < 3; ++a) { sm[wave][a] = dmn[a]; sm[wave][3 + a] = dmx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = sm[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? fmin(v, sm[w][threadIdx.x]) : fmax(v, sm[w][threadIdx.x]);
+        part[(size_t)blockIdx.x * 6 + threadIdx.x] = v;
+    }
+}
+
+// key = x' + y'*M + z'*M^2 with x' = int64(x - min) evaluated in the input dtype (pcc_utils.py:18-20)
+template <typename T>
+__global__ __launch_bounds__(TB) void k_order_keys(const T *__restrict__ x, int64_t n, T mnx, T mny, T mnz, uint64_t M, uint64_t flip,
+                                                   uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t sx = (uint64_t)(int64_t)(T)(x[3 * i] - mnx), sy = (uint64_t)(int64_t)(T)(x[3 * i + 1] - mny), sz = (uint64_t)(int64_t)(T)(x[3 * i + 2] - mnz);
+    key[i] = (sx + sy * M + sz * M * M) ^ flip;
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(TB) void k_widen_perm(const uint32_t *__restrict__ idx, int64_t n, int64_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) out[i] = (int64_t)idx[i];
+}
+
+template <typename T>
+int raster_order_t(gpcc_ctx *ctx, hipStream_t st, const T *x, int64_t n, int64_t *perm)
+{
+    ctx->arena.reset();
+    const int grid = (int)std::min<int64_t>(cdiv(n, TB), 512);
+    TAKE(part, double, (size_t)grid * 6);
+    GP_TRY(ctx->hstage.reserve((size_t)grid * 48 + 64));
+    k_minmax<T><<<grid, TB, 0, st>>>(x, n, part);
+    LAUNCH_CHECK();
+    double *hp = reinterpret_cast<double *>(ctx->hstage.p);
+    HIP_TRY(hipMemcpyAsync(hp, part, (size_t)grid * 48, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int b = 0; b < grid; ++b)
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], hp[b * 6 + a]); mx[a] = std::max(mx[a], hp[b * 6 + 3 + a]); }
+    int64_t mmax = 0;
+    for (int a = 0; a < 3; ++a) mmax = std::max<int64_t>(mmax, (int64_t)(T)((T)mx[a] - (T)mn[a]));
+    const uint64_t M = (uint64_t)mmax + 1;
+    int bits; uint64_t flip = 0;
+    if (M <= (1ull << 21)) { const uint64_t top = M * M * M - 1; bits = 1; while (bits < 64 && (top >> bits)) ++bits; }
+    else { bits = 64; flip = 0x8000000000000000ull; }  // the reference's int64 arithmetic may wrap here; sort as signed
+    TAKE(ka, uint64_t, n); TAKE(kb, uint64_t, n); TAKE(va, uint32_t, n); TAKE(vb, uint32_t, n);
+    k_order_keys<T><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(x, n, (T)mn[0], (T)mn[1], (T)mn[2], M, flip, ka, va);
+    LAUNCH_CHECK();
+    uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
+    GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, n, bits));
+    k_widen_perm<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(v0, n, perm);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int gpcc_raster_order(gpcc_ctx *ctx, const void *xyz, int dtype, int64_t n, int64_t *perm, void *stream)
+{
+    if (!ctx || !xyz || !perm) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0) return fail(GPCC_ERR_ARG, "empty point cloud");
+    if (n >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many points");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t want = (size_t)n * 64 + ((size_t)8 << 20);
+    GP_TRY(ctx->arena.reserve(want));
+    switch (dtype) {
+    case GPCC_F32: return raster_order_t<float>(ctx, st, (const float *)xyz, n, perm);
+    case GPCC_F64: return raster_order_t<double>(ctx, st, (const double *)xyz, n, perm);
+    case GPCC_I32: return raster_order_t<int32_t>(ctx, st, (const int32_t *)xyz, n, perm);
+    case GPCC_I64: return raster_order_t<int64_t>(ctx, st, (const int64_t *)xyz, n, perm);
+    default: return fail(GPCC_ERR_ARG, "unsupported dtype %d", dtype);
+    }
+}
+
+// ------------------------------------------------------------------ stage-level entry points
+namespace {
+
+__global__ __launch_bounds__(TB) void k_zyx_keys(const int32_t *__restrict__ xyz, int64_t n, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    key[i] = rkey3((uint32_t)(xyz[3 * i] + CB), (uint32_t)(xyz[3 * i + 1] + CB), (uint32_t)(xyz[3 * i + 2] + CB));
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(TB) void k_double_coords(const int32_t *__restrict__ in, int64_t n3, int32_t *__restrict__ out)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n3) out[i] = in[i] * 2;
+}
+
+// rows given in raster order, logical channels  <->  Morton order, physical channels
+__global__ __launch_bounds__(TB) void k_rows_in(const float *__restrict__ in, const uint32_t *__restrict__ m2r, int64_t n, float *__restrict__ out)
+{
+    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * 32) return;
+    const int64_t i = t >> 5; const int c = (int)(t & 31);
+    out[i * 32 + phys_of(c)] = in[(int64_t)m2r[i] * 32 + c];
+}
+__global__ __launch_bounds__(TB) void k_rows_out(const float *__restrict__ in, const uint32_t *__restrict__ m2r, int64_t n, float *__restrict__ out)
+{
+    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * 32) return;
+    const int64_t i = t >> 5; const int c = (int)(t & 31);
+    out[(int64_t)m2r[i] * 32 + c] = in[i * 32 + phys_of(c)];
+}
+
+__global__ __launch_bounds__(TB) void k_pack_lohi(const uint16_t *__restrict__ cdf, int lp, const uint8_t *__restrict__ sym, int64_t n, uint32_t *__restrict__ lohi)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const int s = sym[i];
+    const uint32_t lo = cdf[i * lp + s];
+    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf[i * lp + s + 1];
+    lohi[i] = lo | ((hi - 1u) << 16);
+}
+
+}  // namespace
+
+extern "C" int gpcc_sort_zyx(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, uint32_t *perm, void *stream)
+{
+    if (!ctx || !xyz || !perm || n <= 0) return fail(GPCC_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    GP_TRY(ctx->arena.reserve((size_t)n * 64 + ((size_t)8 << 20)));
+    ctx->arena.reset();
+    TAKE(ka, uint64_t, n); TAKE(kb, uint64_t, n); TAKE(va, uint32_t, n); TAKE(vb, uint32_t, n);
+    k_zyx_keys<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(xyz, n, ka, va);
+    LAUNCH_CHECK();
+    uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
+    GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, n, 63));
+    HIP_TRY(hipMemcpyAsync(perm, v0, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, int32_t *levels_out, int64_t *level_nodes_out,
+                                 int32_t **coords_out_host, uint8_t **occ_out_host, int64_t cap_nodes, void *stream)
+{
+    if (!ctx || !xyz || !levels_out || !level_nodes_out) return fail(GPCC_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    size_t want = (size_t)n * 400 + ((size_t)32 << 20);
+    int rc = GPCC_OK;
+    Tree T;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        GP_TRY(ctx->arena.reserve(want));
+        ctx->arena.reset();
+        T = Tree();
+        rc = tree_build(ctx, st, xyz, n, &T);
+        if (rc != GPCC_ERR_NOMEM) break;
+        want *= 2;
+    }
+    GP_TRY(rc);
+    *levels_out = T.L;
+    for (int d = 0; d < T.L; ++d) {
+        level_nodes_out[d] = T.lv[d].n;
+        if (coords_out_host && occ_out_host) {
+            if (T.lv[d].n > cap_nodes) return fail(GPCC_ERR_ARG, "level %d has %lld nodes, capacity %lld", d, (long long)T.lv[d].n, (long long)cap_nodes);
+            size_t mk = ctx->arena.mark();
+            TAKE(dx, int32_t, 3 * T.lv[d].n); TAKE(dox, uint8_t, T.lv[d].n);
+            GP_TRY(level_to_raster(ctx, st, &T.lv[d], dx, dox));
+            HIP_TRY(hipMemcpyAsync(coords_out_host[d], dx, 12 * (size_t)T.lv[d].n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(occ_out_host[d], dox, (size_t)T.lv[d].n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            ctx->arena.rewind(mk);
+        }
+    }
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, int channels, int kernel_size, const float *in_dev,
+                           const float *w_host, const float *res_dev, int relu, float *out_dev, int64_t *pairs_out, void *stream)
+{
+    if (!ctx || !xyz_sorted || !in_dev || !w_host || !out_dev) return fail(GPCC_ERR_ARG, "null argument");
+    if (channels != CH) return fail(GPCC_ERR_ARG, "channels must be 32");
+    if (kernel_size != 3 && kernel_size != 5 && kernel_size != 7) return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int K = kernel_size * kernel_size * kernel_size;
+    size_t want = (size_t)n * (size_t)(2 * K * 4 + 1200) + ((size_t)32 << 20);
+    for (int attempt = 0;; ++attempt) {
+        GP_TRY(ctx->arena.reserve(want));
+        ctx->arena.reset();
+        int rc = [&]() -> int {
+            // The points become the finest STORED level by building the tree of 2*xyz (every point alone in
+            // its voxel pair), so the neighbour map comes from the production top-down path.
+            TAKE(x2, int32_t, 3 * n);
+            k_double_coords<<<(unsigned)cdiv(3 * n, TB), TB, 0, st>>>(xyz_sorted, 3 * n, x2);
+            LAUNCH_CHECK();
+            Tree T;
+            GP_TRY(tree_build(ctx, st, x2, n, &T));
+            const Level *fin = &T.lv[T.L - 1];
+            if (fin->n != n) return fail(GPCC_ERR_ARG, "internal: finest level has %lld nodes for %lld points", (long long)fin->n, (long long)n);
+            int64_t nmax = 0;
+            for (int d = 0; d < T.L; ++d) nmax = std::max(nmax, T.lv[d].n);
+            TAKE(nbA, int32_t, (int64_t)K * nmax); TAKE(nbB, int32_t, (int64_t)K * nmax);
+            int32_t *p = nbA, *c = nbB;
+            GP_TRY(nbr_base(ctx, st, &T.lv[0], kernel_size, p));
+            for (int d = 0; d + 1 < T.L; ++d) { GP_TRY(nbr_child(ctx, st, &T.lv[d], p, &T.lv[d + 1], kernel_size, c)); std::swap(p, c); }
+            TAKE(pairs, unsigned long long, 1);
+            HIP_TRY(hipMemsetAsync(pairs, 0, 8, st));
+            GP_TRY(nbr_count(ctx, st, p, (int64_t)K * n, pairs));
+            // weights -> B-fragment order
+            std::vector<float> wf((size_t)K * 1024);
+            for (int o = 0; o < K; ++o)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int kk = 0; kk < 16; ++kk) wf[((size_t)o * 64 + lane) * 16 + kk] = w_host[((size_t)o * 32 + (2 * kk + (lane >> 5))) * 32 + (lane & 31)];
+            TAKE(dw, float, (size_t)K * 1024); TAKE(xin, float, n * 32); TAKE(xres, float, n * 32); TAKE(xout, float, n * 32);
+            HIP_TRY(hipMemcpyAsync(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(in_dev, fin->m2r, n, xin);
+            if (res_dev) k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(res_dev, fin->m2r, n, xres);
+            LAUNCH_CHECK();
+            ConvBatch cb = {};
+            cb.job[0] = ConvJob{xin, dw, res_dev ? xres : nullptr, xout};
+            GP_TRY(sparse_conv(st, cb, 1, p, n, K, relu));
+            k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
+            LAUNCH_CHECK();
+            unsigned long long hpairs = 0;
+            HIP_TRY(hipMemcpyAsync(&hpairs, pairs, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (pairs_out) *pairs_out = (int64_t)hpairs;
+            return GPCC_OK;
+        }();
+        if (rc != GPCC_ERR_NOMEM || attempt >= 3) return rc;
+        want *= 2;
+    }
+}
+
+extern "C" int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int channels, int m, const float *w1, const float *b1,
+                             const float *w2, const float *b2, float *prob_dev, uint16_t *cdf_dev, void *stream)
+{
+    if (!ctx || !x_dev || !w1 || !b1 || !w2 || !b2) return fail(GPCC_ERR_ARG, "null argument");
+    if (channels != CH) return fail(GPCC_ERR_ARG, "channels must be 32");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    GP_TRY(ctx->arena.reserve((size_t)1 << 20));
+    ctx->arena.reset();
+    TAKE(dw, float, 32 * 32 + 32 + 16 * 32 + 16 + 64);
+    HIP_TRY(hipMemcpyAsync(dw, w1, 4 * 1024, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + 1024, b1, 4 * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + 1056, w2, 4 * (size_t)m * 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + 1056 + 512, b2, 4 * (size_t)m, hipMemcpyHostToDevice, st));
+    HeadArgs ha = {};
+    ha.x = x_dev; ha.n = n; ha.stage_m = m; ha.w1 = dw; ha.b1 = dw + 1024; ha.w2 = dw + 1056; ha.b2 = dw + 1056 + 512;
+    ha.prob = prob_dev; ha.cdf = cdf_dev; ha.mode = 2;
+    GP_TRY(head_cdf(st, ha));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *sym_dev, int64_t n, int chunk_log2,
+                              const uint8_t **bytes_out, int64_t *nbytes_out, void *stream)
+{
+    if (!ctx || !cdf_dev || !sym_dev || !bytes_out || !nbytes_out || n <= 0) return fail(GPCC_ERR_ARG, "bad argument");
+    if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
+    const int nch = (int)cdiv(n, S);
+    const uint32_t stride = rc_scratch_stride((uint32_t)std::min<int64_t>(S, n));
+    GP_TRY(ctx->arena.reserve((size_t)n * 8 + 2 * (size_t)nch * stride + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    std::vector<RcChunk> chunks((size_t)nch);
+    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)(c * S), (uint32_t)std::min<int64_t>(S, n - c * S), 0, 0};
+    TAKE(lohi, uint32_t, n); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
+    TAKE(scratch, uint8_t, (size_t)nch * stride); TAKE(payload, uint8_t, (size_t)nch * stride);
+    HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    k_pack_lohi<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(cdf_dev, lp, sym_dev, n, lohi);
+    LAUNCH_CHECK();
+    GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt));
+    GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
+    GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nch, payload));
+    std::vector<uint32_t> hcnt((size_t)nch + 1);
+    HIP_TRY(hipMemcpyAsync(hcnt.data(), dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hcnt.data() + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t total = hcnt[(size_t)nch], hdr = chunk_log2 ? 2 * (size_t)nch : 0;
+    GP_TRY(ctx->hbytes.reserve(total + hdr + 16));
+    uint8_t *out = ctx->hbytes.p;
+    if (chunk_log2)
+        for (int c = 0; c < nch; ++c) { out[2 * c] = (uint8_t)hcnt[(size_t)c]; out[2 * c + 1] = (uint8_t)(hcnt[(size_t)c] >> 8); }
+    if (total) HIP_TRY(hipMemcpyAsync(out + hdr, payload, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *bytes_out = out; *nbytes_out = (int64_t)(total + hdr);
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *bytes, int64_t nbytes, int64_t n,
+                              int chunk_log2, uint8_t *sym_dev, void *stream)
+{
+    if (!ctx || !cdf_dev || !bytes || !sym_dev || n <= 0) return fail(GPCC_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
+    const int nch = (int)cdiv(n, S);
+    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    std::vector<RcChunk> chunks((size_t)nch);
+    if (chunk_log2) {
+        if (nbytes < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream shorter than its chunk table");
+        int64_t p = 2 * (int64_t)nch;
+        for (int c = 0; c < nch; ++c) {
+            const uint32_t cb = bytes[2 * c] | bytes[2 * c + 1] << 8;
+            if (p + cb > nbytes) return fail(GPCC_ERR_FORMAT, "chunk %d overruns the stream", c);
+            chunks[(size_t)c] = RcChunk{(uint32_t)(c * S), (uint32_t)std::min<int64_t>(S, n - c * S), (uint32_t)p, cb};
+            p += cb;
+        }
+    } else chunks[0] = RcChunk{0, (uint32_t)n, 0, (uint32_t)nbytes};
+    TAKE(db, uint8_t, nbytes + 16); TAKE(dch, RcChunk, nch);
+    HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    GP_TRY(rc_decode_launch(st, cdf_dev, lp, db, dch, nch, sym_dev));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}

@@ -1,0 +1,457 @@
+// codec.hip -- gpcc_encode / gpcc_decode: the device pipeline behind compress_point_cloud /
+// decompress_point_cloud (HAC/utils/pcc_utils.py:24-217, 230-400).
+//
+// Encode: octree build (Morton order) -> per level: neighbour map, prior trunk (5 convs on the
+// parent level), child features, target trunk (5 convs on the child level), the four teacher-forced
+// stages batched into two 4-job conv launches, four head launches that emit one packed
+// (c_low, c_high) word per symbol in raster order -> ONE range-coder launch over every chunk of
+// every stream -> scan + compaction -> one D2H copy -> container assembly on the host.
+// Host syncs: bbox, level sizes, final byte count (3 per encode; the reference does 8 per level).
+//
+// Decode: the same network kernels, but stage s+1 needs the symbols of stage s, so each level runs
+// 4 x (stage input, 2 convs, head -> CDF rows, chunk-parallel range decode).
+#include <algorithm>
+#include <chrono>
+
+#include "network.hpp"
+#include "octree.hpp"
+#include "primitives.hpp"
+#include "rangecoder.hpp"
+
+using namespace gpcc;
+
+namespace {
+
+struct Trunk { float *x, *a, *b; };
+
+// Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; kit/nn.py:18-22).  Result in t.a.
+int run_trunk(hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const int32_t *nbrT, int64_t n)
+{
+    ConvBatch cb = {};
+    auto one = [&](const float *in, int ci, const float *res, float *out) {
+        cb.job[0] = ConvJob{in, m->conv[ci], res, out};
+        return sparse_conv(st, cb, 1, nbrT, n, m->K, 1);
+    };
+    GP_TRY(one(t.x, conv0, nullptr, t.a));
+    GP_TRY(one(t.a, conv0 + 1, nullptr, t.b));
+    GP_TRY(one(t.b, conv0 + 2, t.a, t.x));
+    GP_TRY(one(t.x, conv0 + 3, nullptr, t.b));
+    GP_TRY(one(t.b, conv0 + 4, t.x, t.a));
+    return GPCC_OK;
+}
+
+inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+inline uint32_t get32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+size_t arena_estimate(int64_t n, int K) { return (size_t)n * (size_t)(2 * K * 4 + 2400) + ((size_t)48 << 20); }
+
+int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t n, int chunk_log2, uint16_t posq,
+                const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, hipStream_t st)
+{
+    ctx->arena.reset();
+    Tree T;
+    GP_TRY(tree_build(ctx, st, xyz, n, &T));
+    const int L = T.L, K = m->K;
+    int64_t coded = 0, nmax = 0;
+    for (int d = 0; d < L; ++d) { nmax = std::max(nmax, T.lv[d].n); if (d) coded += T.lv[d].n; }
+    if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
+    // stream-major packed symbols: stream (d, s), d = 1..L-1 -> offset 4*prefix(d) + s*n_d
+    TAKE(lohi, uint32_t, std::max<int64_t>(4 * coded, 1));
+    TAKE(nbrA, int32_t, (int64_t)K * nmax);
+    TAKE(nbrB, int32_t, (int64_t)K * nmax);
+    TAKE(pairs_dev, unsigned long long, MAXLV);
+    HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
+    int32_t *nbrP = nbrA, *nbrC = nbrB;
+    GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, nbrP));
+    GP_TRY(nbr_count(ctx, st, nbrP, (int64_t)K * T.lv[0].n, pairs_dev));
+    int64_t prefix = 0;
+    for (int d = 0; d + 1 < L; ++d) {
+        const Level *par = &T.lv[d], *chi = &T.lv[d + 1];
+        const int64_t np = par->n, nc = chi->n;
+        GP_TRY(nbr_child(ctx, st, par, nbrP, chi, m->k, nbrC));
+        GP_TRY(nbr_count(ctx, st, nbrC, (int64_t)K * nc, pairs_dev + d + 1));
+        const size_t mk = ctx->arena.mark();
+        TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
+        GP_TRY(embed_occ(st, m->prior_emb, par->occ, np, pF));
+        GP_TRY(run_trunk(st, m, 0, Trunk{pF, pA, pB}, nbrP, np));                      // -> pA
+        TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32);
+        GP_TRY(child_features(st, pA, chi->parent, chi->rkey, m->temb, nc, cX));
+        GP_TRY(run_trunk(st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));                      // -> cA  (X of pcc_utils.py:109)
+        // stages: cX, cB are free now; inputs u[s], mid v[s], outputs back into u[s]
+        TAKE(u1, float, nc * 32); TAKE(u2, float, nc * 32); TAKE(u3, float, nc * 32);
+        TAKE(v1, float, nc * 32); TAKE(v2, float, nc * 32);
+        float *u[4] = {cA, u1, u2, u3};
+        float *v[4] = {cX, cB, v1, v2};
+        for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], chi->occ, s, nc, u[s]));
+        ConvBatch cb = {};
+        for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
+        GP_TRY(sparse_conv(st, cb, 4, nbrC, nc, K, 1));
+        TAKE(y0, float, nc * 32);
+        float *y[4] = {y0, u1, u2, u3};   // u[0] = cA must survive only until conv a is done; still use a fresh buffer for clarity
+        for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
+        GP_TRY(sparse_conv(st, cb, 4, nbrC, nc, K, 0));
+        for (int s = 0; s < 4; ++s) {
+            HeadArgs ha = {};
+            ha.x = y[s]; ha.n = nc; ha.stage_m = STAGE_M[s];
+            ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
+            ha.m2r = chi->m2r; ha.occ = chi->occ; ha.stage = s; ha.lohi = lohi + 4 * prefix + (int64_t)s * nc; ha.mode = 0;
+            GP_TRY(head_cdf(st, ha));
+        }
+        ctx->arena.rewind(mk);
+        prefix += nc;
+        std::swap(nbrP, nbrC);
+    }
+    // ---- range coder over every chunk of every stream
+    const int nstreams = 4 * (L - 1);
+    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
+    std::vector<RcChunk> chunks;
+    std::vector<int> stream_first(nstreams + 1, 0);
+    uint32_t max_syms = 1;
+    {
+        int64_t pre = 0; int si = 0;
+        for (int d = 1; d < L; ++d) {
+            const int64_t nc = T.lv[d].n;
+            for (int s = 0; s < 4; ++s, ++si) {
+                stream_first[si] = (int)chunks.size();
+                const int64_t base = 4 * pre + (int64_t)s * nc;
+                for (int64_t c0 = 0; c0 < nc; c0 += S) {
+                    const int64_t cn = std::min<int64_t>(S, nc - c0);
+                    chunks.push_back(RcChunk{(uint32_t)(base + c0), (uint32_t)cn, 0, 0});
+                    max_syms = std::max<uint32_t>(max_syms, (uint32_t)cn);
+                    if (chunk_log2 == 0) break;
+                }
+            }
+            pre += nc;
+        }
+        stream_first[nstreams] = (int)chunks.size();
+    }
+    const int nchunks = (int)chunks.size();
+    const Level *base = &T.lv[0];
+    TAKE(base_xyz, int32_t, 3 * base->n);
+    TAKE(base_occ, uint8_t, base->n);
+    GP_TRY(level_to_raster(ctx, st, base, base_xyz, base_occ));
+    // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ]
+    const size_t off_desc = 0, off_cnt = off_desc + sizeof(RcChunk) * (size_t)std::max(nchunks, 1);
+    const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * MAXLV, off_bo = off_bx + 12 * (size_t)base->n;
+    GP_TRY(ctx->hstage.reserve(off_bo + (size_t)base->n + 64));
+    uint8_t *hs = ctx->hstage.p;
+    uint32_t total_payload = 0;
+    uint8_t *payload_dev = nullptr;
+    if (nchunks) {
+        memcpy(hs + off_desc, chunks.data(), sizeof(RcChunk) * (size_t)nchunks);
+        const uint32_t stride = rc_scratch_stride(max_syms);
+        TAKE(dchunks, RcChunk, nchunks);
+        TAKE(dcnt, uint32_t, nchunks + 1);
+        TAKE(doff, uint32_t, nchunks + 1);
+        TAKE(scratch, uint8_t, (size_t)nchunks * stride);
+        HIP_TRY(hipMemcpyAsync(dchunks, hs + off_desc, sizeof(RcChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+        GP_TRY(rc_encode_launch(st, lohi, dchunks, nchunks, scratch, stride, dcnt));
+        GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
+        HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hs + off_cnt + 4 * (size_t)nchunks, doff + nchunks, 4, hipMemcpyDeviceToHost, st));
+        // worst case payload = all scratch; compact into a buffer of that size, copy back only the used part
+        TAKE(payload, uint8_t, (size_t)nchunks * stride);
+        GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nchunks, payload));
+        payload_dev = payload;
+    }
+    HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * MAXLV, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + off_bx, base_xyz, 12 * (size_t)base->n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + off_bo, base_occ, (size_t)base->n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
+    if (nchunks) total_payload = hcnt[nchunks];
+    // ---- container
+    size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
+    GP_TRY(ctx->hbytes.reserve(fsize + 16));
+    uint8_t *out = ctx->hbytes.p;
+    size_t pos = 0;
+    if (chunk_log2) {
+        out[0] = 0xFF; out[1] = 0xFF; out[2] = 1; out[3] = (uint8_t)chunk_log2; out[4] = (uint8_t)posq; out[5] = (uint8_t)(posq >> 8); out[6] = (uint8_t)L; out[7] = 0;
+        pos = 8;
+        for (int d = 0; d < L; ++d) { put32(out + pos, (uint32_t)T.lv[d].n); pos += 4; }
+        put32(out + pos, (uint32_t)n); pos += 4;
+    } else {
+        out[0] = (uint8_t)posq; out[1] = (uint8_t)(posq >> 8); pos = 2;
+    }
+    put32(out + pos, (uint32_t)base->n); pos += 4;
+    memcpy(out + pos, hs + off_bx, 12 * (size_t)base->n); pos += 12 * (size_t)base->n;
+    memcpy(out + pos, hs + off_bo, (size_t)base->n); pos += (size_t)base->n;
+    out[pos] = (uint8_t)nstreams; out[pos + 1] = (uint8_t)(nstreams >> 8); pos += 2;
+    // payload bytes come straight from the device into their final place, stream by stream
+    {
+        size_t src = 0;
+        for (int si = 0; si < nstreams; ++si) {
+            const int c0 = stream_first[si], c1 = stream_first[si + 1];
+            size_t plen = 0;
+            for (int c = c0; c < c1; ++c) plen += hcnt[c];
+            const size_t slen = plen + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0);
+            put32(out + pos, (uint32_t)slen); pos += 4;
+            if (chunk_log2)
+                for (int c = c0; c < c1; ++c) {
+                    if (hcnt[c] > 0xFFFF) return fail(GPCC_ERR_ARG, "chunk byte count overflows uint16");
+                    out[pos] = (uint8_t)hcnt[c]; out[pos + 1] = (uint8_t)(hcnt[c] >> 8); pos += 2;
+                }
+            if (plen) HIP_TRY(hipMemcpyAsync(out + pos, payload_dev + src, plen, hipMemcpyDeviceToHost, st));
+            pos += plen; src += plen;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    if (pos != fsize) return fail(GPCC_ERR_HIP, "internal: container size mismatch (%zu vs %zu)", pos, fsize);
+    *bytes_out = out; *nbytes_out = (int64_t)pos;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->num_points = n; stats->num_bytes = (int64_t)pos; stats->num_levels = L; stats->coded_nodes = coded;
+        const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hs + off_pairs);
+        int64_t cp = 0;
+        for (int d = 0; d < L; ++d) {
+            stats->level_nodes[d] = T.lv[d].n;
+            cp += (int64_t)hp[d] * ((d + 1 < L ? 5 : 0) + (d > 0 ? 13 : 0));
+        }
+        stats->conv_pairs = cp;
+    }
+    return GPCC_OK;
+}
+
+int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t nbytes, const int32_t **xyz_out, int64_t *n_out,
+                uint16_t *posq_out, gpcc_stats *stats, hipStream_t st)
+{
+    ctx->arena.reset();
+    const int K = m->K;
+    int64_t pos = 0;
+    int chunk_log2 = 0, L = -1;
+    int64_t lvl_n[MAXLV] = {0};
+    int64_t npts_hdr = -1;
+#define NEED(b) do { if (pos + (int64_t)(b) > nbytes) return fail(GPCC_ERR_FORMAT, "truncated bitstream (need %lld bytes at %lld of %lld)", (long long)(b), (long long)pos, (long long)nbytes); } while (0)
+    NEED(2);
+    const bool v1 = in[0] == 0xFF && in[1] == 0xFF;
+    if (v1) {
+        NEED(8);
+        if (in[2] != 1) return fail(GPCC_ERR_FORMAT, "unknown container version %d", in[2]);
+        chunk_log2 = in[3];
+        if (chunk_log2 < 6 || chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "bad chunk_log2 %d", chunk_log2);
+        *posq_out = (uint16_t)(in[4] | in[5] << 8);
+        L = in[6]; pos = 8;
+        if (L < 1 || L > 21) return fail(GPCC_ERR_FORMAT, "bad level count %d", L);
+        NEED(4 * L + 4);
+        for (int d = 0; d < L; ++d) { lvl_n[d] = get32(in + pos); pos += 4; }
+        npts_hdr = get32(in + pos); pos += 4;
+    } else {
+        *posq_out = (uint16_t)(in[0] | in[1] << 8); pos = 2;
+    }
+    NEED(4);
+    const int64_t bn = (int32_t)get32(in + pos); pos += 4;
+    if (bn <= 0 || bn >= 64) return fail(GPCC_ERR_FORMAT, "bad base length %lld", (long long)bn);
+    NEED(13 * bn + 2);
+    const uint8_t *bxyz = in + pos; pos += 12 * bn;
+    const uint8_t *bocc = in + pos; pos += bn;
+    const int nstreams = in[pos] | in[pos + 1] << 8; pos += 2;
+    if (nstreams % 4) return fail(GPCC_ERR_FORMAT, "stream count %d is not a multiple of 4", nstreams);
+    if (v1) { if (nstreams != 4 * (L - 1) || lvl_n[0] != bn) return fail(GPCC_ERR_FORMAT, "header/stream count mismatch"); }
+    else { L = nstreams / 4 + 1; if (L > 21) return fail(GPCC_ERR_FORMAT, "too many levels"); lvl_n[0] = bn; }
+    std::vector<int64_t> s_off(nstreams), s_len(nstreams);
+    for (int si = 0; si < nstreams; ++si) {
+        NEED(4);
+        const int64_t len = get32(in + pos); pos += 4;
+        NEED(len);
+        s_off[si] = pos; s_len[si] = len; pos += len;
+    }
+#undef NEED
+    // ---- base level -> Morton order on the host (< 64 nodes)
+    const int bias = CB >> L;
+    struct BN { uint64_t mk, rk; uint8_t occ; };
+    std::vector<BN> bnodes((size_t)bn);
+    uint32_t mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0, 0, 0};
+    for (int64_t i = 0; i < bn; ++i) {
+        uint32_t b[3];
+        for (int a = 0; a < 3; ++a) {
+            const int64_t c = (int32_t)get32(bxyz + 12 * i + 4 * a) + (int64_t)bias;
+            if (c < 0 || c >= ((int64_t)1 << (21 - L))) return fail(GPCC_ERR_FORMAT, "base coordinate out of range");
+            b[a] = (uint32_t)c; mn[a] = std::min(mn[a], b[a]); mx[a] = std::max(mx[a], b[a]);
+        }
+        bnodes[(size_t)i] = BN{morton3(b[0], b[1], b[2]), rkey3(b[0], b[1], b[2]), bocc[i]};
+        if (!bocc[i]) return fail(GPCC_ERR_FORMAT, "empty base occupancy");
+    }
+    std::sort(bnodes.begin(), bnodes.end(), [](const BN &a, const BN &b) { return a.mk < b.mk; });
+    for (int64_t i = 1; i < bn; ++i) if (bnodes[(size_t)i].mk == bnodes[(size_t)i - 1].mk) return fail(GPCC_ERR_FORMAT, "duplicate base node");
+    int hb = 1;
+    for (int a = 0; a < 3; ++a) { int b = 0; uint32_t v = mn[a] ^ mx[a]; while (v) { ++b; v >>= 1; } hb = std::max(hb, b); }
+
+    // ---- device state
+    auto alloc_level = [&](Level *lv, int64_t n, int lvl) -> int {
+        lv->n = n; lv->lvl = lvl;
+        TAKE(rkey, uint64_t, n); TAKE(occ, uint8_t, n); TAKE(cstart, uint32_t, n + 1); TAKE(parent, uint32_t, n); TAKE(m2r, uint32_t, n); TAKE(r2m, uint32_t, n);
+        lv->rkey = rkey; lv->occ = occ; lv->cstart = cstart; lv->parent = parent; lv->m2r = m2r; lv->r2m = r2m;
+        return GPCC_OK;
+    };
+    TAKE(dbytes, uint8_t, nbytes);
+    HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    GP_TRY(ctx->hstage.reserve(4096 + 16 * (size_t)bn));
+    Level cur;
+    GP_TRY(alloc_level(&cur, bn, L));
+    {
+        uint64_t *hr = reinterpret_cast<uint64_t *>(ctx->hstage.p + 1024);
+        uint8_t *ho = ctx->hstage.p + 1024 + 8 * (size_t)bn;
+        for (int64_t i = 0; i < bn; ++i) { hr[i] = bnodes[(size_t)i].rk; ho[i] = bnodes[(size_t)i].occ; }
+        HIP_TRY(hipMemcpyAsync(cur.rkey, hr, 8 * (size_t)bn, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(cur.occ, ho, (size_t)bn, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // staging is reused below
+    }
+    GP_TRY(level_raster_rank(ctx, st, &cur, hb));
+    TAKE(dtotal, uint32_t, 4);
+    uint32_t *htotal = reinterpret_cast<uint32_t *>(ctx->hstage.p);
+    // the two neighbour maps ping-pong; sizes are only known level by level in v0, so they are
+    // carved per level from the arena (a level's arrays live until the level after it is done)
+    int32_t *nbrP = nullptr;
+    {
+        TAKE(nb0, int32_t, (int64_t)K * bn);
+        nbrP = nb0;
+        GP_TRY(nbr_base(ctx, st, &cur, m->k, nbrP));
+    }
+    int64_t coded = 0;
+    std::vector<RcChunk> chunks;
+    // Arena discipline: level g allocates [child arrays | child neighbour map | chunk table] (kept: they are
+    // level g+1's parent data) and then its work buffers, which are rewound at the end of the level.
+    for (int g = 0; g + 1 < L; ++g) {
+        Level chi;
+        int64_t nc = lvl_n[g + 1];
+        if (!v1) {
+            GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
+            HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            nc = htotal[0];
+            lvl_n[g + 1] = nc;
+        }
+        if (nc <= 0 || nc > 8 * cur.n) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", g + 1);
+        GP_TRY(alloc_level(&chi, nc, L - g - 1));
+        GP_TRY(level_expand(ctx, st, &cur, &chi, dtotal));
+        if (v1) {  // verify the header against the occupancy actually decoded (checked at the next sync)
+            HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, st));
+        }
+        GP_TRY(level_raster_rank(ctx, st, &chi, hb + g + 1));
+        TAKE(nbrC, int32_t, (int64_t)K * nc);
+        GP_TRY(nbr_child(ctx, st, &cur, nbrP, &chi, m->k, nbrC));
+        // chunk descriptors of this level's four streams
+        const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
+        const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
+        chunks.assign((size_t)4 * nch, RcChunk{});
+        for (int s = 0; s < 4; ++s) {
+            const int si = 4 * g + s;
+            const int64_t off = s_off[si], len = s_len[si];
+            if (chunk_log2) {
+                if (len < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream %d shorter than its chunk table", si);
+                int64_t p = off + 2 * (int64_t)nch;
+                for (int c = 0; c < nch; ++c) {
+                    const uint32_t cb = in[off + 2 * c] | in[off + 2 * c + 1] << 8;
+                    if (p + cb > off + len) return fail(GPCC_ERR_FORMAT, "stream %d chunk %d overruns the stream", si, c);
+                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)((int64_t)c * S), (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)p, cb};
+                    p += cb;
+                }
+                if (p != off + len) return fail(GPCC_ERR_FORMAT, "stream %d has trailing bytes", si);
+            } else {
+                chunks[(size_t)s] = RcChunk{0, (uint32_t)nc, (uint32_t)off, (uint32_t)len};
+            }
+        }
+        TAKE(dchunks, RcChunk, 4 * nch);
+        // pageable source -> the runtime stages it before returning, so `chunks` may be reused next level
+        HIP_TRY(hipMemcpyAsync(dchunks, chunks.data(), sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (v1 && htotal[1 + g] != (uint32_t)nc) return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)nc, htotal[1 + g]);
+        const size_t mk = ctx->arena.mark();
+        const int64_t np = cur.n;
+        TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
+        GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
+        GP_TRY(run_trunk(st, m, 0, Trunk{pF, pA, pB}, nbrP, np));
+        TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
+        GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
+        GP_TRY(run_trunk(st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));  // -> cA
+        TAKE(cdf, uint16_t, nc * 17);
+        uint8_t *sym[4];
+        for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
+        for (int s = 0; s < 4; ++s) {
+            const float *xin = cA;
+            if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
+            ConvBatch cb = {};
+            cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
+            GP_TRY(sparse_conv(st, cb, 1, nbrC, nc, K, 1));
+            cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
+            GP_TRY(sparse_conv(st, cb, 1, nbrC, nc, K, 0));
+            HeadArgs ha = {};
+            ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
+            ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
+            ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1;
+            GP_TRY(head_cdf(st, ha));
+            GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
+        }
+        GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ));
+        ctx->arena.rewind(mk);
+        coded += nc;
+        cur = chi; nbrP = nbrC;
+    }
+    // ---- leaves
+    GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
+    HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t npts = htotal[0];
+    if (v1 && npts != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)npts, (long long)npts_hdr);
+    TAKE(xyz, int32_t, 3 * std::max<int64_t>(npts, 1));
+    GP_TRY(leaves_reference_order(ctx, st, &cur, xyz, npts));
+    HIP_TRY(hipStreamSynchronize(st));
+    *xyz_out = xyz; *n_out = npts;
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->num_points = npts; stats->num_bytes = nbytes; stats->num_levels = L; stats->coded_nodes = coded;
+        for (int d = 0; d < L; ++d) stats->level_nodes[d] = lvl_n[d];
+    }
+    return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz_dev, int64_t n, int chunk_log2, uint16_t posq_f16,
+                           const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, void *stream)
+{
+    if (!ctx || !m || !xyz_dev || !bytes_out || !nbytes_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t want = arena_estimate(n, m->K);
+    int rc = GPCC_OK;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        GP_TRY(ctx->arena.reserve(want));
+        rc = encode_body(ctx, m, xyz_dev, n, chunk_log2, posq_f16, bytes_out, nbytes_out, stats, st);
+        if (rc != GPCC_ERR_NOMEM) break;
+        HIP_TRY(hipStreamSynchronize(st));
+        want *= 2;  // deep / very sparse trees: more nodes per point than the estimate
+    }
+    if (rc == GPCC_OK && stats) stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+extern "C" int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes, const int32_t **xyz_dev_out,
+                           int64_t *n_out, uint16_t *posq_f16_out, gpcc_stats *stats, void *stream)
+{
+    if (!ctx || !m || !bytes || !xyz_dev_out || !n_out || !posq_f16_out) return fail(GPCC_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    // v1 headers carry the node counts; otherwise start from a size-based guess and grow on demand
+    size_t want = arena_estimate(std::max<int64_t>(nbytes, 1 << 16), m->K);
+    if (nbytes >= 8 && bytes[0] == 0xFF && bytes[1] == 0xFF && bytes[6] >= 1 && bytes[6] <= 21 && nbytes >= 12 + 4 * (int64_t)bytes[6]) {
+        const int L = bytes[6];
+        int64_t nodes = 0, nmax = 0;
+        for (int d = 0; d < L; ++d) { const int64_t v = get32(bytes + 8 + 4 * d); nodes += v; nmax = std::max(nmax, v); }
+        const int64_t npts = get32(bytes + 8 + 4 * L);
+        want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * m->K + 64) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
+    }
+    int rc = GPCC_OK;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        GP_TRY(ctx->arena.reserve(want));
+        rc = decode_body(ctx, m, bytes, nbytes, xyz_dev_out, n_out, posq_f16_out, stats, st);
+        if (rc != GPCC_ERR_NOMEM) break;
+        HIP_TRY(hipStreamSynchronize(st));
+        want *= 2;
+    }
+    if (rc == GPCC_OK && stats) stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}

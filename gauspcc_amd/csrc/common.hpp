@@ -1,0 +1,106 @@
+// common.hpp -- context, workspace arena, error plumbing shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gauspcc.h"
+
+namespace gpcc {
+
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+inline int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return gpcc::fail(GPCC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define GP_TRY(expr)                 \
+    do {                             \
+        int s_ = (expr);             \
+        if (s_ != GPCC_OK) return s_; \
+    } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+constexpr int CB = 1 << 20;        // coordinate bias at level 0
+constexpr int CLIM = CB - 8;       // |coordinate| limit
+constexpr int MAXLV = 24;
+constexpr int NSTAGE = 4;
+constexpr int CH = 32;             // channels the MFMA kernels are specialised for
+
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Bump allocator over one hipMalloc'd slab; reset at the start of every API call.
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return GPCC_OK;
+        if (base) HIP_TRY(hipFree(base));
+        base = nullptr; cap = 0;
+        size_t want = bytes + (bytes >> 3) + (1 << 20);
+        HIP_TRY(hipMalloc((void **)&base, want));
+        cap = want;
+        return GPCC_OK;
+    }
+    void reset() { off = 0; }
+    template <typename T> T *take(size_t count)
+    {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        if (off + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + off);
+        off += bytes;
+        return p;
+    }
+    size_t mark() const { return off; }
+    void rewind(size_t m) { off = m; }
+};
+
+template <typename T> struct HostBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return GPCC_OK;
+        if (p) HIP_TRY(hipHostFree(p));
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 2) + 1024;
+        HIP_TRY(hipHostMalloc((void **)&p, want * sizeof(T), hipHostMallocDefault));
+        cap = want;
+        return GPCC_OK;
+    }
+};
+
+}  // namespace gpcc
+
+struct gpcc_ctx {
+    int device = 0;
+    gpcc::Arena arena;              // device workspace
+    gpcc::HostBuf<uint8_t> hbytes;  // pinned output / staging bytes
+    gpcc::HostBuf<uint8_t> hstage;  // pinned small staging (counts, flags, descriptors)
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define TAKE(var, T, count)                                                                        \
+    T *var = ctx->arena.take<T>((size_t)(count));                                                  \
+    if (!var) return gpcc::fail(GPCC_ERR_NOMEM, "%s:%d workspace arena exhausted (%s x %lld)", __FILE__, __LINE__, #T, (long long)(count))

@@ -1,0 +1,403 @@
+// octree.hip -- octree build / expansion / neighbour maps on gfx950.
+// All kernels here are HBM-bound integer work: coalesced 4/8-byte streams, no LDS tiling needed
+// except the level histogram.  See octree.hpp for the data model.
+#include "octree.hpp"
+#include "primitives.hpp"
+
+namespace gpcc {
+
+constexpr int TB = 256;
+static inline unsigned nblk(int64_t n, int per = TB) { return (unsigned)cdiv(n, per); }
+
+// ------------------------------------------------------------------ leaves
+__global__ __launch_bounds__(TB) void k_bbox(const int32_t *__restrict__ xyz, int64_t n, int32_t *__restrict__ bbox)
+{
+    int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            int v = xyz[3 * i + a];
+            mn[a] = min(mn[a], v);
+            mx[a] = max(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = min(mn[a], __shfl_xor(mn[a], d, 64));
+            mx[a] = max(mx[a], __shfl_xor(mx[a], d, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&bbox[a], mn[a]);
+            atomicMax(&bbox[3 + a], mx[a]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_leaf_keys(const int32_t *__restrict__ xyz, int64_t n, uint64_t *__restrict__ mkey)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    mkey[i] = morton3((uint32_t)(xyz[3 * i] + CB), (uint32_t)(xyz[3 * i + 1] + CB), (uint32_t)(xyz[3 * i + 2] + CB));
+}
+
+// counts[l] (l = 0..21): number of sorted leaves whose highest differing Morton triple vs the
+// previous leaf is l (leaf 0 counts as 21); counts[22] = number of duplicates.
+__global__ __launch_bounds__(TB) void k_leaf_levels(const uint64_t *__restrict__ mkey, int64_t n, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t c[24];
+    if (threadIdx.x < 24) c[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) {
+        int l;
+        if (i == 0) l = 21;
+        else {
+            uint64_t d = mkey[i] ^ mkey[i - 1];
+            l = d == 0 ? 22 : (63 - __clzll((long long)d)) / 3;
+        }
+        atomicAdd(&c[l], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 24 && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ bottom-up level build
+__global__ __launch_bounds__(TB) void k_level_flags(const uint64_t *__restrict__ key, int64_t n, uint32_t *__restrict__ flag)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    flag[i] = (i == 0 || (key[i] >> 3) != (key[i - 1] >> 3)) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__ key, int64_t n, const uint32_t *__restrict__ pos,
+                                                    uint64_t *__restrict__ key_up, uint32_t *__restrict__ cstart_up,
+                                                    uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i], pk = k >> 3;
+    const bool head = i == 0 || (key[i - 1] >> 3) != pk;
+    const uint32_t p = pos[i] - (head ? 0u : 1u);  // pos = exclusive scan of head flags
+    if (parent_lo) parent_lo[i] = p;
+    if (head) {
+        uint32_t occ = 0;
+        for (int j = 0; j < 8 && i + j < n; ++j) {
+            uint64_t kj = key[i + j];
+            if ((kj >> 3) != pk) break;
+            occ |= 1u << (kj & 7);
+        }
+        key_up[p] = pk;
+        cstart_up[p] = (uint32_t)i;
+        occ_up[p] = (uint8_t)occ;
+    }
+    if (i == n - 1) cstart_up[p + 1] = (uint32_t)n;  // sentinel: cstart[n_up] = n_lo
+}
+
+__global__ __launch_bounds__(TB) void k_mkey_to_rkey(const uint64_t *__restrict__ mkey, int64_t n, uint64_t *__restrict__ rkey)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    uint64_t m = mkey[i];
+    rkey[i] = rkey3(compact1by2(m), compact1by2(m >> 1), compact1by2(m >> 2));
+}
+
+// ------------------------------------------------------------------ raster ranks
+__global__ __launch_bounds__(TB) void k_rank_keys(const uint64_t *__restrict__ rkey, int64_t n, int hb, uint64_t *__restrict__ skey, uint32_t *__restrict__ idx)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = rkey[i], msk = (1ull << hb) - 1;
+    skey[i] = ((uint64_t)(rk_z(k) & msk) << (2 * hb)) | ((uint64_t)(rk_y(k) & msk) << hb) | (rk_x(k) & msk);
+    idx[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(TB) void k_invert_perm(const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ m2r)
+{
+    int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    m2r[r2m[r]] = (uint32_t)r;
+}
+
+int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level)
+{
+    const int64_t n = lv->n;
+    if (hb_level < 1) hb_level = 1;
+    if (hb_level > 21) hb_level = 21;
+    size_t mk = ctx->arena.mark();
+    TAKE(ka, uint64_t, n);
+    TAKE(kb, uint64_t, n);
+    TAKE(vb, uint32_t, n);
+    uint32_t *va = lv->r2m;
+    k_rank_keys<<<nblk(n), TB, 0, st>>>(lv->rkey, n, hb_level, ka, va);
+    LAUNCH_CHECK();
+    uint64_t *k0 = ka, *k1 = kb;
+    uint32_t *v0 = va, *v1 = vb;
+    GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, n, 3 * hb_level));
+    if (v0 != lv->r2m) HIP_TRY(hipMemcpyAsync(lv->r2m, v0, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, st));
+    k_invert_perm<<<nblk(n), TB, 0, st>>>(lv->r2m, n, lv->m2r);
+    LAUNCH_CHECK();
+    ctx->arena.rewind(mk);
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ encode-side tree build
+static inline int bitlen(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+static int level_alloc(gpcc_ctx *ctx, Level *lv, int64_t n, int lvl)
+{
+    lv->n = n; lv->lvl = lvl;
+    TAKE(rkey, uint64_t, n); TAKE(occ, uint8_t, n); TAKE(cstart, uint32_t, n + 1); TAKE(parent, uint32_t, n);
+    TAKE(m2r, uint32_t, n); TAKE(r2m, uint32_t, n);
+    lv->rkey = rkey; lv->occ = occ; lv->cstart = cstart; lv->parent = parent; lv->m2r = m2r; lv->r2m = r2m;
+    return GPCC_OK;
+}
+
+int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tree *T)
+{
+    if (n <= 0) return fail(GPCC_ERR_ARG, "empty point cloud");
+    if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "point count must be < 2^31");
+    GP_TRY(ctx->hstage.reserve(4096));
+    int32_t *hb32 = reinterpret_cast<int32_t *>(ctx->hstage.p);
+    TAKE(dsmall, int32_t, 64);
+    // bbox: one sync
+    for (int a = 0; a < 3; ++a) { hb32[a] = INT32_MAX; hb32[3 + a] = INT32_MIN; }
+    HIP_TRY(hipMemcpyAsync(dsmall, hb32, 24, hipMemcpyHostToDevice, st));
+    k_bbox<<<(unsigned)std::min<int64_t>(cdiv(n, TB), 1024), TB, 0, st>>>(xyz, n, dsmall);
+    LAUNCH_CHECK();
+    HIP_TRY(hipMemcpyAsync(hb32, dsmall, 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    int hb = 1;
+    for (int a = 0; a < 3; ++a) {
+        if (hb32[a] < -CLIM || hb32[3 + a] >= CLIM) return fail(GPCC_ERR_RANGE, "coordinate out of range: axis %d spans [%d, %d], limit |c| < 2^20-8", a, hb32[a], hb32[3 + a]);
+        hb = std::max(hb, bitlen((uint32_t)(hb32[a] + CB) ^ (uint32_t)(hb32[3 + a] + CB)));
+    }
+    T->hb = hb; T->npts = n;
+    // sorted Morton keys of the leaves
+    TAKE(mk0, uint64_t, n);
+    TAKE(mk1, uint64_t, n);
+    k_leaf_keys<<<nblk(n), TB, 0, st>>>(xyz, n, mk0);
+    LAUNCH_CHECK();
+    uint64_t *ka = mk0, *kb = mk1;
+    GP_TRY(radix_sort_u64(ctx, st, &ka, &kb, nullptr, nullptr, n, 3 * hb));
+    T->leaf_mkey = ka;
+    // level sizes: one sync
+    uint32_t *dcounts = reinterpret_cast<uint32_t *>(dsmall);
+    HIP_TRY(hipMemsetAsync(dcounts, 0, 24 * 4, st));
+    k_leaf_levels<<<nblk(n), TB, 0, st>>>(ka, n, dcounts);
+    LAUNCH_CHECK();
+    uint32_t *hc = reinterpret_cast<uint32_t *>(ctx->hstage.p);
+    HIP_TRY(hipMemcpyAsync(hc, dcounts, 24 * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hc[22]) return fail(GPCC_ERR_DUPLICATE, "input has %u duplicate point(s); the octree occupancy code needs unique voxels", hc[22]);
+    int64_t nl[24] = {0};
+    {
+        int64_t acc = 0;
+        for (int l = 21; l >= 1; --l) { acc += hc[l]; nl[l] = acc; }
+    }
+    int L = 1;
+    while (L < 21 && nl[L] >= 64) ++L;  // pcc_utils.py:83-89: stop at the first level with < 64 nodes
+    T->L = L;
+    // bottom-up: level l from level l-1 (Morton keys); stored depth d = L - l
+    const uint64_t *key_lo = ka;
+    int64_t n_lo = n;
+    Level *lo = nullptr;
+    for (int l = 1; l <= L; ++l) {
+        Level *up = &T->lv[L - l];
+        GP_TRY(level_alloc(ctx, up, nl[l], l));
+        TAKE(key_up, uint64_t, nl[l]);
+        size_t mk = ctx->arena.mark();
+        TAKE(flag, uint32_t, n_lo);
+        k_level_flags<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag);
+        LAUNCH_CHECK();
+        GP_TRY(exclusive_scan_u32(ctx, st, flag, flag, n_lo, nullptr));
+        k_level_build<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag, key_up, up->cstart, up->occ, lo ? lo->parent : nullptr);
+        LAUNCH_CHECK();
+        ctx->arena.rewind(mk);
+        k_mkey_to_rkey<<<nblk(nl[l]), TB, 0, st>>>(key_up, nl[l], up->rkey);
+        LAUNCH_CHECK();
+        GP_TRY(level_raster_rank(ctx, st, up, hb - l));
+        key_lo = key_up; n_lo = nl[l]; lo = up;
+    }
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ decode-side expansion
+__global__ __launch_bounds__(TB) void k_popc(const uint8_t *__restrict__ occ, int64_t n, uint32_t *__restrict__ cnt)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) cnt[i] = (uint32_t)__popc((uint32_t)occ[i]);
+}
+
+__global__ __launch_bounds__(TB) void k_expand(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart,
+                                               int64_t n, uint64_t *__restrict__ rkey_c, uint32_t *__restrict__ parent_c)
+{
+    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    int64_t p = t >> 3;
+    const int q = (int)(t & 7);
+    if (p >= n) return;
+    const uint32_t o = occ[p];
+    if (!((o >> q) & 1u)) return;
+    const uint32_t idx = cstart[p] + (uint32_t)__popc(o & ((1u << q) - 1u));
+    const uint64_t k = rkey[p];
+    rkey_c[idx] = rkey3(2 * rk_x(k) + (q & 1), 2 * rk_y(k) + ((q >> 1) & 1), 2 * rk_z(k) + ((q >> 2) & 1));
+    parent_c[idx] = (uint32_t)p;
+}
+
+int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev)
+{
+    const int64_t n = par->n;
+    k_popc<<<nblk(n), TB, 0, st>>>(par->occ, n, par->cstart);
+    LAUNCH_CHECK();
+    GP_TRY(exclusive_scan_u32(ctx, st, par->cstart, par->cstart, n, par->cstart + n));
+    if (total_dev) HIP_TRY(hipMemcpyAsync(total_dev, par->cstart + n, 4, hipMemcpyDeviceToDevice, st));
+    if (chi) {
+        k_expand<<<nblk(n * 8), TB, 0, st>>>(par->rkey, par->occ, par->cstart, n, chi->rkey, chi->parent);
+        LAUNCH_CHECK();
+    }
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ neighbour maps
+__global__ __launch_bounds__(TB) void k_nbr_base(const uint64_t *__restrict__ rkey, int n, int k, int32_t *__restrict__ nbrT)
+{
+    const int K = k * k * k, r = k / 2;
+    int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= n * K) return;
+    const int o = t / n, i = t - o * n;
+    const int dx = o % k - r, dy = (o / k) % k - r, dz = o / (k * k) - r;
+    const uint64_t ki = rkey[i];
+    const int tx = (int)rk_x(ki) + dx, ty = (int)rk_y(ki) + dy, tz = (int)rk_z(ki) + dz;
+    int32_t res = -1;
+    if (tx >= 0 && ty >= 0 && tz >= 0) {
+        const uint64_t tgt = rkey3((uint32_t)tx, (uint32_t)ty, (uint32_t)tz);
+        for (int j = 0; j < n; ++j)
+            if (rkey[j] == tgt) res = j;
+    }
+    nbrT[t] = res;
+}
+
+int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT)
+{
+    if (lv->n > 4096) return fail(GPCC_ERR_ARG, "nbr_base is O(n^2): base level only");
+    const int K = k * k * k;
+    k_nbr_base<<<nblk(lv->n * K), TB, 0, st>>>(lv->rkey, (int)lv->n, k, nbrT);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+// child (i) x offset (o): the target voxel's parent is one of the 27 neighbours of i's parent
+// (already in the parent's map), its octant bit says whether it exists and the parent's child
+// start + popcount of the lower octant bits says where (children are stored octant-ascending).
+__global__ __launch_bounds__(TB) void k_nbr_child(const uint64_t *__restrict__ rkey_c, const uint32_t *__restrict__ parent_c, int64_t nc,
+                                                  const int32_t *__restrict__ nbrT_p, const uint8_t *__restrict__ occ_p,
+                                                  const uint32_t *__restrict__ cstart_p, int64_t np, int k, int32_t *__restrict__ nbrT_c)
+{
+    const int r = k / 2;
+    const int o = blockIdx.y;
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= nc) return;
+    const int dx = o % k - r, dy = (o / k) % k - r, dz = o / (k * k) - r;
+    const uint64_t kc = rkey_c[i];
+    const int tx = (int)(rk_x(kc) & 1) + dx, ty = (int)(rk_y(kc) & 1) + dy, tz = (int)(rk_z(kc) & 1) + dz;
+    const int px = tx >> 1, py = ty >> 1, pz = tz >> 1;  // floor: -1, 0 or 1 (k <= 5); up to +-2 for k = 7
+    const int po = (px + r) + k * (py + r) + k * k * (pz + r);
+    const int32_t pn = nbrT_p[(int64_t)po * np + parent_c[i]];
+    int32_t res = -1;
+    if (pn >= 0) {
+        const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
+        const uint32_t oc = occ_p[pn];
+        if ((oc >> tq) & 1u) res = (int32_t)(cstart_p[pn] + (uint32_t)__popc(oc & ((1u << tq) - 1u)));
+    }
+    nbrT_c[(int64_t)o * nc + i] = res;
+}
+
+int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT)
+{
+    const int K = k * k * k;
+    k_nbr_child<<<dim3(nblk(chi->n), (unsigned)K), TB, 0, st>>>(chi->rkey, chi->parent, chi->n, nbrT_par, par->occ, par->cstart, par->n, k, nbrT);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+__global__ __launch_bounds__(TB) void k_nbr_count(const int32_t *__restrict__ nbrT, int64_t total, unsigned long long *__restrict__ count)
+{
+    uint32_t c = 0;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) c += nbrT[i] >= 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
+int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev)
+{
+    k_nbr_count<<<(unsigned)std::min<int64_t>(cdiv(total, TB), 4096), TB, 0, st>>>(nbrT, total, count_dev);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ outputs
+__global__ __launch_bounds__(TB) void k_popc_raster(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ cnt)
+{
+    int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r < n) cnt[r] = (uint32_t)__popc((uint32_t)occ[r2m[r]]);
+}
+
+__global__ __launch_bounds__(TB) void k_leaves_out(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m,
+                                                   const uint32_t *__restrict__ start_r, int64_t n, int32_t *__restrict__ xyz)
+{
+    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    int64_t r = t >> 3;
+    const int q = (int)(t & 7);
+    if (r >= n) return;
+    const uint32_t m = r2m[r];
+    const uint32_t o = occ[m];
+    if (!((o >> q) & 1u)) return;
+    const int64_t idx = (int64_t)start_r[r] + __popc(o & ((1u << q) - 1u));
+    const uint64_t k = rkey[m];
+    xyz[3 * idx] = (int32_t)(2 * rk_x(k) + (q & 1)) - CB;
+    xyz[3 * idx + 1] = (int32_t)(2 * rk_y(k) + ((q >> 1) & 1)) - CB;
+    xyz[3 * idx + 2] = (int32_t)(2 * rk_z(k) + ((q >> 2) & 1)) - CB;
+}
+
+int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int32_t *xyz_out, int64_t npts)
+{
+    if (last->lvl != 1) return fail(GPCC_ERR_ARG, "leaves_reference_order: level is not the parents of the leaves");
+    const int64_t n = last->n;
+    size_t mk = ctx->arena.mark();
+    TAKE(cnt, uint32_t, n);
+    k_popc_raster<<<nblk(n), TB, 0, st>>>(last->occ, last->r2m, n, cnt);
+    LAUNCH_CHECK();
+    GP_TRY(exclusive_scan_u32(ctx, st, cnt, cnt, n, nullptr));
+    k_leaves_out<<<nblk(n * 8), TB, 0, st>>>(last->rkey, last->occ, last->r2m, cnt, n, xyz_out);
+    LAUNCH_CHECK();
+    ctx->arena.rewind(mk);
+    (void)npts;
+    return GPCC_OK;
+}
+
+__global__ __launch_bounds__(TB) void k_level_to_raster(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ m2r,
+                                                        int64_t n, int bias, int32_t *__restrict__ xyz, uint8_t *__restrict__ occ_out)
+{
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = m2r[i];
+    const uint64_t k = rkey[i];
+    xyz[3 * (int64_t)r] = (int32_t)rk_x(k) - bias;
+    xyz[3 * (int64_t)r + 1] = (int32_t)rk_y(k) - bias;
+    xyz[3 * (int64_t)r + 2] = (int32_t)rk_z(k) - bias;
+    occ_out[r] = occ[i];
+}
+
+int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int32_t *xyz_out_dev, uint8_t *occ_out_dev)
+{
+    k_level_to_raster<<<nblk(lv->n), TB, 0, st>>>(lv->rkey, lv->occ, lv->m2r, lv->n, CB >> lv->lvl, xyz_out_dev, occ_out_dev);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+}  // namespace gpcc

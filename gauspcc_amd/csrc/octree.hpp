@@ -1,0 +1,86 @@
+// octree.hpp -- device octree of a voxelised point set (the FOG/FCG machinery of
+// kit/nn.py:25-98 without torchsparse), in Morton order internally, with the
+// per-level raster ranks the bitstream order needs (kit/op.py:17-30) and the k^3
+// neighbour maps the sparse convolutions consume.
+#pragma once
+#include "common.hpp"
+
+namespace gpcc {
+
+// 21-bit-per-axis bit interleave, z most significant inside each triple (octant index
+// x | y<<1 | z<<2, kit/nn.py:43-45,64-73).
+__host__ __device__ __forceinline__ uint64_t part1by2(uint64_t v)
+{
+    v &= 0x1FFFFFull;
+    v = (v | (v << 32)) & 0x1F00000000FFFFull;
+    v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+    v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+    v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+__host__ __device__ __forceinline__ uint32_t compact1by2(uint64_t v)
+{
+    v &= 0x1249249249249249ull;
+    v = (v | (v >> 2)) & 0x10C30C30C30C30C3ull;
+    v = (v | (v >> 4)) & 0x100F00F00F00F00Full;
+    v = (v | (v >> 8)) & 0x1F0000FF0000FFull;
+    v = (v | (v >> 16)) & 0x1F00000000FFFFull;
+    v = (v | (v >> 32)) & 0x1FFFFFull;
+    return (uint32_t)v;
+}
+__host__ __device__ __forceinline__ uint64_t morton3(uint32_t x, uint32_t y, uint32_t z)
+{
+    return part1by2(x) | (part1by2(y) << 1) | (part1by2(z) << 2);
+}
+// raster key of BIASED coordinates (each < 2^21): z | y | x, 21 bits per field
+__host__ __device__ __forceinline__ uint64_t rkey3(uint32_t x, uint32_t y, uint32_t z)
+{
+    return ((uint64_t)z << 42) | ((uint64_t)y << 21) | (uint64_t)x;
+}
+__host__ __device__ __forceinline__ uint32_t rk_x(uint64_t k) { return (uint32_t)(k & 0x1FFFFF); }
+__host__ __device__ __forceinline__ uint32_t rk_y(uint64_t k) { return (uint32_t)((k >> 21) & 0x1FFFFF); }
+__host__ __device__ __forceinline__ uint32_t rk_z(uint64_t k) { return (uint32_t)((k >> 42) & 0x1FFFFF); }
+
+// One stored level, Morton order.  Biased coordinate b = c + (2^20 >> lvl) where lvl is the
+// number of halvings from the input resolution.
+struct Level {
+    int64_t n = 0;
+    int lvl = 0;            // halvings from the leaves (leaves = 0)
+    uint64_t *rkey = nullptr;   // (n) raster key of biased coordinates
+    uint8_t *occ = nullptr;     // (n) occupancy byte
+    uint32_t *cstart = nullptr; // (n) index of the first child in the next finer level
+    uint32_t *parent = nullptr; // (n) index of the parent in the next coarser level
+    uint32_t *m2r = nullptr;    // (n) Morton index -> raster rank
+    uint32_t *r2m = nullptr;    // (n) raster rank  -> Morton index
+};
+
+struct Tree {
+    int L = 0;             // stored levels: lv[0] base ... lv[L-1] parents of the leaves
+    int hb = 0;            // varying low bits per axis at leaf resolution
+    Level lv[MAXLV];
+    int64_t npts = 0;
+    uint64_t *leaf_mkey = nullptr;  // (npts) sorted Morton keys of the input points
+};
+
+// encode side: build every level bottom-up from the raw points (one bbox sync + one counts sync)
+int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz_dev, int64_t n, Tree *T);
+
+// raster ranks (m2r / r2m) of one level
+int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level);
+
+// decode side: children of `par` (occupancy known) -> `chi` (rkey, parent; n must be known)
+int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
+
+// neighbour map, offset-major: nbrT[o*n + i], o = (dx+r) + k*(dy+r) + k*k*(dz+r), -1 = absent
+int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT);
+int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT);
+// count present neighbours (pairs) into *count_dev (uint64 accumulate)
+int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev);
+
+// leaves of the last level in the reference's decoder order (parents in raster order, octants ascending)
+int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int32_t *xyz_out, int64_t npts);
+// copy a level to host-visible buffers in raster order: coords (n,3) int32 (un-biased), occ (n)
+int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int32_t *xyz_out_dev, uint8_t *occ_out_dev);
+
+}  // namespace gpcc

@@ -1,0 +1,190 @@
+// primitives.hip -- exclusive scan + radix sort for gfx950 (wave64).
+//
+// Radix sort: 8-bit digits, three kernels per pass
+//   k_radix_hist     per 1024-key tile: LDS-atomic digit histogram -> hist[digit][tile]
+//   exclusive scan   over the digit-major table (global digit offsets per tile)
+//   k_radix_scatter  one wave per tile; stable in-tile rank by wave ballots (8 ballots give the
+//                    lanes that hold the same digit, popcount of the lower lanes is the rank),
+//                    running per-digit counters in LDS across the 16 rounds of a tile.
+// HBM-bound integer work: per pass it reads keys twice and writes them once.
+#include "primitives.hpp"
+
+namespace gpcc {
+
+constexpr int SCAN_T = 256;             // threads per scan block
+constexpr int SCAN_E = 4;               // elements per thread
+constexpr int SCAN_TILE = SCAN_T * SCAN_E;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread across a 256-thread block; returns exclusive prefix,
+// *total = block sum (valid in every thread).
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *total, uint32_t *lds /*>=8*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = wave_incl_scan(v, lane);
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+    uint32_t base = wave == 0 ? 0 : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2;
+    *total = w0 + w1 + w2 + w3;
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ bsum, int64_t n)
+{
+    __shared__ uint32_t lds[8];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_E;
+    uint32_t s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e)
+        if (base + e < n) s += in[base + e];
+    uint32_t total;
+    block_excl_scan_256(s, &total, lds);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of bsum[0..nb) in place, total -> *total_out (may be null)
+__global__ __launch_bounds__(SCAN_T) void k_scan_bsums(uint32_t *bsum, int64_t nb, uint32_t *total_out)
+{
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += SCAN_T) {
+        int64_t i = b0 + threadIdx.x;
+        uint32_t v = i < nb ? bsum[i] : 0;
+        uint32_t total;
+        uint32_t ex = block_excl_scan_256(v, &total, lds);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_T) void k_scan_apply(const uint32_t *in, uint32_t *out, const uint32_t *__restrict__ bsum, int64_t n)
+{
+    __shared__ uint32_t lds[8];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_E;
+    uint32_t v[SCAN_E];
+    uint32_t s = 0;
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) {
+        v[e] = base + e < n ? in[base + e] : 0;
+        s += v[e];
+    }
+    uint32_t total;
+    uint32_t ex = block_excl_scan_256(s, &total, lds) + bsum[blockIdx.x];
+#pragma unroll
+    for (int e = 0; e < SCAN_E; ++e) {
+        if (base + e < n) out[base + e] = ex;
+        ex += v[e];
+    }
+}
+
+int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev)
+{
+    if (n <= 0) {
+        if (total_dev) HIP_TRY(hipMemsetAsync(total_dev, 0, 4, st));
+        return GPCC_OK;
+    }
+    const int64_t nb = cdiv(n, SCAN_TILE);
+    size_t mk = ctx->arena.mark();
+    TAKE(bsum, uint32_t, nb);
+    k_scan_reduce<<<dim3((unsigned)nb), SCAN_T, 0, st>>>(in, bsum, n);
+    k_scan_bsums<<<1, SCAN_T, 0, st>>>(bsum, nb, total_dev);
+    k_scan_apply<<<dim3((unsigned)nb), SCAN_T, 0, st>>>(in, out, bsum, n);
+    LAUNCH_CHECK();
+    ctx->arena.rewind(mk);  // stream-ordered reuse: later kernels on `st` run after these
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ radix sort
+constexpr int RS_TILE = 1024;  // keys per tile
+constexpr int RS_ROUNDS = RS_TILE / 64;
+
+__global__ __launch_bounds__(256) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n, int shift, uint32_t *__restrict__ hist, int64_t ntiles)
+{
+    __shared__ uint32_t cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_TILE / 256; ++r) {
+        int64_t i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];
+}
+
+template <bool HAS_VAL>
+__global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+                                                      int shift, const uint32_t *__restrict__ offs, int64_t ntiles)
+{
+    __shared__ uint32_t cnt[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cnt[lane + 64 * i] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int64_t i = base + r * 64 + lane;
+        const bool ok = i < n;
+        uint64_t key = ok ? keys[i] : 0;
+        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        uint64_t peers = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t bal = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? bal : ~bal;
+        }
+        // peers: valid lanes with my digit (meaningful only when ok)
+        const uint32_t rank = (uint32_t)__popcll(peers & lt);
+        const uint32_t prior = cnt[d];
+        __syncthreads();
+        if (ok && rank == 0) cnt[d] = prior + (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (ok) {
+            const int64_t pos = (int64_t)offs[(int64_t)d * ntiles + blockIdx.x] + prior + rank;
+            keys_out[pos] = key;
+            if (HAS_VAL) vals_out[pos] = vals[i];
+        }
+    }
+}
+
+int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t **keys_tmp_io, uint32_t **vals_io,
+                   uint32_t **vals_tmp_io, int64_t n, int bits)
+{
+    if (n <= 1 || bits <= 0) return GPCC_OK;
+    if (bits > 64) bits = 64;
+    const int64_t ntiles = cdiv(n, RS_TILE);
+    size_t mk = ctx->arena.mark();
+    TAKE(hist, uint32_t, 256 * ntiles);
+    const bool has_val = vals_io && *vals_io;
+    for (int shift = 0; shift < bits; shift += 8) {
+        k_radix_hist<<<dim3((unsigned)ntiles), 256, 0, st>>>(*keys_io, n, shift, hist, ntiles);
+        LAUNCH_CHECK();
+        GP_TRY(exclusive_scan_u32(ctx, st, hist, hist, 256 * ntiles, nullptr));
+        if (has_val)
+            k_radix_scatter<true><<<dim3((unsigned)ntiles), 64, 0, st>>>(*keys_io, *vals_io, *keys_tmp_io, *vals_tmp_io, n, shift, hist, ntiles);
+        else
+            k_radix_scatter<false><<<dim3((unsigned)ntiles), 64, 0, st>>>(*keys_io, nullptr, *keys_tmp_io, nullptr, n, shift, hist, ntiles);
+        LAUNCH_CHECK();
+        uint64_t *tk = *keys_io; *keys_io = *keys_tmp_io; *keys_tmp_io = tk;
+        if (has_val) { uint32_t *tv = *vals_io; *vals_io = *vals_tmp_io; *vals_tmp_io = tv; }
+    }
+    ctx->arena.rewind(mk);
+    return GPCC_OK;
+}
+
+}  // namespace gpcc

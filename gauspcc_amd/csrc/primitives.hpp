@@ -1,0 +1,18 @@
+// primitives.hpp -- device-wide exclusive scan and LSD radix sort (hand-written, wave64).
+#pragma once
+#include "common.hpp"
+
+namespace gpcc {
+
+// out[i] = sum_{j<i} in[j] (uint32).  in == out allowed.  If total_dev != nullptr the grand
+// total is stored there.  Workspace comes from ctx->arena (released before return).
+int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n,
+                       uint32_t *total_dev);
+
+// Stable LSD radix sort of (key, val) pairs on the low `bits` bits of key, 8 bits per pass.
+// keys/vals are ping-ponged with keys_tmp/vals_tmp; on return *keys_io / *vals_io point at the
+// buffers holding the result.  vals may be nullptr (keys only).
+int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t **keys_tmp_io,
+                   uint32_t **vals_io, uint32_t **vals_tmp_io, int64_t n, int bits);
+
+}  // namespace gpcc

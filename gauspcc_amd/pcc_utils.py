@@ -1,0 +1,185 @@
+"""Drop-in for the reference's plugin API (identical file in HAC / HAC-plus / TC-GS /
+CAT-3DGS: src/gs_compress/*/utils/pcc_utils.py).
+
+Same names, arguments, defaults and returned dict keys as the reference
+(pcc_utils.py:12-22, 24-217, 230-400); the work happens in libgauspcc.so on the
+MI355X.  There is no CPU path: without the HIP library or a GPU these functions raise.
+
+Deliberate differences, all on the error side:
+  * duplicate input points raise (the reference silently corrupts occupancy);
+  * a bare file name as output_path works (reference: os.makedirs('') raises, :47);
+  * decompress_point_cloud(output_path=...) really writes the ASCII PLY (reference: NameError,
+    `io` is never imported, :392).
+The container written by default is v1 (chunked streams, parallel decode);
+chunk_log2=0 writes the reference's exact layout.  Both are read back transparently.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, runtime
+
+DEFAULT_CHUNK_LOG2 = int(os.environ.get("GAUSPCC_CHUNK_LOG2", "10"))
+
+_DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
+
+
+def calculate_morton_order(x: torch.Tensor) -> torch.Tensor:
+    """Calculate Morton order of the input points.
+
+    (Reference semantics, pcc_utils.py:12-22: despite the name this is the raster order
+    of x + y*M + z*M^2 after the per-axis min shift.)  Returns a LongTensor permutation on
+    x.device.  The reference round-trips through the host and np.argsort; here key build
+    and the radix sort run on the device.
+    """
+    assert len(x.shape) == 2 and x.shape[1] == 3, f'Input data must be a 3D point cloud, but got {x.shape}.'
+    if not x.is_cuda:
+        raise RuntimeError("gauspcc_amd.calculate_morton_order needs a tensor on the MI355X (no CPU path)")
+    xs = x.detach()
+    if xs.dtype not in _DTYPES:
+        xs = xs.to(torch.float32) if xs.is_floating_point() else xs.to(torch.int64)
+    xs = xs.contiguous()
+    out = torch.empty(xs.shape[0], dtype=torch.int64, device=xs.device)
+    if xs.shape[0] == 0:
+        return out
+    ctx = runtime.context(xs.device)
+    _lib.check(_lib.lib().gpcc_raster_order(ctx, xs.data_ptr(), _DTYPES[xs.dtype], xs.shape[0], out.data_ptr(), runtime.stream_ptr(xs.device)))
+    return out
+
+
+def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
+    ctx = runtime.context(xyz_int32.device)
+    pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
+    _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
+                                      C.byref(pb), C.byref(nb), C.byref(st), runtime.stream_ptr(xyz_int32.device)))
+    data = C.string_at(pb, nb.value)
+    return data, st
+
+
+def compress_point_cloud(
+    xyz_quantized,            # Quantized point cloud coordinates, numpy array or torch tensor
+    ckpt_path,                # Path to pre-trained weights file
+    output_path,              # Output bin file path
+    channels=32,              # Network channel count
+    kernel_size=5,            # Convolution kernel size
+    posQ=1,                   # Quantization scale
+    *,
+    chunk_log2=None,          # extension: 0 = reference container, 6..14 = v1 chunk size (default 10)
+):
+    """Compress point cloud into a bin file (reference: pcc_utils.py:24-217).
+
+    Returns {'bpp', 'enc_time', 'file_size_bits', 'num_points', 'output_path'}; enc_time
+    covers the same span as the reference (:78-189: octree build .. packed byte stream,
+    excluding model load and the file write).
+    """
+    d = os.path.dirname(output_path)
+    if d:
+        os.makedirs(d, exist_ok=True)
+    if chunk_log2 is None:
+        chunk_log2 = DEFAULT_CHUNK_LOG2
+    if isinstance(xyz_quantized, np.ndarray):
+        xyz = torch.tensor(xyz_quantized)
+    else:
+        xyz = xyz_quantized.clone()
+    if not torch.cuda.is_available():
+        raise RuntimeError("gauspcc_amd.compress_point_cloud needs an MI355X (no CPU path)")
+    device = xyz.device if xyz.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    model = runtime.get_model(ckpt_path, channels, kernel_size, device)
+    N = xyz.shape[0]
+    xyz = xyz.to(device).int().contiguous()          # reference: torch.cat(...).int()  (:73)
+
+    torch.cuda.synchronize(device)
+    enc_time_start = time.time()
+    data, st = _encode_to_bytes(xyz, model, chunk_log2, posQ)
+    torch.cuda.synchronize(device)
+    enc_time_end = time.time()
+
+    with open(output_path, 'wb') as f:
+        f.write(data)
+
+    enc_time = enc_time_end - enc_time_start
+    file_size_bits = os.stat(output_path).st_size * 8
+    bpp = file_size_bits / N
+    return {
+        'bpp': bpp,
+        'enc_time': enc_time,
+        'file_size_bits': file_size_bits,
+        'num_points': N,
+        'output_path': output_path,
+    }
+
+
+def save_ply_ascii_geo(coords, filedir):
+    """ASCII PLY writer with the layout of kit/io.py:36-49 (without the open3d dependency)."""
+    coords = np.asarray(coords, dtype=np.float32)
+    with open(filedir, "w") as f:
+        f.write("ply\nformat ascii 1.0\n")
+        f.write("element vertex " + str(coords.shape[0]) + "\n")
+        f.write("property float x\nproperty float y\nproperty float z\n")
+        f.write("end_header\n")
+        for p in coords:
+            f.write(f"{p[0]} {p[1]} {p[2]}\n")
+
+
+def _decode_bytes(data: bytes, model, device):
+    ctx = runtime.context(device)
+    px, n, pq, st = C.c_void_p(), C.c_int64(), C.c_uint16(), _lib.Stats()
+    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    _lib.check(_lib.lib().gpcc_decode(ctx, model.handle, C.cast(buf, C.c_void_p), len(data), C.byref(px), C.byref(n), C.byref(pq),
+                                      C.byref(st), runtime.stream_ptr(device)))
+    out = torch.empty((n.value, 3), dtype=torch.int32, device=device)
+    if n.value:
+        # context-owned device buffer -> caller-owned tensor (D2D on the current stream)
+        _lib.check(_lib.lib().gpcc_memcpy_d2d(ctx, out.data_ptr(), px, 12 * n.value, runtime.stream_ptr(device)))
+    return out, runtime.bits_f16(pq.value), st
+
+
+def decompress_point_cloud(
+    bin_file_path,           # Path to compressed bin file
+    ckpt_path,               # Path to pre-trained weights file
+    output_path=None,        # Path for output ply file (optional)
+    channels=32,             # Network channel count
+    kernel_size=5,           # Convolution kernel size
+    is_data_pre_quantized=True  # Whether original point cloud is pre-quantized
+):
+    """Decompress point cloud from bin file (reference: pcc_utils.py:230-400).
+
+    Returns {'dec_time', 'num_points', 'point_cloud', 'output_path'}; point_cloud is an
+    (N,3) float tensor on the device in the reference's decoder order (callers re-sort
+    with calculate_morton_order).
+    """
+    if output_path:
+        d = os.path.dirname(output_path)
+        if d:
+            os.makedirs(d, exist_ok=True)
+    if not torch.cuda.is_available():
+        raise RuntimeError("gauspcc_amd.decompress_point_cloud needs an MI355X (no CPU path)")
+    device = torch.device('cuda', torch.cuda.current_device())
+    model = runtime.get_model(ckpt_path, channels, kernel_size, device)
+    with open(bin_file_path, 'rb') as f:
+        data = f.read()
+
+    torch.cuda.synchronize(device)
+    dec_time_start = time.time()
+    with torch.no_grad():
+        scan, posQ, st = _decode_bytes(data, model, device)
+        if is_data_pre_quantized:
+            scan = scan * posQ.item()                       # :378-379
+        else:
+            scan = (scan * posQ.item() - 131072) * 0.001    # :381
+    torch.cuda.synchronize(device)
+    dec_time_end = time.time()
+    dec_time = dec_time_end - dec_time_start
+
+    point_cloud = scan
+    if output_path:
+        save_ply_ascii_geo(point_cloud.cpu().numpy(), output_path)
+    return {
+        'dec_time': dec_time,
+        'num_points': point_cloud.shape[0],
+        'point_cloud': point_cloud,
+        'output_path': output_path,
+    }

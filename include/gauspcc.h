@@ -1,0 +1,145 @@
+/*
+ * gauspcc.h -- C ABI of libgauspcc.so, the MI355X (gfx950) implementation of the
+ * GausPcc hot path.  Plain pointers and sizes only; every device pointer is a HIP
+ * device address on the context's device, every `stream` is a hipStream_t passed
+ * as void* (NULL = the legacy default stream).
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).  All functions return 0 on success or a negative
+ * gpcc_status; gpcc_last_error() gives the thread-local message.  The Python shim
+ * (gauspcc_amd/) raises on non-zero, mirroring the reference's Python exceptions.
+ */
+#ifndef GAUSPCC_H
+#define GAUSPCC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPCC_API __attribute__((visibility("default")))
+
+typedef enum {
+    GPCC_OK = 0,
+    GPCC_ERR_HIP = -1,        /* a HIP runtime call failed */
+    GPCC_ERR_ARG = -2,        /* bad argument */
+    GPCC_ERR_RANGE = -3,      /* coordinate outside [-2^20+8, 2^20-8) */
+    GPCC_ERR_DUPLICATE = -4,  /* duplicate point (the reference silently corrupts occupancy here) */
+    GPCC_ERR_FORMAT = -5,     /* malformed / truncated bitstream */
+    GPCC_ERR_NOMEM = -6
+} gpcc_status;
+
+typedef enum { GPCC_F32 = 0, GPCC_F64 = 1, GPCC_I32 = 2, GPCC_I64 = 3 } gpcc_dtype;
+
+typedef struct gpcc_ctx gpcc_ctx;     /* per-device context: workspace arena, staging buffers */
+typedef struct gpcc_model gpcc_model; /* GausPcgc weights resident in HBM, MFMA-friendly layout */
+
+GPCC_API const char *gpcc_last_error(void);
+GPCC_API int gpcc_version(void);
+
+GPCC_API int gpcc_ctx_create(int device, gpcc_ctx **out);
+GPCC_API void gpcc_ctx_destroy(gpcc_ctx *ctx);
+
+/* ---- a2  calculate_morton_order            src/gs_compress/HAC/utils/pcc_utils.py:12-22
+ * perm_out[N] (int64, device): argsort of x + y*M + z*M^2 after the per-axis min shift
+ * (M = max over all axes + 1), i.e. the (z,y,x) raster order; stable for equal keys. */
+GPCC_API int gpcc_raster_order(gpcc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n,
+                      int64_t *perm_out_dev, void *stream);
+
+/* ---- Network(channels, kernel_size).load_state_dict     pcc_utils.py:65-67, 266-268
+ * tensors: GPCC_T_COUNT host pointers to contiguous float32 arrays, upstream layouts
+ * (conv kernels (k^3, Cin, Cout); Linear (out, in)); order = gpcc_tensor_id. */
+typedef enum {
+    GPCC_T_PRIOR_EMB = 0,  /* prior_embedding.weight (256, C) */
+    GPCC_T_CONV0 = 1,      /* 18 conv kernels: prior_resnet.{0,2.conv0,2.conv1,3.conv0,3.conv1},
+                              target_resnet.{same five}, spatial_conv_s{0..3}.{0,2} */
+    GPCC_T_TEMB = 19,      /* target_embedding.target_res_embedding.weight (8, C) */
+    GPCC_T_HW1 = 20,       /* pred_head_s{0..3}.0.weight (C, C) */
+    GPCC_T_HB1 = 24,       /* pred_head_s{0..3}.0.bias   (C)    */
+    GPCC_T_HW2 = 28,       /* pred_head_s{0..3}.2.weight ({2,2,4,16}, C) */
+    GPCC_T_HB2 = 32,       /* pred_head_s{0..3}.2.bias   ({2,2,4,16})    */
+    GPCC_T_SEMB = 36,      /* pred_head_s{1,2,3}_emb.weight ({2,4,16}, C) */
+    GPCC_T_COUNT = 39
+} gpcc_tensor_id;
+
+GPCC_API int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, const float *const *tensors,
+                      gpcc_model **out);
+GPCC_API void gpcc_model_destroy(gpcc_model *m);
+
+typedef struct {
+    int64_t num_points;
+    int64_t num_bytes;
+    int32_t num_levels;        /* stored levels L (base + coded) */
+    int32_t reserved;
+    int64_t level_nodes[24];   /* nodes per stored level, base first */
+    int64_t coded_nodes;       /* sum of nodes over coded levels */
+    int64_t conv_pairs;        /* sum over all 18*levels convs of (output node, present neighbour) pairs */
+    double device_ms;          /* wall time between the syncs that bracket the call */
+} gpcc_stats;
+
+/* ---- a12  compress_point_cloud (the timed span :78-189 + container :192-203)
+ * xyz_dev: (N,3) int32 device, duplicate-free, any order.  chunk_log2 = 0 writes the
+ * reference container layout (one range-coder stream per level and stage, decoded by
+ * a single lane); 6..14 writes container v1 whose streams are cut into
+ * 2^chunk_log2-symbol chunks that decode in parallel.  posq_f16 = bits of np.float16(posQ).
+ * On success *bytes_out points at a context-owned host buffer valid until the next call. */
+GPCC_API int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz_dev, int64_t n,
+                int chunk_log2, uint16_t posq_f16, const uint8_t **bytes_out, int64_t *nbytes_out,
+                gpcc_stats *stats, void *stream);
+
+/* ---- a13  decompress_point_cloud (the timed span :279-385)
+ * bytes: the whole .bin file (host).  On success *xyz_dev_out points at a context-owned
+ * (N,3) int32 DEVICE buffer (integer leaf coordinates, before the posQ multiply) in the
+ * reference's output order (FCG of the raster-sorted last level, pcc_utils.py:375),
+ * valid until the next call on this context. */
+GPCC_API int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes,
+                const int32_t **xyz_dev_out, int64_t *n_out, uint16_t *posq_f16_out,
+                gpcc_stats *stats, void *stream);
+
+/* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
+ * ordered on `stream`; returns after the copy has completed. */
+GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);
+
+/* ---- stage-level entry points (what the reference does through torch / torchsparse /
+ * torchac calls); used by the parity tests and by callers that want a single stage. */
+
+/* op.sort_CF order of integer coordinates             src/ai_pcc/GausPcgc/kit/op.py:17-30
+ * xyz (n,3) int32 device -> perm (n) uint32 device such that xyz[perm] is (z,y,x) sorted. */
+GPCC_API int gpcc_sort_zyx(gpcc_ctx *ctx, const int32_t *xyz_dev, int64_t n, uint32_t *perm_dev, void *stream);
+
+/* FOG loop                                            kit/nn.py:38-55, pcc_utils.py:83-89
+ * Builds the octree of xyz on the device and copies every stored level to the host in
+ * raster order: coords_out[d] (n_d,3) int32, occ_out[d] (n_d) uint8; capacity per level
+ * cap_nodes.  levels_out/level_nodes_out as in gpcc_stats. */
+GPCC_API int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz_dev, int64_t n, int32_t *levels_out,
+                      int64_t *level_nodes_out, int32_t **coords_out_host, uint8_t **occ_out_host,
+                      int64_t cap_nodes, void *stream);
+
+/* spnn.Conv3d (stride 1) on raster-sorted coordinates: torchsparse 2.1.0 (not in tree), call
+ * sites network_ue_4stage_conv.py:17-62.  in/out (n,C) float32 device in LOGICAL channel
+ * order; w = upstream (k^3,C,C) host; residual may be NULL.  Also returns the number of
+ * (node, neighbour) pairs. */
+GPCC_API int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted_dev, int64_t n, int channels, int kernel_size,
+                const float *in_dev, const float *w_host, const float *res_dev, int relu,
+                float *out_dev, int64_t *pairs_out, void *stream);
+
+/* pred_head_s* + cdf + _convert_to_int_and_normalize  network_ue_4stage_conv.py:65-94,
+ * pcc_utils.py:146-171, kit/op.py:50-79.  x (n,C) device logical order; prob (n,m) float32,
+ * cdf (n,m+1) uint16 device outputs (either may be NULL). */
+GPCC_API int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int channels, int m,
+                  const float *w1_host, const float *b1_host, const float *w2_host, const float *b2_host,
+                  float *prob_dev, uint16_t *cdf_dev, void *stream);
+
+/* torchac.encode_int16_normalized_cdf / decode_int16_normalized_cdf   pcc_utils.py:174-177,322-366
+ * cdf (n,Lp) uint16 device, sym (n) uint8 device.  chunk_log2 as in gpcc_encode
+ * (0 = one stream, bytes identical to torchac's).  encode: *bytes_out context-owned host buffer. */
+GPCC_API int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *sym_dev, int64_t n,
+                   int chunk_log2, const uint8_t **bytes_out, int64_t *nbytes_out, void *stream);
+GPCC_API int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *bytes, int64_t nbytes,
+                   int64_t n, int chunk_log2, uint8_t *sym_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAUSPCC_H */

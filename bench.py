@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on its configs[1]: Mpoints/s for GausPcgc
+encode + decode of a 1M-anchor synthetic cloud on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one scene: gpcc_encode (points resident in
+HBM -> container bytes on the host) followed by gpcc_decode (container bytes -> points
+in HBM).  Scenes are independent, so with N GPUs every rank codes its own scene (weak
+scaling, no data-path collective); one RCCL all_gather collates the bitstream stats.
+Weights are seeded synthetic (the reference ships no checkpoint) and the cloud comes
+from the in-repo counter-based generator -- "data": "synthetic".
+
+One JSON line on stdout (rank 0).  Besides the contract keys it carries
+  roofline      the dominant kernel (k_sparse_conv, fp32 MFMA) timed live with HIP
+                events on its own stream inside libgauspcc (gpcc_profile_*)
+  cpu_baseline  the oracle (CPU restatement of the reference algorithm) on a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--kernel-size", type=int, default=5)
+    ap.add_argument("--chunk-log2", type=int, default=10)
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="points of the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    from gauspcc_amd import _lib, runtime
+    from gauspcc_amd.pcc_utils import _decode_bytes, _encode_to_bytes
+    from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+
+    k = args.kernel_size
+    sd = synthetic_state_dict(32, k)
+    model = runtime.Model(sd, 32, k, local_rank)
+    seed = 1234 + rank  # one independent scene per GPU
+    pts = synthetic_cloud(args.points, seed=seed)
+    x = torch.tensor(pts, device=device)  # inputs resident in HBM before the timed region
+    ctx = runtime.context(device)
+    L = _lib.lib()
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    def step():
+        t0 = time.perf_counter()
+        data, st = _encode_to_bytes(x, model, args.chunk_log2, 1)
+        torch.cuda.synchronize(device)
+        t1 = time.perf_counter()
+        dec, _, _ = _decode_bytes(data, model, device)
+        torch.cuda.synchronize(device)
+        t2 = time.perf_counter()
+        return data, st, dec, t1 - t0, t2 - t1
+
+    for _ in range(args.warmup):
+        step()
+    _lib.check(L.gpcc_profile_enable(ctx, 1))
+    barrier()
+    t_start = time.perf_counter()
+    enc_s = dec_s = 0.0
+    for _ in range(args.steps):
+        data, st, dec, te, td = step()
+        enc_s += te
+        dec_s += td
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    prof = _lib.Profile()
+    _lib.check(L.gpcc_profile_get(ctx, C.byref(prof)))
+    _lib.check(L.gpcc_profile_enable(ctx, 0))
+
+    # correctness of what was just timed: decoded geometry == input geometry (as sets; bit-identical)
+    d = dec.cpu().numpy()
+    ok = d.shape == pts.shape and np.array_equal(d[np.lexsort((d[:, 0], d[:, 1], d[:, 2]))], pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))])
+    if not ok:
+        raise SystemExit("round trip failed: decoded geometry differs from the input")
+
+    # max over ranks; stats collation over RCCL
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    stats = torch.tensor([float(len(data)), enc_s / args.steps, dec_s / args.steps, float(st.coded_nodes), float(st.conv_pairs)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(gathered, stats)
+        allstats = torch.stack(gathered).cpu().numpy()
+    else:
+        allstats = stats.cpu().numpy()[None]
+    elapsed = float(tmax.item())
+
+    if rank == 0:
+        total_points = args.points * world * args.steps
+        value = total_points / elapsed / 1e6
+        conv_flops = 2.0 * 32 * 32 * prof.conv_pair_jobs
+        achieved = conv_flops / (prof.conv_ms * 1e-3) / 1e12 if prof.conv_ms > 0 else 0.0
+        out = {
+            "metric": "Mpoints/s encode+decode @1M anchors",
+            "value": round(value, 4),
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "GausPcgc encode+decode of one synthetic anchor cloud per GPU (BASELINE configs[1])",
+                "points_per_scene": args.points,
+                "scenes_per_gpu": 1,
+                "channels": 32,
+                "kernel_size": k,
+                "container": f"v1 chunk_log2={args.chunk_log2}" if args.chunk_log2 else "v0 (reference layout)",
+                "weights": "seeded synthetic (reference initialisers, conv gain 4)",
+            },
+            "enc_ms": round(float(allstats[:, 1].mean()) * 1e3, 3),
+            "dec_ms": round(float(allstats[:, 2].mean()) * 1e3, 3),
+            "bpp": round(float(allstats[:, 0].mean()) * 8 / args.points, 4),
+            "coded_nodes": int(allstats[0, 3]),
+            "roundtrip_bit_identical": True,
+            "roofline": {
+                "kernel": "k_sparse_conv",
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": MFMA_F32_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launches": int(prof.conv_launches),
+                "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
+                "algorithmic_flops_per_step": conv_flops / args.steps,
+                "conv_time_frac_of_step": round(prof.conv_ms * 1e-3 / (enc_s + dec_s), 4),
+            },
+        }
+        if args.cpu_sample > 0:
+            from gauspcc_amd.model import tensor_table
+            from oracle import oracle as orc
+
+            om = orc.Model(tensor_table(sd, 32, k), 32, k)
+            sp = synthetic_cloud(args.cpu_sample, seed=seed)
+            t0 = time.perf_counter()
+            ref = orc.encode(om, sp, chunk_log2=args.chunk_log2)
+            t1 = time.perf_counter()
+            od, _ = orc.decode(om, ref)
+            t2 = time.perf_counter()
+            assert od.shape == sp.shape
+            out["cpu_baseline"] = {
+                "value": round(args.cpu_sample / (t2 - t0) / 1e6, 5),
+                "unit": "Mpoints/s",
+                "cores": len(os.sched_getaffinity(0)),
+                "kind": "port",
+                "sample": f"oracle encode+decode of a {args.cpu_sample}-point cloud from the same generator "
+                          f"(enc {t1 - t0:.2f} s, dec {t2 - t1:.2f} s; OpenMP convs, single-thread range coder as torchac)",
+            }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

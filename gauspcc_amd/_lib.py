@@ -31,10 +31,15 @@ class Stats(C.Structure):
     ]
 
 
+class Profile(C.Structure):
+    _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_pair_jobs", C.c_int64)]
+
+
 EXPORTS = [
     "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_raster_order",
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
+    "gpcc_profile_enable", "gpcc_profile_get",
 ]
 
 
@@ -66,6 +71,8 @@ def lib():
     L.gpcc_rc_encode.argtypes = [vp, vp, i32, vp, i64, i32, C.POINTER(vp), C.POINTER(i64), vp]
     L.gpcc_rc_decode.argtypes = [vp, vp, i32, vp, i64, i64, i32, vp, vp]
     L.gpcc_memcpy_d2d.argtypes = [vp, vp, vp, i64, vp]
+    L.gpcc_profile_enable.argtypes = [vp, i32]
+    L.gpcc_profile_get.argtypes = [vp, C.POINTER(Profile)]
     _lib = L
     return L
 

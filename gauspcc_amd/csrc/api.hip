@@ -36,10 +36,29 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
     delete c;
+}
+
+extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)
+{
+    if (!ctx) return fail(GPCC_ERR_ARG, "null argument");
+    ctx->prof.on = on != 0;
+    ctx->prof.conv_ms = 0.0; ctx->prof.conv_launches = 0; ctx->prof.conv_pair_jobs = 0;
+    ctx->prof.recs.clear(); ctx->prof.used = 0;
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out)
+{
+    if (!ctx || !out) return fail(GPCC_ERR_ARG, "null argument");
+    out->conv_ms = ctx->prof.conv_ms;
+    out->conv_launches = ctx->prof.conv_launches;
+    out->conv_pair_jobs = ctx->prof.conv_pair_jobs;
+    return GPCC_OK;
 }
 
 extern "C" int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst, const void *src, int64_t nbytes, void *stream)
@@ -368,7 +387,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             LAUNCH_CHECK();
             ConvBatch cb = {};
             cb.job[0] = ConvJob{xin, dw, res_dev ? xres : nullptr, xout};
-            GP_TRY(sparse_conv(st, cb, 1, p, n, K, relu));
+            GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, p, n, K, relu));
             k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
             LAUNCH_CHECK();
             unsigned long long hpairs = 0;

@@ -25,12 +25,12 @@ namespace {
 struct Trunk { float *x, *a, *b; };
 
 // Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; kit/nn.py:18-22).  Result in t.a.
-int run_trunk(hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const int32_t *nbrT, int64_t n)
+int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const int32_t *nbrT, int64_t n)
 {
     ConvBatch cb = {};
     auto one = [&](const float *in, int ci, const float *res, float *out) {
         cb.job[0] = ConvJob{in, m->conv[ci], res, out};
-        return sparse_conv(st, cb, 1, nbrT, n, m->K, 1);
+        return sparse_conv(ctx, level, st, cb, 1, nbrT, n, m->K, 1);
     };
     GP_TRY(one(t.x, conv0, nullptr, t.a));
     GP_TRY(one(t.a, conv0 + 1, nullptr, t.b));
@@ -73,10 +73,10 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         const size_t mk = ctx->arena.mark();
         TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
         GP_TRY(embed_occ(st, m->prior_emb, par->occ, np, pF));
-        GP_TRY(run_trunk(st, m, 0, Trunk{pF, pA, pB}, nbrP, np));                      // -> pA
+        GP_TRY(run_trunk(ctx, d, st, m, 0, Trunk{pF, pA, pB}, nbrP, np));              // -> pA
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32);
         GP_TRY(child_features(st, pA, chi->parent, chi->rkey, m->temb, nc, cX));
-        GP_TRY(run_trunk(st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));                      // -> cA  (X of pcc_utils.py:109)
+        GP_TRY(run_trunk(ctx, d + 1, st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));          // -> cA  (X of pcc_utils.py:109)
         // stages: cX, cB are free now; inputs u[s], mid v[s], outputs back into u[s]
         TAKE(u1, float, nc * 32); TAKE(u2, float, nc * 32); TAKE(u3, float, nc * 32);
         TAKE(v1, float, nc * 32); TAKE(v2, float, nc * 32);
@@ -85,11 +85,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], chi->occ, s, nc, u[s]));
         ConvBatch cb = {};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
-        GP_TRY(sparse_conv(st, cb, 4, nbrC, nc, K, 1));
+        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, nbrC, nc, K, 1));
         TAKE(y0, float, nc * 32);
         float *y[4] = {y0, u1, u2, u3};   // u[0] = cA must survive only until conv a is done; still use a fresh buffer for clarity
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
-        GP_TRY(sparse_conv(st, cb, 4, nbrC, nc, K, 0));
+        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, nbrC, nc, K, 0));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};
             ha.x = y[s]; ha.n = nc; ha.stage_m = STAGE_M[s];
@@ -160,6 +160,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
     if (nchunks) total_payload = hcnt[nchunks];
+    if (ctx->prof.on) GP_TRY(prof_collect(ctx, reinterpret_cast<const unsigned long long *>(hs + off_pairs), L));
     // ---- container
     size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
     GP_TRY(ctx->hbytes.reserve(fsize + 16));
@@ -307,6 +308,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         nbrP = nb0;
         GP_TRY(nbr_base(ctx, st, &cur, m->k, nbrP));
     }
+    TAKE(pairs_dev, unsigned long long, MAXLV);
+    HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
+    GP_TRY(nbr_count(ctx, st, nbrP, (int64_t)K * bn, pairs_dev));
     int64_t coded = 0;
     std::vector<RcChunk> chunks;
     // Arena discipline: level g allocates [child arrays | child neighbour map | chunk table] (kept: they are
@@ -330,6 +334,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         GP_TRY(level_raster_rank(ctx, st, &chi, hb + g + 1));
         TAKE(nbrC, int32_t, (int64_t)K * nc);
         GP_TRY(nbr_child(ctx, st, &cur, nbrP, &chi, m->k, nbrC));
+        GP_TRY(nbr_count(ctx, st, nbrC, (int64_t)K * nc, pairs_dev + g + 1));
         // chunk descriptors of this level's four streams
         const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
         const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
@@ -360,10 +365,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const int64_t np = cur.n;
         TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
         GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
-        GP_TRY(run_trunk(st, m, 0, Trunk{pF, pA, pB}, nbrP, np));
+        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, nbrP, np));
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
-        GP_TRY(run_trunk(st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));  // -> cA
+        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));  // -> cA
         TAKE(cdf, uint16_t, nc * 17);
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
@@ -372,9 +377,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
-            GP_TRY(sparse_conv(st, cb, 1, nbrC, nc, K, 1));
+            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, nbrC, nc, K, 1));
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
-            GP_TRY(sparse_conv(st, cb, 1, nbrC, nc, K, 0));
+            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, nbrC, nc, K, 0));
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
@@ -395,12 +400,20 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     if (v1 && npts != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)npts, (long long)npts_hdr);
     TAKE(xyz, int32_t, 3 * std::max<int64_t>(npts, 1));
     GP_TRY(leaves_reference_order(ctx, st, &cur, xyz, npts));
+    unsigned long long hpairs[MAXLV];
+    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->prof.on) GP_TRY(prof_collect(ctx, hpairs, L));
     *xyz_out = xyz; *n_out = npts;
     if (stats) {
         memset(stats, 0, sizeof *stats);
         stats->num_points = npts; stats->num_bytes = nbytes; stats->num_levels = L; stats->coded_nodes = coded;
-        for (int d = 0; d < L; ++d) stats->level_nodes[d] = lvl_n[d];
+        int64_t cp = 0;
+        for (int d = 0; d < L; ++d) {
+            stats->level_nodes[d] = lvl_n[d];
+            cp += (int64_t)hpairs[d] * ((d + 1 < L ? 5 : 0) + (d > 0 ? 13 : 0));
+        }
+        stats->conv_pairs = cp;
     }
     return GPCC_OK;
 }

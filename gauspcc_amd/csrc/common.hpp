@@ -93,8 +93,22 @@ template <typename T> struct HostBuf {
 
 }  // namespace gpcc
 
+namespace gpcc {
+// HIP-event timing of the dominant kernel (k_sparse_conv), on the stream it is launched on.
+struct ConvRec { int e0, e1, level, njobs; };
+struct Prof {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    int used = 0;
+    std::vector<ConvRec> recs;
+    double conv_ms = 0.0;
+    int64_t conv_launches = 0, conv_pair_jobs = 0;
+};
+}  // namespace gpcc
+
 struct gpcc_ctx {
     int device = 0;
+    gpcc::Prof prof;
     gpcc::Arena arena;              // device workspace
     gpcc::HostBuf<uint8_t> hbytes;  // pinned output / staging bytes
     gpcc::HostBuf<uint8_t> hstage;  // pinned small staging (counts, flags, descriptors)

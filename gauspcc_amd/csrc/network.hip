@@ -74,13 +74,45 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void k_sparse_conv(ConvBatch jobs,
     }
 }
 
-int sparse_conv(hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu)
+static int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
+{
+    Prof &p = ctx->prof;
+    if (p.used == (int)p.pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        p.pool.push_back(e);
+    }
+    *idx = p.used++;
+    HIP_TRY(hipEventRecord(p.pool[(size_t)*idx], st));
+    return GPCC_OK;
+}
+
+int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu)
 {
     if (n <= 0) return GPCC_OK;
     if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
+    const bool prof = ctx && ctx->prof.on;
+    ConvRec rec = {0, 0, level, njobs};
+    if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
     dim3 grid((unsigned)cdiv(n, 32 * CONV_WAVES), (unsigned)njobs);
     k_sparse_conv<<<grid, 64 * CONV_WAVES, 0, st>>>(jobs, nbrT, (int)n, K, relu);
     LAUNCH_CHECK();
+    if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+    return GPCC_OK;
+}
+
+int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
+{
+    Prof &p = ctx->prof;
+    for (const ConvRec &r : p.recs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
+        p.conv_ms += ms;
+        p.conv_launches += 1;
+        if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs;
+    }
+    p.recs.clear();
+    p.used = 0;
     return GPCC_OK;
 }
 

@@ -34,7 +34,10 @@ struct ConvJob {
 struct ConvBatch { ConvJob job[4]; };
 
 // out = conv(in) (+res) (relu); up to 4 independent jobs on the same neighbour map in one launch
-int sparse_conv(hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu);
+// ctx/level: when ctx->prof.on the launch is bracketed by HIP events tagged with `level` (bench.py roofline)
+int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu);
+// fold the recorded events into ctx->prof (call after the stream is synchronised); pairs[level] = present neighbours
+int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs_per_level, int nlevels);
 
 // F[i] = Emb256[occ[i]]                                    (pcc_utils.py:99)
 int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out);

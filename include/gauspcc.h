@@ -97,6 +97,17 @@ GPCC_API int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *byte
                 const int32_t **xyz_dev_out, int64_t *n_out, uint16_t *posq_f16_out,
                 gpcc_stats *stats, void *stream);
 
+/* Live timing of the dominant kernel (the sparse convolution): while enabled, every launch is
+ * bracketed by HIP events on the stream it runs on.  conv_pair_jobs = sum over launches of
+ * (output node, present neighbour) pairs x jobs in the launch; algorithmic flops = 2*C*C*conv_pair_jobs. */
+typedef struct {
+    double conv_ms;
+    int64_t conv_launches;
+    int64_t conv_pair_jobs;
+} gpcc_profile;
+GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* also resets the accumulators */
+GPCC_API int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out);
+
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */
 GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);

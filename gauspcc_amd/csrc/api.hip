@@ -94,15 +94,11 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
         while (h.size() % 64) h.push_back(0.0f);
     };
     push_rows_phys(t[GPCC_T_PRIOR_EMB], 256);
-    for (int ci = 0; ci < 18; ++ci) {  // (K, C, C) -> per offset the B fragments of 16 MFMAs: [lane][kk] = W[o][2kk + lane/32][lane%32]
+    for (int ci = 0; ci < 18; ++ci) {  // (K, C, C) -> MFMA B fragments per offset
         off.push_back(h.size());
         size_t b = h.size();
         h.resize(b + (size_t)K * C * C);
-        const float *W = t[GPCC_T_CONV0 + ci];
-        for (int o = 0; o < K; ++o)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int kk = 0; kk < 16; ++kk)
-                    h[b + ((size_t)o * 64 + lane) * 16 + kk] = W[((size_t)o * C + (2 * kk + (lane >> 5))) * C + (lane & 31)];
+        conv_weight_fragments(t[GPCC_T_CONV0 + ci], K, h.data() + b);
     }
     push_rows_phys(t[GPCC_T_TEMB], 8);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW1 + s], (size_t)C * C);
@@ -351,7 +347,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int K = kernel_size * kernel_size * kernel_size;
-    size_t want = (size_t)n * (size_t)(2 * K * 4 + 1200) + ((size_t)32 << 20);
+    size_t want = (size_t)n * (size_t)(2 * K * 4 + K * 81 / 16 + 1300) + ((size_t)32 << 20);
     for (int attempt = 0;; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         ctx->arena.reset();
@@ -373,12 +369,12 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             for (int d = 0; d + 1 < T.L; ++d) { GP_TRY(nbr_child(ctx, st, &T.lv[d], p, &T.lv[d + 1], kernel_size, c)); std::swap(p, c); }
             TAKE(pairs, unsigned long long, 1);
             HIP_TRY(hipMemsetAsync(pairs, 0, 8, st));
-            GP_TRY(nbr_count(ctx, st, p, (int64_t)K * n, pairs));
+            ConvTiles tiles;
+            GP_TRY(conv_tiles_alloc(ctx, n, K, &tiles));
+            GP_TRY(conv_tiles_build(ctx, st, p, n, K, &tiles, pairs));
             // weights -> B-fragment order
             std::vector<float> wf((size_t)K * 1024);
-            for (int o = 0; o < K; ++o)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int kk = 0; kk < 16; ++kk) wf[((size_t)o * 64 + lane) * 16 + kk] = w_host[((size_t)o * 32 + (2 * kk + (lane >> 5))) * 32 + (lane & 31)];
+            conv_weight_fragments(w_host, K, wf.data());
             TAKE(dw, float, (size_t)K * 1024); TAKE(xin, float, n * 32); TAKE(xres, float, n * 32); TAKE(xout, float, n * 32);
             HIP_TRY(hipMemcpyAsync(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -387,7 +383,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             LAUNCH_CHECK();
             ConvBatch cb = {};
             cb.job[0] = ConvJob{xin, dw, res_dev ? xres : nullptr, xout};
-            GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, p, n, K, relu));
+            GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, tiles, n, relu));
             k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
             LAUNCH_CHECK();
             unsigned long long hpairs = 0;

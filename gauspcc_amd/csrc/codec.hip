@@ -25,12 +25,12 @@ namespace {
 struct Trunk { float *x, *a, *b; };
 
 // Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; kit/nn.py:18-22).  Result in t.a.
-int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const int32_t *nbrT, int64_t n)
+int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const ConvTiles &tiles, int64_t n)
 {
     ConvBatch cb = {};
     auto one = [&](const float *in, int ci, const float *res, float *out) {
         cb.job[0] = ConvJob{in, m->conv[ci], res, out};
-        return sparse_conv(ctx, level, st, cb, 1, nbrT, n, m->K, 1);
+        return sparse_conv(ctx, level, st, cb, 1, tiles, n, 1);
     };
     GP_TRY(one(t.x, conv0, nullptr, t.a));
     GP_TRY(one(t.a, conv0 + 1, nullptr, t.b));
@@ -43,7 +43,8 @@ int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int
 inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 inline uint32_t get32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-size_t arena_estimate(int64_t n, int K) { return (size_t)n * (size_t)(2 * K * 4 + 2400) + ((size_t)48 << 20); }
+// two dense neighbour maps + two tile lists (K*81/16 bytes per node worst case) + features / symbols
+size_t arena_estimate(int64_t n, int K) { return (size_t)n * (size_t)(2 * K * 4 + 2 * (K * 81 / 16 + 8) + 2400) + ((size_t)48 << 20); }
 
 int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t n, int chunk_log2, uint16_t posq,
                 const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, hipStream_t st)
@@ -62,21 +63,25 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     TAKE(pairs_dev, unsigned long long, MAXLV);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
     int32_t *nbrP = nbrA, *nbrC = nbrB;
+    ConvTiles tilesA, tilesB;
+    GP_TRY(conv_tiles_alloc(ctx, nmax, K, &tilesA));
+    GP_TRY(conv_tiles_alloc(ctx, nmax, K, &tilesB));
+    ConvTiles *tilesP = &tilesA, *tilesC = &tilesB;
     GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, nbrP));
-    GP_TRY(nbr_count(ctx, st, nbrP, (int64_t)K * T.lv[0].n, pairs_dev));
+    GP_TRY(conv_tiles_build(ctx, st, nbrP, T.lv[0].n, K, tilesP, pairs_dev));
     int64_t prefix = 0;
     for (int d = 0; d + 1 < L; ++d) {
         const Level *par = &T.lv[d], *chi = &T.lv[d + 1];
         const int64_t np = par->n, nc = chi->n;
         GP_TRY(nbr_child(ctx, st, par, nbrP, chi, m->k, nbrC));
-        GP_TRY(nbr_count(ctx, st, nbrC, (int64_t)K * nc, pairs_dev + d + 1));
+        GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, tilesC, pairs_dev + d + 1));
         const size_t mk = ctx->arena.mark();
         TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
         GP_TRY(embed_occ(st, m->prior_emb, par->occ, np, pF));
-        GP_TRY(run_trunk(ctx, d, st, m, 0, Trunk{pF, pA, pB}, nbrP, np));              // -> pA
+        GP_TRY(run_trunk(ctx, d, st, m, 0, Trunk{pF, pA, pB}, *tilesP, np));           // -> pA
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32);
         GP_TRY(child_features(st, pA, chi->parent, chi->rkey, m->temb, nc, cX));
-        GP_TRY(run_trunk(ctx, d + 1, st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));          // -> cA  (X of pcc_utils.py:109)
+        GP_TRY(run_trunk(ctx, d + 1, st, m, 5, Trunk{cX, cA, cB}, *tilesC, nc));       // -> cA  (X of pcc_utils.py:109)
         // stages: cX, cB are free now; inputs u[s], mid v[s], outputs back into u[s]
         TAKE(u1, float, nc * 32); TAKE(u2, float, nc * 32); TAKE(u3, float, nc * 32);
         TAKE(v1, float, nc * 32); TAKE(v2, float, nc * 32);
@@ -85,11 +90,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], chi->occ, s, nc, u[s]));
         ConvBatch cb = {};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
-        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, nbrC, nc, K, 1));
+        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, *tilesC, nc, 1));
         TAKE(y0, float, nc * 32);
         float *y[4] = {y0, u1, u2, u3};   // u[0] = cA must survive only until conv a is done; still use a fresh buffer for clarity
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
-        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, nbrC, nc, K, 0));
+        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, *tilesC, nc, 0));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};
             ha.x = y[s]; ha.n = nc; ha.stage_m = STAGE_M[s];
@@ -100,6 +105,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         ctx->arena.rewind(mk);
         prefix += nc;
         std::swap(nbrP, nbrC);
+        std::swap(tilesP, tilesC);
     }
     // ---- range coder over every chunk of every stream
     const int nstreams = 4 * (L - 1);
@@ -310,7 +316,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     }
     TAKE(pairs_dev, unsigned long long, MAXLV);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
-    GP_TRY(nbr_count(ctx, st, nbrP, (int64_t)K * bn, pairs_dev));
+    ConvTiles tilesP;
+    GP_TRY(conv_tiles_alloc(ctx, bn, K, &tilesP));
+    GP_TRY(conv_tiles_build(ctx, st, nbrP, bn, K, &tilesP, pairs_dev));
     int64_t coded = 0;
     std::vector<RcChunk> chunks;
     // Arena discipline: level g allocates [child arrays | child neighbour map | chunk table] (kept: they are
@@ -334,7 +342,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         GP_TRY(level_raster_rank(ctx, st, &chi, hb + g + 1));
         TAKE(nbrC, int32_t, (int64_t)K * nc);
         GP_TRY(nbr_child(ctx, st, &cur, nbrP, &chi, m->k, nbrC));
-        GP_TRY(nbr_count(ctx, st, nbrC, (int64_t)K * nc, pairs_dev + g + 1));
+        ConvTiles tilesC;
+        GP_TRY(conv_tiles_alloc(ctx, nc, K, &tilesC));
+        GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
         // chunk descriptors of this level's four streams
         const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
         const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
@@ -365,10 +375,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const int64_t np = cur.n;
         TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
         GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
-        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, nbrP, np));
+        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
-        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, nbrC, nc));  // -> cA
+        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
         TAKE(cdf, uint16_t, nc * 17);
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
@@ -377,9 +387,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
-            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, nbrC, nc, K, 1));
+            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 1));
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
-            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, nbrC, nc, K, 0));
+            GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
@@ -390,7 +400,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ));
         ctx->arena.rewind(mk);
         coded += nc;
-        cur = chi; nbrP = nbrC;
+        cur = chi; nbrP = nbrC; tilesP = tilesC;
     }
     // ---- leaves
     GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
@@ -455,7 +465,7 @@ extern "C" int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *by
         int64_t nodes = 0, nmax = 0;
         for (int d = 0; d < L; ++d) { const int64_t v = get32(bytes + 8 + 4 * d); nodes += v; nmax = std::max(nmax, v); }
         const int64_t npts = get32(bytes + 8 + 4 * L);
-        want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * m->K + 64) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
+        want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * m->K + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
     }
     int rc = GPCC_OK;
     for (int attempt = 0; attempt < 6; ++attempt) {

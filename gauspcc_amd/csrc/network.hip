@@ -1,75 +1,247 @@
 // network.hip -- GausPcgc context network kernels for gfx950.
 //
-// k_sparse_conv   submanifold 3-D convolution, C = 32, exact fp32 on v_mfma_f32_32x32x2_f32.
-//                 One wave owns 32 output nodes x 32 output channels (16 accumulator VGPRs) and
-//                 walks the k^3 offsets in ascending order; an offset whose 32 neighbour slots are
-//                 all empty is skipped by a wave ballot.  Per offset: 4 x 16-byte gathers of the
-//                 neighbour row half (A operand, contiguous thanks to the physical channel order),
-//                 4 x 16-byte loads of the pre-swizzled weight fragment (B operand), 16 MFMAs.
-//                 The accumulation order per output element is the oracle's: offsets ascending,
-//                 k = 0..31, one fma per term (MFMA f32 == fmaf chain), so results are bit-exact.
-//                 Bound: fp32 MFMA (2*32*32 flop per (node, neighbour) pair).
+// k_sparse_conv   submanifold 3-D convolution, C = 32, exact fp32 on v_mfma_f32_16x16x4_f32.
+//                 A submanifold conv on an octree level is ~90 % empty (7..25 of the 125 taps exist),
+//                 so the work is the list of (output row, neighbour row) PAIRS, not rows x offsets.
+//                 Each wave owns 128 consecutive Morton-ordered output rows (spatially compact) and
+//                 keeps their 128 x 32 fp32 accumulators in wave-private LDS (16 KiB).  Per kernel
+//                 offset the block's pairs were compacted (k_conv_tiles, once per level) into tiles
+//                 of 16 rows; per tile the wave gathers the 16 neighbour rows (A operand: one
+//                 contiguous 32-byte load per lane thanks to the physical channel order), loads the
+//                 pre-swizzled 4 KiB weight fragment of the offset (B operand), pulls the 16 x 32
+//                 partial sums out of LDS into the MFMA C registers, issues 16 MFMAs and puts the
+//                 result back.  Offsets are visited in ascending order and every output element is
+//                 one fma chain over (offset, k) -- exactly the oracle's order, so results are
+//                 bit-exact no matter how rows are packed into tiles.
+//                 Bound: fp32 MFMA (2*32*32 flop per pair); gathers come from L2/MALL.
 // k_head          Linear-ReLU-Linear-softmax-cumsum-integerise, one node per lane, weights through
 //                 the scalar cache.  Negligible next to the convolutions.
 #include "network.hpp"
 #include "octree.hpp"
+#include "primitives.hpp"
 
 namespace gpcc {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CONV_WAVES = 4;
 
-__global__ __launch_bounds__(64 * CONV_WAVES) void k_sparse_conv(ConvBatch jobs, const int32_t *__restrict__ nbrT, int n, int K, int relu)
+// ------------------------------------------------------------------ tile list
+template <int R, bool FILL>
+__global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *__restrict__ nbrT, int n, int K, int nblk, uint32_t *__restrict__ per_block,
+                                                                int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc,
+                                                                unsigned long long *__restrict__ pairs)
 {
-    const ConvJob J = jobs.job[blockIdx.y];
+    constexpr int Q = (R + 63) / 64;  // rows per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row0 = (blockIdx.x * CONV_WAVES + wave) * 32;
-    if (row0 >= n) return;
-    const int r = lane & 31, h = lane >> 5;
-    const int node = row0 + r;
-    const bool inb = node < n;
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const float4 *__restrict__ wf = reinterpret_cast<const float4 *>(J.w) + (size_t)lane * 4;
+    const int blk = blockIdx.x * CONV_WAVES + wave;
+    if (blk >= nblk) return;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    uint32_t t = FILL ? per_block[blk] : 0u, npairs = 0;
     for (int o = 0; o < K; ++o) {
-        const int j = inb ? nbrT[(size_t)o * n + node] : -1;
-        if (__ballot(j >= 0) == 0ull) continue;
-        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-        if (j >= 0) {
-            const float4 *__restrict__ p = reinterpret_cast<const float4 *>(J.in + (size_t)j * 32 + 16 * h);
-            a0 = p[0]; a1 = p[1]; a2 = p[2]; a3 = p[3];
-        }
-        const float4 *__restrict__ w = wf + (size_t)o * 256;
-        const float4 b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.z, b2.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.w, b2.w, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.x, b3.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.y, b3.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.z, b3.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3.w, b3.w, acc, 0, 0, 0);
-    }
-    // D layout: lane holds output channel c = lane & 31 for rows (i&3) + 8*(i>>2) + 4*h
-    const int pc = phys_of(r);
+        int j[Q];
+        uint64_t b[Q];
+        uint32_t cnt = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int row = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (row < n) {
-            float v = acc[i];
-            if (J.res) v = v + J.res[(size_t)row * 32 + pc];
-            if (relu) v = v > 0.0f ? v : 0.0f;
-            J.out[(size_t)row * 32 + pc] = v;
+        for (int q = 0; q < Q; ++q) {
+            const int lr = q * 64 + lane, row = blk * R + lr;
+            j[q] = (lr < R && row < n) ? nbrT[(size_t)o * n + row] : -1;
+            b[q] = __ballot(j[q] >= 0);
+            cnt += (uint32_t)__popcll(b[q]);
+        }
+        if (cnt == 0) continue;
+        const uint32_t nt = (cnt + 15u) >> 4;
+        if (FILL) {
+            uint32_t base = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                if (j[q] >= 0) {
+                    const uint32_t p = base + (uint32_t)__popcll(b[q] & lt);
+                    tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = j[q];
+                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane);
+                }
+                base += (uint32_t)__popcll(b[q]);
+            }
+            if ((uint32_t)lane < nt * 16u - cnt) {
+                const uint32_t p = cnt + (uint32_t)lane;
+                tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;
+                tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)R;
+            }
+            if ((uint32_t)lane < nt) toc[t + lane] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)lane) << 16);
+        }
+        t += nt;
+        npairs += cnt;
+    }
+    if (!FILL && lane == 0) {
+        per_block[blk] = t;
+        if (pairs && npairs) atomicAdd(pairs, (unsigned long long)npairs);
+    }
+}
+
+int conv_pick_rows(int64_t n)
+{
+    static int forced = -1;
+    if (forced < 0) {
+        const char *e = getenv("GAUSPCC_CONV_R");
+        forced = e ? atoi(e) : 0;
+        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 128) forced = 0;
+    }
+    if (forced) return forced;
+    // enough waves to cover the chip a few times over before growing the block height
+    if (n >= 768 * 1024) return 128;
+    if (n >= 128 * 1024) return 64;
+    if (n >= 24 * 1024) return 32;
+    return 16;
+}
+
+int conv_tiles_alloc(gpcc_ctx *ctx, int64_t n_cap, int K, ConvTiles *T)
+{
+    const int64_t cap = conv_tiles_capacity(n_cap, K);
+    TAKE(first, uint32_t, conv_blocks_capacity(n_cap) + 1);
+    TAKE(tj, int32_t, cap * 16);
+    TAKE(tr, uint8_t, cap * 16);
+    TAKE(toc, uint32_t, cap);
+    T->first = first; T->tj = tj; T->tr = tr; T->toc = toc; T->nblk = 0;
+    return GPCC_OK;
+}
+
+template <int R>
+static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
+{
+    const int64_t nblk = cdiv(n, R);
+    T->nblk = nblk; T->R = R;
+    const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
+    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, T->first, nullptr, nullptr, nullptr, pairs_dev);
+    LAUNCH_CHECK();
+    GP_TRY(exclusive_scan_u32(ctx, st, T->first, T->first, nblk, T->first + nblk));
+    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, T->first, T->tj, T->tr, T->toc, nullptr);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
+{
+    if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
+    switch (conv_pick_rows(n)) {
+    case 16: return conv_tiles_build_r<16>(ctx, st, nbrT, n, K, T, pairs_dev);
+    case 32: return conv_tiles_build_r<32>(ctx, st, nbrT, n, K, T, pairs_dev);
+    case 64: return conv_tiles_build_r<64>(ctx, st, nbrT, n, K, T, pairs_dev);
+    default: return conv_tiles_build_r<128>(ctx, st, nbrT, n, K, T, pairs_dev);
+    }
+}
+
+// ------------------------------------------------------------------ convolution
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+
+template <int R>
+__global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
+{
+    constexpr int CONV_LDS_WAVE = (R + 1) * 32;  // floats: R rows + 1 dummy row for padding entries
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const ConvJob J = jobs.job[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    // everything derived from the wave index is wave-uniform: keep it in SGPRs (scalar loads for the tile
+    // headers, scalar address arithmetic for the weight fragments)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = blockIdx.x * CONV_WAVES + wave;
+    if (blk >= (int)T.nblk) return;  // no block-wide barrier below: every wave works on its own LDS slice
+    float *acc = lds + wave * CONV_LDS_WAVE;
+    float4 *acc4 = reinterpret_cast<float4 *>(acc);
+#pragma unroll
+    for (int it = 0; it < (R * 8 + 63) / 64; ++it)
+        if (it * 64 + lane < R * 8) acc4[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int e = lane & 15, g = lane >> 4;
+    // column of this lane inside an accumulator row (physical order) for output halves 0 / 1
+    const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
+    const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
+    const float *__restrict__ in = J.in + 4 * g;
+    const float *__restrict__ wf = J.w + lane * 4;
+    const int32_t *__restrict__ tje = T.tj + e;
+    const uint32_t *__restrict__ tr4 = reinterpret_cast<const uint32_t *>(T.tr) + g;
+    const uint32_t *__restrict__ toc = T.toc;
+    struct AB { float4 a0, a1, b00, b01, b10, b11; };
+    auto load_ab = [&](int j, uint32_t o) -> AB {
+        const float *p = in + (size_t)(uint32_t)j * 32;
+        const float *w = wf + (size_t)o * 1024;
+        AB r;
+        r.a0 = ld4(p); r.a1 = ld4(p + 16);
+        r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
+        return r;
+    };
+    auto compute = [&](const AB &v, uint32_t r4) {
+        f32x4 c0, c1;
+        int row[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            row[k] = (int)((r4 >> (8 * k)) & 255u) * 32;
+            c0[k] = acc[row[k] + col0];
+            c1[k] = acc[row[k] + col1];
+        }
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b00.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b10.x, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.y, v.b00.y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.y, v.b10.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.z, v.b00.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.z, v.b10.z, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.w, v.b00.w, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.w, v.b10.w, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.x, v.b01.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.x, v.b11.x, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.y, v.b01.y, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.y, v.b11.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.z, v.b01.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.z, v.b11.z, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b01.w, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b11.w, c1, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { acc[row[k] + col0] = c0[k]; acc[row[k] + col1] = c1[k]; }
+    };
+    if (t0 < t1) {
+        // Software pipeline inside one instruction stream, two tiles per iteration with ping-pong register
+        // sets X / Y: while tile t computes out of X the loads of tile t+1 land in Y and vice versa -- no
+        // register rotation, so nothing forces a load to complete inside the iteration that issued it.  The
+        // loop body is branch-free up to the odd tail (indices clamped to the last tile, padding entries
+        // gather row 0 and accumulate into the dummy LDS row) so that the compiler can count outstanding
+        // loads instead of draining them with s_waitcnt vmcnt(0).
+        const uint32_t tl = t1 - 1;
+        uint32_t tn = min(t0 + 1, tl);
+        uint32_t r4_cur = tr4[t0 * 4];
+        AB X = load_ab(tje[t0 * 16], toc[t0] & 0xFFFFu), Y;
+        int j1 = tje[tn * 16];
+        uint32_t r4_1 = tr4[tn * 4], o1 = toc[tn] & 0xFFFFu;
+        for (uint32_t t = t0; t < t1; t += 2) {
+            tn = min(t + 2, tl);
+            const int j2 = tje[tn * 16];
+            const uint32_t r4_2 = tr4[tn * 4], o2 = toc[tn] & 0xFFFFu;
+            Y = load_ab(j1, o1);
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's LDS reads + MFMAs (hipcc sinks it otherwise)
+            compute(X, r4_cur);
+            __builtin_amdgcn_sched_barrier(0);
+            tn = min(t + 3, tl);
+            j1 = tje[tn * 16];
+            r4_cur = r4_1;  // tile t+1's rows, consumed below
+            const uint32_t r4_3 = tr4[tn * 4], o3 = toc[tn] & 0xFFFFu;
+            X = load_ab(j2, o2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < t1) compute(Y, r4_cur);
+            __builtin_amdgcn_sched_barrier(0);
+            r4_cur = r4_2; r4_1 = r4_3; o1 = o3;
+        }
+    }
+    // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
+    const int row0 = blk * R;
+    const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res);
+    float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out);
+#pragma unroll 4
+    for (int it = 0; it < (R * 8 + 63) / 64; ++it) {
+        const int idx = it * 64 + lane;
+        const int grow = row0 + (idx >> 3);
+        if (idx < R * 8 && grow < n) {
+            float4 v = acc4[idx];
+            const size_t gi = (size_t)grow * 8 + (idx & 7);
+            if (res4) { const float4 r = res4[gi]; v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
+            if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+            out4[gi] = v;
         }
     }
 }
@@ -87,15 +259,26 @@ static int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
     return GPCC_OK;
 }
 
-int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu)
+int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const ConvTiles &T, int64_t n, int relu)
 {
     if (n <= 0) return GPCC_OK;
     if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
     const bool prof = ctx && ctx->prof.on;
     ConvRec rec = {0, 0, level, njobs};
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
-    dim3 grid((unsigned)cdiv(n, 32 * CONV_WAVES), (unsigned)njobs);
-    k_sparse_conv<<<grid, 64 * CONV_WAVES, 0, st>>>(jobs, nbrT, (int)n, K, relu);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {  // 128-row blocks need 66048 B of LDS per workgroup (> the 64 KiB default cap)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
+        lds_attr_set = true;
+    }
+    dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
+    const size_t lds_bytes = (size_t)CONV_WAVES * (T.R + 1) * 128;
+    switch (T.R) {
+    case 16: k_sparse_conv<16><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 32: k_sparse_conv<32><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 64: k_sparse_conv<64><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    default: k_sparse_conv<128><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    }
     LAUNCH_CHECK();
     if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
     return GPCC_OK;

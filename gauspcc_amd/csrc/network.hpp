@@ -2,9 +2,12 @@
 // embeddings, submanifold sparse convolution on fp32 MFMA, prediction heads + CDF integerisation.
 //
 // Feature rows are (n, 32) fp32 in a PHYSICAL channel order chosen so that the MFMA A-operand
-// of v_mfma_f32_32x32x2_f32 is a contiguous 64-byte load per lane: physical position p holds
-// logical channel 2p (p < 16) or 2(p-16)+1 (p >= 16).  The accumulation chain is still the
-// logical order k = 0..31 (see oracle/gpcc_oracle.c "NORMATIVE NUMERICS").
+// of v_mfma_f32_16x16x4_f32 is two 16-byte loads per lane that are contiguous across the four
+// lane groups: lane group g = lane/16 supplies k = 4*kk + g for the 8 k-steps kk; physical position
+// 4*g + kk (kk < 4) or 16 + 4*g + (kk - 4) holds logical channel 4*kk + g, so the four lanes that
+// gather one row read its first 64 bytes with the first load and the second 64 with the second.
+// The accumulation chain is still the logical order k = 0..31 (oracle/gpcc_oracle.c
+// "NORMATIVE NUMERICS").
 #pragma once
 #include "common.hpp"
 
@@ -12,7 +15,7 @@ struct gpcc_model {
     int C = 32, k = 5, K = 125;
     float *slab = nullptr;         // one allocation
     const float *prior_emb = nullptr;   // (256, 32) physical order
-    const float *conv[18] = {0};        // (K, 64 lanes, 16) MFMA B-fragment order
+    const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order
     const float *temb = nullptr;        // (8, 32) physical
     const float *hw1[4] = {0}, *hb1[4] = {0}, *hw2[4] = {0}, *hb2[4] = {0};  // upstream layouts (logical)
     const float *semb[3] = {0};         // ({2,4,16}, 32) physical
@@ -20,8 +23,28 @@ struct gpcc_model {
 
 namespace gpcc {
 
-__host__ __device__ __forceinline__ int phys_of(int c) { return (c >> 1) + 16 * (c & 1); }   // logical -> physical
-__host__ __device__ __forceinline__ int logical_of(int p) { return p < 16 ? 2 * p : 2 * (p - 16) + 1; }
+__host__ __device__ __forceinline__ int phys_of(int c)   // logical -> physical
+{
+    const int kk = c >> 2, g = c & 3;
+    return kk < 4 ? 4 * g + kk : 16 + 4 * g + (kk - 4);
+}
+__host__ __device__ __forceinline__ int logical_of(int p)
+{
+    const int kk = 4 * (p >> 4) + (p & 3), g = (p & 15) >> 2;
+    return 4 * kk + g;
+}
+
+// (K, C, C) upstream kernel -> B fragments, 4 x 1 KiB fully coalesced loads per offset:
+// [o][half][q][lane][r] = W[o][4*(4q + r) + lane/16][16*half + lane%16]     (k-step kk = 4q + r)
+inline void conv_weight_fragments(const float *W, int K, float *out)
+{
+    for (int o = 0; o < K; ++o)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int q = 0; q < 2; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r)
+                        out[((((size_t)o * 2 + hh) * 2 + q) * 64 + lane) * 4 + r] = W[((size_t)o * 32 + (4 * (4 * q + r) + (lane >> 4))) * 32 + 16 * hh + (lane & 15)];
+}
 
 constexpr int STAGE_M[4] = {2, 2, 4, 16};
 
@@ -33,9 +56,32 @@ struct ConvJob {
 };
 struct ConvBatch { ConvJob job[4]; };
 
-// out = conv(in) (+res) (relu); up to 4 independent jobs on the same neighbour map in one launch
+// Compacted work list of one level: every wave owns R consecutive (Morton-ordered) output rows;
+// for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of
+// 16 rows (one v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per level, used by all
+// 5 / 13 convolutions that run on that level.  R (16, 32, 64 or 128) is picked per level: tall blocks
+// pack tiles better, short blocks give more waves and shorter serial chains on small levels.
+constexpr int CONV_R_MAX = 128;
+struct ConvTiles {
+    int32_t *tj = nullptr;     // [tiles][16] neighbour row (padding: 0, a valid row whose result is discarded)
+    uint8_t *tr = nullptr;     // [tiles][16] output row inside the block (padding: R = the dummy row)
+    uint32_t *toc = nullptr;   // [tiles]     offset | valid entries << 16
+    uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
+    int64_t nblk = 0;
+    int R = CONV_R_MAX;
+};
+int conv_pick_rows(int64_t n);  // policy (env GAUSPCC_CONV_R overrides)
+// worst case over every admissible R: every pair alone in its tile, i.e. K tiles per 16 rows
+static inline int64_t conv_tiles_capacity(int64_t n, int K) { return (cdiv(n, 16) + 8) * (int64_t)K; }
+static inline int64_t conv_blocks_capacity(int64_t n) { return cdiv(n, 16) + 1; }
+// allocate from the arena for a level of up to n_cap nodes (worst case: every pair alone in its tile)
+int conv_tiles_alloc(gpcc_ctx *ctx, int64_t n_cap, int K, ConvTiles *T);
+// build from the dense neighbour map; if pairs_dev != nullptr the number of (node, neighbour) pairs is added to it
+int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev);
+
+// out = conv(in) (+res) (relu); up to 4 independent jobs on the same tile list in one launch
 // ctx/level: when ctx->prof.on the launch is bracketed by HIP events tagged with `level` (bench.py roofline)
-int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const int32_t *nbrT, int64_t n, int K, int relu);
+int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const ConvTiles &T, int64_t n, int relu);
 // fold the recorded events into ctx->prof (call after the stream is synchronised); pairs[level] = present neighbours
 int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs_per_level, int nlevels);
 

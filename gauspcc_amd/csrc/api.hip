@@ -274,16 +274,6 @@ __global__ __launch_bounds__(TB) void k_rows_out(const float *__restrict__ in, c
     out[(int64_t)m2r[i] * 32 + c] = in[i * 32 + phys_of(c)];
 }
 
-__global__ __launch_bounds__(TB) void k_pack_lohi(const uint16_t *__restrict__ cdf, int lp, const uint8_t *__restrict__ sym, int64_t n, uint32_t *__restrict__ lohi)
-{
-    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    const int s = sym[i];
-    const uint32_t lo = cdf[i * lp + s];
-    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf[i * lp + s + 1];
-    lohi[i] = lo | ((hi - 1u) << 16);
-}
-
 }  // namespace
 
 extern "C" int gpcc_sort_zyx(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, uint32_t *perm, void *stream)
@@ -429,16 +419,15 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
     const int nch = (int)cdiv(n, S);
     const uint32_t stride = rc_scratch_stride((uint32_t)std::min<int64_t>(S, n));
-    GP_TRY(ctx->arena.reserve((size_t)n * 8 + 2 * (size_t)nch * stride + ((size_t)4 << 20)));
+    GP_TRY(ctx->arena.reserve((size_t)n * 8 + (size_t)nch * S * 4 + 2 * (size_t)nch * stride + ((size_t)4 << 20)));
     ctx->arena.reset();
     std::vector<RcChunk> chunks((size_t)nch);
-    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)(c * S), (uint32_t)std::min<int64_t>(S, n - c * S), 0, 0};
-    TAKE(lohi, uint32_t, n); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
+    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, n - c * S), 0, 0, 0};
+    TAKE(lohi, uint32_t, (int64_t)nch * S); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
     TAKE(scratch, uint8_t, (size_t)nch * stride); TAKE(payload, uint8_t, (size_t)nch * stride);
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    k_pack_lohi<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(cdf_dev, lp, sym_dev, n, lohi);
-    LAUNCH_CHECK();
+    GP_TRY(rc_pack_lohi(st, cdf_dev, lp, sym_dev, n, chunk_log2, lohi));
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
     GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nch, payload));
@@ -465,7 +454,7 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     hipStream_t st = (hipStream_t)stream;
     const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
     const int nch = (int)cdiv(n, S);
-    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + ((size_t)4 << 20)));
+    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + (size_t)nch * S * 32 + ((size_t)4 << 20)));
     ctx->arena.reset();
     std::vector<RcChunk> chunks((size_t)nch);
     if (chunk_log2) {
@@ -474,15 +463,17 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
         for (int c = 0; c < nch; ++c) {
             const uint32_t cb = bytes[2 * c] | bytes[2 * c + 1] << 8;
             if (p + cb > nbytes) return fail(GPCC_ERR_FORMAT, "chunk %d overruns the stream", c);
-            chunks[(size_t)c] = RcChunk{(uint32_t)(c * S), (uint32_t)std::min<int64_t>(S, n - c * S), (uint32_t)p, cb};
+            chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, n - c * S), (uint32_t)(c * S), (uint32_t)p, cb};
             p += cb;
         }
-    } else chunks[0] = RcChunk{0, (uint32_t)n, 0, (uint32_t)nbytes};
+    } else chunks[0] = RcChunk{0, 1, (uint32_t)n, 0, 0, (uint32_t)nbytes};
     TAKE(db, uint8_t, nbytes + 16); TAKE(dch, RcChunk, nch);
+    TAKE(rows, uint16_t, (int64_t)nch * S * rc_row_stride(lp) + 64);
+    GP_TRY(rc_pack_rows(st, cdf_dev, lp, n, chunk_log2, rows));
     HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    GP_TRY(rc_decode_launch(st, cdf_dev, lp, db, dch, nch, sym_dev));
+    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, sym_dev));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
 }

@@ -56,8 +56,13 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     int64_t coded = 0, nmax = 0;
     for (int d = 0; d < L; ++d) { nmax = std::max(nmax, T.lv[d].n); if (d) coded += T.lv[d].n; }
     if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
-    // stream-major packed symbols: stream (d, s), d = 1..L-1 -> offset 4*prefix(d) + s*n_d
-    TAKE(lohi, uint32_t, std::max<int64_t>(4 * coded, 1));
+    // stream-major packed symbols: stream (d, s), d = 1..L-1, occupies slots(d) words (the chunk-interleaved
+    // layout pads the last chunk): offset 4 * sum_{d' < d} slots(d') + s * slots(d)
+    auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? cdiv(nc, (int64_t)1 << chunk_log2) << chunk_log2 : nc; };
+    int64_t lohi_words = 0;
+    for (int d = 1; d < L; ++d) lohi_words += 4 * slots(T.lv[d].n);
+    if (lohi_words >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many octree nodes");
+    TAKE(lohi, uint32_t, std::max<int64_t>(lohi_words, 1));
     TAKE(nbrA, int32_t, (int64_t)K * nmax);
     TAKE(nbrB, int32_t, (int64_t)K * nmax);
     TAKE(pairs_dev, unsigned long long, MAXLV);
@@ -99,11 +104,12 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             HeadArgs ha = {};
             ha.x = y[s]; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
-            ha.m2r = chi->m2r; ha.occ = chi->occ; ha.stage = s; ha.lohi = lohi + 4 * prefix + (int64_t)s * nc; ha.mode = 0;
+            ha.m2r = chi->m2r; ha.occ = chi->occ; ha.stage = s; ha.lohi = lohi + prefix + (int64_t)s * slots(nc); ha.mode = 0;
+            ha.chunk_log2 = chunk_log2; ha.nch = chunk_log2 ? (uint32_t)cdiv(nc, (int64_t)1 << chunk_log2) : 1u;
             GP_TRY(head_cdf(st, ha));
         }
         ctx->arena.rewind(mk);
-        prefix += nc;
+        prefix += 4 * slots(nc);
         std::swap(nbrP, nbrC);
         std::swap(tilesP, tilesC);
     }
@@ -119,15 +125,15 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             const int64_t nc = T.lv[d].n;
             for (int s = 0; s < 4; ++s, ++si) {
                 stream_first[si] = (int)chunks.size();
-                const int64_t base = 4 * pre + (int64_t)s * nc;
-                for (int64_t c0 = 0; c0 < nc; c0 += S) {
-                    const int64_t cn = std::min<int64_t>(S, nc - c0);
-                    chunks.push_back(RcChunk{(uint32_t)(base + c0), (uint32_t)cn, 0, 0});
+                const int64_t base = pre + (int64_t)s * slots(nc);
+                const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(nc, S) : 1u;
+                for (uint32_t c = 0; c < nch; ++c) {
+                    const int64_t cn = chunk_log2 ? std::min<int64_t>(S, nc - (int64_t)c * S) : nc;
+                    chunks.push_back(RcChunk{(uint32_t)(base + c), nch, (uint32_t)cn, 0, 0, 0});
                     max_syms = std::max<uint32_t>(max_syms, (uint32_t)cn);
-                    if (chunk_log2 == 0) break;
                 }
             }
-            pre += nc;
+            pre += 4 * slots(nc);
         }
         stream_first[nstreams] = (int)chunks.size();
     }
@@ -290,7 +296,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         lv->rkey = rkey; lv->occ = occ; lv->cstart = cstart; lv->parent = parent; lv->m2r = m2r; lv->r2m = r2m;
         return GPCC_OK;
     };
-    TAKE(dbytes, uint8_t, nbytes);
+    TAKE(dbytes, uint8_t, nbytes + 16);
     HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, st));
     GP_TRY(ctx->hstage.reserve(4096 + 16 * (size_t)bn));
     Level cur;
@@ -358,12 +364,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
                 for (int c = 0; c < nch; ++c) {
                     const uint32_t cb = in[off + 2 * c] | in[off + 2 * c + 1] << 8;
                     if (p + cb > off + len) return fail(GPCC_ERR_FORMAT, "stream %d chunk %d overruns the stream", si, c);
-                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)((int64_t)c * S), (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)p, cb};
+                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)((int64_t)c * S), (uint32_t)p, cb};
                     p += cb;
                 }
                 if (p != off + len) return fail(GPCC_ERR_FORMAT, "stream %d has trailing bytes", si);
             } else {
-                chunks[(size_t)s] = RcChunk{0, (uint32_t)nc, (uint32_t)off, (uint32_t)len};
+                chunks[(size_t)s] = RcChunk{0, 1, (uint32_t)nc, 0, (uint32_t)off, (uint32_t)len};
             }
         }
         TAKE(dchunks, RcChunk, 4 * nch);
@@ -379,7 +385,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        TAKE(cdf, uint16_t, nc * 17);
+        TAKE(cdf, uint16_t, ((int64_t)nch << (chunk_log2 ? chunk_log2 : 0)) * 16 + nc * 16);  // interleaved rows: nch * S slots (nc when unchunked)
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
         for (int s = 0; s < 4; ++s) {
@@ -393,7 +399,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
-            ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1;
+            ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = chunk_log2; ha.nch = (uint32_t)nch;
             GP_TRY(head_cdf(st, ha));
             GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
         }

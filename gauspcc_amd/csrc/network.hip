@@ -19,6 +19,7 @@
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
+#include "rangecoder.hpp"
 
 namespace gpcc {
 
@@ -493,11 +494,22 @@ __global__ __launch_bounds__(TB) void k_head(HeadArgs a)
 #pragma unroll
         for (int j = 0; j < M; ++j)
             if (j == sym) { lo = v[j]; hi = j == M - 1 ? 0x10000u : v[j + 1]; }
-        a.lohi[a.m2r[i]] = lo | ((hi - 1u) << 16);
+        a.lohi[rc_interleaved(a.m2r[i], a.chunk_log2, a.nch)] = lo | ((hi - 1u) << 16);
+    } else if (MODE == 1) {
+        constexpr int RS = M == 2 ? 1 : M == 4 ? 4 : 16;
+        uint16_t *dst = a.cdf + (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch) * RS;
+        if (M == 2) dst[0] = (uint16_t)v[1];
+        else if (M == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(v[1] | (v[2] << 16), v[3]);
+        else {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = v[2 * k + 1] | ((2 * k + 2 < M ? v[2 * k + 2] : 0u) << 16);
+            reinterpret_cast<uint4 *>(dst)[0] = make_uint4(w[0], w[1], w[2], w[3]);
+            reinterpret_cast<uint4 *>(dst)[1] = make_uint4(w[4], w[5], w[6], w[7]);
+        }
     } else {
-        const size_t row = MODE == 1 ? (size_t)a.m2r[i] : (size_t)i;
         if (a.cdf) {
-            uint16_t *dst = a.cdf + row * (M + 1);
+            uint16_t *dst = a.cdf + (size_t)i * (M + 1);
 #pragma unroll
             for (int j = 0; j <= M; ++j) dst[j] = (uint16_t)v[j];
         }

@@ -94,14 +94,16 @@ int stage_input_gt(hipStream_t st, const float *X, const float *emb, const uint8
 // ... or from the symbols decoded so far (raster order, looked up through m2r)
 int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out);
 
-// Heads.  mode 0: encode -> lohi[m2r[i]] = c_low | (c_high-1) << 16 for the ground-truth symbol of `stage`
-//         mode 1: decode -> cdf rows (Lp u16) at raster position m2r[i]
+// Heads.  mode 0: encode -> lohi[pos] = c_low | (c_high-1) << 16 for the ground-truth symbol of `stage`
+//         mode 1: decode -> compact cdf row (interior values only, rc_row_stride u16) at row pos
 //         mode 2: test   -> prob (n,m) and cdf (n,Lp) in input order, x in LOGICAL channel order
+// pos = rc_interleaved(m2r[i], chunk_log2, nch): raster rank -> chunk-interleaved slot of the stream
 struct HeadArgs {
     const float *x; int64_t n; int stage_m;
     const float *w1, *b1, *w2, *b2;
     const uint32_t *m2r; const uint8_t *occ; int stage;
     uint32_t *lohi; uint16_t *cdf; float *prob; int mode;
+    int chunk_log2; uint32_t nch;
 };
 int head_cdf(hipStream_t st, const HeadArgs &a);
 

@@ -4,17 +4,34 @@
 
 namespace gpcc {
 
+// One chunk = one lane.  Element t of the chunk (packed symbol word on encode, compact CDF row on
+// decode) lives at index first + t * stride: chunks of one stream are interleaved so that the 64
+// lanes of a wave touch consecutive addresses.
 struct RcChunk {
-    uint32_t start;     // first symbol (index into the stream-major symbol / lohi / cdf-row arrays)
+    uint32_t first;     // index of element 0
+    uint32_t stride;    // elements between consecutive symbols of this chunk (= chunks in the stream)
     uint32_t n;         // symbols in the chunk
+    uint32_t out;       // decode: index of the chunk's first symbol in the (raster-ordered) output
     uint32_t byte_off;  // decode: offset of the chunk's bytes in the uploaded file
     uint32_t nbytes;    // decode: byte count
 };
 
-static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 16u + 15u) & ~15u; }
+// compact CDF row: only the interior values v[1..Lp-2] are stored (v[0] = 0, v[Lp-1] is never read)
+static inline int rc_row_stride(int lp) { return lp == 3 ? 1 : lp == 5 ? 4 : 16; }  // uint16 units
+// position of raster rank r inside a stream cut into 2^chunk_log2-symbol chunks (chunk_log2 = 0: one chunk)
+__host__ __device__ __forceinline__ uint32_t rc_interleaved(uint32_t r, int chunk_log2, uint32_t nch)
+{
+    return chunk_log2 ? (r & ((1u << chunk_log2) - 1u)) * nch + (r >> chunk_log2) : r;
+}
+
+static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);
 int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, int nchunks, uint8_t *payload);
+// cdf: compact interleaved rows (rc_row_stride uint16 per row)
 int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym);
+// full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words
+int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int chunk_log2, uint16_t *rows);
+int rc_pack_lohi(hipStream_t st, const uint16_t *cdf_full, int lp, const uint8_t *sym, int64_t n, int chunk_log2, uint32_t *lohi);
 
 }  // namespace gpcc

@@ -85,7 +85,7 @@ int conv_pick_rows(int64_t n)
     if (forced < 0) {
         const char *e = getenv("GAUSPCC_CONV_R");
         forced = e ? atoi(e) : 0;
-        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 128 && forced != 255) forced = 0;
+        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 128) forced = 0;
     }
     if (forced) return forced;
     // enough waves to cover the chip a few times over before growing the block height
@@ -127,7 +127,6 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
     case 16: return conv_tiles_build_r<16>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 32: return conv_tiles_build_r<32>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 64: return conv_tiles_build_r<64>(ctx, st, nbrT, n, K, T, pairs_dev);
-    case 255: return conv_tiles_build_r<255>(ctx, st, nbrT, n, K, T, pairs_dev);
     default: return conv_tiles_build_r<128>(ctx, st, nbrT, n, K, T, pairs_dev);
     }
 }
@@ -136,7 +135,7 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 template <int R>
-__global__ __launch_bounds__(64 * CONV_WAVES, (R > 128 ? 1 : R == 128 ? 2 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
+__global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
 {
     constexpr int CONV_LDS_WAVE = (R + 1) * 32;  // floats: R rows + 1 dummy row for padding entries
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -168,17 +167,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R > 128 ? 1 : R == 128 ? 2 : 4)) 
         AB r;
         r.a0 = ld4(p); r.a1 = ld4(p + 16);
         r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
-        return r;
-    };
-    // same, but the previous tile's weight fragment is kept when the offset did not change (wave-uniform)
-    auto load_ab_reuse = [&](int j, uint32_t o, uint32_t o_prev, const AB &prev) -> AB {
-        const float *p = in + (size_t)(uint32_t)j * 32;
-        AB r;
-        r.a0 = ld4(p); r.a1 = ld4(p + 16);
-        if (o != o_prev) {
-            const float *w = wf + (size_t)o * 1024;
-            r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
-        } else { r.b00 = prev.b00; r.b01 = prev.b01; r.b10 = prev.b10; r.b11 = prev.b11; }
         return r;
     };
     auto compute = [&](const AB &v, uint32_t r4) {
@@ -282,7 +270,6 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 128-row blocks need 66048 B of LDS per workgroup (> the 64 KiB default cap)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 256 * 128));
         lds_attr_set = true;
     }
     dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
@@ -291,7 +278,6 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 16: k_sparse_conv<16><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
     case 32: k_sparse_conv<32><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
     case 64: k_sparse_conv<64><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 255: k_sparse_conv<255><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
     default: k_sparse_conv<128><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
     }
     LAUNCH_CHECK();

@@ -59,11 +59,10 @@ struct ConvBatch { ConvJob job[4]; };
 // Compacted work list of one level: every wave owns R consecutive (Morton-ordered) output rows;
 // for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of
 // 16 rows (one v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per level, used by all
-// 5 / 13 convolutions that run on that level.  R (16, 32, 64, 128 or 255) is picked per level: tall
-// blocks pack tiles better and reuse the weight fragment across the tiles of one offset, short blocks
-// give more waves and shorter serial chains on small levels.  (255, not 256: row indices are bytes and
-// one value is the dummy row.)
-constexpr int CONV_R_MAX = 255;
+// 5 / 13 convolutions that run on that level.  R (16, 32, 64 or 128) is picked per level: tall blocks
+// pack tiles better, short blocks give more waves and shorter serial chains on small levels.
+// (Measured on MI355X, 1M-point cloud: 255-row blocks at 1 wave/SIMD lose to 128-row blocks at 2.)
+constexpr int CONV_R_MAX = 128;
 struct ConvTiles {
     int32_t *tj = nullptr;     // [tiles][16] neighbour row (padding: 0, a valid row whose result is discarded)
     uint8_t *tr = nullptr;     // [tiles][16] output row inside the block (padding: R = the dummy row)

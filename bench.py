@@ -62,13 +62,14 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     from gauspcc_amd import _lib, runtime
+    from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed
     from gauspcc_amd.pcc_utils import _decode_bytes, _encode_to_bytes
     from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
 
     k = args.kernel_size
     sd = synthetic_state_dict(32, k)
     model = runtime.Model(sd, 32, k, local_rank)
-    seed = 1234 + rank  # one independent scene per GPU
+    seed = scene_seed(1234, rank)  # one independent scene per GPU
     pts = synthetic_cloud(args.points, seed=seed)
     x = torch.tensor(pts, device=device)  # inputs resident in HBM before the timed region
     ctx = runtime.context(device)
@@ -112,17 +113,12 @@ def main():
     if not ok:
         raise SystemExit("round trip failed: decoded geometry differs from the input")
 
-    # max over ranks; stats collation over RCCL
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    stats = torch.tensor([float(len(data)), enc_s / args.steps, dec_s / args.steps, float(st.coded_nodes), float(st.conv_pairs)], dtype=torch.float64, device=device)
-    if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        allstats = torch.stack(gathered).cpu().numpy()
-    else:
-        allstats = stats.cpu().numpy()[None]
-    elapsed = float(tmax.item())
+    # max over ranks; bitstream stats collated with one all_gather (RCCL over xGMI when N > 1)
+    mine = SceneStats(num_points=args.points, num_bytes=len(data), enc_s=enc_s / args.steps, dec_s=dec_s / args.steps,
+                      coded_nodes=st.coded_nodes, conv_pairs=st.conv_pairs, levels=st.num_levels, status=0)
+    scenes = collate_stats([mine], device)
+    elapsed = max_over_ranks(elapsed, device)
+    allstats = np.array([[s.num_bytes, s.enc_s, s.dec_s, s.coded_nodes, s.conv_pairs] for s in scenes], dtype=np.float64)
 
     if rank == 0:
         total_points = args.points * world * args.steps

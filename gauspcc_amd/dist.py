@@ -1,0 +1,75 @@
+"""Multi-GPU harness for the path: independent scenes shard across ranks (SURVEY.md
+section 8e), nothing is exchanged on the data path, and one all_gather collates the
+per-scene bitstream statistics.  Works over any torch.distributed backend: RCCL
+("nccl") on the MI355X node, gloo in the CPU tests.
+"""
+from dataclasses import dataclass
+
+import torch
+
+STAT_FIELDS = ("num_points", "num_bytes", "enc_s", "dec_s", "coded_nodes", "conv_pairs", "levels", "status")
+
+
+@dataclass
+class SceneStats:
+    num_points: int = 0
+    num_bytes: int = 0
+    enc_s: float = 0.0
+    dec_s: float = 0.0
+    coded_nodes: int = 0
+    conv_pairs: int = 0
+    levels: int = 0
+    status: int = 0
+
+    def to_tensor(self, device) -> torch.Tensor:
+        return torch.tensor([float(getattr(self, f)) for f in STAT_FIELDS], dtype=torch.float64, device=device)
+
+    @classmethod
+    def from_row(cls, row) -> "SceneStats":
+        kw = {}
+        for f, v in zip(STAT_FIELDS, row):
+            kw[f] = float(v) if f in ("enc_s", "dec_s") else int(round(float(v)))
+        return cls(**kw)
+
+
+def scenes_for_rank(n_scenes: int, rank: int, world: int):
+    """Scene i -> rank i mod world (each rank owns its model replica and its output files)."""
+    return list(range(rank, n_scenes, world))
+
+
+def scene_seed(base_seed: int, scene: int) -> int:
+    return base_seed + scene
+
+
+def collate_stats(local, device, group=None):
+    """all_gather the per-scene records of every rank; returns the flat list ordered by
+    (rank, local index).  `local` is a list of SceneStats (may be empty on some ranks)."""
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(local)
+    world = dist.get_world_size(group)
+    count = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    cmax = max(int(c.item()) for c in counts)
+    buf = torch.zeros((max(cmax, 1), len(STAT_FIELDS)), dtype=torch.float64, device=device)
+    for i, s in enumerate(local):
+        buf[i] = s.to_tensor(device)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = []
+    for r in range(world):
+        rows = bufs[r].cpu().numpy()
+        for i in range(int(counts[r].item())):
+            out.append(SceneStats.from_row(rows[i]))
+    return out
+
+
+def max_over_ranks(seconds: float, device, group=None) -> float:
+    import torch.distributed as dist
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())

@@ -1,0 +1,50 @@
+"""world_size-2 gloo test of the N>1 path: scene sharding + stats all_gather + MAX timing
+(the same code bench.py runs over RCCL)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed, scenes_for_rank
+
+    scenes = scenes_for_rank(5, rank, world)
+    local = [SceneStats(num_points=1000 + s, num_bytes=10 * s + rank, enc_s=0.5 + s, dec_s=0.25 * s,
+                        coded_nodes=scene_seed(1234, s), conv_pairs=2 ** 40 + s, levels=10 + s, status=0) for s in scenes]
+    allst = collate_stats(local, torch.device("cpu"))
+    tmax = max_over_ranks(1.0 + rank, torch.device("cpu"))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, scenes, [(s.num_points, s.num_bytes, s.enc_s, s.coded_nodes, s.conv_pairs, s.levels) for s in allst], tmax))
+
+
+def test_scene_sharding_and_stats_allgather_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 2, 4] and res[1][1] == [1, 3]
+    assert res[0][2] == res[1][2]                      # every rank sees the same collated table
+    pts = [r[0] for r in res[0][2]]
+    assert pts == [1000, 1002, 1004, 1001, 1003]       # ordered by (rank, local index)
+    assert [r[4] for r in res[0][2]][0] == 2 ** 40     # int64-sized counters survive the float64 transport
+    assert res[0][3] == res[1][3] == 2.0               # MAX over ranks

@@ -40,6 +40,7 @@ EXPORTS = [
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get",
+    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsge_forward",
 ]
 
 
@@ -73,6 +74,10 @@ def lib():
     L.gpcc_memcpy_d2d.argtypes = [vp, vp, vp, i64, vp]
     L.gpcc_profile_enable.argtypes = [vp, i32]
     L.gpcc_profile_get.argtypes = [vp, C.POINTER(Profile)]
+    L.gsac_calculate_cdf.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
+    L.gsac_encode.argtypes = [vp, vp, vp, i32, i64, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
+    L.gsac_decode.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, vp, vp]
+    L.gsge_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]
     _lib = L
     return L
 

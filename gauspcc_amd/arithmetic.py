@@ -1,0 +1,61 @@
+"""Mirror of the reference's `arithmetic` extension module
+(HAC/submodules/arithmetic.zip!arithmetic/arithmetic.cpp:4-49): same three functions,
+same argument order, same tensor types, same byte format -- backed by libgauspcc.so.
+
+    calculate_cdf(mean, scale, Q, min_value, max_value) -> Tensor (n, max-min+2) float32
+    arithmetic_encode(sym, cdf, chunk_size, N, Lp)      -> (Tensor uint8, Tensor int32[chunks])
+    arithmetic_decode(cdf, bytes, cnt, chunk_size, N, Lp) -> Tensor int16 (N)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, runtime
+
+
+def _chk(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")      # CHECK_CUDA  (include/utils.h:3)
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")          # CHECK_CONTIGUOUS (include/utils.h:4)
+
+
+def calculate_cdf(mean, scale, Q, min_value, max_value):
+    for t, nm in ((mean, "mean"), (scale, "scale"), (Q, "Q")):
+        _chk(t, nm)
+    mn, mx = int(min_value), int(max_value)
+    n = mean.shape[0]
+    lower = torch.zeros((n, mx - mn + 2), dtype=torch.float32, device=mean.device)
+    if n:
+        _lib.check(_lib.lib().gsac_calculate_cdf(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(),
+                                                  n, mn, mx, lower.data_ptr(), runtime.stream_ptr(mean.device)))
+    return lower
+
+
+def arithmetic_encode(sym, cdf, chunk_size, N, Lp):
+    _chk(sym, "sym"); _chk(cdf, "cdf")
+    if sym.dim() != 1:
+        raise RuntimeError(f"Expected sym to have 1 dimension, but got {sym.dim()}")
+    if cdf.dim() != 2:
+        raise RuntimeError(f"Expected cdf to have 2 dimensions, but got {cdf.dim()}")
+    sym = sym.to(torch.int16)
+    cdf = cdf.to(torch.float32)
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode(runtime.context(sym.device), sym.data_ptr(), cdf.data_ptr(), int(chunk_size), int(N), int(Lp),
+                                      C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(sym.device)))
+    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
+    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    return torch.from_numpy(out).to(sym.device), torch.from_numpy(cnt).to(sym.device)
+
+
+def arithmetic_decode(cdf, in_cache_all, in_cnt_all, chunk_size, N, Lp):
+    _chk(cdf, "cdf")
+    cdf = cdf.to(torch.float32)
+    data = in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False)
+    cnt = in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False)
+    data = np.ascontiguousarray(data); cnt = np.ascontiguousarray(cnt)
+    out = torch.zeros(int(N), dtype=torch.int16, device=cdf.device)
+    _lib.check(_lib.lib().gsac_decode(runtime.context(cdf.device), cdf.data_ptr(), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
+                                      int(N), int(Lp), out.data_ptr(), runtime.stream_ptr(cdf.device)))
+    return out

@@ -1,0 +1,336 @@
+// attributes.hip -- the HAC attribute-side kernels around the geometry path:
+//   gsac_calculate_cdf   arithmetic.calculate_cdf      arithmetic.zip!arithmetic/arithmetic_kernel.cu:7-54
+//   gsac_encode/_decode  arithmetic.arithmetic_encode / arithmetic_decode   ...:94-232, 265-403
+//   gsge_forward         _gridencoder.grid_encode_forward   gridencoder.zip!gridencoder/src/gridencoder.cu:46-361
+// Same byte format as the reference's CUDA coder (chunks of `chunk_size` symbols, per-chunk byte
+// counts), same integerisation of the float CDF rows (rint(cdf * (65536 - (Lp-1))) + index).
+//
+// Where the reference runs ONE THREAD per chunk (<<<chunks, 1>>>) this version
+//   * encodes with the geometry path's lane-per-chunk coder after a fully parallel pre-pass that
+//     turns (cdf row, symbol) into the two integers the coder needs;
+//   * decodes with one WAVE per chunk: the 64 lanes integerise and scale a whole CDF row at once,
+//     a ballot finds the symbol (no binary search, no division), rows are prefetched 4 symbols ahead.
+#include "octree.hpp"
+#include "primitives.hpp"
+#include "rangecoder.hpp"
+
+using namespace gpcc;
+
+namespace {
+
+constexpr int TB = 256;
+
+// ------------------------------------------------------------------ calculate_cdf
+__global__ __launch_bounds__(TB) void k_gaussian_cdf(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q, int64_t n,
+                                                     int min_value, int lp, float *__restrict__ lower)
+{
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * lp) return;
+    const int64_t idx = t / lp;
+    const int i = (int)(t - idx * lp);
+    const float sc = (float)fmax((double)scale[idx], 1e-9);                            // max(scale[idx], 1e-9)
+    const float sample = (float)(((double)(min_value + i) - 0.5) * (double)Q[idx]);    // (min + i - 0.5) * Q
+    const float arg = -(sample - mean[idx]) / (sc * sqrtf(2.0f));
+    lower[t] = (float)(0.5 * (double)erfcf(arg));
+}
+
+// ------------------------------------------------------------------ encode pre-pass
+__global__ __launch_bounds__(TB) void k_hac_pack(const float *__restrict__ cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
+                                                 uint32_t *__restrict__ lohi)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    const float scale = (float)(65536 - (lp - 1));
+    const int s = sym[r];
+    const uint32_t lo = (uint32_t)((int)__builtin_rintf(cdf[r * lp + s] * scale) + s);
+    const uint32_t hi = s == lp - 2 ? 0x10000u : (uint32_t)((int)__builtin_rintf(cdf[r * lp + s + 1] * scale) + s + 1);
+    const uint32_t c = (uint32_t)(r / chunk), t = (uint32_t)(r - (int64_t)c * chunk);
+    lohi[(size_t)t * nch + c] = (lo & 0xFFFFu) | ((hi - 1u) << 16);
+}
+
+// ------------------------------------------------------------------ decode: one wave per chunk
+struct WaveBits {  // every lane holds the same reader state (broadcast loads)
+    const uint8_t *p, *end;
+    uint64_t buf;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t take(uint32_t k)
+    {
+        if (n <= 32) {
+            uint32_t wv = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) wv = (wv << 8) | (p + q < end ? (uint32_t)p[q] : 0u);
+            p += 4;
+            buf |= (uint64_t)wv << (32 - n);
+            n += 32;
+        }
+        const uint32_t r = (uint32_t)(buf >> (64 - k));
+        buf <<= k;
+        n -= k;
+        return r;
+    }
+};
+
+__device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
+
+__global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
+                                                   const uint32_t *__restrict__ cnt_cum, int16_t *__restrict__ sym, int64_t n, int lp, int chunk)
+{
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int64_t base = (int64_t)c * chunk;
+    const int cn = (int)min((int64_t)chunk, n - base);
+    const float scale = (float)(65536 - (lp - 1));
+    const int max_symbol = lp - 2;
+    WaveBits in = {bytes + cnt_cum[c], bytes + cnt_cum[c] + cnt[c], 0, 0};
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t value = in.take(32);
+    const int nseg = (lp - 1 + 63) / 64;  // indices 0 .. lp-2 are searched
+    for (int i0 = 0; i0 < cn; i0 += 4) {
+        // prefetch the first segment of the next four rows (rows do not depend on decoded symbols)
+        float pre[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf[(base + i0 + u) * lp + lane] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            if (i >= cn) break;
+            const float *row = cdf + (base + i) * lp;
+            const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+            const uint32_t x = value - low;
+            int s;
+            uint32_t lo, hi;
+            if (nseg == 1) {
+                // the whole row in one go: lane m integerises and scales cdf[m]; the symbol is the highest lane
+                // whose scaled bound is <= value - low (index 0 is never compared: binsearch starts with left = 0)
+                const uint32_t v = (uint32_t)((int)__builtin_rintf(pre[u] * scale) + lane);
+                const uint32_t t = (uint32_t)((span * (uint64_t)v) >> 16);
+                const uint64_t bal = __ballot(lane <= max_symbol && (lane == 0 || t <= x));
+                s = 63 - __clzll((long long)bal);
+                lo = __shfl(t, s);
+                const uint32_t nxt = __shfl(t, min(s + 1, 63));
+                hi = s == max_symbol ? (uint32_t)span : nxt;
+            } else {
+                // alphabets wider than a wave: wave-uniform binary search (broadcast loads)
+                int left = 0, right = max_symbol + 1;
+                while (left + 1 < right) {
+                    const int m = (left + right) / 2;
+                    const uint32_t v = (uint32_t)((int)__builtin_rintf(row[m] * scale) + m);
+                    if ((uint32_t)((span * (uint64_t)v) >> 16) <= x) left = m; else right = m;
+                }
+                s = left;
+                lo = (uint32_t)((span * (uint64_t)(uint32_t)((int)__builtin_rintf(row[s] * scale) + s)) >> 16);
+                hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)(uint32_t)((int)__builtin_rintf(row[s + 1] * scale) + s + 1)) >> 16);
+            }
+            if (lane == 0) sym[base + i] = (int16_t)s;
+            high = (low - 1u) + hi;
+            low = low + lo;
+            const int n1 = clz32(low ^ high);
+            if (n1) { low <<= n1; high = (high << n1) | ((1u << n1) - 1u); value = (value << n1) | in.take((uint32_t)n1); }
+            const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
+            if (n2) { low = (low << n2) & 0x7FFFFFFFu; high = (high << n2) | 0x80000000u | ((1u << n2) - 1u); value = ((value << n2) ^ 0x80000000u) | in.take((uint32_t)n2); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ hash-grid forward
+__device__ __forceinline__ uint32_t grid_index(int D, uint32_t F, uint32_t hashmap_size, uint32_t res, const uint32_t *pg)
+{
+    uint32_t stride = 1, index = 0;
+    for (int d = 0; d < D && stride <= hashmap_size; ++d) { index += pg[d] * stride; stride *= res; }
+    if (stride > hashmap_size) {  // gridencoder.cu:46-60: xor of coordinate * prime
+        const uint32_t primes[3] = {1u, 2654435761u, 805459861u};
+        uint32_t h = 0;
+        for (int d = 0; d < D; ++d) h ^= pg[d] * primes[d];
+        index = h;
+    }
+    return (index % hashmap_size) * F;
+}
+
+template <int D, int F>
+__global__ __launch_bounds__(TB) void k_grid_forward(const float *__restrict__ inputs, const float *__restrict__ grid, const int *__restrict__ offsets,
+                                                     const int *__restrict__ resolutions, float *__restrict__ outputs, uint32_t N, uint32_t Rb,
+                                                     const uint8_t *__restrict__ binary_vxl, const int *__restrict__ min_level_id)
+{
+    const uint32_t b = blockIdx.x * TB + threadIdx.x;
+    if (b >= N) return;
+    const uint32_t level = min_level_id ? (uint32_t)min_level_id[b] + blockIdx.y : blockIdx.y;
+    grid += (size_t)(uint32_t)offsets[level] * F;
+    const float *x = inputs + (size_t)b * D;
+    float *out = outputs + ((size_t)blockIdx.y * N + b) * F;
+    bool oob = false;
+    for (int d = 0; d < D; ++d) oob |= (x[d] < 0.0f || x[d] > 1.0f);
+    if (oob) { for (int ch = 0; ch < F; ++ch) out[ch] = 0.0f; return; }
+    const uint32_t hashmap_size = (uint32_t)(offsets[level + 1] - offsets[level]);
+    const uint32_t res = (uint32_t)resolutions[level];
+    float pos[D];
+    uint32_t pg[D];
+    for (int d = 0; d < D; ++d) {
+        const float t = x[d] * (float)(res - 2);
+        pos[d] = t + 0.5f;                           // (float)((double)t + 0.5): identical rounding
+        pg[d] = (uint32_t)floorf(pos[d]);
+        pos[d] -= (float)pg[d];
+    }
+    float w_list[1 << D];
+    uint32_t idx_list[1 << D];
+    bool use[1 << D];
+    float wn = 0.0f;
+    for (int c = 0; c < (1 << D); ++c) {
+        float w = 1.0f;
+        uint32_t pl[D];
+        for (int d = 0; d < D; ++d) {
+            if ((c & (1 << d)) == 0) { w *= 1.0f - pos[d]; pl[d] = pg[d]; }
+            else { w *= pos[d]; pl[d] = min(pg[d] + 1u, res - 1u); }
+        }
+        bool zero = false;
+        for (int d = 0; d < D; ++d) zero |= (pl[d] == 0u || pl[d] == res - 1u);
+        bool m = true;
+        if (binary_vxl) {  // gridencoder.cu:262-317: any occupied voxel in the corner's footprint
+            m = false;
+            const float scale_re = (float)(1.0 / ((double)(float)res - 2.0));
+            int g0[D], g1[D];
+            for (int d = 0; d < D; ++d) {
+                const float pn = (float)(((double)(float)pl[d] - 0.5) * (double)scale_re);
+                float a = (pn - scale_re) * (float)Rb;
+                a = a < 0.0f ? 0.0f : a; a = a > (float)(Rb - 1) ? (float)(Rb - 1) : a;
+                g0[d] = (int)a;
+                float bb = (pn + scale_re) * (float)Rb;
+                bb = bb < 0.0f ? 0.0f : bb; bb = bb > (float)(Rb - 1) ? (float)(Rb - 1) : bb;
+                g1[d] = (int)bb;
+            }
+            if (D == 2) {
+                for (int ia = g0[0]; ia <= g1[0] && !m; ++ia)
+                    for (int ib = g0[1]; ib <= g1[1] && !m; ++ib) m = binary_vxl[(size_t)ia * Rb + ib] != 0;
+            } else if (D == 3) {
+                for (int ia = g0[0]; ia <= g1[0] && !m; ++ia)
+                    for (int ib = g0[1]; ib <= g1[1] && !m; ++ib)
+                        for (int ic = g0[D - 1]; ic <= g1[D - 1] && !m; ++ic) m = binary_vxl[((size_t)ia * Rb + ib) * Rb + ic] != 0;
+            } else {
+                for (int ia = g0[0]; ia <= g1[0] && !m; ++ia) m = binary_vxl[ia] != 0;
+            }
+        }
+        w_list[c] = w;
+        use[c] = !zero && m;
+        idx_list[c] = 0;
+        if (use[c]) { idx_list[c] = grid_index(D, F, hashmap_size, res, pl); wn += w; }
+    }
+    if (wn == 0.0f) wn = (float)((double)wn + 1e-9);
+    const float wn_re = (float)(1.0 / (double)wn);
+    float r[F];
+    for (int ch = 0; ch < F; ++ch) r[ch] = 0.0f;
+    for (int c = 0; c < (1 << D); ++c)
+        if (use[c]) {
+            const float ww = w_list[c] * wn_re;
+            for (int ch = 0; ch < F; ++ch) r[ch] = __builtin_fmaf(ww, grid[idx_list[c] + ch], r[ch]);  // nvcc contracts mul+add (fmad) here
+        }
+    for (int ch = 0; ch < F; ++ch) out[ch] = r[ch];
+}
+
+template <int D>
+int grid_launch_f(hipStream_t st, int F, dim3 g, const float *in, const float *emb, const int *off, const int *res, float *out, uint32_t N, uint32_t Rb,
+                  const uint8_t *bv, const int *ml)
+{
+    switch (F) {
+    case 1: k_grid_forward<D, 1><<<g, TB, 0, st>>>(in, emb, off, res, out, N, Rb, bv, ml); break;
+    case 2: k_grid_forward<D, 2><<<g, TB, 0, st>>>(in, emb, off, res, out, N, Rb, bv, ml); break;
+    case 4: k_grid_forward<D, 4><<<g, TB, 0, st>>>(in, emb, off, res, out, N, Rb, bv, ml); break;
+    case 8: k_grid_forward<D, 8><<<g, TB, 0, st>>>(in, emb, off, res, out, N, Rb, bv, ml); break;
+    default: return fail(GPCC_ERR_ARG, "GridEncoding: n_features must be 1, 2, 4 or 8");
+    }
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int gsac_calculate_cdf(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, int64_t n, int min_value, int max_value,
+                                  float *lower, void *stream)
+{
+    if (!ctx || !mean || !scale || !Q || !lower) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0) return GPCC_OK;
+    const int lp = max_value - min_value + 2;
+    if (lp < 2) return fail(GPCC_ERR_ARG, "max_value < min_value");
+    HIP_TRY(hipSetDevice(ctx->device));
+    k_gaussian_cdf<<<(unsigned)cdiv(n * lp, TB), TB, 0, (hipStream_t)stream>>>(mean, scale, Q, n, min_value, lp, lower);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+                           int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    if (!ctx || !sym || !cdf || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0 || lp < 2) return fail(GPCC_ERR_ARG, "bad size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    const uint32_t sstride = rc_scratch_stride((uint32_t)std::min<int64_t>(chunk_size, n));
+    GP_TRY(ctx->arena.reserve((size_t)nch * chunk_size * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    std::vector<RcChunk> chunks((size_t)nch);
+    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(chunk_size, n - (int64_t)c * chunk_size), 0, 0, 0};
+    TAKE(lohi, uint32_t, (int64_t)nch * chunk_size); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
+    TAKE(scratch, uint8_t, (size_t)nch * sstride); TAKE(payload, uint8_t, (size_t)nch * sstride);
+    HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    k_hac_pack<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
+    LAUNCH_CHECK();
+    GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
+    GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
+    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nch, payload));
+    GP_TRY(ctx->hstage.reserve(4 * (size_t)nch + 64));
+    uint32_t *hcnt = reinterpret_cast<uint32_t *>(ctx->hstage.p);
+    HIP_TRY(hipMemcpyAsync(hcnt, dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hcnt + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const size_t total = hcnt[nch];
+    GP_TRY(ctx->hbytes.reserve(total + 16));
+    if (total) HIP_TRY(hipMemcpyAsync(ctx->hbytes.p, payload, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *bytes_out = ctx->hbytes.p; *nbytes_out = (int64_t)total;
+    *cnt_out = reinterpret_cast<const int32_t *>(hcnt); *nchunks_out = nch;
+    return GPCC_OK;
+}
+
+extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+                           int16_t *sym_out, void *stream)
+{
+    if (!ctx || !cdf || !bytes || !cnt || !sym_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0 || lp < 2) return fail(GPCC_ERR_ARG, "bad size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    std::vector<uint32_t> cum((size_t)nch + 1, 0);
+    for (int c = 0; c < nch; ++c) {
+        if (cnt[c] < 0) return fail(GPCC_ERR_FORMAT, "negative chunk size");
+        cum[(size_t)c + 1] = cum[(size_t)c] + (uint32_t)cnt[c];
+    }
+    if ((int64_t)cum[(size_t)nch] > nbytes) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
+    GP_TRY(ctx->arena.reserve((size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(db, uint8_t, nbytes + 16); TAKE(dcnt, int32_t, nch); TAKE(dcum, uint32_t, nch + 1);
+    HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dcnt, cnt, 4 * (size_t)nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dcum, cum.data(), 4 * ((size_t)nch + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    k_hac_decode<<<(unsigned)nch, 64, 0, st>>>(cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}
+
+extern "C" int gsge_forward(gpcc_ctx *ctx, const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,
+                            float *outputs, int64_t N, int num_dim, int n_features, int n_levels, int Rb, const uint8_t *binary_vxl,
+                            const int32_t *min_level_id, void *stream)
+{
+    if (!ctx || !inputs || !embeddings || !offsets || !resolutions || !outputs) return fail(GPCC_ERR_ARG, "null argument");
+    if (N <= 0 || n_levels <= 0) return GPCC_OK;
+    if (N >= ((int64_t)1 << 31)) return fail(GPCC_ERR_ARG, "too many points");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    dim3 g((unsigned)cdiv(N, TB), (unsigned)n_levels);
+    switch (num_dim) {
+    case 1: return grid_launch_f<1>(st, n_features, g, inputs, embeddings, offsets, resolutions, outputs, (uint32_t)N, (uint32_t)Rb, binary_vxl, min_level_id);
+    case 2: return grid_launch_f<2>(st, n_features, g, inputs, embeddings, offsets, resolutions, outputs, (uint32_t)N, (uint32_t)Rb, binary_vxl, min_level_id);
+    case 3: return grid_launch_f<3>(st, n_features, g, inputs, embeddings, offsets, resolutions, outputs, (uint32_t)N, (uint32_t)Rb, binary_vxl, min_level_id);
+    default: return fail(GPCC_ERR_ARG, "GridEncoding: num_dim must be 1, 2 or 3");
+    }
+}

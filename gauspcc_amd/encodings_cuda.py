@@ -1,0 +1,125 @@
+"""The HAC attribute codec wrappers with the reference's names, arguments and `.b` file
+formats (src/gs_compress/HAC/utils/encodings_cuda.py:317-492), on top of
+gauspcc_amd.arithmetic instead of the CUDA `arithmetic` extension.
+
+    encoder_gaussian(_chunk) / decoder_gaussian(_chunk)   :317-433
+    encoder / decoder (Bernoulli, one global p)            :435-492
+"""
+import numpy as np
+import torch
+
+from . import arithmetic
+
+chunk_size_cuda = 10000
+
+
+def encoder_gaussian_chunk(x, mean, scale, Q, file_name='tmp.b', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 1
+    x_view, mean_view, scale_view = x.view(-1), mean.view(-1), scale.view(-1)
+    N = x_view.shape[0]
+    chunks = int(np.ceil(N / chunk_size))
+    is_q_tensor = isinstance(Q, torch.Tensor)
+    if is_q_tensor:
+        Q_view = Q.view(-1)
+    bit_len_list = []
+    for c in range(chunks):
+        sl = slice(c * chunk_size, c * chunk_size + chunk_size)
+        bit_len_list.append(encoder_gaussian(x=x_view[sl], mean=mean_view[sl], scale=scale_view[sl],
+                                             Q=Q_view[sl] if is_q_tensor else Q, file_name=file_name.replace('.b', f'_{str(c)}.b')))
+    return sum(bit_len_list)
+
+
+def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 1
+    if not isinstance(Q, torch.Tensor):
+        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
+    x_int_round = torch.round(x / Q)
+    max_value = x_int_round.max()
+    min_value = x_int_round.min()
+    lower = arithmetic.calculate_cdf(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value)
+    x_int_round_idx = (x_int_round - min_value).to(torch.int16)
+    byte_stream_torch, cnt_torch = arithmetic.arithmetic_encode(x_int_round_idx.contiguous(), lower, chunk_size_cuda,
+                                                                int(lower.shape[0]), int(lower.shape[1]))
+    cnt_bytes = cnt_torch.cpu().numpy().tobytes()
+    byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
+    with open(file_name, 'wb') as fout:
+        fout.write(min_value.to(torch.float32).cpu().numpy().tobytes())
+        fout.write(max_value.to(torch.float32).cpu().numpy().tobytes())
+        fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
+        fout.write(cnt_bytes)
+        fout.write(byte_stream_bytes)
+    return (len(byte_stream_bytes) + len(cnt_bytes)) * 8 + 32 * 3
+
+
+def decoder_gaussian_chunk(mean, scale, Q, file_name='tmp.b', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    mean_view, scale_view = mean.view(-1), scale.view(-1)
+    N = mean_view.shape[0]
+    chunks = int(np.ceil(N / chunk_size))
+    is_q_tensor = isinstance(Q, torch.Tensor)
+    if is_q_tensor:
+        Q_view = Q.view(-1)
+    out = []
+    for c in range(chunks):
+        sl = slice(c * chunk_size, c * chunk_size + chunk_size)
+        out.append(decoder_gaussian(mean=mean_view[sl], scale=scale_view[sl], Q=Q_view[sl] if is_q_tensor else Q,
+                                    file_name=file_name.replace('.b', f'_{str(c)}.b')))
+    return torch.cat(out, dim=0).type_as(mean)
+
+
+def decoder_gaussian(mean, scale, Q, file_name='tmp.b'):
+    assert file_name.endswith('.b')
+    assert len(mean.shape) == 1
+    assert mean.shape == scale.shape
+    if not isinstance(Q, torch.Tensor):
+        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
+    with open(file_name, 'rb') as fin:
+        min_value = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy(), device=mean.device)
+        max_value = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy(), device=mean.device)
+        len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy(), device=mean.device)
+        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy(), device=mean.device)
+    lower = arithmetic.calculate_cdf(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value)
+    sym_out = arithmetic.arithmetic_decode(lower, byte_stream_torch, cnt_torch, chunk_size_cuda,
+                                           int(lower.shape[0]), int(lower.shape[1])).to(mean.device).to(torch.float32)
+    x = sym_out + min_value
+    return x * Q
+
+
+def _bernoulli_cdf(p1: torch.Tensor, n: int, device):
+    p = torch.zeros(size=[n], dtype=torch.float32, device=device)
+    p[...] = p1
+    p_u = 1 - p.unsqueeze(-1)
+    return torch.cat([torch.zeros_like(p_u), p_u, torch.ones_like(p_u)], dim=-1).contiguous()
+
+
+def encoder(x, file_name='tmp.b'):
+    assert file_name[-2:] == '.b'
+    x = x.detach().view(-1)
+    prob_1 = x.sum() / x.numel()
+    output_cdf = _bernoulli_cdf(prob_1, x.numel(), x.device)
+    sym = torch.floor(x).to(torch.int16)
+    byte_stream_torch, cnt_torch = arithmetic.arithmetic_encode(sym.contiguous(), output_cdf, chunk_size_cuda,
+                                                                int(output_cdf.shape[0]), int(output_cdf.shape[1]))
+    cnt_bytes = cnt_torch.cpu().numpy().tobytes()
+    byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
+    with open(file_name, 'wb') as fout:
+        fout.write(prob_1.to(torch.float32).cpu().numpy().tobytes())
+        fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
+        fout.write(cnt_bytes)
+        fout.write(byte_stream_bytes)
+    return (len(byte_stream_bytes) + len(cnt_bytes)) * 8 + 32 * 2
+
+
+def decoder(N_len, file_name='tmp.b', device='cuda'):
+    assert file_name[-2:] == '.b'
+    with open(file_name, 'rb') as fin:
+        prob_1 = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy())
+        len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy(), device=device)
+        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy(), device=device)
+    output_cdf = _bernoulli_cdf(prob_1.to(device), N_len, device)
+    return arithmetic.arithmetic_decode(output_cdf, byte_stream_torch, cnt_torch, chunk_size_cuda,
+                                        int(output_cdf.shape[0]), int(output_cdf.shape[1]))

@@ -150,6 +150,30 @@ GPCC_API int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, cons
 GPCC_API int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *bytes, int64_t nbytes,
                    int64_t n, int chunk_log2, uint8_t *sym_dev, void *stream);
 
+/* ================= HAC attribute-side kernels (a15, a17-a19) ================= */
+
+/* arithmetic.calculate_cdf(mean, scale, Q, min_value, max_value) -> lower (n, max-min+2) float32
+ * HAC/submodules/arithmetic.zip!arithmetic/arithmetic.cpp:4-15, arithmetic_kernel.cu:7-54.  All device. */
+GPCC_API int gsac_calculate_cdf(gpcc_ctx *ctx, const float *mean_dev, const float *scale_dev, const float *q_dev, int64_t n,
+                                int min_value, int max_value, float *lower_dev, void *stream);
+
+/* arithmetic.arithmetic_encode(sym int16 (n), cdf float (n,Lp), chunk_size, N, Lp) -> (bytes uint8, cnt int32[chunks])
+ * arithmetic.cpp:18-29, arithmetic_kernel.cu:94-232.  sym / cdf device; outputs are context-owned HOST buffers. */
+GPCC_API int gsac_encode(gpcc_ctx *ctx, const int16_t *sym_dev, const float *cdf_dev, int chunk_size, int64_t n, int lp,
+                         const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream);
+
+/* arithmetic.arithmetic_decode(cdf, bytes, cnt, chunk_size, N, Lp) -> sym int16 (n)
+ * arithmetic.cpp:32-43, arithmetic_kernel.cu:265-403.  cdf device, bytes / cnt host, sym_out device. */
+GPCC_API int gsac_decode(gpcc_ctx *ctx, const float *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
+                         int64_t n, int lp, int16_t *sym_out_dev, void *stream);
+
+/* _gridencoder.grid_encode_forward (inputs (N,D) in [0,1], embeddings (sO,F), offsets (L+1), resolutions (L),
+ * outputs (L,N,F), ..., Rb, binary_vxl, min_level_id)   gridencoder.zip!gridencoder/src/gridencoder.h:12-22,
+ * gridencoder.cu:100-361 (forward only; dy_dx / backward are training-side and out of scope).  All device. */
+GPCC_API int gsge_forward(gpcc_ctx *ctx, const float *inputs_dev, const float *embeddings_dev, const int32_t *offsets_dev,
+                          const int32_t *resolutions_dev, float *outputs_dev, int64_t n, int num_dim, int n_features, int n_levels,
+                          int rb, const uint8_t *binary_vxl_dev, const int32_t *min_level_id_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

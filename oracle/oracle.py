@@ -58,6 +58,7 @@ def lib():
         L.orc_hac_encode.restype = i64
         L.orc_hac_encode.argtypes = [vp, i32, vp, i64, i32, vp, i64, vp]
         L.orc_hac_decode.argtypes = [vp, i32, vp, vp, i64, i32, vp]
+        L.orc_grid_forward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
         _LIB = L
     return _LIB
 
@@ -278,4 +279,20 @@ def hac_decode(cdf: np.ndarray, data: np.ndarray, cnt: np.ndarray, chunk: int = 
     cnt = np.ascontiguousarray(cnt, dtype=np.int32)
     out = np.empty(cdf.shape[0], dtype=np.int16)
     lib().orc_hac_decode(_p(cdf), cdf.shape[1], _p(data), _p(cnt), cdf.shape[0], chunk, _p(out))
+    return out
+
+
+def grid_forward(inputs, emb, offsets, resolutions, rb=128, binary_vxl=None, min_level_id=None):
+    """_gridencoder.grid_encode_forward restated: returns (n_levels, N, F) float32."""
+    inputs = np.ascontiguousarray(inputs, dtype=np.float32)
+    emb = np.ascontiguousarray(emb, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    resolutions = np.ascontiguousarray(resolutions, dtype=np.int32)
+    n, d = inputs.shape
+    f = emb.shape[1]
+    nl = resolutions.size
+    out = np.empty((nl, n, f), dtype=np.float32)
+    bv = None if binary_vxl is None else np.ascontiguousarray(binary_vxl, dtype=np.uint8)
+    ml = None if min_level_id is None else np.ascontiguousarray(min_level_id, dtype=np.int32)
+    lib().orc_grid_forward(_p(inputs), _p(emb), _p(offsets), _p(resolutions), _p(out), n, d, f, nl, rb, _p(bv), _p(ml))
     return out

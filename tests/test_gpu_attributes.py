@@ -1,0 +1,105 @@
+"""GPU parity of the HAC attribute-side kernels against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    return torch
+
+
+def test_calculate_cdf_matches_oracle(torch_cuda, orc):
+    torch = torch_cuda
+    from gauspcc_amd import arithmetic
+
+    rng = np.random.RandomState(0)
+    n = 5000
+    mean = rng.randn(n).astype(np.float32) * 3
+    scale = np.abs(rng.randn(n)).astype(np.float32) * 2 + 1e-3
+    scale[:5] = 0.0                     # clamped to 1e-9
+    q = (rng.rand(n).astype(np.float32) + 0.5)
+    lower = arithmetic.calculate_cdf(torch.tensor(mean).cuda(), torch.tensor(scale).cuda(), torch.tensor(q).cuda(), -12, 15).cpu().numpy()
+    ref = orc.gaussian_cdf(mean, scale, q, -12, 15)
+    assert lower.shape == ref.shape == (n, 29)
+    # erfc comes from two different math libraries (ocml vs glibc): a few ulp, far below one CDF quantum (1/65536)
+    np.testing.assert_allclose(lower, ref, atol=2e-7, rtol=0)
+
+
+@pytest.mark.parametrize("lp,chunk", [(3, 10000), (30, 10000), (30, 777), (100, 5000)])
+def test_hac_coder_bytes_and_roundtrip(torch_cuda, orc, lp, chunk):
+    torch = torch_cuda
+    from gauspcc_amd import arithmetic
+
+    rng = np.random.RandomState(lp + chunk)
+    n = 23456
+    logits = rng.randn(n, lp - 1).astype(np.float32) * 2
+    p = np.exp(logits - logits.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
+    cdf = np.concatenate([np.zeros((n, 1)), np.cumsum(p, 1)], 1).clip(0, 1).astype(np.float32)
+    sym = np.array([rng.choice(lp - 1, p=pi / pi.sum()) for pi in p.astype(np.float64)], dtype=np.int16)
+    b, cnt = arithmetic.arithmetic_encode(torch.tensor(sym).cuda(), torch.tensor(cdf).cuda(), chunk, n, lp)
+    rb, rcnt = orc.hac_encode(sym, cdf, chunk)
+    assert np.array_equal(cnt.cpu().numpy(), rcnt)
+    assert np.array_equal(b.cpu().numpy(), rb)          # byte-identical to the coder loop of arithmetic_kernel.cu
+    dec = arithmetic.arithmetic_decode(torch.tensor(cdf).cuda(), b, cnt, chunk, n, lp).cpu().numpy()
+    assert np.array_equal(dec, sym)
+    assert np.array_equal(orc.hac_decode(cdf, rb, rcnt, chunk), sym)
+
+
+def test_encodings_cuda_file_roundtrip(torch_cuda, tmp_path):
+    torch = torch_cuda
+    from gauspcc_amd import encodings_cuda as ec
+
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n = 150_000 // 5
+    mean = (torch.randn(n, generator=g) * 2).cuda()
+    scale = (torch.rand(n, generator=g) * 3 + 0.05).cuda()
+    Q = torch.full((n,), 0.5).cuda()
+    x = torch.round((mean + scale * torch.randn(n, generator=g).cuda()) / Q) * Q
+    bits = ec.encoder_gaussian_chunk(x, mean, scale, Q, file_name=str(tmp_path / "feat.b"), chunk_size=20000)
+    assert bits > 0 and (tmp_path / "feat_0.b").exists() and (tmp_path / "feat_1.b").exists()
+    y = ec.decoder_gaussian_chunk(mean, scale, Q, file_name=str(tmp_path / "feat.b"), chunk_size=20000)
+    assert torch.equal(y, x)
+    mask = (torch.rand(40000, generator=g) < 0.3).float().cuda()
+    ec.encoder(mask, file_name=str(tmp_path / "masks.b"))
+    assert torch.equal(ec.decoder(40000, file_name=str(tmp_path / "masks.b")).float(), mask)
+
+
+@pytest.mark.parametrize("num_dim,n_features", [(3, 4), (2, 4), (3, 2)])
+def test_gridencoder_forward_bit_exact(torch_cuda, orc, num_dim, n_features):
+    torch = torch_cuda
+    from gauspcc_amd.gridencoder import GridEncoder
+
+    torch.manual_seed(num_dim * 10 + n_features)
+    res = (18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514) if num_dim == 3 else (130, 258, 514, 1026)
+    enc = GridEncoder(num_dim=num_dim, n_features=n_features, resolutions_list=res, log2_hashmap_size=13 if num_dim == 3 else 15, ste_binary=True).cuda()
+    enc.params.data.uniform_(-1, 1)
+    x = torch.rand(3000, num_dim).cuda()
+    x[:4] = torch.tensor([[0.0] * num_dim, [1.0] * num_dim, [1.5] * num_dim, [0.5] * num_dim])  # borders and out of range
+    out = enc(x).cpu().numpy()
+    emb = np.where(enc.params.detach().cpu().numpy() >= 0, 1.0, -1.0).astype(np.float32)
+    ref = orc.grid_forward(x.cpu().numpy(), emb, enc.offsets_list.cpu().numpy(), enc.resolutions_list.cpu().numpy())
+    ref = ref.transpose(1, 0, 2).reshape(3000, -1)
+    assert out.shape == ref.shape == (3000, len(res) * n_features)
+    assert np.array_equal(out, ref)
+    assert np.all(out[2] == 0)          # out-of-range input -> zeros (gridencoder.cu:135-160)
+
+
+def test_gridencoder_binary_voxel_mask(torch_cuda, orc):
+    torch = torch_cuda
+    from gauspcc_amd.gridencoder import GridEncoder
+
+    torch.manual_seed(5)
+    enc = GridEncoder(num_dim=3, n_features=4, resolutions_list=(18, 33, 59), log2_hashmap_size=13, ste_binary=False).cuda()
+    enc.params.data.uniform_(-1, 1)
+    x = torch.rand(2000, 3).cuda()
+    bv = (torch.rand(32, 32, 32) < 0.2).cuda()
+    out = enc(x, binary_vxl=bv).cpu().numpy()
+    ref = orc.grid_forward(x.cpu().numpy(), enc.params.detach().cpu().numpy(), enc.offsets_list.cpu().numpy(), enc.resolutions_list.cpu().numpy(),
+                           rb=32, binary_vxl=bv.cpu().numpy().astype(np.uint8)).transpose(1, 0, 2).reshape(2000, -1)
+    assert np.array_equal(out, ref)

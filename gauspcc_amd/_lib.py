@@ -40,7 +40,7 @@ EXPORTS = [
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get",
-    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsge_forward",
+    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsge_forward", "gsr_visible_filter", "gsr_forward",
 ]
 
 
@@ -78,6 +78,9 @@ def lib():
     L.gsac_encode.argtypes = [vp, vp, vp, i32, i64, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
     L.gsac_decode.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, vp, vp]
     L.gsge_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]
+    f32 = C.c_float
+    L.gsr_visible_filter.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp]
+    L.gsr_forward.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp, C.POINTER(i64), vp]
     _lib = L
     return L
 

@@ -1,0 +1,271 @@
+// rasterizer.hip -- forward pass of the tile-binned Gaussian splat rasteriser + visible_filter
+// (diff-gaussian-rasterization, Scaffold-GS fork; the zip is missing from the reference tree, see
+// SURVEY.md App. E; call contract: HAC/gaussian_renderer/__init__.py:199-225, 268-303 and
+// TC-GS/SIBR_viewers/src/projects/gaussianviewer/renderer/GaussianView.cpp:535-553, 660-688).
+// Forward only: RD evaluation (render -> PSNR) never needs the backward.
+//
+// gfx950 mapping:
+//   k_preprocess     one lane per Gaussian, coalesced SoA outputs (HBM-bound)
+//   scan / sort      the library's own wave-ballot radix sort on (tile << 32 | depth bits)
+//   k_tile_ranges    boundary detection on the sorted keys
+//   k_render         one 256-lane workgroup per 16x16 tile; batches of 256 Gaussians staged in LDS
+//                    (id -> xy, conic+opacity, rgb = 36 B each), every lane blends its pixel front to
+//                    back and the workgroup leaves when all 256 lanes are saturated
+#include "primitives.hpp"
+
+using namespace gpcc;
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int BX = 16, BY = 16;
+
+struct Cam {
+    float view[16], proj[16];
+    float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+    int W, H, gx, gy;
+};
+
+__device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
+
+__global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
+                                                   const float *__restrict__ cov3d_pre, const float *__restrict__ opac, Cam cam, int *__restrict__ radii,
+                                                   float2 *__restrict__ xy, float *__restrict__ depth, float4 *__restrict__ conic_op,
+                                                   uint32_t *__restrict__ tiles_touched)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= P) return;
+    radii[i] = 0;
+    if (tiles_touched) tiles_touched[i] = 0;
+    const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
+    const float *V = cam.view, *M = cam.proj;
+    // transformPoint4x3 / 4x4 with the row-vector (transposed) matrices the Python side passes
+    const float tx0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
+    const float ty0 = V[1] * px + V[5] * py + V[9] * pz + V[13];
+    const float tz = V[2] * px + V[6] * py + V[10] * pz + V[14];
+    if (tz <= 0.2f) return;  // in_frustum
+    const float hx = M[0] * px + M[4] * py + M[8] * pz + M[12];
+    const float hy = M[1] * px + M[5] * py + M[9] * pz + M[13];
+    const float hw = M[3] * px + M[7] * py + M[11] * pz + M[15];
+    const float pw = 1.0f / (hw + 0.0000001f);
+    const float prx = hx * pw, pry = hy * pw;
+    // 3-D covariance (upper triangle)
+    float c[6];
+    if (cov3d_pre) {
+        for (int k = 0; k < 6; ++k) c[k] = cov3d_pre[6 * i + k];
+    } else {
+        const float sx = cam.scale_modifier * scales[3 * i], sy = cam.scale_modifier * scales[3 * i + 1], sz = cam.scale_modifier * scales[3 * i + 2];
+        const float r = rots[4 * i], x = rots[4 * i + 1], y = rots[4 * i + 2], z = rots[4 * i + 3];
+        // R (row-major) from the quaternion (r, x, y, z); M = S * R; Sigma = M^T M
+        const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+        const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+        const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+        // Sigma = R diag(s^2) R^T  (== M^T M with glm's column-major M = S * R)
+        const float ax = sx * sx, ay = sy * sy, az = sz * sz;
+        c[0] = ax * R00 * R00 + ay * R01 * R01 + az * R02 * R02;
+        c[1] = ax * R00 * R10 + ay * R01 * R11 + az * R02 * R12;
+        c[2] = ax * R00 * R20 + ay * R01 * R21 + az * R02 * R22;
+        c[3] = ax * R10 * R10 + ay * R11 * R11 + az * R12 * R12;
+        c[4] = ax * R10 * R20 + ay * R11 * R21 + az * R12 * R22;
+        c[5] = ax * R20 * R20 + ay * R21 * R21 + az * R22 * R22;
+    }
+    // 2-D covariance: A Sigma A^T, A = J * Rwc, with the +-1.3 tan(fov) clamp of the view-space position
+    const float limx = 1.3f * cam.tan_fovx, limy = 1.3f * cam.tan_fovy;
+    const float tx = fminf(limx, fmaxf(-limx, tx0 / tz)) * tz;
+    const float ty = fminf(limy, fmaxf(-limy, ty0 / tz)) * tz;
+    const float j00 = cam.focal_x / tz, j02 = -(cam.focal_x * tx) / (tz * tz);
+    const float j11 = cam.focal_y / tz, j12 = -(cam.focal_y * ty) / (tz * tz);
+    const float a0x = j00 * V[0] + j02 * V[2], a0y = j00 * V[4] + j02 * V[6], a0z = j00 * V[8] + j02 * V[10];
+    const float a1x = j11 * V[1] + j12 * V[2], a1y = j11 * V[5] + j12 * V[6], a1z = j11 * V[9] + j12 * V[10];
+    const float s0x = c[0] * a0x + c[1] * a0y + c[2] * a0z, s0y = c[1] * a0x + c[3] * a0y + c[4] * a0z, s0z = c[2] * a0x + c[4] * a0y + c[5] * a0z;
+    const float s1x = c[0] * a1x + c[1] * a1y + c[2] * a1z, s1y = c[1] * a1x + c[3] * a1y + c[4] * a1z, s1z = c[2] * a1x + c[4] * a1y + c[5] * a1z;
+    const float cxx = a0x * s0x + a0y * s0y + a0z * s0z + 0.3f;
+    const float cxy = a0x * s1x + a0y * s1y + a0z * s1z;
+    const float cyy = a1x * s1x + a1y * s1y + a1z * s1z + 0.3f;
+    const float det = cxx * cyy - cxy * cxy;
+    if (det == 0.0f) return;
+    const float det_inv = 1.0f / det;
+    const float mid = 0.5f * (cxx + cyy);
+    const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.0f * sqrtf(lam));  // lambda1 >= lambda2
+    const float ix = ndc2pix(prx, cam.W), iy = ndc2pix(pry, cam.H);
+    const int rx0 = min(cam.gx, max(0, (int)((ix - my_radius) / BX))), ry0 = min(cam.gy, max(0, (int)((iy - my_radius) / BY)));
+    const int rx1 = min(cam.gx, max(0, (int)((ix + my_radius + BX - 1) / BX))), ry1 = min(cam.gy, max(0, (int)((iy + my_radius + BY - 1) / BY)));
+    const int area = (rx1 - rx0) * (ry1 - ry0);
+    if (area == 0) return;
+    radii[i] = (int)my_radius;
+    if (tiles_touched) {
+        tiles_touched[i] = (uint32_t)area;
+        xy[i] = make_float2(ix, iy);
+        depth[i] = tz;
+        conic_op[i] = make_float4(cyy * det_inv, -cxy * det_inv, cxx * det_inv, opac[i]);
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restrict__ xy, const float *__restrict__ depth, const uint32_t *__restrict__ offs,
+                                                  const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= P || radii[i] <= 0) return;
+    uint32_t off = offs[i];
+    const float r = (float)radii[i];
+    const float2 p = xy[i];
+    const int rx0 = min(gx, max(0, (int)((p.x - r) / BX))), ry0 = min(gy, max(0, (int)((p.y - r) / BY)));
+    const int rx1 = min(gx, max(0, (int)((p.x + r + BX - 1) / BX))), ry1 = min(gy, max(0, (int)((p.y + r + BY - 1) / BY)));
+    const uint32_t dbits = __float_as_uint(depth[i]);
+    for (int y = ry0; y < ry1; ++y)
+        for (int x = rx0; x < rx1; ++x) {
+            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+            vals[off] = (uint32_t)i;
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(TB) void k_tile_ranges(int L, const uint64_t *__restrict__ keys, uint2 *__restrict__ ranges)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= L) return;
+    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    if (i == 0) ranges[t].x = 0;
+    else {
+        const uint32_t pt = (uint32_t)(keys[i - 1] >> 32);
+        if (t != pt) { ranges[pt].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
+    }
+    if (i == L - 1) ranges[t].y = (uint32_t)L;
+}
+
+__global__ __launch_bounds__(BX * BY) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int gx,
+                                                     const float2 *__restrict__ xy, const float *__restrict__ colors, const float4 *__restrict__ conic_op,
+                                                     float bg0, float bg1, float bg2, float *__restrict__ out)
+{
+    __shared__ float2 s_xy[BX * BY];
+    __shared__ float4 s_co[BX * BY];
+    __shared__ float s_rgb[BX * BY * 3];
+    const int tile = blockIdx.y * gx + blockIdx.x;
+    const int pxi = blockIdx.x * BX + (threadIdx.x & 15), pyi = blockIdx.y * BY + (threadIdx.x >> 4);
+    const bool inside = pxi < W && pyi < H;
+    const float pxf = (float)pxi, pyf = (float)pyi;
+    const uint2 range = ranges[tile];
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    for (uint32_t b0 = range.x; b0 < range.y; b0 += BX * BY) {
+        if (__syncthreads_count(done) == BX * BY) break;
+        const uint32_t k = b0 + threadIdx.x;
+        if (k < range.y) {
+            const uint32_t id = point_list[k];
+            s_xy[threadIdx.x] = xy[id];
+            s_co[threadIdx.x] = conic_op[id];
+            s_rgb[3 * threadIdx.x] = colors[3 * id]; s_rgb[3 * threadIdx.x + 1] = colors[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = colors[3 * id + 2];
+        }
+        __syncthreads();
+        const int cnt = (int)min((uint32_t)(BX * BY), range.y - b0);
+        for (int j = 0; !done && j < cnt; ++j) {
+            const float2 p = s_xy[j];
+            const float dx = p.x - pxf, dy = p.y - pyf;
+            const float4 co = s_co[j];
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < 1.0f / 255.0f) continue;
+            const float test_T = T * (1.0f - alpha);
+            if (test_T < 0.0001f) { done = true; continue; }
+            const float wgt = alpha * T;
+            C0 += s_rgb[3 * j] * wgt; C1 += s_rgb[3 * j + 1] * wgt; C2 += s_rgb[3 * j + 2] * wgt;
+            T = test_T;
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)pyi * W + pxi, plane = (size_t)W * H;
+        out[pix] = C0 + T * bg0;
+        out[plane + pix] = C1 + T * bg1;
+        out[2 * plane + pix] = C2 + T * bg2;
+    }
+}
+
+int make_cam(Cam *cam, int W, int H, const float *view_dev, const float *proj_dev, float tan_fovx, float tan_fovy, float scale_modifier)
+{
+    HIP_TRY(hipMemcpy(cam->view, view_dev, 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(cam->proj, proj_dev, 64, hipMemcpyDeviceToHost));
+    cam->tan_fovx = tan_fovx; cam->tan_fovy = tan_fovy;
+    cam->focal_x = (float)W / (2.0f * tan_fovx); cam->focal_y = (float)H / (2.0f * tan_fovy);
+    cam->scale_modifier = scale_modifier;
+    cam->W = W; cam->H = H; cam->gx = (W + BX - 1) / BX; cam->gy = (H + BY - 1) / BY;
+    return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const float *means3D, const float *scales, float scale_modifier,
+                                  const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                  float tan_fovx, float tan_fovy, int prefiltered, int *radii, void *stream)
+{
+    (void)prefiltered;
+    if (!ctx || !means3D || !viewmatrix || !projmatrix || !radii) return fail(GPCC_ERR_ARG, "null argument");
+    if (!cov3D_precomp && (!scales || !rotations)) return fail(GPCC_ERR_ARG, "provide scales + rotations or cov3D_precomp");
+    if (P <= 0) return GPCC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    Cam cam;
+    GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
+    k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W, int H, const float *means3D, const float *colors_precomp,
+                           const float *opacities, const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                           const float *viewmatrix, const float *projmatrix, float tan_fovx, float tan_fovy, int prefiltered, float *out_color,
+                           int *radii, int64_t *num_rendered_out, void *stream)
+{
+    (void)prefiltered;
+    if (!ctx || !background || !viewmatrix || !projmatrix || !out_color) return fail(GPCC_ERR_ARG, "null argument");
+    if (P > 0 && (!means3D || !colors_precomp || !opacities || !radii)) return fail(GPCC_ERR_ARG, "null argument");
+    if (P > 0 && !cov3D_precomp && (!scales || !rotations)) return fail(GPCC_ERR_ARG, "provide scales + rotations or cov3D_precomp");
+    if (W <= 0 || H <= 0) return fail(GPCC_ERR_ARG, "bad image size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipStreamSynchronize(st));
+    Cam cam;
+    GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
+    float bg[3];
+    HIP_TRY(hipMemcpy(bg, background, 12, hipMemcpyDeviceToHost));
+    const int ntiles = cam.gx * cam.gy;
+    size_t want = (size_t)std::max(P, 1) * 64 + (size_t)ntiles * 8 + ((size_t)8 << 20);
+    uint32_t L = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        GP_TRY(ctx->arena.reserve(want + (size_t)L * 40));
+        ctx->arena.reset();
+        TAKE(xy, float2, std::max(P, 1)); TAKE(depth, float, std::max(P, 1)); TAKE(conic_op, float4, std::max(P, 1));
+        TAKE(touched, uint32_t, std::max(P, 1) + 1); TAKE(ranges, uint2, ntiles);
+        HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st));
+        if (P > 0) {
+            k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched);
+            LAUNCH_CHECK();
+            GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
+            HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (num_rendered_out) *num_rendered_out = L;
+        uint32_t *vals_sorted = nullptr;
+        if (L > 0) {
+            uint64_t *ka = ctx->arena.take<uint64_t>(L), *kb = ctx->arena.take<uint64_t>(L);
+            uint32_t *va = ctx->arena.take<uint32_t>(L), *vb = ctx->arena.take<uint32_t>(L);
+            if (!ka || !kb || !va || !vb || ctx->arena.cap - ctx->arena.off < (size_t)L * 2 + ((size_t)2 << 20)) { want += (size_t)L * 4; continue; }  // grow and redo
+            k_duplicate<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, xy, depth, touched, radii, cam.gx, cam.gy, ka, va);
+            LAUNCH_CHECK();
+            int tbits = 1;
+            while ((1 << tbits) < ntiles) ++tbits;
+            uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
+            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, 32 + tbits));
+            k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, ranges);
+            LAUNCH_CHECK();
+            vals_sorted = v0;
+        }
+        k_render<<<dim3((unsigned)cam.gx, (unsigned)cam.gy), BX * BY, 0, st>>>(ranges, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
+        LAUNCH_CHECK();
+        HIP_TRY(hipStreamSynchronize(st));
+        return GPCC_OK;
+    }
+    return fail(GPCC_ERR_NOMEM, "rasteriser workspace");
+}

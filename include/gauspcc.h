@@ -174,6 +174,21 @@ GPCC_API int gsge_forward(gpcc_ctx *ctx, const float *inputs_dev, const float *e
                           const int32_t *resolutions_dev, float *outputs_dev, int64_t n, int num_dim, int n_features, int n_levels,
                           int rb, const uint8_t *binary_vxl_dev, const int32_t *min_level_id_dev, void *stream);
 
+/* ================= Gaussian splat rasteriser, forward only (a20) =================
+ * diff_gaussian_rasterization (Scaffold-GS fork; zip missing from the reference tree).  Mirrors the C++ API the
+ * reference's viewer calls: CudaRasterizer::Rasterizer::visible_filter / ::forward,
+ * TC-GS/SIBR_viewers/src/projects/gaussianviewer/renderer/GaussianView.cpp:535-553, 660-688; Python call
+ * sites HAC/gaussian_renderer/__init__.py:199-225, 268-303.  All pointers are device pointers; viewmatrix /
+ * projmatrix are the 4x4 row-vector (transposed) matrices of HAC/scene/cameras.py:48-57; colours are
+ * precomputed (shs = None in every call site); out_color is (3, H, W). */
+GPCC_API int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const float *means3D, const float *scales, float scale_modifier,
+                                const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                                float tan_fovx, float tan_fovy, int prefiltered, int *radii, void *stream);
+GPCC_API int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W, int H, const float *means3D, const float *colors_precomp,
+                         const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+                         const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, float tan_fovx, float tan_fovy,
+                         int prefiltered, float *out_color, int *radii, int64_t *num_rendered_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,8 @@ def lib():
         L.orc_hac_encode.argtypes = [vp, i32, vp, i64, i32, vp, i64, vp]
         L.orc_hac_decode.argtypes = [vp, i32, vp, vp, i64, i32, vp]
         L.orc_grid_forward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
+        L.orc_raster_forward.restype = i64
+        L.orc_raster_forward.argtypes = [i32, vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_float, C.c_float, vp, vp]
         _LIB = L
     return _LIB
 
@@ -296,3 +298,17 @@ def grid_forward(inputs, emb, offsets, resolutions, rb=128, binary_vxl=None, min
     ml = None if min_level_id is None else np.ascontiguousarray(min_level_id, dtype=np.int32)
     lib().orc_grid_forward(_p(inputs), _p(emb), _p(offsets), _p(resolutions), _p(out), n, d, f, nl, rb, _p(bv), _p(ml))
     return out
+
+
+def raster_forward(bg, W, H, means, colors, opac, scales, scale_modifier, rots, viewmatrix, projmatrix, tan_fovx, tan_fovy):
+    """Rasteriser forward restated.  colors=None -> radii only (visible_filter).
+    Returns (image (3,H,W) or None, radii (P,) int32, number of (tile, gaussian) instances)."""
+    f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+    means, colors, opac, scales, rots, bg = f(means), f(colors), f(opac), f(scales), f(rots), f(bg)
+    V, M = f(viewmatrix).reshape(-1), f(projmatrix).reshape(-1)
+    P = means.shape[0]
+    radii = np.zeros(P, dtype=np.int32)
+    out = None if colors is None else np.zeros((3, H, W), dtype=np.float32)
+    n = lib().orc_raster_forward(P, _p(bg), W, H, _p(means), _p(colors), _p(opac), _p(scales), float(scale_modifier), _p(rots), _p(V), _p(M),
+                                 float(tan_fovx), float(tan_fovy), _p(out), _p(radii))
+    return out, radii, int(n)

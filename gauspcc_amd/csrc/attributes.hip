@@ -49,21 +49,30 @@ __global__ __launch_bounds__(TB) void k_hac_pack(const float *__restrict__ cdf, 
 }
 
 // ------------------------------------------------------------------ decode: one wave per chunk
-struct WaveBits {  // every lane holds the same reader state (broadcast loads)
-    const uint8_t *p, *end;
+struct WaveBits {  // every lane holds the same reader state (wave-uniform addresses: broadcast loads); see BitIn in rangecoder.hip
+    const uint8_t *p;
+    int32_t rem;
+    uint32_t nw;
     uint64_t buf;
     uint32_t n;
+    __device__ __forceinline__ static uint32_t fetch(const uint8_t *q, int32_t rem)
+    {
+        uint32_t w;
+        __builtin_memcpy(&w, q, 4);
+        w = __builtin_bswap32(w);
+        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem));
+        return w & keep;
+    }
+    __device__ __forceinline__ void init(const uint8_t *base, uint32_t nbytes) { p = base; rem = (int32_t)nbytes; buf = 0; n = 0; nw = fetch(p, rem); }
     __device__ __forceinline__ uint32_t take(uint32_t k)
     {
         if (n <= 32) {
-            uint32_t wv = 0;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wv = (wv << 8) | (p + q < end ? (uint32_t)p[q] : 0u);
-            p += 4;
-            buf |= (uint64_t)wv << (32 - n);
+            buf |= (uint64_t)nw << (32 - n);
             n += 32;
+            p += 4; rem -= 4;
+            nw = fetch(p, rem);
         }
-        const uint32_t r = (uint32_t)(buf >> (64 - k));
+        const uint32_t r = (uint32_t)((buf >> 1) >> (63 - k));
         buf <<= k;
         n -= k;
         return r;
@@ -80,7 +89,8 @@ __global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf
     const int cn = (int)min((int64_t)chunk, n - base);
     const float scale = (float)(65536 - (lp - 1));
     const int max_symbol = lp - 2;
-    WaveBits in = {bytes + cnt_cum[c], bytes + cnt_cum[c] + cnt[c], 0, 0};
+    WaveBits in;
+    in.init(bytes + cnt_cum[c], (uint32_t)cnt[c]);
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = in.take(32);
     const int nseg = (lp - 1 + 63) / 64;  // indices 0 .. lp-2 are searched
@@ -124,9 +134,11 @@ __global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf
             high = (low - 1u) + hi;
             low = low + lo;
             const int n1 = clz32(low ^ high);
-            if (n1) { low <<= n1; high = (high << n1) | ((1u << n1) - 1u); value = (value << n1) | in.take((uint32_t)n1); }
+            low <<= n1; high = (high << n1) | ((1u << n1) - 1u); value = (value << n1) | in.take((uint32_t)n1);
             const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-            if (n2) { low = (low << n2) & 0x7FFFFFFFu; high = (high << n2) | 0x80000000u | ((1u << n2) - 1u); value = ((value << n2) ^ 0x80000000u) | in.take((uint32_t)n2); }
+            low = (low << n2) & (n2 ? 0x7FFFFFFFu : 0xFFFFFFFFu);
+            high = (high << n2) | (n2 ? 0x80000000u : 0u) | ((1u << n2) - 1u);
+            value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
         }
     }
 }

@@ -98,25 +98,39 @@ __global__ __launch_bounds__(256) void k_rc_compact(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------ decode
+// Bit reservoir over a chunk's bytes.  The next 32 bits of the stream are always already loaded (or in
+// flight) in `nw`, so a refill is a handful of ALU ops plus the ISSUE of one unaligned dword load whose
+// result is not needed before the following refill -- no wait on the decoder's critical path.  Bytes past
+// the end of the chunk read as zero (arithmetic_kernel.cu:244-262); the byte buffer is padded so the
+// load itself never leaves the allocation.
 struct BitIn {
-    const uint8_t *p, *end;
-    uint64_t buf;   // next bits in the top `n` bits
+    const uint8_t *p;   // address of the word held in nw
+    int32_t rem;        // bytes of the chunk at and after p (may go negative)
+    uint32_t nw;        // big-endian word at p, zero-masked beyond the chunk
+    uint64_t buf;       // next bits in the top `n` bits
     uint32_t n;
-    __device__ __forceinline__ void refill()
+    __device__ __forceinline__ static uint32_t fetch(const uint8_t *q, int32_t rem)
+    {
+        uint32_t w;
+        __builtin_memcpy(&w, q, 4);  // one global_load_dword (unaligned access is legal on gfx950)
+        w = __builtin_bswap32(w);
+        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem));
+        return w & keep;
+    }
+    __device__ __forceinline__ void init(const uint8_t *base, uint32_t nbytes)
+    {
+        p = base; rem = (int32_t)nbytes; buf = 0; n = 0;
+        nw = fetch(p, rem);
+    }
+    __device__ __forceinline__ uint32_t take(uint32_t k)  // k in [0, 32]
     {
         if (n <= 32) {
-            uint32_t wv = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wv = (wv << 8) | (p + k < end ? (uint32_t)p[k] : 0u);  // zero fill past the chunk (arithmetic_kernel.cu:244-262)
-            p += 4;
-            buf |= (uint64_t)wv << (32 - n);
+            buf |= (uint64_t)nw << (32 - n);
             n += 32;
+            p += 4; rem -= 4;
+            nw = fetch(p, rem);
         }
-    }
-    __device__ __forceinline__ uint32_t take(uint32_t k)  // k in [1, 32]
-    {
-        refill();
-        const uint32_t r = (uint32_t)(buf >> (64 - k));
+        const uint32_t r = (uint32_t)((buf >> 1) >> (63 - k));  // == buf >> (64 - k), and 0 for k == 0
         buf <<= k;
         n -= k;
         return r;
@@ -134,7 +148,8 @@ __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ c
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= nchunks) return;
     const RcChunk ch = chunks[c];
-    BitIn in = {bytes + ch.byte_off, bytes + ch.byte_off + ch.nbytes, 0, 0};
+    BitIn in;
+    in.init(bytes + ch.byte_off, ch.nbytes);
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = in.take(32);
     uint16_t v[16];
@@ -195,18 +210,15 @@ __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ c
         sym[ch.out + i] = (uint8_t)s;
         high = (low - 1u) + hi;
         low = low + lo;
-        const int n1 = clz32(low ^ high);
-        if (n1) {
-            low <<= n1;
-            high = (high << n1) | ((1u << n1) - 1u);
-            value = (value << n1) | in.take((uint32_t)n1);
-        }
+        // branch-free renormalisation: shifts by zero are no-ops
+        const int n1 = clz32(low ^ high);  // < 32: low < high
+        low <<= n1;
+        high = (high << n1) | ((1u << n1) - 1u);
+        value = (value << n1) | in.take((uint32_t)n1);
         const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-        if (n2) {
-            low = (low << n2) & 0x7FFFFFFFu;
-            high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
-            value = ((value << n2) ^ 0x80000000u) | in.take((uint32_t)n2);
-        }
+        low = (low << n2) & (n2 ? 0x7FFFFFFFu : 0xFFFFFFFFu);
+        high = (high << n2) | (n2 ? 0x80000000u : 0u) | ((1u << n2) - 1u);
+        value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
     }
 }
 

@@ -110,7 +110,7 @@ template <int R>
 static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
 {
     const int64_t nblk = cdiv(n, R);
-    T->nblk = nblk; T->R = R;
+    T->nblk = nblk; T->R = R; T->K = K;
     const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
     k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, T->first, nullptr, nullptr, nullptr, pairs_dev);
     LAUNCH_CHECK();

@@ -70,6 +70,7 @@ struct ConvTiles {
     uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
     int64_t nblk = 0;
     int R = CONV_R_MAX;
+    int K = 0;                 // kernel offsets
 };
 int conv_pick_rows(int64_t n);  // policy (env GAUSPCC_CONV_R overrides)
 // worst case over every admissible R: every pair alone in its tile, i.e. K tiles per 16 rows

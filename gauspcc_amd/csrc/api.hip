@@ -360,7 +360,6 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             TAKE(pairs, unsigned long long, 1);
             HIP_TRY(hipMemsetAsync(pairs, 0, 8, st));
             ConvTiles tiles;
-            GP_TRY(conv_tiles_alloc(ctx, n, K, &tiles));
             GP_TRY(conv_tiles_build(ctx, st, p, n, K, &tiles, pairs));
             // weights -> B-fragment order
             std::vector<float> wf((size_t)K * 1024);

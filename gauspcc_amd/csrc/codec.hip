@@ -43,8 +43,21 @@ int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int
 inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 inline uint32_t get32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-// two dense neighbour maps + two tile lists (K*81/16 bytes per node worst case) + features / symbols
-size_t arena_estimate(int64_t n, int K) { return (size_t)n * (size_t)(2 * K * 4 + 2 * (K * 81 / 16 + 8) + 2400) + ((size_t)48 << 20); }
+// encode keeps the whole tree resident: ~3 nodes per point, per node two dense neighbour maps (prior / target
+// set) + tile lists (~150 B) + ~12 feature rows of 128 B; grown and retried when a cloud needs more
+size_t arena_estimate(int64_t n, int K) { return (size_t)n * 3 * (size_t)(2 * K * 4 + 200 + 12 * 128 + 64) + (size_t)n * (size_t)(2 * K * 4) + ((size_t)64 << 20); }
+
+// per-row metadata of the concatenated coded levels: global parent row, lohi slot of stage 0, stage stride
+__global__ __launch_bounds__(256) void k_child_meta(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ m2r, int64_t n, uint32_t parent_base,
+                                                    uint32_t lohi_base, uint32_t slots, int chunk_log2, uint32_t nch, uint32_t *__restrict__ parent_out,
+                                                    uint32_t *__restrict__ pos_out, uint32_t *__restrict__ slots_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    parent_out[i] = parent_base + parent[i];
+    pos_out[i] = lohi_base + rc_interleaved(m2r[i], chunk_log2, nch);
+    slots_out[i] = slots;
+}
 
 int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t n, int chunk_log2, uint16_t posq,
                 const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, hipStream_t st)
@@ -63,55 +76,78 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     for (int d = 1; d < L; ++d) lohi_words += 4 * slots(T.lv[d].n);
     if (lohi_words >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many octree nodes");
     TAKE(lohi, uint32_t, std::max<int64_t>(lohi_words, 1));
-    TAKE(nbrA, int32_t, (int64_t)K * nmax);
-    TAKE(nbrB, int32_t, (int64_t)K * nmax);
     TAKE(pairs_dev, unsigned long long, MAXLV);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
-    int32_t *nbrP = nbrA, *nbrC = nbrB;
-    ConvTiles tilesA, tilesB;
-    GP_TRY(conv_tiles_alloc(ctx, nmax, K, &tilesA));
-    GP_TRY(conv_tiles_alloc(ctx, nmax, K, &tilesB));
-    ConvTiles *tilesP = &tilesA, *tilesC = &tilesB;
-    GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, nbrP));
-    GP_TRY(conv_tiles_build(ctx, st, nbrP, T.lv[0].n, K, tilesP, pairs_dev));
-    int64_t prefix = 0;
-    for (int d = 0; d + 1 < L; ++d) {
-        const Level *par = &T.lv[d], *chi = &T.lv[d + 1];
-        const int64_t np = par->n, nc = chi->n;
-        GP_TRY(nbr_child(ctx, st, par, nbrP, chi, m->k, nbrC));
-        GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, tilesC, pairs_dev + d + 1));
-        const size_t mk = ctx->arena.mark();
-        TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
-        GP_TRY(embed_occ(st, m->prior_emb, par->occ, np, pF));
-        GP_TRY(run_trunk(ctx, d, st, m, 0, Trunk{pF, pA, pB}, *tilesP, np));           // -> pA
-        TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32);
-        GP_TRY(child_features(st, pA, chi->parent, chi->rkey, m->temb, nc, cX));
-        GP_TRY(run_trunk(ctx, d + 1, st, m, 5, Trunk{cX, cA, cB}, *tilesC, nc));       // -> cA  (X of pcc_utils.py:109)
-        // stages: cX, cB are free now; inputs u[s], mid v[s], outputs back into u[s]
-        TAKE(u1, float, nc * 32); TAKE(u2, float, nc * 32); TAKE(u3, float, nc * 32);
-        TAKE(v1, float, nc * 32); TAKE(v2, float, nc * 32);
+    // Encoding is teacher-forced, so every level is independent of the others: all parent levels are
+    // concatenated into one "prior set" P (levels 0..L-2) and all coded levels into one "target set" C
+    // (levels 1..L-1).  Each of the 18 network layers is then ONE launch over a set instead of one per level.
+    int64_t nP = 0;
+    for (int d = 0; d + 1 < L; ++d) nP += T.lv[d].n;
+    const int64_t nC = coded;
+    if (L > 1) {
+        int64_t pb[MAXLV] = {0}, cbase[MAXLV] = {0};
+        for (int d = 1; d < L; ++d) { pb[d] = pb[d - 1] + T.lv[d - 1].n; }
+        for (int d = 2; d < L; ++d) { cbase[d] = cbase[d - 1] + T.lv[d - 1].n; }
+        TAKE(nbrPs, int32_t, (int64_t)K * nP);
+        TAKE(nbrCs, int32_t, (int64_t)K * nC);
+        TAKE(occP, uint8_t, nP); TAKE(occC, uint8_t, nC); TAKE(rkeyC, uint64_t, nC);
+        TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
+        {   // per-level neighbour maps (top-down, two buffers) copied into the set maps
+            const size_t mk = ctx->arena.mark();
+            TAKE(nbrA, int32_t, (int64_t)K * nmax);
+            TAKE(nbrB, int32_t, (int64_t)K * nmax);
+            int32_t *cur = nbrA, *nxt = nbrB;
+            GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, cur));
+            int64_t lohi_base = 0;
+            for (int d = 0; d < L; ++d) {
+                const Level *lv = &T.lv[d];
+                if (d + 1 < L) {
+                    GP_TRY(nbr_concat(ctx, st, cur, lv->n, K, nbrPs, nP, pb[d]));
+                    HIP_TRY(hipMemcpyAsync(occP + pb[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                }
+                if (d >= 1) {
+                    GP_TRY(nbr_concat(ctx, st, cur, lv->n, K, nbrCs, nC, cbase[d]));
+                    HIP_TRY(hipMemcpyAsync(occC + cbase[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                    HIP_TRY(hipMemcpyAsync(rkeyC + cbase[d], lv->rkey, 8 * (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                    const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << chunk_log2) : 1u;
+                    k_child_meta<<<(unsigned)cdiv(lv->n, 256), 256, 0, st>>>(lv->parent, lv->m2r, lv->n, (uint32_t)pb[d - 1], (uint32_t)lohi_base, (uint32_t)slots(lv->n),
+                                                                             chunk_log2, nch, parentC + cbase[d], posC + cbase[d], slotsC + cbase[d]);
+                    LAUNCH_CHECK();
+                    lohi_base += 4 * slots(lv->n);
+                }
+                if (d + 1 < L) { GP_TRY(nbr_child(ctx, st, lv, cur, &T.lv[d + 1], m->k, nxt)); std::swap(cur, nxt); }
+            }
+            ctx->arena.rewind(mk);
+        }
+        ConvTiles tilesP, tilesC;
+        GP_TRY(conv_tiles_build(ctx, st, nbrPs, nP, K, &tilesP, pairs_dev));
+        GP_TRY(conv_tiles_build(ctx, st, nbrCs, nC, K, &tilesC, pairs_dev + 1));
+        TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
+        GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF));
+        GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
+        TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
+        GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX));
+        GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)
+        // stages: cX, cB are free now; inputs u[s], mid v[s], outputs y[s]
+        TAKE(u1, float, nC * 32); TAKE(u2, float, nC * 32); TAKE(u3, float, nC * 32);
+        TAKE(v1, float, nC * 32); TAKE(v2, float, nC * 32);
         float *u[4] = {cA, u1, u2, u3};
         float *v[4] = {cX, cB, v1, v2};
-        for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], chi->occ, s, nc, u[s]));
+        for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], occC, s, nC, u[s]));
         ConvBatch cb = {};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
-        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, *tilesC, nc, 1));
-        TAKE(y0, float, nc * 32);
-        float *y[4] = {y0, u1, u2, u3};   // u[0] = cA must survive only until conv a is done; still use a fresh buffer for clarity
+        GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 1));
+        TAKE(y0, float, nC * 32);
+        float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
-        GP_TRY(sparse_conv(ctx, d + 1, st, cb, 4, *tilesC, nc, 0));
+        GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};
-            ha.x = y[s]; ha.n = nc; ha.stage_m = STAGE_M[s];
+            ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
-            ha.m2r = chi->m2r; ha.occ = chi->occ; ha.stage = s; ha.lohi = lohi + prefix + (int64_t)s * slots(nc); ha.mode = 0;
-            ha.chunk_log2 = chunk_log2; ha.nch = chunk_log2 ? (uint32_t)cdiv(nc, (int64_t)1 << chunk_log2) : 1u;
+            ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
             GP_TRY(head_cdf(st, ha));
         }
-        ctx->arena.rewind(mk);
-        prefix += 4 * slots(nc);
-        std::swap(nbrP, nbrC);
-        std::swap(tilesP, tilesC);
     }
     // ---- range coder over every chunk of every stream
     const int nstreams = 4 * (L - 1);
@@ -172,7 +208,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
     if (nchunks) total_payload = hcnt[nchunks];
-    if (ctx->prof.on) GP_TRY(prof_collect(ctx, reinterpret_cast<const unsigned long long *>(hs + off_pairs), L));
+    if (ctx->prof.on) GP_TRY(prof_collect(ctx, reinterpret_cast<const unsigned long long *>(hs + off_pairs), 2));
     // ---- container
     size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
     GP_TRY(ctx->hbytes.reserve(fsize + 16));
@@ -215,12 +251,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         memset(stats, 0, sizeof *stats);
         stats->num_points = n; stats->num_bytes = (int64_t)pos; stats->num_levels = L; stats->coded_nodes = coded;
         const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hs + off_pairs);
-        int64_t cp = 0;
-        for (int d = 0; d < L; ++d) {
-            stats->level_nodes[d] = T.lv[d].n;
-            cp += (int64_t)hp[d] * ((d + 1 < L ? 5 : 0) + (d > 0 ? 13 : 0));
-        }
-        stats->conv_pairs = cp;
+        for (int d = 0; d < L; ++d) stats->level_nodes[d] = T.lv[d].n;
+        stats->conv_pairs = (int64_t)hp[0] * 5 + (int64_t)hp[1] * 13;   // prior set: 5 convs, target set: 5 + 8
     }
     return GPCC_OK;
 }
@@ -323,7 +355,6 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     TAKE(pairs_dev, unsigned long long, MAXLV);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
     ConvTiles tilesP;
-    GP_TRY(conv_tiles_alloc(ctx, bn, K, &tilesP));
     GP_TRY(conv_tiles_build(ctx, st, nbrP, bn, K, &tilesP, pairs_dev));
     int64_t coded = 0;
     std::vector<RcChunk> chunks;
@@ -349,7 +380,6 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(nbrC, int32_t, (int64_t)K * nc);
         GP_TRY(nbr_child(ctx, st, &cur, nbrP, &chi, m->k, nbrC));
         ConvTiles tilesC;
-        GP_TRY(conv_tiles_alloc(ctx, nc, K, &tilesC));
         GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
         // chunk descriptors of this level's four streams
         const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;

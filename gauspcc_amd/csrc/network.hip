@@ -95,27 +95,26 @@ int conv_pick_rows(int64_t n)
     return 16;
 }
 
-int conv_tiles_alloc(gpcc_ctx *ctx, int64_t n_cap, int K, ConvTiles *T)
-{
-    const int64_t cap = conv_tiles_capacity(n_cap, K);
-    TAKE(first, uint32_t, conv_blocks_capacity(n_cap) + 1);
-    TAKE(tj, int32_t, cap * 16);
-    TAKE(tr, uint8_t, cap * 16);
-    TAKE(toc, uint32_t, cap);
-    T->first = first; T->tj = tj; T->tr = tr; T->toc = toc; T->nblk = 0;
-    return GPCC_OK;
-}
-
 template <int R>
 static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
 {
     const int64_t nblk = cdiv(n, R);
     T->nblk = nblk; T->R = R; T->K = K;
+    TAKE(first, uint32_t, nblk + 1);
+    T->first = first;
     const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
-    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, T->first, nullptr, nullptr, nullptr, pairs_dev);
+    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, nullptr, nullptr, nullptr, pairs_dev);
     LAUNCH_CHECK();
-    GP_TRY(exclusive_scan_u32(ctx, st, T->first, T->first, nblk, T->first + nblk));
-    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, T->first, T->tj, T->tr, T->toc, nullptr);
+    GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
+    uint32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int64_t cap = (int64_t)total + 4;  // the conv kernel's clamped prefetch never reads past the last tile
+    TAKE(tj, int32_t, cap * 16);
+    TAKE(tr, uint8_t, cap * 16);
+    TAKE(toc, uint32_t, cap);
+    T->tj = tj; T->tr = tr; T->toc = toc;
+    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -494,7 +493,8 @@ __global__ __launch_bounds__(TB) void k_head(HeadArgs a)
 #pragma unroll
         for (int j = 0; j < M; ++j)
             if (j == sym) { lo = v[j]; hi = j == M - 1 ? 0x10000u : v[j + 1]; }
-        a.lohi[rc_interleaved(a.m2r[i], a.chunk_log2, a.nch)] = lo | ((hi - 1u) << 16);
+        const size_t slot = a.pos ? (size_t)a.pos[i] + (size_t)a.stage * a.slots[i] : (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch);
+        a.lohi[slot] = lo | ((hi - 1u) << 16);
     } else if (MODE == 1) {
         constexpr int RS = M == 2 ? 1 : M == 4 ? 4 : 16;
         uint16_t *dst = a.cdf + (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch) * RS;

@@ -73,12 +73,11 @@ struct ConvTiles {
     int K = 0;                 // kernel offsets
 };
 int conv_pick_rows(int64_t n);  // policy (env GAUSPCC_CONV_R overrides)
-// worst case over every admissible R: every pair alone in its tile, i.e. K tiles per 16 rows
-static inline int64_t conv_tiles_capacity(int64_t n, int K) { return (cdiv(n, 16) + 8) * (int64_t)K; }
 static inline int64_t conv_blocks_capacity(int64_t n) { return cdiv(n, 16) + 1; }
-// allocate from the arena for a level of up to n_cap nodes (worst case: every pair alone in its tile)
-int conv_tiles_alloc(gpcc_ctx *ctx, int64_t n_cap, int K, ConvTiles *T);
-// build from the dense neighbour map; if pairs_dev != nullptr the number of (node, neighbour) pairs is added to it
+// Build the tile list of a level (or of several concatenated levels) from its dense neighbour map.
+// Two passes over the map (count, fill) with one stream sync in between to size the arrays exactly
+// (the worst case -- every pair alone in its tile -- would be ~6x larger).  Arrays come from the arena.
+// If pairs_dev != nullptr the number of (node, neighbour) pairs is added to it.
 int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev);
 
 // out = conv(in) (+res) (relu); up to 4 independent jobs on the same tile list in one launch
@@ -106,6 +105,9 @@ struct HeadArgs {
     const uint32_t *m2r; const uint8_t *occ; int stage;
     uint32_t *lohi; uint16_t *cdf; float *prob; int mode;
     int chunk_log2; uint32_t nch;
+    // mode 0 over several concatenated levels: per-row slot of stage 0 and per-row stride between stages
+    // (then m2r / chunk_log2 / nch are unused)
+    const uint32_t *pos; const uint32_t *slots;
 };
 int head_cdf(hipStream_t st, const HeadArgs &a);
 

@@ -324,6 +324,22 @@ int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nb
     return GPCC_OK;
 }
 
+__global__ __launch_bounds__(TB) void k_nbr_concat(const int32_t *__restrict__ src, int64_t n, int32_t *__restrict__ dst, int64_t ntot, int64_t col_off)
+{
+    const int o = blockIdx.y;
+    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const int32_t v = src[(int64_t)o * n + i];
+    dst[(int64_t)o * ntot + col_off + i] = v >= 0 ? v + (int32_t)col_off : -1;
+}
+
+int nbr_concat(gpcc_ctx *ctx, hipStream_t st, const int32_t *src, int64_t n, int K, int32_t *dst, int64_t ntot, int64_t col_off)
+{
+    k_nbr_concat<<<dim3(nblk(n), (unsigned)K), TB, 0, st>>>(src, n, dst, ntot, col_off);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
 __global__ __launch_bounds__(TB) void k_nbr_count(const int32_t *__restrict__ nbrT, int64_t total, unsigned long long *__restrict__ count)
 {
     uint32_t c = 0;

@@ -75,6 +75,8 @@ int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t
 // neighbour map, offset-major: nbrT[o*n + i], o = (dx+r) + k*(dy+r) + k*k*(dz+r), -1 = absent
 int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT);
 int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT);
+// copy a level's map into the map of a set of concatenated levels: dst[o*ntot + col_off + i] = src[o*n + i] (+ col_off when present)
+int nbr_concat(gpcc_ctx *ctx, hipStream_t st, const int32_t *src, int64_t n, int K, int32_t *dst, int64_t ntot, int64_t col_off);
 // count present neighbours (pairs) into *count_dev (uint64 accumulate)
 int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev);
 

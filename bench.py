@@ -121,6 +121,14 @@ def main():
     allstats = np.array([[s.num_bytes, s.enc_s, s.dec_s, s.coded_nodes, s.conv_pairs] for s in scenes], dtype=np.float64)
 
     if rank == 0:
+        # HBM traffic of the conv kernel comes from separate rocprofv3 --pmc passes of this same command
+        # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_conv.json")) as f:
+                traffic = round(json.load(f)["hbm_bytes_per_launch"])
+        except Exception:
+            pass
         total_points = args.points * world * args.steps
         value = total_points / elapsed / 1e6
         conv_flops = 2.0 * 32 * 32 * prof.conv_pair_jobs
@@ -159,7 +167,8 @@ def main():
                 "peak": MFMA_F32_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "algorithmic_per_launch": conv_flops / max(prof.conv_launches, 1),
                 "launches": int(prof.conv_launches),
                 "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
                 "algorithmic_flops_per_step": conv_flops / args.steps,

@@ -56,7 +56,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run, also for a single rank
         import torch.distributed as dist
 
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI

@@ -85,7 +85,7 @@ int conv_pick_rows(int64_t n)
     if (forced < 0) {
         const char *e = getenv("GAUSPCC_CONV_R");
         forced = e ? atoi(e) : 0;
-        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 128) forced = 0;
+        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128) forced = 0;
     }
     if (forced) return forced;
     // enough waves to cover the chip a few times over before growing the block height
@@ -93,6 +93,14 @@ int conv_pick_rows(int64_t n)
     if (n >= 96 * 1024) return 64;
     if (n >= 24 * 1024) return 32;
     return 16;
+}
+
+__global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__ first, int nblk, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    key[b] = 0xFFFFFFFFull - (uint64_t)(first[b + 1] - first[b]);  // ascending sort of this = descending tile count
+    idx[b] = (uint32_t)b;
 }
 
 template <int R>
@@ -116,6 +124,19 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     T->tj = tj; T->tr = tr; T->toc = toc;
     k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
+    // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling)
+    TAKE(order, uint32_t, nblk);
+    {
+        const size_t mk = ctx->arena.mark();
+        TAKE(ka, uint64_t, nblk); TAKE(kb, uint64_t, nblk); TAKE(vb, uint32_t, nblk);
+        k_order_keys<<<(unsigned)cdiv(nblk, 256), 256, 0, st>>>(first, (int)nblk, ka, order);
+        LAUNCH_CHECK();
+        uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = order, *v1 = vb;
+        GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, nblk, 32));
+        if (v0 != order) HIP_TRY(hipMemcpyAsync(order, v0, 4 * (size_t)nblk, hipMemcpyDeviceToDevice, st));
+        ctx->arena.rewind(mk);
+    }
+    T->order = order;
     return GPCC_OK;
 }
 
@@ -126,6 +147,7 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
     case 16: return conv_tiles_build_r<16>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 32: return conv_tiles_build_r<32>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 64: return conv_tiles_build_r<64>(ctx, st, nbrT, n, K, T, pairs_dev);
+    case 96: return conv_tiles_build_r<96>(ctx, st, nbrT, n, K, T, pairs_dev);
     default: return conv_tiles_build_r<128>(ctx, st, nbrT, n, K, T, pairs_dev);
     }
 }
@@ -133,8 +155,8 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 // ------------------------------------------------------------------ convolution
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
-template <int R>
-__global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
+template <int R, int DIST>
+__global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
 {
     constexpr int CONV_LDS_WAVE = (R + 1) * 32;  // floats: R rows + 1 dummy row for padding entries
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -143,8 +165,9 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : 4)) void k_sparse_
     // everything derived from the wave index is wave-uniform: keep it in SGPRs (scalar loads for the tile
     // headers, scalar address arithmetic for the weight fragments)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int blk = blockIdx.x * CONV_WAVES + wave;
-    if (blk >= (int)T.nblk) return;  // no block-wide barrier below: every wave works on its own LDS slice
+    const int slot = blockIdx.x * CONV_WAVES + wave;
+    if (slot >= (int)T.nblk) return;  // no block-wide barrier below: every wave works on its own LDS slice
+    const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);
     float *acc = lds + wave * CONV_LDS_WAVE;
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
 #pragma unroll
@@ -197,35 +220,42 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : 4)) void k_sparse_
         for (int k = 0; k < 4; ++k) { acc[row[k] + col0] = c0[k]; acc[row[k] + col1] = c1[k]; }
     };
     if (t0 < t1) {
-        // Software pipeline inside one instruction stream, two tiles per iteration with ping-pong register
-        // sets X / Y: while tile t computes out of X the loads of tile t+1 land in Y and vice versa -- no
-        // register rotation, so nothing forces a load to complete inside the iteration that issued it.  The
-        // loop body is branch-free up to the odd tail (indices clamped to the last tile, padding entries
-        // gather row 0 and accumulate into the dummy LDS row) so that the compiler can count outstanding
-        // loads instead of draining them with s_waitcnt vmcnt(0).
+        // Software pipeline inside one instruction stream: a ring of RING = DIST + 1 register sets, RING tiles
+        // per (fully unrolled) iteration.  While tile t computes out of set t % RING the gathered rows and the
+        // weight fragment of tile t + DIST land in set (t + DIST) % RING, and the index words of tile
+        // t + DIST + 1 are fetched -- no register rotation of the big sets, so nothing forces a load to complete
+        // inside the step that issued it.  The body is branch-free up to the tail guard (indices clamped to
+        // the last tile, padding entries gather row 0 and accumulate into the dummy LDS row) so that the
+        // compiler can count outstanding loads instead of draining them with s_waitcnt vmcnt(0).
+        constexpr int RING = DIST + 1;
         const uint32_t tl = t1 - 1;
-        uint32_t tn = min(t0 + 1, tl);
-        uint32_t r4_cur = tr4[t0 * 4];
-        AB X = load_ab(tje[t0 * 16], toc[t0] & 0xFFFFu), Y;
-        int j1 = tje[tn * 16];
-        uint32_t r4_1 = tr4[tn * 4], o1 = toc[tn] & 0xFFFFu;
-        for (uint32_t t = t0; t < t1; t += 2) {
-            tn = min(t + 2, tl);
-            const int j2 = tje[tn * 16];
-            const uint32_t r4_2 = tr4[tn * 4], o2 = toc[tn] & 0xFFFFu;
-            Y = load_ab(j1, o1);
-            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's LDS reads + MFMAs (hipcc sinks it otherwise)
-            compute(X, r4_cur);
-            __builtin_amdgcn_sched_barrier(0);
-            tn = min(t + 3, tl);
-            j1 = tje[tn * 16];
-            r4_cur = r4_1;  // tile t+1's rows, consumed below
-            const uint32_t r4_3 = tr4[tn * 4], o3 = toc[tn] & 0xFFFFu;
-            X = load_ab(j2, o2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < t1) compute(Y, r4_cur);
-            __builtin_amdgcn_sched_barrier(0);
-            r4_cur = r4_2; r4_1 = r4_3; o1 = o3;
+        AB ring[RING];
+        uint32_t r4r[RING];
+        // prologue: tiles t0 .. t0+DIST-1 in flight, indices of tile t0+DIST ready
+#pragma unroll
+        for (int s = 0; s < DIST; ++s) {
+            const uint32_t tt = min(t0 + (uint32_t)s, tl);
+            r4r[s] = tr4[tt * 4];
+            ring[s] = load_ab(tje[tt * 16], toc[tt] & 0xFFFFu);
+        }
+        uint32_t tn = min(t0 + (uint32_t)DIST, tl);
+        int j_n = tje[tn * 16];
+        uint32_t r4_n = tr4[tn * 4], o_n = toc[tn] & 0xFFFFu;
+        for (uint32_t t = t0; t < t1; t += RING) {
+#pragma unroll
+            for (int s = 0; s < RING; ++s) {
+                constexpr int dummy = 0; (void)dummy;
+                const int sl = (s + DIST) % RING;            // set that receives tile t + s + DIST
+                tn = min(t + (uint32_t)(s + DIST + 1), tl);
+                const int j_nn = tje[tn * 16];
+                const uint32_t r4_nn = tr4[tn * 4], o_nn = toc[tn] & 0xFFFFu;
+                r4r[sl] = r4_n;
+                ring[sl] = load_ab(j_n, o_n);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's LDS reads + MFMAs (hipcc sinks it otherwise)
+                if (t + (uint32_t)s < t1) compute(ring[s], r4r[s]);
+                __builtin_amdgcn_sched_barrier(0);
+                j_n = j_nn; r4_n = r4_nn; o_n = o_nn;
+            }
         }
     }
     // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
@@ -268,16 +298,25 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 128-row blocks need 66048 B of LDS per workgroup (> the 64 KiB default cap)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
         lds_attr_set = true;
     }
+    static int dist = -1;
+    if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
     dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
     const size_t lds_bytes = (size_t)CONV_WAVES * (T.R + 1) * 128;
     switch (T.R) {
-    case 16: k_sparse_conv<16><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 32: k_sparse_conv<32><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 64: k_sparse_conv<64><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    default: k_sparse_conv<128><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 16: k_sparse_conv<16, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 32: k_sparse_conv<32, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 64: k_sparse_conv<64, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 96: k_sparse_conv<96, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    default:
+        if (dist == 3) k_sparse_conv<128, 3><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
+        else if (dist == 2) k_sparse_conv<128, 2><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
+        else k_sparse_conv<128, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
+        break;
     }
     LAUNCH_CHECK();
     if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }

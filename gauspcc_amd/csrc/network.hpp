@@ -59,7 +59,7 @@ struct ConvBatch { ConvJob job[4]; };
 // Compacted work list of one level: every wave owns R consecutive (Morton-ordered) output rows;
 // for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of
 // 16 rows (one v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per level, used by all
-// 5 / 13 convolutions that run on that level.  R (16, 32, 64 or 128) is picked per level: tall blocks
+// 5 / 13 convolutions that run on that level.  R (16, 32, 64, 96 or 128) is picked per level: tall blocks
 // pack tiles better, short blocks give more waves and shorter serial chains on small levels.
 // (Measured on MI355X, 1M-point cloud: 255-row blocks at 1 wave/SIMD lose to 128-row blocks at 2.)
 constexpr int CONV_R_MAX = 128;
@@ -68,6 +68,7 @@ struct ConvTiles {
     uint8_t *tr = nullptr;     // [tiles][16] output row inside the block (padding: R = the dummy row)
     uint32_t *toc = nullptr;   // [tiles]     offset | valid entries << 16
     uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
+    uint32_t *order = nullptr; // [nblk]      blocks sorted by tile count, longest first (dispatch order)
     int64_t nblk = 0;
     int R = CONV_R_MAX;
     int K = 0;                 // kernel offsets

@@ -191,15 +191,22 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
         r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
         return r;
     };
-    auto compute = [&](const AB &v, uint32_t r4) {
-        f32x4 c0, c1;
-        int row[4];
+    // The accumulator rows of a tile are read from LDS one tile EARLY: LDS operations of a wave execute in
+    // order, so issuing tile t+1's reads right behind tile t's writes is correct even when the two tiles
+    // share output rows, and their latency is covered by the next step's prefetch / bookkeeping.
+    struct CT { f32x4 c0, c1; int row[4]; };
+    auto fetch_c = [&](uint32_t r4) -> CT {
+        CT c;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            row[k] = (int)((r4 >> (8 * k)) & 255u) * 32;
-            c0[k] = acc[row[k] + col0];
-            c1[k] = acc[row[k] + col1];
+            c.row[k] = (int)((r4 >> (8 * k)) & 255u) * 32;
+            c.c0[k] = acc[c.row[k] + col0];
+            c.c1[k] = acc[c.row[k] + col1];
         }
+        return c;
+    };
+    auto compute = [&](const AB &v, CT c) {
+        f32x4 c0 = c.c0, c1 = c.c1;
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b00.x, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b10.x, c1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.y, v.b00.y, c0, 0, 0, 0);
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b01.w, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b11.w, c1, 0, 0, 0);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[row[k] + col0] = c0[k]; acc[row[k] + col1] = c1[k]; }
+        for (int k = 0; k < 4; ++k) { acc[c.row[k] + col0] = c0[k]; acc[c.row[k] + col1] = c1[k]; }
     };
     if (t0 < t1) {
         // Software pipeline inside one instruction stream: a ring of RING = DIST + 1 register sets, RING tiles
@@ -241,18 +248,21 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
         uint32_t tn = min(t0 + (uint32_t)DIST, tl);
         int j_n = tje[tn * 16];
         uint32_t r4_n = tr4[tn * 4], o_n = toc[tn] & 0xFFFFu;
+        CT cnext = fetch_c(r4r[0]);
         for (uint32_t t = t0; t < t1; t += RING) {
 #pragma unroll
             for (int s = 0; s < RING; ++s) {
-                constexpr int dummy = 0; (void)dummy;
                 const int sl = (s + DIST) % RING;            // set that receives tile t + s + DIST
                 tn = min(t + (uint32_t)(s + DIST + 1), tl);
                 const int j_nn = tje[tn * 16];
                 const uint32_t r4_nn = tr4[tn * 4], o_nn = toc[tn] & 0xFFFFu;
                 r4r[sl] = r4_n;
                 ring[sl] = load_ab(j_n, o_n);
-                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's LDS reads + MFMAs (hipcc sinks it otherwise)
-                if (t + (uint32_t)s < t1) compute(ring[s], r4r[s]);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (hipcc sinks it otherwise)
+                if (t + (uint32_t)s < t1) {
+                    compute(ring[s], cnext);
+                    cnext = fetch_c(r4r[(s + 1) % RING]);   // next tile's rows (the clamped prefetch makes this valid at the tail too)
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 j_n = j_nn; r4_n = r4_nn; o_n = o_nn;
             }

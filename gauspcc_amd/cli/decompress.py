@@ -1,0 +1,48 @@
+"""Decompress `.bin` files back to ASCII PLY (reference CLI: src/ai_pcc/GausPcgc/decompress_ue_4stage_conv.py:31-192).
+
+Same flags and defaults; each <name>.bin becomes <output_folder>/<name>.bin.ply (:64) and the summary
+line reports the mean decoding time.  The per-file codec is pcc_utils.decompress_point_cloud.
+"""
+import argparse
+import os
+from glob import glob
+
+import numpy as np
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="gauspcc_amd.cli.decompress", description="Decompress point cloud geometry data using unequal 4-stage convolution network",
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument("--input_glob", default="./data/kittidet_compressed/*.bin", help="Glob pattern for compressed bin files")
+    p.add_argument("--output_folder", default="./data/kittidet_decompressed/", help="Folder to save decompressed ply files")
+    p.add_argument("--is_data_pre_quantized", type=bool, default=False, help="Whether the original data was pre-quantized")
+    p.add_argument("--channels", type=int, help="Neural network channel count", default=32)
+    p.add_argument("--kernel_size", type=int, help="Convolution kernel size", default=3)
+    p.add_argument("--ckpt", help="Checkpoint loading path ('synthetic[:seed]' = seeded random weights)", default="./model/KITTIDetection/ckpt_ue_4stage_conv.pt")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    import torch
+
+    from .. import pcc_utils
+
+    os.makedirs(args.output_folder, exist_ok=True)
+    files = sorted(glob(args.input_glob))
+    if not files:
+        raise SystemExit(f"no input files match {args.input_glob}")
+    dec_time_ls = []
+    for path in files:
+        name = os.path.split(path)[-1]
+        r = pcc_utils.decompress_point_cloud(path, args.ckpt, os.path.join(args.output_folder, name + ".ply"), channels=args.channels,
+                                             kernel_size=args.kernel_size, is_data_pre_quantized=args.is_data_pre_quantized)
+        print(f"Points after decompression: {r['num_points']}")
+        dec_time_ls.append(r["dec_time"])
+    print("Total: {total_n:d} | Decoding time:{dec_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
+        total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=torch.cuda.max_memory_allocated() / 1024 / 1024))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -1,0 +1,63 @@
+"""Point-cloud file I/O of the codec CLIs (reference: src/ai_pcc/GausPcgc/kit/io.py:12-49).
+
+read_points keeps the reference's two readers -- KITTI `.bin` (float32 x,y,z,intensity) and the
+line-oriented ASCII reader that skips every line that is not all numbers (which is how it reads
+ASCII PLY) -- and adds `.npy` and binary little-endian PLY, which the reference's glob filter
+accepts (compress_ue_4stage_conv.py:58) but its reader cannot parse.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2", "uint16": "u2",
+              "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4", "double": "f8", "float64": "f8"}
+
+
+def _read_ply_binary(path, header_len, props, count):
+    dt = np.dtype([(n, "<" + _PLY_TYPES[t]) for t, n in props])
+    with open(path, "rb") as f:
+        f.seek(header_len)
+        v = np.frombuffer(f.read(dt.itemsize * count), dtype=dt, count=count)
+    return np.stack([v["x"], v["y"], v["z"]], axis=1).astype(np.float64)
+
+
+def read_points(filedir):
+    ext = os.path.splitext(filedir)[-1]
+    if ext == ".bin":
+        return np.fromfile(filedir, dtype=np.float32).reshape(-1, 4)[:, :3]
+    if ext == ".npy":
+        return np.load(filedir)[:, :3]
+    if ext == ".ply":
+        with open(filedir, "rb") as f:
+            head = f.read(4096)
+        end = head.find(b"end_header\n")
+        if end >= 0 and b"format binary_little_endian" in head[:end]:
+            props, count, in_vertex = [], 0, False
+            for line in head[:end].decode("ascii", "replace").split("\n"):
+                w = line.split()
+                if w[:2] == ["element", "vertex"]:
+                    count, in_vertex = int(w[2]), True
+                elif w[:1] == ["element"]:
+                    in_vertex = False
+                elif w[:1] == ["property"] and in_vertex:
+                    if w[1] == "list":
+                        raise ValueError(f"{filedir}: list property inside the vertex element")
+                    props.append((w[1], w[2]))
+            return _read_ply_binary(filedir, end + len(b"end_header\n"), props, count)
+    data = []
+    with open(filedir) as f:
+        for line in f:
+            try:
+                vals = [float(v) for v in line.split(" ") if v != "\n" and v != ""]
+            except ValueError:
+                continue
+            if vals:
+                data.append(vals)
+    return np.array(data)[:, 0:3]
+
+
+def read_point_clouds(file_path_list, workers=8):
+    print("Loading point clouds...")
+    with ThreadPoolExecutor(max_workers=workers) as p:
+        return list(p.map(read_points, file_path_list))

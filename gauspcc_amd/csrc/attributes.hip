@@ -35,15 +35,21 @@ __global__ __launch_bounds__(TB) void k_gaussian_cdf(const float *__restrict__ m
 }
 
 // ------------------------------------------------------------------ encode pre-pass
-__global__ __launch_bounds__(TB) void k_hac_pack(const float *__restrict__ cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
+// CDF entry -> integer: float rows are integerised on the fly (arithmetic_kernel.cu:124-125 == kit/op.py:67-79),
+// uint16 rows (torchac's *_int16_normalized_cdf) are used as they are
+__device__ __forceinline__ uint32_t cdf_int(const float *row, int m, float scale) { return (uint32_t)((int)__builtin_rintf(row[m] * scale) + m); }
+__device__ __forceinline__ uint32_t cdf_int(const uint16_t *row, int m, float) { return row[m]; }
+
+template <typename CT>
+__global__ __launch_bounds__(TB) void k_hac_pack(const CT *__restrict__ cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
                                                  uint32_t *__restrict__ lohi)
 {
     const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (r >= n) return;
     const float scale = (float)(65536 - (lp - 1));
     const int s = sym[r];
-    const uint32_t lo = (uint32_t)((int)__builtin_rintf(cdf[r * lp + s] * scale) + s);
-    const uint32_t hi = s == lp - 2 ? 0x10000u : (uint32_t)((int)__builtin_rintf(cdf[r * lp + s + 1] * scale) + s + 1);
+    const uint32_t lo = cdf_int(cdf + r * lp, s, scale);
+    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf_int(cdf + r * lp, s + 1, scale);
     const uint32_t c = (uint32_t)(r / chunk), t = (uint32_t)(r - (int64_t)c * chunk);
     lohi[(size_t)t * nch + c] = (lo & 0xFFFFu) | ((hi - 1u) << 16);
 }
@@ -81,7 +87,8 @@ struct WaveBits {  // every lane holds the same reader state (wave-uniform addre
 
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
-__global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
+template <typename CT>
+__global__ __launch_bounds__(64) void k_hac_decode(const CT *__restrict__ cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
                                                    const uint32_t *__restrict__ cnt_cum, int16_t *__restrict__ sym, int64_t n, int lp, int chunk)
 {
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -96,14 +103,14 @@ __global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf
     const int nseg = (lp - 1 + 63) / 64;  // indices 0 .. lp-2 are searched
     for (int i0 = 0; i0 < cn; i0 += 4) {
         // prefetch the first segment of the next four rows (rows do not depend on decoded symbols)
-        float pre[4];
+        uint32_t pre[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf[(base + i0 + u) * lp + lane] : 0.0f;
+        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf_int(cdf + (base + i0 + u) * lp, lane, scale) : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u;
             if (i >= cn) break;
-            const float *row = cdf + (base + i) * lp;
+            const CT *row = cdf + (base + i) * lp;
             const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
             const uint32_t x = value - low;
             int s;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf
             if (nseg == 1) {
                 // the whole row in one go: lane m integerises and scales cdf[m]; the symbol is the highest lane
                 // whose scaled bound is <= value - low (index 0 is never compared: binsearch starts with left = 0)
-                const uint32_t v = (uint32_t)((int)__builtin_rintf(pre[u] * scale) + lane);
+                const uint32_t v = pre[u];
                 const uint32_t t = (uint32_t)((span * (uint64_t)v) >> 16);
                 const uint64_t bal = __ballot(lane <= max_symbol && (lane == 0 || t <= x));
                 s = 63 - __clzll((long long)bal);
@@ -123,12 +130,12 @@ __global__ __launch_bounds__(64) void k_hac_decode(const float *__restrict__ cdf
                 int left = 0, right = max_symbol + 1;
                 while (left + 1 < right) {
                     const int m = (left + right) / 2;
-                    const uint32_t v = (uint32_t)((int)__builtin_rintf(row[m] * scale) + m);
+                    const uint32_t v = cdf_int(row, m, scale);
                     if ((uint32_t)((span * (uint64_t)v) >> 16) <= x) left = m; else right = m;
                 }
                 s = left;
-                lo = (uint32_t)((span * (uint64_t)(uint32_t)((int)__builtin_rintf(row[s] * scale) + s)) >> 16);
-                hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)(uint32_t)((int)__builtin_rintf(row[s + 1] * scale) + s + 1)) >> 16);
+                lo = (uint32_t)((span * (uint64_t)cdf_int(row, s, scale)) >> 16);
+                hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)cdf_int(row, s + 1, scale)) >> 16);
             }
             if (lane == 0) sym[base + i] = (int16_t)s;
             high = (low - 1u) + hi;
@@ -266,7 +273,7 @@ extern "C" int gsac_calculate_cdf(gpcc_ctx *ctx, const float *mean, const float 
     return GPCC_OK;
 }
 
-extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, const void *cdf, bool cdf_is_u16, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
                            int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
     if (!ctx || !sym || !cdf || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out) return fail(GPCC_ERR_ARG, "null argument");
@@ -283,7 +290,8 @@ extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, 
     TAKE(scratch, uint8_t, (size_t)nch * sstride); TAKE(payload, uint8_t, (size_t)nch * sstride);
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    k_hac_pack<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
+    if (cdf_is_u16) k_hac_pack<uint16_t><<<(unsigned)cdiv(n, TB), TB, 0, st>>>((const uint16_t *)cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
+    else k_hac_pack<float><<<(unsigned)cdiv(n, TB), TB, 0, st>>>((const float *)cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
     LAUNCH_CHECK();
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
@@ -302,7 +310,19 @@ extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, 
     return GPCC_OK;
 }
 
-extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+                           int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    return gsac_encode_impl(ctx, sym, cdf, false, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+}
+
+extern "C" int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym, const uint16_t *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+                               int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    return gsac_encode_impl(ctx, sym, cdf, true, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+}
+
+static int gsac_decode_impl(gpcc_ctx *ctx, const void *cdf, bool cdf_is_u16, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
                            int16_t *sym_out, void *stream)
 {
     if (!ctx || !cdf || !bytes || !cnt || !sym_out) return fail(GPCC_ERR_ARG, "null argument");
@@ -323,10 +343,23 @@ extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes
     HIP_TRY(hipMemcpyAsync(dcnt, cnt, 4 * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dcum, cum.data(), 4 * ((size_t)nch + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    k_hac_decode<<<(unsigned)nch, 64, 0, st>>>(cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
+    if (cdf_is_u16) k_hac_decode<uint16_t><<<(unsigned)nch, 64, 0, st>>>((const uint16_t *)cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
+    else k_hac_decode<float><<<(unsigned)nch, 64, 0, st>>>((const float *)cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
+}
+
+extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+                           int16_t *sym_out, void *stream)
+{
+    return gsac_decode_impl(ctx, cdf, false, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
+}
+
+extern "C" int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+                               int16_t *sym_out, void *stream)
+{
+    return gsac_decode_impl(ctx, cdf, true, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
 }
 
 extern "C" int gsge_forward(gpcc_ctx *ctx, const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,

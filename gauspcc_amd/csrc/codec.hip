@@ -146,6 +146,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
             ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
+            ha.bits = stats ? reinterpret_cast<double *>(pairs_dev + 8) : nullptr;   // slots 8..23 of the zeroed counter block
             GP_TRY(head_cdf(st, ha));
         }
     }
@@ -253,6 +254,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hs + off_pairs);
         for (int d = 0; d < L; ++d) stats->level_nodes[d] = T.lv[d].n;
         stats->conv_pairs = (int64_t)hp[0] * 5 + (int64_t)hp[1] * 13;   // prior set: 5 convs, target set: 5 + 8
+        const double *hb = reinterpret_cast<const double *>(hp + 8);
+        for (int i = 0; i < 16; ++i) stats->ideal_bits += hb[i];
     }
     return GPCC_OK;
 }

@@ -527,9 +527,11 @@ __global__ __launch_bounds__(TB) void k_head(HeadArgs a)
     uint32_t v[M + 1];
     v[0] = 0;
     float c = 0.0f;
+    float pr[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
         const float p = e[j] / s;
+        pr[j] = p;
         if (MODE == 2 && a.prob) a.prob[(size_t)i * M + j] = p;
         c = c + p;
         const float cc = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
@@ -544,6 +546,20 @@ __global__ __launch_bounds__(TB) void k_head(HeadArgs a)
             if (j == sym) { lo = v[j]; hi = j == M - 1 ? 0x10000u : v[j + 1]; }
         const size_t slot = a.pos ? (size_t)a.pos[i] + (size_t)a.stage * a.slots[i] : (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch);
         a.lohi[slot] = lo | ((hi - 1u) << 16);
+        if (a.bits) {  // ideal code length of the ground-truth symbol (the training loss of the reference, a14)
+            float pg = pr[0];
+#pragma unroll
+            for (int j = 1; j < M; ++j) pg = j == sym ? pr[j] : pg;
+            double b = -log2((double)pg + 1e-10);
+            b = b < 0.0 ? 0.0 : (b > 50.0 ? 50.0 : b);
+            if ((int64_t)(blockIdx.x + 1) * TB <= a.n) {   // every lane of the block is live: reduce over the wave first
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d);
+                if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(a.bits + (blockIdx.x & 15), b);
+            } else {
+                unsafeAtomicAdd(a.bits + (blockIdx.x & 15), b);
+            }
+        }
     } else if (MODE == 1) {
         constexpr int RS = M == 2 ? 1 : M == 4 ? 4 : 16;
         uint16_t *dst = a.cdf + (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch) * RS;

@@ -109,6 +109,8 @@ struct HeadArgs {
     // mode 0 over several concatenated levels: per-row slot of stage 0 and per-row stride between stages
     // (then m2r / chunk_log2 / nch are unused)
     const uint32_t *pos; const uint32_t *slots;
+    // mode 0, optional: 16 accumulators of sum clamp(-log2(p_gt + 1e-10), 0, 50) (network_ue_4stage_conv.py:176-179)
+    double *bits;
 };
 int head_cdf(hipStream_t st, const HeadArgs &a);
 

@@ -76,6 +76,8 @@ typedef struct {
     int64_t coded_nodes;       /* sum of nodes over coded levels */
     int64_t conv_pairs;        /* sum over all 18*levels convs of (output node, present neighbour) pairs */
     double device_ms;          /* wall time between the syncs that bracket the call */
+    double ideal_bits;         /* encode only: sum over coded symbols of clamp(-log2(p_gt + 1e-10), 0, 50), the reference's
+                                  bpp estimator before the division by N (network_ue_4stage_conv.py:100-182, a14) */
 } gpcc_stats;
 
 /* ---- a12  compress_point_cloud (the timed span :78-189 + container :192-203)
@@ -166,6 +168,14 @@ GPCC_API int gsac_encode(gpcc_ctx *ctx, const int16_t *sym_dev, const float *cdf
  * arithmetic.cpp:32-43, arithmetic_kernel.cu:265-403.  cdf device, bytes / cnt host, sym_out device. */
 GPCC_API int gsac_decode(gpcc_ctx *ctx, const float *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
                          int64_t n, int lp, int16_t *sym_out_dev, void *stream);
+
+/* The same coder over already-integerised rows: torchac.encode_int16_normalized_cdf / decode_int16_normalized_cdf
+ * (requirements.txt:6; call sites src/gs_compress/HAC/utils/pcc_utils.py:174-177, TC-GS/utils/encodings.py:38-174).
+ * cdf (n, Lp) uint16 device.  chunk_size = n gives torchac's single stream. */
+GPCC_API int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym_dev, const uint16_t *cdf_dev, int chunk_size, int64_t n, int lp,
+                             const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
+                             int64_t n, int lp, int16_t *sym_out_dev, void *stream);
 
 /* _gridencoder.grid_encode_forward (inputs (N,D) in [0,1], embeddings (sO,F), offsets (L+1), resolutions (L),
  * outputs (L,N,F), ..., Rb, binary_vxl, min_level_id)   gridencoder.zip!gridencoder/src/gridencoder.h:12-22,

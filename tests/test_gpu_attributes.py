@@ -103,3 +103,29 @@ def test_gridencoder_binary_voxel_mask(torch_cuda, orc):
     ref = orc.grid_forward(x.cpu().numpy(), enc.params.detach().cpu().numpy(), enc.offsets_list.cpu().numpy(), enc.resolutions_list.cpu().numpy(),
                            rb=32, binary_vxl=bv.cpu().numpy().astype(np.uint8)).transpose(1, 0, 2).reshape(2000, -1)
     assert np.array_equal(out, ref)
+
+
+def test_torchac_interface_bytes_match_oracle(torch_cuda, orc):
+    """torchac.encode_float_cdf / encode_int16_normalized_cdf are one range-coder stream: bytes must equal the
+    oracle's coder (which follows torchac's loop) on the same integerised CDF."""
+    torch = torch_cuda
+    from gauspcc_amd import torchac
+
+    rng = np.random.RandomState(11)
+    n, lp = 6000, 9
+    p = rng.dirichlet(np.ones(lp - 1), size=n).astype(np.float32)
+    cdf = np.concatenate([np.zeros((n, 1), np.float32), np.cumsum(p, 1)], 1).clip(0, 1).astype(np.float32)
+    sym = np.array([rng.choice(lp - 1, p=pi / pi.sum()) for pi in p.astype(np.float64)], dtype=np.int16)
+    cdf_i = orc.cdf_to_int16(cdf)
+    ref = orc.rc_encode(cdf_i.view(np.uint16), sym.astype(np.uint8))
+    b1 = torchac.encode_float_cdf(torch.tensor(cdf), torch.tensor(sym), check_input_bounds=True)       # CPU tensors, as torchac takes them
+    b2 = torchac.encode_int16_normalized_cdf(torch.tensor(cdf_i).cuda(), torch.tensor(sym).cuda())
+    assert b1 == ref and b2 == ref
+    d1 = torchac.decode_float_cdf(torch.tensor(cdf), b1)
+    d2 = torchac.decode_int16_normalized_cdf(torch.tensor(cdf_i), b2)
+    assert d1.dtype == torch.int16 and not d1.is_cuda
+    assert np.array_equal(d1.numpy(), sym) and np.array_equal(d2.numpy(), sym)
+    # leading dims are flattened like torchac does
+    b3 = torchac.encode_float_cdf(torch.tensor(cdf).view(60, 100, lp), torch.tensor(sym).view(60, 100))
+    assert b3 == ref
+    assert torchac.decode_float_cdf(torch.tensor(cdf).view(60, 100, lp), b3).shape == (60, 100)

@@ -3,6 +3,8 @@
 that the device results equal the oracle's exactly -- the asserted tolerance is 0; the
 1e-5 the north star allows on probabilities is the budget towards the *reference's*
 torchsparse numerics, which cannot run here)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -234,6 +236,23 @@ def test_codec_bitstream_identical_to_oracle(gh, orc, k, chunk_log2, dev_model_k
     assert float(posq) == 1.0
 
 
+def test_ideal_bits_estimator_and_coder_overhead(gh, orc, dev_model_k5, synth_model_k5):
+    """a14: the reference's bpp estimator (network_ue_4stage_conv.py:100-182), sum clamp(-log2(p_gt + 1e-10), 0, 50),
+    accumulated on the device beside the coder; the actual range-coder payload must sit within a small
+    overhead of it (the estimator prices the float p, the coder the 16-bit integerised CDF)."""
+    pts = _cloud(20_000, seed=5)
+    data, st = gh.encode(dev_model_k5, pts, 0)
+    orc.encode(synth_model_k5, pts, chunk_log2=0)
+    ref_bits = orc.ideal_bits()
+    assert ref_bits > 0
+    assert abs(st.ideal_bits - ref_bits) <= 1e-9 * ref_bits          # same probabilities; only the summation order differs
+    nstreams = 4 * (st.num_levels - 1)
+    header = 2 + 4 + 13 * st.level_nodes[0] + 2 + 4 * nstreams
+    payload_bits = 8 * (len(data) - header)
+    assert payload_bits >= 0.999 * st.ideal_bits
+    assert payload_bits <= 1.01 * st.ideal_bits + 32 * nstreams      # flush of each stream + integerisation loss
+
+
 def test_codec_cross_decode(gh, orc, dev_model_k5, synth_model_k5):
     """Device stream decoded by the oracle and vice versa (negative coordinates, posQ != 1)."""
     pts = _cloud(4000, seed=99, negative=True)
@@ -301,3 +320,35 @@ def test_full_size_roundtrip_1m(gh, dev_model_k5):
     assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts))
     assert list(st.level_nodes[: st.num_levels]) == list(st2.level_nodes[: st2.num_levels])
     assert st.level_nodes[0] < 64
+
+
+def test_cli_compress_decompress_roundtrip(gh, tmp_path):
+    """python -m gauspcc_amd.cli.compress / .decompress over a folder: .bin per file, CSV with an avg row,
+    PLYs holding exactly the quantised input geometry (reference CLIs: compress_ue_4stage_conv.py, decompress_ue_4stage_conv.py)."""
+    import pandas as pd
+    from gauspcc_amd.cli import compress, decompress, io
+    from gauspcc_amd.pcc_utils import save_ply_ascii_geo
+    from gauspcc_amd.synth import synthetic_cloud
+
+    src, out, rec, res = (tmp_path / n for n in ("src", "bin", "rec", "res"))
+    src.mkdir()
+    clouds = {}
+    for i, n in enumerate((3000, 7000)):
+        c = synthetic_cloud(n, seed=50 + i).astype(np.float32)
+        clouds[f"c{i}.ply"] = c
+        save_ply_ascii_geo(c, str(src / f"c{i}.ply"))
+    common = ["--channels", "32", "--kernel_size", "3", "--ckpt", "synthetic:3"]
+    assert compress.main(["--input_glob", str(src), "--output_folder", str(out), "--is_data_pre_quantized", "1", "--posQ", "1",
+                          "--resultdir", str(res), "--prefix", "t", "--chunk_log2", "0"] + common) == 0
+    df = pd.read_csv(res / "t_data2.csv")
+    assert df["filedir"].tolist() == ["c0.ply", "c1.ply", "avg"]
+    for i, name in enumerate(clouds):
+        size = os.path.getsize(out / (name + ".bin")) * 8
+        assert df["file_size_bits"][i] == size and df["num_points"][i] == len(clouds[name])
+        assert abs(df["bpp"][i] - size / len(clouds[name])) < 1e-9
+    assert decompress.main(["--input_glob", str(out / "*.bin"), "--output_folder", str(rec), "--is_data_pre_quantized", "1"] + common) == 0
+    for name, c in clouds.items():
+        d = io.read_points(str(rec / (name + ".bin.ply"))).astype(np.int64)
+        c = c.astype(np.int64)
+        assert d.shape == c.shape
+        assert np.array_equal(d[np.lexsort((d[:, 0], d[:, 1], d[:, 2]))], c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))])

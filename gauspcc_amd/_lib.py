@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgauspcc.so")
+LIB_PATH = os.environ.get("GAUSPCC_LIB") or os.path.join(_HERE, "libgauspcc.so")  # env override: kernel-variant experiments (tools/)
 
 _lib = None
 

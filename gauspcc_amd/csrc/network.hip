@@ -26,6 +26,12 @@ namespace gpcc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CONV_WAVES = 4;
+#ifndef CONV_EXP
+#define CONV_EXP 0   // developer experiments (tools/build_variants.sh): 1 no LDS accumulate, 2 no weight loads, 4 no gathers
+#endif
+constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
+// LDS floats per wave: R accumulator rows + 1 dummy row, then the 32-slot tile-header ring (512 + 128 + 32 dwords)
+__host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + 672; }
 
 // ------------------------------------------------------------------ tile list
 template <int R, bool FILL>
@@ -117,11 +123,14 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     uint32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const int64_t cap = (int64_t)total + 4;  // the conv kernel's clamped prefetch never reads past the last tile
+    const int64_t cap = (int64_t)total + CONV_HDR_PAD;  // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
     TAKE(tj, int32_t, cap * 16);
     TAKE(tr, uint8_t, cap * 16);
     TAKE(toc, uint32_t, cap);
     T->tj = tj; T->tr = tr; T->toc = toc;
+    HIP_TRY(hipMemsetAsync(tj + (size_t)total * 16, 0, (size_t)CONV_HDR_PAD * 64, st));
+    HIP_TRY(hipMemsetAsync(tr + (size_t)total * 16, 0, (size_t)CONV_HDR_PAD * 16, st));
+    HIP_TRY(hipMemsetAsync(toc + total, 0, (size_t)CONV_HDR_PAD * 4, st));
     k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
     // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling)
@@ -154,11 +163,13 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 
 // ------------------------------------------------------------------ convolution
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// ds_add_f32 without return: IEEE fp32 add performed by the LDS, in the wave's program order
+__device__ __forceinline__ void lds_add(float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 template <int R, int DIST>
 __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
 {
-    constexpr int CONV_LDS_WAVE = (R + 1) * 32;  // floats: R rows + 1 dummy row for padding entries
+    constexpr int CONV_LDS_WAVE = conv_lds_wave_floats(R);  // R rows + 1 dummy row for padding entries + the tile-header ring
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const ConvJob J = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63;
@@ -170,6 +181,10 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
     const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);
     float *acc = lds + wave * CONV_LDS_WAVE;
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
+    // tile-header ring: 32 slots = two batches of 16 tiles (neighbour rows 32 x 16 dwords, output rows 32 x 4 dwords,
+    // offsets 32 dwords).  The tile list of a block is streamed from HBM exactly once, so its latency is the full
+    // DRAM latency: a batch is fetched with three wide loads a whole batch ahead of its first use.
+    int32_t *hdr = reinterpret_cast<int32_t *>(acc + (R + 1) * 32);
 #pragma unroll
     for (int it = 0; it < (R * 8 + 63) / 64; ++it)
         if (it * 64 + lane < R * 8) acc4[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -179,109 +194,188 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
     const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
     const float *__restrict__ in = J.in + 4 * g;
     const float *__restrict__ wf = J.w + lane * 4;
-    const int32_t *__restrict__ tje = T.tj + e;
-    const uint32_t *__restrict__ tr4 = reinterpret_cast<const uint32_t *>(T.tr) + g;
-    const uint32_t *__restrict__ toc = T.toc;
+    const int32_t *hj = hdr + e;            // + slot * 16
+    const int32_t *hr = hdr + 512 + g;      // + slot * 4
+    const int32_t *ho = hdr + 640;          // + slot
     struct AB { float4 a0, a1, b00, b01, b10, b11; };
+#if CONV_EXP
+    const float4 XB0 = ld4(wf), XB1 = ld4(wf + 256);
+#endif
     auto load_ab = [&](int j, uint32_t o) -> AB {
         const float *p = in + (size_t)(uint32_t)j * 32;
         const float *w = wf + (size_t)o * 1024;
         AB r;
+#if CONV_EXP & 4
+        r.a0 = XB0; r.a1 = XB1; r.a0.x += (float)j;
+#else
         r.a0 = ld4(p); r.a1 = ld4(p + 16);
+#endif
+#if CONV_EXP & 2
+        r.b00 = XB0; r.b01 = XB1; r.b10 = XB0; r.b11 = XB1; r.b00.x += (float)o;
+#else
         r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
+#endif
         return r;
     };
-    // The accumulator rows of a tile are read from LDS one tile EARLY: LDS operations of a wave execute in
-    // order, so issuing tile t+1's reads right behind tile t's writes is correct even when the two tiles
-    // share output rows, and their latency is covered by the next step's prefetch / bookkeeping.
-    struct CT { f32x4 c0, c1; int row[4]; };
-    auto fetch_c = [&](uint32_t r4) -> CT {
-        CT c;
+    // Per tile: 16 MFMAs build the tile's 16 x 32 partial products from a ZERO accumulator (an fma chain over
+    // k = 0..31 per output element), then 8 ds_add_f32 per lane add them to the rows' running sums in LDS.  Nothing
+    // in the MFMA block depends on LDS, and the LDS adds of a wave execute in program order, so consecutive
+    // tiles may share output rows without any wait; the adds of tile t are issued behind the MFMAs of tile
+    // t + 1 (their operands have long left the matrix pipe by then).
+    // Per tile: 16 MFMAs build the tile's 16 x 32 partial products from a ZERO accumulator (an fma chain over
+    // k = 0..31 per output element); the partial products are then added to the rows' running sums in LDS
+    // (read - add - write).  Nothing in the MFMA block depends on LDS, and the LDS operations of a wave execute
+    // in program order, so consecutive tiles may share output rows.  The read-add-write of tile t is slotted
+    // between the MFMAs of tile t + 1: reads behind the first MFMAs, adds and writes six MFMAs later, when the
+    // LDS data has long arrived -- the matrix pipe never waits for LDS.
+    struct PT { f32x4 c0, c1; uint32_t r4; };
+#define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+    auto step = [&](const AB &v, const PT &p, PT &q) {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#if !(CONV_EXP & 1)
+        float s0[4], s1[4];
+        int row[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            c.row[k] = (int)((r4 >> (8 * k)) & 255u) * 32;
-            c.c0[k] = acc[c.row[k] + col0];
-            c.c1[k] = acc[c.row[k] + col1];
+            row[k] = (int)((p.r4 >> (8 * k)) & 255u) * 32;
+            s0[k] = acc[row[k] + col0];
+            s1[k] = acc[row[k] + col1];
         }
-        return c;
-    };
-    auto compute = [&](const AB &v, CT c) {
-        f32x4 c0 = c.c0, c1 = c.c1;
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b00.x, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.x, v.b10.x, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.y, v.b00.y, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.y, v.b10.y, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.z, v.b00.z, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.z, v.b10.z, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.w, v.b00.w, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a0.w, v.b10.w, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.x, v.b01.x, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.x, v.b11.x, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.y, v.b01.y, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.y, v.b11.y, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.z, v.b01.z, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.z, v.b11.z, c1, 0, 0, 0);
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b01.w, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(v.a1.w, v.b11.w, c1, 0, 0, 0);
+#endif
+        MF(c0, v.a0.x, v.b00.x); MF(c1, v.a0.x, v.b10.x);
+        MF(c0, v.a0.y, v.b00.y); MF(c1, v.a0.y, v.b10.y);
+        MF(c0, v.a0.z, v.b00.z); MF(c1, v.a0.z, v.b10.z);
+        __builtin_amdgcn_sched_barrier(0);
+#if !(CONV_EXP & 1)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { acc[c.row[k] + col0] = c0[k]; acc[c.row[k] + col1] = c1[k]; }
+        for (int k = 0; k < 4; ++k) {
+            acc[row[k] + col0] = s0[k] + p.c0[k];
+            acc[row[k] + col1] = s1[k] + p.c1[k];
+        }
+#endif
+        MF(c0, v.a0.w, v.b00.w); MF(c1, v.a0.w, v.b10.w);
+        MF(c0, v.a1.x, v.b01.x); MF(c1, v.a1.x, v.b11.x);
+        __builtin_amdgcn_sched_barrier(0);
+        MF(c0, v.a1.y, v.b01.y); MF(c1, v.a1.y, v.b11.y);
+        MF(c0, v.a1.z, v.b01.z); MF(c1, v.a1.z, v.b11.z);
+        MF(c0, v.a1.w, v.b01.w); MF(c1, v.a1.w, v.b11.w);
+#if CONV_EXP & 1
+        q.c0 = c0 + p.c0; q.c1 = c1 + p.c1;
+#else
+        q.c0 = c0; q.c1 = c1;
+#endif
+    };
+#undef MF
+    auto accumulate = [&](const PT &p) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (int)((p.r4 >> (8 * k)) & 255u) * 32;
+            acc[row + col0] = acc[row + col0] + p.c0[k];
+            acc[row + col1] = acc[row + col1] + p.c1[k];
+        }
     };
     if (t0 < t1) {
         // Software pipeline inside one instruction stream: a ring of RING = DIST + 1 register sets, RING tiles
-        // per (fully unrolled) iteration.  While tile t computes out of set t % RING the gathered rows and the
-        // weight fragment of tile t + DIST land in set (t + DIST) % RING, and the index words of tile
-        // t + DIST + 1 are fetched -- no register rotation of the big sets, so nothing forces a load to complete
-        // inside the step that issued it.  The body is branch-free up to the tail guard (indices clamped to
-        // the last tile, padding entries gather row 0 and accumulate into the dummy LDS row) so that the
-        // compiler can count outstanding loads instead of draining them with s_waitcnt vmcnt(0).
+        // per (fully unrolled) iteration.  While tile u computes out of set u % RING the gathered rows and the
+        // weight fragment of tile u + DIST land in set (u + DIST) % RING, and the header words of tile
+        // u + DIST + 1 are read from the LDS ring -- no register rotation of the big sets, so nothing forces a
+        // load to complete inside the step that issued it.  The body has no data-dependent branch: steps past the
+        // last tile work on the headers that follow in memory (the next block's, or the zeroed padding of the
+        // list) and accumulate into the dummy LDS row.
         constexpr int RING = DIST + 1;
-        const uint32_t tl = t1 - 1;
+        constexpr uint32_t DUMMY4 = (uint32_t)R * 0x01010101u;
+        const uint32_t nt = t1 - t0;
+        const int4 *__restrict__ gtj = reinterpret_cast<const int4 *>(T.tj + (size_t)t0 * 16) + lane;
+        const uint32_t *__restrict__ gtr = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16) + lane;
+        const uint32_t *__restrict__ gto = T.toc + t0 + (lane & 15);
+        int4 *sj = reinterpret_cast<int4 *>(hdr) + lane;   // + (batch & 1) * 64
+        int32_t *sr = hdr + 512 + lane;                    // + (batch & 1) * 64
+        int32_t *so = hdr + 640 + (lane & 15);             // + (batch & 1) * 16
+        {   // batches 0 and 1 straight into the ring
+            const int4 a0 = gtj[0], a1 = gtj[64];
+            const uint32_t b0 = gtr[0], b1 = gtr[64], c0 = gto[0], c1 = gto[16];
+            sj[0] = a0; sj[64] = a1;
+            sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
+            so[0] = (int32_t)c0; so[16] = (int32_t)c1;
+        }
+        int4 st_j = make_int4(0, 0, 0, 0);
+        uint32_t st_r = 0, st_o = 0;
         AB ring[RING];
         uint32_t r4r[RING];
-        // prologue: tiles t0 .. t0+DIST-1 in flight, indices of tile t0+DIST ready
+        // prologue: tiles 0 .. DIST-1 in flight, headers of tile DIST in registers
 #pragma unroll
         for (int s = 0; s < DIST; ++s) {
-            const uint32_t tt = min(t0 + (uint32_t)s, tl);
-            r4r[s] = tr4[tt * 4];
-            ring[s] = load_ab(tje[tt * 16], toc[tt] & 0xFFFFu);
+            const uint32_t r4_ld = (uint32_t)hr[s * 4];
+            r4r[s] = (uint32_t)s < nt ? r4_ld : DUMMY4;
+            ring[s] = load_ab(hj[s * 16], (uint32_t)ho[s] & 0xFFFFu);
         }
-        uint32_t tn = min(t0 + (uint32_t)DIST, tl);
-        int j_n = tje[tn * 16];
-        uint32_t r4_n = tr4[tn * 4], o_n = toc[tn] & 0xFFFFu;
-        CT cnext = fetch_c(r4r[0]);
-        for (uint32_t t = t0; t < t1; t += RING) {
+        int j_n = hj[DIST * 16];
+        const uint32_t r4_ld0 = (uint32_t)hr[DIST * 4];
+        uint32_t r4_n = (uint32_t)DIST < nt ? r4_ld0 : DUMMY4, o_n = (uint32_t)ho[DIST] & 0xFFFFu;
+        PT prev;
+        prev.c0 = f32x4{0.f, 0.f, 0.f, 0.f}; prev.c1 = prev.c0; prev.r4 = DUMMY4;
+        for (uint32_t u = 0; u < nt; u += RING) {
 #pragma unroll
             for (int s = 0; s < RING; ++s) {
-                const int sl = (s + DIST) % RING;            // set that receives tile t + s + DIST
-                tn = min(t + (uint32_t)(s + DIST + 1), tl);
-                const int j_nn = tje[tn * 16];
-                const uint32_t r4_nn = tr4[tn * 4], o_nn = toc[tn] & 0xFFFFu;
+                const uint32_t us = u + (uint32_t)s;
+                // header batch (us / 16) + 1: fetched at the first step of batch us / 16, moved into the ring
+                // eight steps later (the half of the ring it replaces was last read before step us)
+                if ((us & 15u) == 0u && us != 0u) {
+                    const uint32_t bo = (us >> 4) + 1u;
+                    st_j = gtj[bo * 64]; st_r = gtr[bo * 64]; st_o = gto[bo * 16];
+                }
+                if ((us & 15u) == 8u && us > 8u) {
+                    const uint32_t bb = ((us >> 4) + 1u) & 1u;
+                    sj[bb * 64] = st_j; sr[bb * 64] = (int32_t)st_r; so[bb * 16] = (int32_t)st_o;
+                }
+                const int sl = (s + DIST) % RING;            // set that receives tile us + DIST
+                const uint32_t tq = us + (uint32_t)(DIST + 1);
+                const uint32_t slot = tq & 31u;
+                const int j_nn = hj[slot * 16];
+                const uint32_t r4_ld = (uint32_t)hr[slot * 4], o_nn = (uint32_t)ho[slot] & 0xFFFFu;
+                __builtin_amdgcn_sched_barrier(0);  // header reads first: the next step needs them before the big loads
+                const uint32_t r4_cur = r4r[s];
                 r4r[sl] = r4_n;
                 ring[sl] = load_ab(j_n, o_n);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of this tile's MFMAs (hipcc sinks it otherwise)
-                if (t + (uint32_t)s < t1) {
-                    compute(ring[s], cnext);
-                    cnext = fetch_c(r4r[(s + 1) % RING]);   // next tile's rows (the clamped prefetch makes this valid at the tail too)
-                }
+                PT cur;
+                step(ring[s], prev, cur);
+                cur.r4 = r4_cur;
+                prev = cur;
+                const uint32_t r4_nn = tq < nt ? r4_ld : DUMMY4;
                 __builtin_amdgcn_sched_barrier(0);
                 j_n = j_nn; r4_n = r4_nn; o_n = o_nn;
             }
         }
+        accumulate(prev);
     }
     // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
     const int row0 = blk * R;
     const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res);
     float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out);
-#pragma unroll 4
-    for (int it = 0; it < (R * 8 + 63) / 64; ++it) {
-        const int idx = it * 64 + lane;
-        const int grow = row0 + (idx >> 3);
-        if (idx < R * 8 && grow < n) {
-            float4 v = acc4[idx];
-            const size_t gi = (size_t)grow * 8 + (idx & 7);
-            if (res4) { const float4 r = res4[gi]; v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
-            if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-            out4[gi] = v;
+    // residual rows are fetched in batches ahead of the LDS reads (one wait per batch instead of one per row group)
+    constexpr int NIT = (R * 8 + 63) / 64;
+    constexpr int EB = NIT < 8 ? NIT : 8;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += EB) {
+        float4 rr[EB];
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            const int idx = (it0 + b) * 64 + lane;
+            const int grow = row0 + (idx >> 3);
+            rr[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (res4 && it0 + b < NIT && idx < R * 8 && grow < n) rr[b] = res4[(size_t)grow * 8 + (idx & 7)];
+        }
+#pragma unroll
+        for (int b = 0; b < EB; ++b) {
+            const int idx = (it0 + b) * 64 + lane;
+            const int grow = row0 + (idx >> 3);
+            if (it0 + b < NIT && idx < R * 8 && grow < n) {
+                float4 v = acc4[idx];
+                if (res4) { const float4 r = rr[b]; v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
+                if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
+                out4[(size_t)grow * 8 + (idx & 7)] = v;
+            }
         }
     }
 }
@@ -308,15 +402,15 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 128-row blocks need 66048 B of LDS per workgroup (> the 64 KiB default cap)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * 129 * 128));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
         lds_attr_set = true;
     }
     static int dist = -1;
     if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
     dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
-    const size_t lds_bytes = (size_t)CONV_WAVES * (T.R + 1) * 128;
+    const size_t lds_bytes = (size_t)CONV_WAVES * conv_lds_wave_floats(T.R) * 4;
     switch (T.R) {
     case 16: k_sparse_conv<16, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
     case 32: k_sparse_conv<32, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;

@@ -467,7 +467,7 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
         }
     } else chunks[0] = RcChunk{0, 1, (uint32_t)n, 0, 0, (uint32_t)nbytes};
     TAKE(db, uint8_t, nbytes + 16); TAKE(dch, RcChunk, nch);
-    TAKE(rows, uint16_t, (int64_t)nch * S * rc_row_stride(lp) + 64);
+    TAKE(rows, uint16_t, rc_rows_capacity(nch, S) * rc_row_stride(lp) + 64);
     GP_TRY(rc_pack_rows(st, cdf_dev, lp, n, chunk_log2, rows));
     HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));

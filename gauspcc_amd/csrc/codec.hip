@@ -418,7 +418,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        TAKE(cdf, uint16_t, ((int64_t)nch << (chunk_log2 ? chunk_log2 : 0)) * 16 + nc * 16);  // interleaved rows: nch * S slots (nc when unchunked)
+        TAKE(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? (int64_t)1 << chunk_log2 : nc) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
         for (int s = 0; s < 4; ++s) {

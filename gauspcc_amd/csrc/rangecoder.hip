@@ -98,127 +98,161 @@ __global__ __launch_bounds__(256) void k_rc_compact(const uint8_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------ decode
-// Bit reservoir over a chunk's bytes.  The next 32 bits of the stream are always already loaded (or in
-// flight) in `nw`, so a refill is a handful of ALU ops plus the ISSUE of one unaligned dword load whose
-// result is not needed before the following refill -- no wait on the decoder's critical path.  Bytes past
-// the end of the chunk read as zero (arithmetic_kernel.cu:244-262); the byte buffer is padded so the
-// load itself never leaves the allocation.
-struct BitIn {
-    const uint8_t *p;   // address of the word held in nw
-    int32_t rem;        // bytes of the chunk at and after p (may go negative)
-    uint32_t nw;        // big-endian word at p, zero-masked beyond the chunk
-    uint64_t buf;       // next bits in the top `n` bits
-    uint32_t n;
-    __device__ __forceinline__ static uint32_t fetch(const uint8_t *q, int32_t rem)
+// Bit window over a chunk's bytes, addressed by the absolute bit position `bp` of the next unread bit.  The
+// eight bytes around bp are fetched as soon as bp is known (end of a symbol) and consumed at the end of the
+// next symbol, so the load hides behind the symbol search; there is no reservoir state and no refill branch.
+// Bits past the end of the chunk read as zero (arithmetic_kernel.cu:244-262); the byte buffer is padded so
+// the clamped load never leaves the allocation.
+struct BitWin {
+    const uint8_t *base;
+    uint32_t nbytes, nbits;   // chunk size
+    uint32_t bp;              // bits consumed
+    uint2 raw;                // the 8 bytes at base + min(bp / 8, nbytes)
+    __device__ __forceinline__ void fetch()
     {
-        uint32_t w;
-        __builtin_memcpy(&w, q, 4);  // one global_load_dword (unaligned access is legal on gfx950)
-        w = __builtin_bswap32(w);
-        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem));
-        return w & keep;
+        __builtin_memcpy(&raw, base + min(bp >> 3, nbytes), 8);  // one global_load_dwordx2 (unaligned access is legal on gfx950)
     }
-    __device__ __forceinline__ void init(const uint8_t *base, uint32_t nbytes)
+    __device__ __forceinline__ void init(const uint8_t *b, uint32_t n) { base = b; nbytes = n; nbits = 8u * n; bp = 0; fetch(); }
+    __device__ __forceinline__ uint32_t peek32() const   // the next 32 bits, zero past the end
     {
-        p = base; rem = (int32_t)nbytes; buf = 0; n = 0;
-        nw = fetch(p, rem);
+        const uint64_t w = ((uint64_t)__builtin_bswap32(raw.x) << 32) | (uint64_t)__builtin_bswap32(raw.y);
+        const uint32_t top = (uint32_t)((w << (bp & 7u)) >> 32);
+        // keep the top min(max(nbits - bp, 0), 32) bits: an arithmetic shift of FFFFFFFF'00000000 drags them in
+        int32_t valid = (int32_t)(nbits - bp);
+        valid = valid < 0 ? 0 : (valid > 32 ? 32 : valid);
+        return top & (uint32_t)((int64_t)0xFFFFFFFF00000000ll >> valid);
     }
-    __device__ __forceinline__ uint32_t take(uint32_t k)  // k in [0, 32]
+    // k in [0, 31]; the caller re-fetches.  Masked shifts keep garbage (lanes past their chunk, corrupt input) defined.
+    __device__ __forceinline__ uint32_t take(uint32_t k)
     {
-        if (n <= 32) {
-            buf |= (uint64_t)nw << (32 - n);
-            n += 32;
-            p += 4; rem -= 4;
-            nw = fetch(p, rem);
-        }
-        const uint32_t r = (uint32_t)((buf >> 1) >> (63 - k));  // == buf >> (64 - k), and 0 for k == 0
-        buf <<= k;
-        n -= k;
-        return r;
+        const uint32_t t = peek32();
+        bp += k;
+        return (t >> 1) >> ((31u - k) & 31u);   // == t >> (32 - k), and 0 for k == 0
     }
+    __device__ __forceinline__ uint32_t take32() { const uint32_t t = peek32(); bp += 32u; return t; }
 };
 
 __device__ __forceinline__ uint32_t scale(uint64_t span, uint32_t v) { return (uint32_t)((span * (uint64_t)v) >> 16); }
+// the same on d = span - 1 (fits 32 bits): (d + 1) * v = d * v + v -> one v_mad_u64_u32 and one v_alignbit
+__device__ __forceinline__ uint32_t scale_d(uint32_t d, uint32_t v) { return (uint32_t)(((uint64_t)d * (uint64_t)v + (uint64_t)v) >> 16); }
 
+// One lane per chunk.  The compact CDF rows of a chunk do not depend on decoded symbols, so they are fetched
+// DEPTH symbols ahead through a register ring (the loop is unrolled over the ring, nothing rotates): the
+// serial part of a symbol is then ALU only.  The loop bound is the longest chunk of the wave, shorter lanes
+// run on with clamped row addresses and masked stores, so the body is free of divergent control flow except
+// the bit-reservoir refill.  Symbols leave four at a time.
 template <int LP>
 __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                   int nchunks, uint8_t *__restrict__ sym)
 {
-    constexpr int NV = LP - 2;                              // interior CDF values per row
     constexpr int RS = LP == 3 ? 1 : LP == 5 ? 4 : 16;      // row stride in uint16
+    constexpr int DEPTH = LP == 17 ? 4 : 8;                 // rows in flight per lane (multiple of 4)
+    struct Row { uint32_t w[LP == 3 ? 1 : LP == 5 ? 2 : 8]; };
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= nchunks) return;
-    const RcChunk ch = chunks[c];
-    BitIn in;
+    RcChunk ch = {0, 0, 0, 0, 0, 0};
+    if (c < nchunks) ch = chunks[c];
+    uint32_t nmax = ch.n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    if (nmax == 0) return;
+    BitWin in;
     in.init(bytes + ch.byte_off, ch.nbytes);
     uint32_t low = 0, high = 0xFFFFFFFFu;
-    uint32_t value = in.take(32);
-    uint16_t v[16];
-    uint16_t vn[16];
-    auto load_row = [&](uint32_t i, uint16_t *dst) {
-        const uint16_t *row = cdf + ((size_t)ch.first + (size_t)i * ch.stride) * RS;
-        if (LP == 3) dst[0] = row[0];
-        else if (LP == 5) { const uint2 q = *reinterpret_cast<const uint2 *>(row); dst[0] = (uint16_t)q.x; dst[1] = (uint16_t)(q.x >> 16); dst[2] = (uint16_t)q.y; }
+    uint32_t value = in.take32();
+    in.fetch();
+    static_assert(DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
+    const uint16_t *rowp = cdf + (size_t)ch.first * RS;      // row of the next fetch; runs DEPTH rows ahead, unclamped
+    const size_t rstep = (size_t)ch.stride * RS;
+    auto load_row = [&]() -> Row {
+        const uint16_t *row = rowp;
+        rowp += rstep;
+        Row r;
+        if (LP == 3) r.w[0] = row[0];
+        else if (LP == 5) { const uint2 q = *reinterpret_cast<const uint2 *>(row); r.w[0] = q.x; r.w[1] = q.y; }
         else {
             const uint4 q0 = reinterpret_cast<const uint4 *>(row)[0], q1 = reinterpret_cast<const uint4 *>(row)[1];
-            const uint32_t w[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { dst[2 * k] = (uint16_t)w[k]; dst[2 * k + 1] = (uint16_t)(w[k] >> 16); }
+            r.w[0] = q0.x; r.w[1] = q0.y; r.w[2] = q0.z; r.w[3] = q0.w; r.w[4] = q1.x; r.w[5] = q1.y; r.w[6] = q1.z; r.w[7] = q1.w;
         }
+        return r;
     };
-    if (ch.n) load_row(0, vn);
-    for (uint32_t i = 0; i < ch.n; ++i) {
+    Row ring[DEPTH];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = vn[k];
-        if (i + 1 < ch.n) load_row(i + 1, vn);  // rows do not depend on decoded symbols: prefetch
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-        const uint32_t x = value - low;
-        // largest s in [0, NV] with scaled(v[s]) <= x, v[0] = 0; lo / hi = scaled bounds of the symbol
-        uint32_t s = 0, lo = 0, hi;
-        if (LP == 3) {
-            const uint32_t t1 = scale(span, v[0]);
-            const bool ge = t1 <= x;
-            s = ge; lo = ge ? t1 : 0u;
-            hi = ge ? (uint32_t)span : t1;  // span == 2^32 wraps to 0: high = low - 1 + 2^32 (mod 2^32), as the reference
-        } else if (LP == 5) {
-            const uint32_t t1 = scale(span, v[0]), t2 = scale(span, v[1]), t3 = scale(span, v[2]);
-            s = (uint32_t)(t1 <= x) + (uint32_t)(t2 <= x) + (uint32_t)(t3 <= x);
-            lo = s == 0 ? 0u : s == 1 ? t1 : s == 2 ? t2 : t3;
-            hi = s == 0 ? t1 : s == 1 ? t2 : s == 2 ? t3 : (uint32_t)span;
-        } else {
-            // binary search over v[1..15] (array index k holds v[k+1]) with register selects
-            const bool b8 = scale(span, v[7]) <= x;
-            const uint16_t m4 = b8 ? v[11] : v[3];
-            const bool b4 = scale(span, m4) <= x;
-            const uint16_t m2 = b8 ? (b4 ? v[13] : v[9]) : (b4 ? v[5] : v[1]);
-            const bool b2 = scale(span, m2) <= x;
-            const uint32_t base = (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u);  // s in {base, base+1}
-            // candidates: v[base] (0 when base == 0), v[base+1], v[base+2] (span when base + 2 == 16)
-            uint16_t cm1 = 0, c0 = 0, cp1 = 0;
+    for (int d = 0; d < DEPTH; ++d) ring[d] = load_row();
+    const bool wide = (ch.out & 3u) == 0u;
+    uint32_t pack = 0;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-            for (int k = 0; k < 15; ++k) {
-                if ((uint32_t)k + 1u == base) cm1 = v[k];
-                if ((uint32_t)k == base) c0 = v[k];
-                if ((uint32_t)k == base + 1u) cp1 = v[k];
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint32_t i = i0 + (uint32_t)d;
+            const Row rw = ring[d];
+            ring[d] = load_row();
+            const uint32_t dd = high - low;   // span - 1
+            const uint32_t x = value - low;
+            // largest s in [0, LP-2] with scaled(v[s]) <= x, v[0] = 0; lo / hi = scaled bounds of the symbol
+            uint32_t s = 0, lo = 0, hi;
+            if (LP == 3) {
+                const uint32_t t1 = scale_d(dd, rw.w[0] & 0xFFFFu);
+                const bool ge = t1 <= x;
+                s = ge; lo = ge ? t1 : 0u;
+                hi = ge ? dd + 1u : t1;  // span == 2^32 wraps to 0: high = low - 1 + 2^32 (mod 2^32), as the reference
+            } else if (LP == 5) {
+                const uint32_t t1 = scale_d(dd, rw.w[0] & 0xFFFFu), t2 = scale_d(dd, rw.w[0] >> 16), t3 = scale_d(dd, rw.w[1] & 0xFFFFu);
+                s = (uint32_t)(t1 <= x) + (uint32_t)(t2 <= x) + (uint32_t)(t3 <= x);
+                lo = s == 0 ? 0u : s == 1 ? t1 : s == 2 ? t2 : t3;
+                hi = s == 0 ? t1 : s == 1 ? t2 : s == 2 ? t3 : dd + 1u;
+            } else {
+                // v[k], k = 1..15, sits in half (k-1)&1 of word (k-1)>>1.  Binary search with register selects.
+                auto V = [&](int k) -> uint32_t { return ((k - 1) & 1) ? rw.w[(k - 1) >> 1] >> 16 : rw.w[(k - 1) >> 1] & 0xFFFFu; };
+                const bool b8 = scale_d(dd, V(8)) <= x;
+                const uint32_t m4 = b8 ? V(12) : V(4);
+                const bool b4 = scale_d(dd, m4) <= x;
+                const uint32_t m2 = b8 ? (b4 ? V(14) : V(10)) : (b4 ? V(6) : V(2));
+                const bool b2 = scale_d(dd, m2) <= x;
+                const uint32_t base = (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u);  // s in {base, base+1}
+                // candidates: v[base] (0 when base == 0), v[base+1], v[base+2] (span when base + 2 == 16):
+                // v[base] / v[base+2] are the two halves around word base>>1 ... pick words, then halves
+                uint32_t wa = 0, wb = 0;   // wa holds v[base] in its high half (base >= 2), wb = {v[base+1], v[base+2]}
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if ((uint32_t)q + 1u == (base >> 1)) wa = rw.w[q];
+                    if ((uint32_t)q == (base >> 1)) wb = rw.w[q];
+                }
+                const uint32_t cm1 = wa >> 16, c0 = wb & 0xFFFFu, cp1 = wb >> 16;
+                const uint32_t tm1 = base ? scale_d(dd, cm1) : 0u, t0 = scale_d(dd, c0);
+                const uint32_t tp1 = base + 2u == 16u ? dd + 1u : scale_d(dd, cp1);
+                const bool b1 = t0 <= x;
+                s = base + (uint32_t)b1;
+                lo = b1 ? t0 : tm1;
+                hi = b1 ? tp1 : t0;
             }
-            const uint32_t tm1 = base ? scale(span, cm1) : 0u, t0 = scale(span, c0);
-            const uint32_t tp1 = base + 2u == 16u ? (uint32_t)span : scale(span, cp1);
-            const bool b1 = t0 <= x;
-            s = base + (uint32_t)b1;
-            lo = b1 ? t0 : tm1;
-            hi = b1 ? tp1 : t0;
+            pack |= s << (8 * (d & 3));
+            if ((d & 3) == 3) {
+                if (wide && i < ch.n) *reinterpret_cast<uint32_t *>(sym + ch.out + i - 3u) = pack;
+                else if (i - 3u < ch.n) {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q)
+                        if (i - 3u + q < ch.n) sym[ch.out + i - 3u + q] = (uint8_t)(pack >> (8 * q));
+                }
+                pack = 0;
+            }
+            high = (low - 1u) + hi;
+            low = low + lo;
+            // Branch-free renormalisation, both phases at once.  Phase 1 drops the n1 leading bits on which low and
+            // high agree; then low = 0..., high = 1... and phase 2 drops the n2 underflow bits (low = 01^n2.., high =
+            // 10^n2..) behind the top bit.  A symbol narrows the interval by at most 2^-16 (+1), so k = n1 + n2 <= 19
+            // for any valid CDF row; the shifts are masked to 5 bits so that garbage (lanes running past their
+            // chunk, corrupt input) stays defined.
+            const uint32_t n1 = (uint32_t)clz32(low ^ high) & 31u;  // low < high
+            const uint32_t l1 = low << n1, h1 = ~((~high) << n1);
+            const uint32_t n2 = (uint32_t)min(min(clz32(~(l1 << 1)), clz32(h1 << 1)), 31);
+            const uint32_t flip = n2 ? 0x80000000u : 0u;
+            const uint32_t k = n1 + n2;
+            low = (l1 << n2) & ~flip;
+            high = ~((~h1) << n2) | flip;
+            value = (((value << n1) << n2) | in.take(k)) ^ flip;
+            in.fetch();
         }
-        sym[ch.out + i] = (uint8_t)s;
-        high = (low - 1u) + hi;
-        low = low + lo;
-        // branch-free renormalisation: shifts by zero are no-ops
-        const int n1 = clz32(low ^ high);  // < 32: low < high
-        low <<= n1;
-        high = (high << n1) | ((1u << n1) - 1u);
-        value = (value << n1) | in.take((uint32_t)n1);
-        const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-        low = (low << n2) & (n2 ? 0x7FFFFFFFu : 0xFFFFFFFFu);
-        high = (high << n2) | (n2 ? 0x80000000u : 0u) | ((1u << n2) - 1u);
-        value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
     }
 }
 

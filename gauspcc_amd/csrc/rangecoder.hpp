@@ -24,6 +24,11 @@ __host__ __device__ __forceinline__ uint32_t rc_interleaved(uint32_t r, int chun
     return chunk_log2 ? (r & ((1u << chunk_log2) - 1u)) * nch + (r >> chunk_log2) : r;
 }
 
+// The decoder fetches compact rows RC_ROW_LOOKAHEAD symbols ahead without clamping: the row buffer of a stream of
+// nch chunks of (at most) S symbols must hold rc_rows_capacity(nch, S) rows (what lies past the last row is never used).
+constexpr int RC_ROW_LOOKAHEAD = 8;
+static inline int64_t rc_rows_capacity(int64_t nch, int64_t S) { return (S + RC_ROW_LOOKAHEAD) * nch; }
+
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);

@@ -1,27 +1,43 @@
 #!/usr/bin/env python3
-"""Gap analysis of a rocprofv3 kernel trace: for the last encode+decode step, total kernel-busy time vs. idle
-gaps between consecutive kernels (launch-bound stretches)."""
-import csv, sys
+"""Gap analysis of a rocprofv3 kernel trace: for the last encode+decode step, kernel-busy time vs idle gaps,
+separately for the encode (k_bbox .. k_rc_compact) and the decode (the rest)."""
+import collections
+import csv
+import sys
+
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
 rows.sort()
-# steps are separated by k_bbox (first kernel of an encode)
 starts = [i for i, r in enumerate(rows) if "k_bbox" in r[2]]
-lo = starts[-1]
-seg = rows[lo:]
-busy = sum(e - s for s, e, _ in seg)
-span = seg[-1][1] - seg[0][0]
-gaps = [(seg[i + 1][0] - seg[i][1]) for i in range(len(seg) - 1)]
-print(f"last step: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms, idle {sum(g for g in gaps if g>0)/1e6:.2f} ms")
-big = sorted(((g, seg[i][2], seg[i + 1][2]) for i, g in enumerate(gaps)), reverse=True)[:25]
-for g, a, b in big:
-    print(f"  gap {g/1e3:8.1f} us  after {a[:60]}  before {b[:60]}")
-import collections
-agg = collections.defaultdict(lambda: [0, 0])
-for s, e, n in seg:
-    agg[n][0] += 1; agg[n][1] += e - s
-print("per kernel (last step):")
-for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-    print(f"  {t/1e3:9.1f} us {c:5d}  {n[:100]}")
+seg = rows[starts[-1]:]
+cut = max(i for i, r in enumerate(seg) if "k_rc_compact" in r[2]) + 1
+
+
+def report(name, seg):
+    busy = sum(e - s for s, e, _ in seg)
+    span = seg[-1][1] - seg[0][0]
+    gaps = [(seg[i + 1][0] - seg[i][1], seg[i][2], seg[i + 1][2]) for i in range(len(seg) - 1)]
+    idle = sum(g for g, _, _ in gaps if g > 0)
+    print(f"== {name}: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms, idle {idle/1e6:.2f} ms")
+    hist = collections.Counter()
+    for g, _, _ in gaps:
+        b = "<2us" if g < 2000 else "2-5us" if g < 5000 else "5-20us" if g < 20000 else "20-100us" if g < 100000 else ">100us"
+        hist[b] += max(g, 0)
+    print("   idle by gap size:", {k: f"{v/1e6:.2f}ms" for k, v in hist.items()})
+    for g, a, b in sorted(gaps, reverse=True)[:8]:
+        print(f"   gap {g/1e3:8.1f} us  after {a[:50]}  before {b[:50]}")
+    agg = collections.defaultdict(lambda: [0, 0])
+    for s, e, n in seg:
+        agg[n][0] += 1
+        agg[n][1] += e - s
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:22]:
+        print(f"   {t/1e3:9.1f} us {c:5d}  {n[:90]}")
+
+
+report("encode", seg[:cut])
+dec = seg[cut:]
+# drop anything after the decode (next step / teardown): decode ends with the last k_expand
+last = max(i for i, r in enumerate(dec) if "k_expand" in r[2] or "k_level" in r[2])
+report("decode", dec[: last + 1])

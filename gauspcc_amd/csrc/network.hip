@@ -20,6 +20,7 @@
 #include "octree.hpp"
 #include "primitives.hpp"
 #include "rangecoder.hpp"
+#include "conv_loop_gfx950.inc"   // generated: tools/gen_conv_loop.py
 
 namespace gpcc {
 
@@ -166,8 +167,10 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 // ds_add_f32 without return: IEEE fp32 add performed by the LDS, in the wave's program order
 __device__ __forceinline__ void lds_add(float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
-template <int R, int DIST>
-__global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
+// ASM = true: the tile loop is the hand-scheduled gfx950 instruction stream of conv_loop_gfx950.inc (row offsets are
+// 32-bit there: n < 2^25).  ASM = false: the same loop in HIP C++ (any n; also the readable statement of the schedule).
+template <int R, int DIST, bool ASM>
+__global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
 {
     constexpr int CONV_LDS_WAVE = conv_lds_wave_floats(R);  // R rows + 1 dummy row for padding entries + the tile-header ring
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
     const int e = lane & 15, g = lane >> 4;
     // column of this lane inside an accumulator row (physical order) for output halves 0 / 1
     const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
-    const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
     const float *__restrict__ in = J.in + 4 * g;
     const float *__restrict__ wf = J.w + lane * 4;
     const int32_t *hj = hdr + e;            // + slot * 16
@@ -296,8 +299,18 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
             const uint32_t b0 = gtr[0], b1 = gtr[64], c0 = gto[0], c1 = gto[16];
             sj[0] = a0; sj[64] = a1;
             sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
-            so[0] = (int32_t)c0; so[16] = (int32_t)c1;
+            so[0] = (int32_t)(c0 & 0xFFFFu); so[16] = (int32_t)(c1 & 0xFFFFu);
         }
+        if constexpr (ASM) {
+            uint32_t su, st0, st1;
+            const uint32_t acc_lds = __builtin_amdgcn_groupstaticsize() + (uint32_t)(wave * CONV_LDS_WAVE * 4);
+            const uint32_t hdr_lds = acc_lds + (uint32_t)((R + 1) * 128);
+            asm volatile(CONV_LOOP_ASM
+                         : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
+                         : [in] "s"(J.in), [w] "s"(J.w), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                           [nt] "s"(nt), [dummy] "s"(DUMMY4), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                         : CONV_LOOP_CLOBBERS);
+        } else {
         int4 st_j = make_int4(0, 0, 0, 0);
         uint32_t st_r = 0, st_o = 0;
         AB ring[RING];
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
                 }
                 if ((us & 15u) == 8u && us > 8u) {
                     const uint32_t bb = ((us >> 4) + 1u) & 1u;
-                    sj[bb * 64] = st_j; sr[bb * 64] = (int32_t)st_r; so[bb * 16] = (int32_t)st_o;
+                    sj[bb * 64] = st_j; sr[bb * 64] = (int32_t)st_r; so[bb * 16] = (int32_t)(st_o & 0xFFFFu);
                 }
                 const int sl = (s + DIST) % RING;            // set that receives tile us + DIST
                 const uint32_t tq = us + (uint32_t)(DIST + 1);
@@ -348,6 +361,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (R >= 128 ? 2 : R >= 96 ? 3 : 4)) 
             }
         }
         accumulate(prev);
+        }
     }
     // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
     const int row0 = blk * R;
@@ -400,28 +414,35 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     const bool prof = ctx && ctx->prof.on;
     ConvRec rec = {0, 0, level, njobs};
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
+    static int dist = -1, use_asm = -1;
+    if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
+    if (use_asm < 0) { const char *e = getenv("GAUSPCC_CONV_ASM"); use_asm = e ? atoi(e) != 0 : 1; }
     static bool lds_attr_set = false;
-    if (!lds_attr_set) {  // 128-row blocks need 66048 B of LDS per workgroup (> the 64 KiB default cap)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(128) * 4));
+    if (!lds_attr_set) {  // 128-row blocks need more LDS per workgroup than the 64 KiB default cap
+        const int bytes = CONV_WAVES * conv_lds_wave_floats(128) * 4;
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         lds_attr_set = true;
     }
-    static int dist = -1;
-    if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
     dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
     const size_t lds_bytes = (size_t)CONV_WAVES * conv_lds_wave_floats(T.R) * 4;
+    const bool asm_ok = use_asm && dist == 1 && n < ((int64_t)1 << 25);   // the asm loop addresses rows with 32-bit byte offsets
+#define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu)
     switch (T.R) {
-    case 16: k_sparse_conv<16, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 32: k_sparse_conv<32, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 64: k_sparse_conv<64, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
-    case 96: k_sparse_conv<96, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu); break;
+    case 16: if (asm_ok) CONV_LAUNCH(16, 1, true); else CONV_LAUNCH(16, 1, false); break;
+    case 32: if (asm_ok) CONV_LAUNCH(32, 1, true); else CONV_LAUNCH(32, 1, false); break;
+    case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
+    case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
     default:
-        if (dist == 3) k_sparse_conv<128, 3><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
-        else if (dist == 2) k_sparse_conv<128, 2><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
-        else k_sparse_conv<128, 1><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu);
+        if (asm_ok) CONV_LAUNCH(128, 1, true);
+        else if (dist == 3) CONV_LAUNCH(128, 3, false);
+        else if (dist == 2) CONV_LAUNCH(128, 2, false);
+        else CONV_LAUNCH(128, 1, false);
         break;
     }
+#undef CONV_LAUNCH
     LAUNCH_CHECK();
     if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
     return GPCC_OK;

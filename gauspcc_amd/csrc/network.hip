@@ -92,9 +92,14 @@ int conv_pick_rows(int64_t n)
     if (forced < 0) {
         const char *e = getenv("GAUSPCC_CONV_R");
         forced = e ? atoi(e) : 0;
-        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128) forced = 0;
+        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128 && forced != 255) forced = 0;
     }
     if (forced) return forced;
+    // the biggest levels: 255-row blocks at one wave per SIMD (4 x 35 KiB of LDS sums per CU) -- per-offset tiles fill
+    // ~20 % better, and the asm loop keeps the matrix pipe fed from a single wave (32-bit row offsets: n < 2^25)
+    static int64_t tall_min = -1;
+    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 768 * 1024; }
+    if (n >= tall_min && n < ((int64_t)1 << 25)) return 255;
     // enough waves to cover the chip a few times over before growing the block height
     if (n >= 192 * 1024) return 128;
     if (n >= 96 * 1024) return 64;
@@ -158,6 +163,7 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
     case 32: return conv_tiles_build_r<32>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 64: return conv_tiles_build_r<64>(ctx, st, nbrT, n, K, T, pairs_dev);
     case 96: return conv_tiles_build_r<96>(ctx, st, nbrT, n, K, T, pairs_dev);
+    case 255: return conv_tiles_build_r<255>(ctx, st, nbrT, n, K, T, pairs_dev);
     default: return conv_tiles_build_r<128>(ctx, st, nbrT, n, K, T, pairs_dev);
     }
 }
@@ -421,6 +427,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     if (!lds_attr_set) {  // 128-row blocks need more LDS per workgroup than the 64 KiB default cap
         const int bytes = CONV_WAVES * conv_lds_wave_floats(128) * 4;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -435,6 +443,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 32: if (asm_ok) CONV_LAUNCH(32, 1, true); else CONV_LAUNCH(32, 1, false); break;
     case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
     case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
+    case 255: if (asm_ok) CONV_LAUNCH(255, 1, true); else CONV_LAUNCH(255, 1, false); break;
     default:
         if (asm_ok) CONV_LAUNCH(128, 1, true);
         else if (dist == 3) CONV_LAUNCH(128, 3, false);

@@ -62,7 +62,7 @@ struct ConvBatch { ConvJob job[4]; };
 // 5 / 13 convolutions that run on that level.  R (16, 32, 64, 96 or 128) is picked per level: tall blocks
 // pack tiles better, short blocks give more waves and shorter serial chains on small levels.
 // (Measured on MI355X, 1M-point cloud: 255-row blocks at 1 wave/SIMD lose to 128-row blocks at 2.)
-constexpr int CONV_R_MAX = 128;
+constexpr int CONV_R_MAX = 255;
 struct ConvTiles {
     int32_t *tj = nullptr;     // [tiles][16] neighbour row (padding: 0, a valid row whose result is discarded)
     uint8_t *tr = nullptr;     // [tiles][16] output row inside the block (padding: R = the dummy row)

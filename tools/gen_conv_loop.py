@@ -10,12 +10,11 @@ the loop is bound by L1 / issue work per tile, which the split doubles; it is no
 Per step (one tile = 16 (output row, neighbour row) pairs of one kernel offset) the v_mfma_f32_16x16x4_f32 are issued
 back to back from a ZERO accumulator; everything else is slotted into the shadow of the matrix pipe (an MFMA occupies
 it for 32 cycles, a wave can issue ~5 other instructions meanwhile):
-    weight fragment (B) of the NEXT tile (L1/L2 resident: one step ahead is enough)
-    gathered rows (A) of the tile THREE steps ahead -- a tile waits for the slowest of its 16 gathered rows, and with
-        ~1/n_bar of all gathers being first touches of a row, nearly every tile contains an HBM miss.  vmcnt retires in
-        order, so the step issues B before A and waits with vmcnt(2): the A loads of the last step stay in flight,
-        everything older (this tile's A from three steps ago, its B from the last step) has landed
-    header words from the wave's LDS ring: neighbour rows of tile u+4, offset and output rows of tile u+2
+    gathered rows (A) and weight fragment (B) of the tile D = 3 steps ahead -- a tile waits for the slowest of its 16
+        gathered rows, and with ~1/n_bar of all gathers being first touches of a row, nearly every tile contains an HBM
+        miss.  vmcnt retires in order, so a step waits with vmcnt(6 (D-1)): the loads of the last D-1 steps stay in
+        flight, this tile's (issued D steps ago) have landed
+    header words from the wave's LDS ring: neighbour rows + offset of tile u+D+1, output rows of tile u+2
     LDS addresses of the PREVIOUS tile's 4 output rows, their running sums read, previous products added, written back
     loop bookkeeping / header staging (three wide loads every 16 tiles, moved into the ring 8 tiles later)
 LDS operations of a wave execute in program order, so consecutive tiles may share output rows.
@@ -25,21 +24,22 @@ Register tuples start on even registers (gfx90a+ requirement).
 import os
 
 EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers
-DA = 3                                           # issue distance of the row gathers (tiles); A ring = DA + 1 sets
+D = 3                                            # issue distance of the tile loads (steps); A and B rings = D + 1 sets
 
 V = dict(
     A=(16, 24, 32, 40),                # 4 sets x 8 regs
-    B=(48, 64),                        # 2 sets x 16 regs
-    C=(80, 88),                        # c0 = C..C+3, c1 = C+4..C+7
-    jn=96, on=97, r4nn=98, r4nxt=99, r4cur=100, r4prev=101,
-    ao=102, bo=103, t0=104, wof=105,
-    ra=106,                            # 106..109
-    s=110,                             # 110..117
-    stj=118, str=122, sto=123,
-    accb=124, hj=125, hr=126, ho=127, goff=128, loff=129, dummy=130, sgr=131, sgo=132, swj=133, swr=134, swo=135,
+    B=(48, 64, 80, 96),                # 4 sets x 16 regs
+    C=(112, 120),                      # c0 = C..C+3, c1 = C+4..C+7
+    jn=128, on=129, r4nn=130, r4nxt=131, r4cur=132, r4prev=133,
+    ao=134, bo=135, t0=136, wof=137,
+    ra=138,                            # 138..141
+    s=142,                             # 142..149
+    stj=150, str=154, sto=155,
+    accb=156, hj=157, hr=158, ho=159, goff=160, loff=161, dummy=162, sgr=163, sgo=164, swj=165, swr=166, swo=167,
 )
-CLOBBER_V = list(range(16, 136))
-NSTEP = 4
+CLOBBER_V = list(range(16, 168))
+NSTEP = 4                              # lcm(D + 1, 2)
+WINDOW = 6 * (D - 1)                   # tile loads that may stay in flight across a step start
 
 
 def vr(base, n=1):
@@ -108,12 +108,12 @@ def r4_validate(du):
 
 
 def header_reads(du):
-    # neighbour rows of tile u+du+DA+1 (its gather is issued in the next step), offset + output rows of tile u+du+2
-    return [f"s_add_u32 %[t0], %[u], {du + DA + 1}", "s_and_b32 %[t0], %[t0], 31",
+    # neighbour rows + offset of tile u+du+D+1 (its loads are issued in the next step), output rows of tile u+du+2
+    return [f"s_add_u32 %[t0], %[u], {du + D + 1}", "s_and_b32 %[t0], %[t0], 31",
             f"v_lshl_add_u32 v{V['t0']}, %[t0], 6, v{V['hj']}", f"ds_read_b32 v{V['jn']}, v{V['t0']}",
+            f"v_lshl_add_u32 v{V['t0']}, %[t0], 2, v{V['ho']}", f"ds_read_b32 v{V['on']}, v{V['t0']}",
             f"s_add_u32 %[t0], %[u], {du + 2}", "s_and_b32 %[t0], %[t0], 31",
-            f"v_lshl_add_u32 v{V['t0']}, %[t0], 4, v{V['hr']}", f"ds_read_b32 v{V['r4nn']}, v{V['t0']}",
-            f"v_lshl_add_u32 v{V['t0']}, %[t0], 2, v{V['ho']}", f"ds_read_b32 v{V['on']}, v{V['t0']}"]
+            f"v_lshl_add_u32 v{V['t0']}, %[t0], 4, v{V['hr']}", f"ds_read_b32 v{V['r4nn']}, v{V['t0']}"]
 
 
 def staging_fetch(label):
@@ -160,40 +160,40 @@ def staging_store(label, younger_loads):
 
 
 def step_wait(du, label):
-    """Everything older than the 2 gathers issued by the previous step must have landed.  The step after a header
-    fetch (du == 1) leaves the 3 fetch loads in flight as well (they were issued behind the gathers)."""
-    if du != 1:
-        return ["s_waitcnt vmcnt(2) lgkmcnt(0)"]
+    """The loads of the last D - 1 steps may stay in flight; everything older (this tile's) must have landed.  For D
+    steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside that window as well."""
+    if not 1 <= du <= D:
+        return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)"]
     return ["s_and_b32 %[t0], %[u], 15",
             "s_cmp_eq_u32 %[t0], 0",
-            f"s_cbranch_scc0 {label}_w2%=",
+            f"s_cbranch_scc0 {label}_wa%=",
             "s_cmp_eq_u32 %[u], 0",
-            f"s_cbranch_scc1 {label}_w2%=",
-            "s_waitcnt vmcnt(5) lgkmcnt(0)",
-            f"s_branch {label}_w5%=",
-            f"{label}_w2%=:",
-            "s_waitcnt vmcnt(2) lgkmcnt(0)",
-            f"{label}_w5%=:"]
+            f"s_cbranch_scc1 {label}_wa%=",
+            f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt(0)",
+            f"s_branch {label}_wb%=",
+            f"{label}_wa%=:",
+            f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)",
+            f"{label}_wb%=:"]
 
 
 def step(du):
-    aset, bset, cset = du % (DA + 1), du % 2, du % 2
-    A, B, CC, CP = V["A"][aset], V["B"][bset], V["C"][cset], V["C"][1 - cset]
+    rset, cset = du % (D + 1), du % 2
+    A, B, CC, CP = V["A"][rset], V["B"][rset], V["C"][cset], V["C"][1 - cset]
     label = f"s{du}"
 
     def mf(kk, first=False):
         return [mfma(CC, A + kk, B + kk, first), mfma(CC + 4, A + kk, B + 8 + kk, first)]
 
-    lb = loads_b(1 - bset)
-    la = loads_a((du + DA) % (DA + 1))
-    o = [f"; ---- step: tile u+{du}: A set {aset}, B set {bset}, C set {cset}"] + step_wait(du, label) + addr_b() + addr_a()
-    o += mf(0, True) + lb[0:2]
-    o += mf(1) + lb[2:4]
-    o += mf(2) + la + (staging_fetch(label) if du == 0 else [])
+    nset = (du + D) % (D + 1)          # the set consumed by the previous step receives tile u+du+D
+    la, lb = loads_a(nset), loads_b(nset)
+    o = [f"; ---- step: tile u+{du}: A/B set {rset}, C set {cset}"] + step_wait(du, label) + addr_a() + addr_b()
+    o += mf(0, True) + la
+    o += mf(1) + lb[0:2]
+    o += mf(2) + lb[2:4] + (staging_fetch(label) if du == 0 else [])
     o += mf(3) + r4_rotate() + row_addr(V["r4prev"], range(4))
     o += mf(4) + sum_reads(range(4))
     o += mf(5) + r4_validate(du) + header_reads(du)
-    o += mf(6) + (staging_store(label, 6) if du == 0 else [])
+    o += mf(6) + (staging_store(label, WINDOW + 6) if du == 0 else [])
     # LDS returns in order: the 4 sum reads are older than the 3 header reads (and than any staging write)
     o += [mfma(CC, A + 7, B + 7, False)] + ([] if EXP & 1 else ["s_waitcnt lgkmcnt(3)"]) + sum_adds_writes(CP)
     o += [mfma(CC + 4, A + 7, B + 15, False)]
@@ -225,21 +225,18 @@ def build():
         f"v_add_u32 v{L['swr']}, %[hdr], v{L['sgr']}",
         f"v_add_u32 v{L['swr']}, 2048, v{L['swr']}",
         f"v_add_u32 v{L['swo']}, v{L['ho']}, v{L['sgo']}",
-        "; ---- pipeline prologue: B of tile 0, A of tiles 0..DA-1 in flight; headers j(DA), o(1), r4(0), r4(1) in registers",
+        "; ---- pipeline prologue: A and B of tiles 0..D-1 in flight; headers j(D), o(D), r4(0), r4(1) in registers",
         "s_waitcnt lgkmcnt(0)",
-        f"ds_read_b32 v{L['jn']}, v{L['hj']}",
         f"ds_read_b32 v{L['r4nxt']}, v{L['hr']}",
-        f"ds_read_b32 v{L['on']}, v{L['ho']}",
         f"v_mov_b32 v{L['r4cur']}, v{L['dummy']}",
-        "s_waitcnt lgkmcnt(0)",
     ]
-    o += addr_b() + addr_a() + loads_b(0) + loads_a(0)
-    for t in range(1, DA):
-        o += [f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * t}", "s_waitcnt lgkmcnt(0)"] + addr_a() + loads_a(t)
+    for t in range(D):
+        o += [f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * t}", f"ds_read_b32 v{L['on']}, v{L['ho']} offset:{4 * t}", "s_waitcnt lgkmcnt(0)"]
+        o += addr_a() + addr_b() + loads_a(t) + loads_b(t)
     o += [
-        f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * DA}",
+        f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * D}",
+        f"ds_read_b32 v{L['on']}, v{L['ho']} offset:{4 * D}",
         f"ds_read_b32 v{L['r4nn']}, v{L['hr']} offset:16",
-        f"ds_read_b32 v{L['on']}, v{L['ho']} offset:4",
         "s_mov_b32 %[u], 0",
         "conv_loop%=:",
     ]

@@ -152,7 +152,7 @@ def main():
                 "scenes_per_gpu": 1,
                 "channels": 32,
                 "kernel_size": k,
-                "container": f"v1 chunk_log2={args.chunk_log2}" if args.chunk_log2 else "v0 (reference layout)",
+                "container": f"v2 (per-level chunks, chunk_log2<={args.chunk_log2})" if args.chunk_log2 else "v0 (reference layout)",
                 "weights": "seeded synthetic (reference initialisers, conv gain 4)",
             },
             "enc_ms": round(float(allstats[:, 1].mean()) * 1e3, 3),

@@ -71,7 +71,9 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
     // stream-major packed symbols: stream (d, s), d = 1..L-1, occupies slots(d) words (the chunk-interleaved
     // layout pads the last chunk): offset 4 * sum_{d' < d} slots(d') + s * slots(d)
-    auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? cdiv(nc, (int64_t)1 << chunk_log2) << chunk_log2 : nc; };
+    constexpr int CONTAINER_VERSION = 2;
+    auto clog = [&](int64_t nc) -> int { return rc_level_chunk_log2(nc, chunk_log2, CONTAINER_VERSION); };
+    auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? cdiv(nc, (int64_t)1 << clog(nc)) << clog(nc) : nc; };
     int64_t lohi_words = 0;
     for (int d = 1; d < L; ++d) lohi_words += 4 * slots(T.lv[d].n);
     if (lohi_words >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many octree nodes");
@@ -92,32 +94,26 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(nbrCs, int32_t, (int64_t)K * nC);
         TAKE(occP, uint8_t, nP); TAKE(occC, uint8_t, nC); TAKE(rkeyC, uint64_t, nC);
         TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
-        {   // per-level neighbour maps (top-down, two buffers) copied into the set maps
-            const size_t mk = ctx->arena.mark();
-            TAKE(nbrA, int32_t, (int64_t)K * nmax);
-            TAKE(nbrB, int32_t, (int64_t)K * nmax);
-            int32_t *cur = nbrA, *nxt = nbrB;
-            GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, cur));
+        {   // per-level neighbour maps, derived top-down and written straight into the two set maps: level d's map lives in
+            // the prior set at rows pb[d].. (d <= L-2) and in the target set at rows cbase[d].. (d >= 1)
+            GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, nbrPs, nP));
+            HIP_TRY(hipMemcpyAsync(occP, T.lv[0].occ, (size_t)T.lv[0].n, hipMemcpyDeviceToDevice, st));
             int64_t lohi_base = 0;
-            for (int d = 0; d < L; ++d) {
+            for (int d = 1; d < L; ++d) {
                 const Level *lv = &T.lv[d];
-                if (d + 1 < L) {
-                    GP_TRY(nbr_concat(ctx, st, cur, lv->n, K, nbrPs, nP, pb[d]));
-                    HIP_TRY(hipMemcpyAsync(occP + pb[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                }
-                if (d >= 1) {
-                    GP_TRY(nbr_concat(ctx, st, cur, lv->n, K, nbrCs, nC, cbase[d]));
-                    HIP_TRY(hipMemcpyAsync(occC + cbase[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                    HIP_TRY(hipMemcpyAsync(rkeyC + cbase[d], lv->rkey, 8 * (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                    const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << chunk_log2) : 1u;
-                    k_child_meta<<<(unsigned)cdiv(lv->n, 256), 256, 0, st>>>(lv->parent, lv->m2r, lv->n, (uint32_t)pb[d - 1], (uint32_t)lohi_base, (uint32_t)slots(lv->n),
-                                                                             chunk_log2, nch, parentC + cbase[d], posC + cbase[d], slotsC + cbase[d]);
-                    LAUNCH_CHECK();
-                    lohi_base += 4 * slots(lv->n);
-                }
-                if (d + 1 < L) { GP_TRY(nbr_child(ctx, st, lv, cur, &T.lv[d + 1], m->k, nxt)); std::swap(cur, nxt); }
+                const NbrView in = {nbrPs + pb[d - 1], nP, (int32_t)pb[d - 1]};
+                const NbrView outC = {nbrCs + cbase[d], nC, (int32_t)cbase[d]};
+                const NbrView outP = d + 1 < L ? NbrView{nbrPs + pb[d], nP, (int32_t)pb[d]} : NbrView{nullptr, 0, 0};
+                GP_TRY(nbr_child_views(ctx, st, &T.lv[d - 1], in, lv, m->k, outC, outP));
+                if (d + 1 < L) HIP_TRY(hipMemcpyAsync(occP + pb[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(occC + cbase[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                HIP_TRY(hipMemcpyAsync(rkeyC + cbase[d], lv->rkey, 8 * (size_t)lv->n, hipMemcpyDeviceToDevice, st));
+                const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << clog(lv->n)) : 1u;
+                k_child_meta<<<(unsigned)cdiv(lv->n, 256), 256, 0, st>>>(lv->parent, lv->m2r, lv->n, (uint32_t)pb[d - 1], (uint32_t)lohi_base, (uint32_t)slots(lv->n),
+                                                                         clog(lv->n), nch, parentC + cbase[d], posC + cbase[d], slotsC + cbase[d]);
+                LAUNCH_CHECK();
+                lohi_base += 4 * slots(lv->n);
             }
-            ctx->arena.rewind(mk);
         }
         ConvTiles tilesP, tilesC;
         GP_TRY(conv_tiles_build(ctx, st, nbrPs, nP, K, &tilesP, pairs_dev));
@@ -152,7 +148,6 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     }
     // ---- range coder over every chunk of every stream
     const int nstreams = 4 * (L - 1);
-    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
     std::vector<RcChunk> chunks;
     std::vector<int> stream_first(nstreams + 1, 0);
     uint32_t max_syms = 1;
@@ -160,6 +155,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         int64_t pre = 0; int si = 0;
         for (int d = 1; d < L; ++d) {
             const int64_t nc = T.lv[d].n;
+            const int64_t S = chunk_log2 ? (int64_t)1 << clog(nc) : INT64_MAX;
             for (int s = 0; s < 4; ++s, ++si) {
                 stream_first[si] = (int)chunks.size();
                 const int64_t base = pre + (int64_t)s * slots(nc);
@@ -216,7 +212,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     uint8_t *out = ctx->hbytes.p;
     size_t pos = 0;
     if (chunk_log2) {
-        out[0] = 0xFF; out[1] = 0xFF; out[2] = 1; out[3] = (uint8_t)chunk_log2; out[4] = (uint8_t)posq; out[5] = (uint8_t)(posq >> 8); out[6] = (uint8_t)L; out[7] = 0;
+        out[0] = 0xFF; out[1] = 0xFF; out[2] = (uint8_t)CONTAINER_VERSION; out[3] = (uint8_t)chunk_log2; out[4] = (uint8_t)posq; out[5] = (uint8_t)(posq >> 8); out[6] = (uint8_t)L; out[7] = 0;
         pos = 8;
         for (int d = 0; d < L; ++d) { put32(out + pos, (uint32_t)T.lv[d].n); pos += 4; }
         put32(out + pos, (uint32_t)n); pos += 4;
@@ -266,7 +262,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     ctx->arena.reset();
     const int K = m->K;
     int64_t pos = 0;
-    int chunk_log2 = 0, L = -1;
+    int chunk_log2 = 0, L = -1, version = 0;
     int64_t lvl_n[MAXLV] = {0};
     int64_t npts_hdr = -1;
 #define NEED(b) do { if (pos + (int64_t)(b) > nbytes) return fail(GPCC_ERR_FORMAT, "truncated bitstream (need %lld bytes at %lld of %lld)", (long long)(b), (long long)pos, (long long)nbytes); } while (0)
@@ -274,7 +270,8 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     const bool v1 = in[0] == 0xFF && in[1] == 0xFF;
     if (v1) {
         NEED(8);
-        if (in[2] != 1) return fail(GPCC_ERR_FORMAT, "unknown container version %d", in[2]);
+        version = in[2];
+        if (version != 1 && version != 2) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
         chunk_log2 = in[3];
         if (chunk_log2 < 6 || chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "bad chunk_log2 %d", chunk_log2);
         *posq_out = (uint16_t)(in[4] | in[5] << 8);
@@ -385,7 +382,8 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         ConvTiles tilesC;
         GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
         // chunk descriptors of this level's four streams
-        const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : INT64_MAX;
+        const int clog = rc_level_chunk_log2(nc, chunk_log2, version);   // this level's chunk size
+        const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
         const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
         chunks.assign((size_t)4 * nch, RcChunk{});
         for (int s = 0; s < 4; ++s) {
@@ -418,7 +416,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        TAKE(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? (int64_t)1 << chunk_log2 : nc) * 16);  // interleaved rows + the decoder's look-ahead
+        TAKE(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? S : nc) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
         for (int s = 0; s < 4; ++s) {
@@ -432,7 +430,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s];
-            ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = chunk_log2; ha.nch = (uint32_t)nch;
+            ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = clog; ha.nch = (uint32_t)nch;
             GP_TRY(head_cdf(st, ha));
             GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
         }

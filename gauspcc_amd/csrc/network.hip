@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nblk) return;
-    key[b] = 0xFFFFFFFFull - (uint64_t)(first[b + 1] - first[b]);  // ascending sort of this = descending tile count
+    key[b] = 0xFFFFull - (uint64_t)min(first[b + 1] - first[b], 0xFFFFu);  // ascending sort of this = descending tile count (16 bits: 2 radix passes)
     idx[b] = (uint32_t)b;
 }
 
@@ -139,16 +139,19 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     HIP_TRY(hipMemsetAsync(toc + total, 0, (size_t)CONV_HDR_PAD * 4, st));
     k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
-    // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling)
+    // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling).  When all
+    // blocks are resident at once (<= 8 waves on each of 256 CUs) the order cannot matter: identity, no sort.
     TAKE(order, uint32_t, nblk);
     {
         const size_t mk = ctx->arena.mark();
         TAKE(ka, uint64_t, nblk); TAKE(kb, uint64_t, nblk); TAKE(vb, uint32_t, nblk);
         k_order_keys<<<(unsigned)cdiv(nblk, 256), 256, 0, st>>>(first, (int)nblk, ka, order);
         LAUNCH_CHECK();
-        uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = order, *v1 = vb;
-        GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, nblk, 32));
-        if (v0 != order) HIP_TRY(hipMemcpyAsync(order, v0, 4 * (size_t)nblk, hipMemcpyDeviceToDevice, st));
+        if (nblk > 2048) {
+            uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = order, *v1 = vb;
+            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, nblk, 16));   // keys are 0xFFFF - min(tiles, 0xFFFF)
+            if (v0 != order) HIP_TRY(hipMemcpyAsync(order, v0, 4 * (size_t)nblk, hipMemcpyDeviceToDevice, st));
+        }
         ctx->arena.rewind(mk);
     }
     T->order = order;

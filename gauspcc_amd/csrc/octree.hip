@@ -29,12 +29,18 @@ __global__ __launch_bounds__(TB) void k_bbox(const int32_t *__restrict__ xyz, in
             mx[a] = max(mx[a], __shfl_xor(mx[a], d, 64));
         }
     }
+    // one set of atomics per block (the six words are a serial hot spot: 4 waves x 1024 blocks of them cost 0.25 ms)
+    __shared__ int red[TB / 64][6];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&bbox[a], mn[a]);
-            atomicMax(&bbox[3 + a], mx[a]);
-        }
+        for (int a = 0; a < 3; ++a) { red[threadIdx.x >> 6][a] = mn[a]; red[threadIdx.x >> 6][3 + a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = red[0][threadIdx.x];
+        for (int w = 1; w < TB / 64; ++w) v = threadIdx.x < 3 ? min(v, red[w][threadIdx.x]) : max(v, red[w][threadIdx.x]);
+        if (threadIdx.x < 3) atomicMin(&bbox[threadIdx.x], v);
+        else atomicMax(&bbox[threadIdx.x], v);
     }
 }
 
@@ -167,7 +173,7 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tre
     // bbox: one sync
     for (int a = 0; a < 3; ++a) { hb32[a] = INT32_MAX; hb32[3 + a] = INT32_MIN; }
     HIP_TRY(hipMemcpyAsync(dsmall, hb32, 24, hipMemcpyHostToDevice, st));
-    k_bbox<<<(unsigned)std::min<int64_t>(cdiv(n, TB), 1024), TB, 0, st>>>(xyz, n, dsmall);
+    k_bbox<<<(unsigned)std::min<int64_t>(cdiv(n, TB), 512), TB, 0, st>>>(xyz, n, dsmall);
     LAUNCH_CHECK();
     HIP_TRY(hipMemcpyAsync(hb32, dsmall, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -263,7 +269,7 @@ int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t
 }
 
 // ------------------------------------------------------------------ neighbour maps
-__global__ __launch_bounds__(TB) void k_nbr_base(const uint64_t *__restrict__ rkey, int n, int k, int32_t *__restrict__ nbrT)
+__global__ __launch_bounds__(TB) void k_nbr_base(const uint64_t *__restrict__ rkey, int n, int k, int32_t *__restrict__ nbrT, int64_t stride)
 {
     const int K = k * k * k, r = k / 2;
     int t = blockIdx.x * TB + threadIdx.x;
@@ -278,14 +284,15 @@ __global__ __launch_bounds__(TB) void k_nbr_base(const uint64_t *__restrict__ rk
         for (int j = 0; j < n; ++j)
             if (rkey[j] == tgt) res = j;
     }
-    nbrT[t] = res;
+    nbrT[(int64_t)o * stride + i] = res;
 }
 
-int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT)
+int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT, int64_t stride)
 {
+    if (stride <= 0) stride = lv->n;
     if (lv->n > 4096) return fail(GPCC_ERR_ARG, "nbr_base is O(n^2): base level only");
     const int K = k * k * k;
-    k_nbr_base<<<nblk(lv->n * K), TB, 0, st>>>(lv->rkey, (int)lv->n, k, nbrT);
+    k_nbr_base<<<nblk(lv->n * K), TB, 0, st>>>(lv->rkey, (int)lv->n, k, nbrT, stride);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -294,8 +301,8 @@ int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbr
 // (already in the parent's map), its octant bit says whether it exists and the parent's child
 // start + popcount of the lower octant bits says where (children are stored octant-ascending).
 __global__ __launch_bounds__(TB) void k_nbr_child(const uint64_t *__restrict__ rkey_c, const uint32_t *__restrict__ parent_c, int64_t nc,
-                                                  const int32_t *__restrict__ nbrT_p, const uint8_t *__restrict__ occ_p,
-                                                  const uint32_t *__restrict__ cstart_p, int64_t np, int k, int32_t *__restrict__ nbrT_c)
+                                                  NbrView in, const uint8_t *__restrict__ occ_p,
+                                                  const uint32_t *__restrict__ cstart_p, int k, NbrView out1, NbrView out2)
 {
     const int r = k / 2;
     const int o = blockIdx.y;
@@ -306,38 +313,29 @@ __global__ __launch_bounds__(TB) void k_nbr_child(const uint64_t *__restrict__ r
     const int tx = (int)(rk_x(kc) & 1) + dx, ty = (int)(rk_y(kc) & 1) + dy, tz = (int)(rk_z(kc) & 1) + dz;
     const int px = tx >> 1, py = ty >> 1, pz = tz >> 1;  // floor: -1, 0 or 1 (k <= 5); up to +-2 for k = 7
     const int po = (px + r) + k * (py + r) + k * k * (pz + r);
-    const int32_t pn = nbrT_p[(int64_t)po * np + parent_c[i]];
+    int32_t pn = in.p[(int64_t)po * in.stride + parent_c[i]];
     int32_t res = -1;
     if (pn >= 0) {
+        pn -= in.voff;
         const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
         const uint32_t oc = occ_p[pn];
         if ((oc >> tq) & 1u) res = (int32_t)(cstart_p[pn] + (uint32_t)__popc(oc & ((1u << tq) - 1u)));
     }
-    nbrT_c[(int64_t)o * nc + i] = res;
+    out1.p[(int64_t)o * out1.stride + i] = res >= 0 ? res + out1.voff : -1;
+    if (out2.p) out2.p[(int64_t)o * out2.stride + i] = res >= 0 ? res + out2.voff : -1;
+}
+
+int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in, const Level *chi, int k, NbrView out1, NbrView out2)
+{
+    const int K = k * k * k;
+    k_nbr_child<<<dim3(nblk(chi->n), (unsigned)K), TB, 0, st>>>(chi->rkey, chi->parent, chi->n, in, par->occ, par->cstart, k, out1, out2);
+    LAUNCH_CHECK();
+    return GPCC_OK;
 }
 
 int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT)
 {
-    const int K = k * k * k;
-    k_nbr_child<<<dim3(nblk(chi->n), (unsigned)K), TB, 0, st>>>(chi->rkey, chi->parent, chi->n, nbrT_par, par->occ, par->cstart, par->n, k, nbrT);
-    LAUNCH_CHECK();
-    return GPCC_OK;
-}
-
-__global__ __launch_bounds__(TB) void k_nbr_concat(const int32_t *__restrict__ src, int64_t n, int32_t *__restrict__ dst, int64_t ntot, int64_t col_off)
-{
-    const int o = blockIdx.y;
-    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
-    const int32_t v = src[(int64_t)o * n + i];
-    dst[(int64_t)o * ntot + col_off + i] = v >= 0 ? v + (int32_t)col_off : -1;
-}
-
-int nbr_concat(gpcc_ctx *ctx, hipStream_t st, const int32_t *src, int64_t n, int K, int32_t *dst, int64_t ntot, int64_t col_off)
-{
-    k_nbr_concat<<<dim3(nblk(n), (unsigned)K), TB, 0, st>>>(src, n, dst, ntot, col_off);
-    LAUNCH_CHECK();
-    return GPCC_OK;
+    return nbr_child_views(ctx, st, par, NbrView{const_cast<int32_t *>(nbrT_par), par->n, 0}, chi, k, NbrView{nbrT, chi->n, 0}, NbrView{nullptr, 0, 0});
 }
 
 __global__ __launch_bounds__(TB) void k_nbr_count(const int32_t *__restrict__ nbrT, int64_t total, unsigned long long *__restrict__ count)

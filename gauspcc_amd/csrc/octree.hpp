@@ -73,10 +73,14 @@ int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level);
 int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
 
 // neighbour map, offset-major: nbrT[o*n + i], o = (dx+r) + k*(dy+r) + k*k*(dz+r), -1 = absent
-int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT);
+// (stride > 0: rows of the map are `stride` apart -- the level is the first of a set of concatenated levels)
+int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT, int64_t stride = 0);
 int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT);
-// copy a level's map into the map of a set of concatenated levels: dst[o*ntot + col_off + i] = src[o*n + i] (+ col_off when present)
-int nbr_concat(gpcc_ctx *ctx, hipStream_t st, const int32_t *src, int64_t n, int K, int32_t *dst, int64_t ntot, int64_t col_off);
+// A level's map inside the map of a SET of concatenated levels (the encoder batches all levels into two sets):
+// element (o, i) of the level at p[o*stride + i], present entries biased by voff (= the level's first row in the set).
+struct NbrView { int32_t *p; int64_t stride; int32_t voff; };
+// child map from the parent's view, written straight into up to two set maps (out2.p may be null)
+int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in, const Level *chi, int k, NbrView out1, NbrView out2);
 // count present neighbours (pairs) into *count_dev (uint64 accumulate)
 int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev);
 

@@ -89,10 +89,43 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_apply(const uint32_t *in, uint3
     }
 }
 
+// one block walks the whole array (carry in a register): for the many short scans of the small octree levels one launch
+// instead of three.  in == out allowed.
+__global__ __launch_bounds__(SCAN_T) void k_scan_single(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_out)
+{
+    __shared__ uint32_t lds[8];
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += SCAN_TILE) {
+        const int64_t base = b0 + (int64_t)threadIdx.x * SCAN_E;
+        uint32_t v[SCAN_E];
+        uint32_t s = 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            v[e] = base + e < n ? in[base + e] : 0;
+            s += v[e];
+        }
+        uint32_t total;
+        uint32_t ex = carry + block_excl_scan_256(s, &total, lds);
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            if (base + e < n) out[base + e] = ex;
+            ex += v[e];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+constexpr int64_t SCAN_SINGLE_MAX = 16 * SCAN_TILE;
+
 int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev)
 {
     if (n <= 0) {
         if (total_dev) HIP_TRY(hipMemsetAsync(total_dev, 0, 4, st));
+        return GPCC_OK;
+    }
+    if (n <= SCAN_SINGLE_MAX) {
+        k_scan_single<<<1, SCAN_T, 0, st>>>(in, out, n, total_dev);
+        LAUNCH_CHECK();
         return GPCC_OK;
     }
     const int64_t nb = cdiv(n, SCAN_TILE);
@@ -162,11 +195,77 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict
     }
 }
 
+// n <= RS_TILE: the whole sort (every 8-bit pass) in ONE launch of one wave, keys and payloads ping-ponging in LDS.
+// Same stable ballot ranking as k_radix_scatter.  The small octree levels sort a few hundred keys at a time, where a
+// pass of the tiled sort costs five launches.
+template <bool HAS_VAL>
+__global__ __launch_bounds__(64) void k_radix_small(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, int n, int bits)
+{
+    __shared__ uint64_t k[2][RS_TILE];
+    __shared__ uint32_t v[2][HAS_VAL ? RS_TILE : 1];
+    __shared__ uint32_t cnt[256];
+    const int lane = threadIdx.x;
+    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int i = lane; i < n; i += 64) {
+        k[0][i] = keys[i];
+        if (HAS_VAL) v[0][i] = vals[i];
+    }
+    int cur = 0;
+    for (int shift = 0; shift < bits; shift += 8) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cnt[lane + 64 * i] = 0;
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) atomicAdd(&cnt[(uint32_t)(k[cur][i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 digit counts: 4 per lane + wave scan
+            const uint32_t c0 = cnt[4 * lane], c1 = cnt[4 * lane + 1], c2 = cnt[4 * lane + 2], c3 = cnt[4 * lane + 3];
+            const uint32_t s = c0 + c1 + c2 + c3;
+            const uint32_t ex = wave_incl_scan(s, lane) - s;
+            __syncthreads();
+            cnt[4 * lane] = ex; cnt[4 * lane + 1] = ex + c0; cnt[4 * lane + 2] = ex + c0 + c1; cnt[4 * lane + 3] = ex + c0 + c1 + c2;
+        }
+        __syncthreads();
+        for (int r = 0; r < (n + 63) / 64; ++r) {
+            const int i = r * 64 + lane;
+            const bool ok = i < n;
+            const uint64_t key = ok ? k[cur][i] : 0;
+            const uint32_t d = (uint32_t)(key >> shift) & 255u;
+            uint64_t peers = __ballot(ok);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint64_t bal = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt);
+            const uint32_t prior = cnt[d];
+            __syncthreads();
+            if (ok && rank == 0) cnt[d] = prior + (uint32_t)__popcll(peers);
+            __syncthreads();
+            if (ok) {
+                k[cur ^ 1][prior + rank] = key;
+                if (HAS_VAL) v[cur ^ 1][prior + rank] = v[cur][i];
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int i = lane; i < n; i += 64) {
+        keys[i] = k[cur][i];
+        if (HAS_VAL) vals[i] = v[cur][i];
+    }
+}
+
 int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t **keys_tmp_io, uint32_t **vals_io,
                    uint32_t **vals_tmp_io, int64_t n, int bits)
 {
     if (n <= 1 || bits <= 0) return GPCC_OK;
     if (bits > 64) bits = 64;
+    if (n <= RS_TILE) {   // in place: the *_io pointers keep pointing at the result
+        if (vals_io && *vals_io) k_radix_small<true><<<1, 64, 0, st>>>(*keys_io, *vals_io, (int)n, bits);
+        else k_radix_small<false><<<1, 64, 0, st>>>(*keys_io, nullptr, (int)n, bits);
+        LAUNCH_CHECK();
+        return GPCC_OK;
+    }
     const int64_t ntiles = cdiv(n, RS_TILE);
     size_t mk = ctx->arena.mark();
     TAKE(hist, uint32_t, 256 * ntiles);

@@ -29,6 +29,20 @@ __host__ __device__ __forceinline__ uint32_t rc_interleaved(uint32_t r, int chun
 constexpr int RC_ROW_LOOKAHEAD = 8;
 static inline int64_t rc_rows_capacity(int64_t nch, int64_t S) { return (S + RC_ROW_LOOKAHEAD) * nch; }
 
+// Container version 2: the chunk size of a level's four streams follows the level's size, so that a small level still
+// spreads over many lanes (the decoder's latency per stream is chunk length x ~0.14 us, whatever the level's size):
+// 2^clog symbols with clog = clamp(ceil_log2(ceil(n / 256)), 7, chunk_log2) -- about 256 chunks per stream until the
+// header's chunk_log2 (the maximum) is reached at n >= 2^(chunk_log2 + 8) nodes.  Version 1 used chunk_log2 everywhere.
+static inline int rc_level_chunk_log2(int64_t n, int chunk_log2, int version)
+{
+    if (chunk_log2 == 0 || version < 2) return chunk_log2;
+    const int64_t want = (n + 255) / 256;
+    int c = 0;
+    while (((int64_t)1 << c) < want) ++c;
+    const int lo = chunk_log2 < 7 ? chunk_log2 : 7;
+    return c < lo ? lo : (c > chunk_log2 ? chunk_log2 : c);
+}
+
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);

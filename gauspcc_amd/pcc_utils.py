@@ -10,7 +10,7 @@ Deliberate differences, all on the error side:
   * a bare file name as output_path works (reference: os.makedirs('') raises, :47);
   * decompress_point_cloud(output_path=...) really writes the ASCII PLY (reference: NameError,
     `io` is never imported, :392).
-The container written by default is v1 (chunked streams, parallel decode, DESIGN.md);
+The container written by default is the chunked one (version 2: per-level chunk sizes, parallel decode, DESIGN.md);
 chunk_log2=0 writes the reference's exact layout.  Both are read back transparently.
 """
 import ctypes as C
@@ -67,7 +67,7 @@ def compress_point_cloud(
     kernel_size=5,            # Convolution kernel size
     posQ=1,                   # Quantization scale
     *,
-    chunk_log2=None,          # extension: 0 = reference container, 6..14 = v1 chunk size (default 10)
+    chunk_log2=None,          # extension: 0 = reference container, 6..14 = largest chunk size of the chunked container (default 10)
 ):
     """Compress point cloud into a bin file (reference: pcc_utils.py:24-217).
 

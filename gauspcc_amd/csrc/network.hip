@@ -403,6 +403,123 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
     }
 }
 
+// Small levels (16-row blocks: every (block, offset) pair is exactly one tile, a block's list is a serial chain of up to
+// 125 tiles, and the whole level is a few hundred blocks): latency, not throughput.  One 16-wave workgroup per block
+// breaks the chain: 32 tiles at a time, phase A -- every wave turns two tiles into their 16 x 32 partial products
+// (MFMAs from a zero accumulator, exactly as in the big kernel) and parks them in LDS; phase B -- one thread per output
+// element adds the products of the tiles that contain its row, in tile (= offset) order.  Same sums in the same
+// order as the wave-serial kernel, so the results are bit-identical; the chain per block drops from ~125 tile
+// latencies to 4 rounds.
+constexpr int COOP_TILES = 32;
+constexpr int COOP_WAVES = 16;
+// LDS: products [32][16][32] f32, row->entry map [16][32] u8, then the block's tile headers (K tiles: 16 + 4 + 1 dwords each)
+static inline size_t coop_lds_bytes(int K) { return (size_t)COOP_TILES * 16 * 32 * 4 + 16 * COOP_TILES + (size_t)K * 84; }
+
+__global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch jobs, ConvTiles T, int n, int relu)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *P = lds;                                                   // [tile][entry][channel (physical)]
+    uint8_t *inv = reinterpret_cast<uint8_t *>(lds + COOP_TILES * 16 * 32);   // [row][tile] -> entry of that row in the tile, 255 = absent
+    int32_t *hj = reinterpret_cast<int32_t *>(inv + 16 * COOP_TILES);  // [tile][16] neighbour rows
+    uint32_t *hr = reinterpret_cast<uint32_t *>(hj + (size_t)T.K * 16); // [tile][4]  output rows (bytes)
+    uint32_t *ho = hr + (size_t)T.K * 4;                                // [tile]     offset | count << 16
+    const ConvJob J = jobs.job[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = blockIdx.x;
+    const int e = lane & 15, g = lane >> 4;
+    const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
+    const int nt = (int)min(t1 - t0, (uint32_t)T.K);   // a 16-row block has at most one tile per kernel offset
+    // the whole header list of the block in one sweep (three latencies instead of one per round)
+    for (int i = tid; i < nt * 16; i += 64 * COOP_WAVES) hj[i] = T.tj[(size_t)t0 * 16 + i];
+    for (int i = tid; i < nt * 4; i += 64 * COOP_WAVES) hr[i] = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16)[i];
+    for (int i = tid; i < nt; i += 64 * COOP_WAVES) ho[i] = T.toc[t0 + i];
+    __syncthreads();
+    const float *__restrict__ in = J.in + 4 * g;
+    const float *__restrict__ wf = J.w + lane * 4;
+    const int orow = tid >> 5, och = tid & 31;     // phase B: threads 0..511 own one output element each
+    float acc = 0.0f;
+    struct AB { float4 a0, a1, b00, b01, b10, b11; };
+    auto fetch = [&](int t) -> AB {   // gathered rows + weight fragment of tile t of this block (t < nt)
+        const float *p = in + (size_t)(uint32_t)hj[t * 16 + e] * 32;
+        const float *w = wf + (size_t)(ho[t] & 0xFFFFu) * 1024;
+        AB r;
+        r.a0 = ld4(p); r.a1 = ld4(p + 16);
+        r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
+        return r;
+    };
+    auto products = [&](const AB &v, int t, int tl) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 c0 = z, c1 = z;
+#define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+        MF(c0, v.a0.x, v.b00.x); MF(c1, v.a0.x, v.b10.x);
+        MF(c0, v.a0.y, v.b00.y); MF(c1, v.a0.y, v.b10.y);
+        MF(c0, v.a0.z, v.b00.z); MF(c1, v.a0.z, v.b10.z);
+        MF(c0, v.a0.w, v.b00.w); MF(c1, v.a0.w, v.b10.w);
+        MF(c0, v.a1.x, v.b01.x); MF(c1, v.a1.x, v.b11.x);
+        MF(c0, v.a1.y, v.b01.y); MF(c1, v.a1.y, v.b11.y);
+        MF(c0, v.a1.z, v.b01.z); MF(c1, v.a1.z, v.b11.z);
+        MF(c0, v.a1.w, v.b01.w); MF(c1, v.a1.w, v.b11.w);
+#undef MF
+        float *dst = P + (size_t)tl * 512;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dst[(4 * g + k) * 32 + col0] = c0[k];
+            dst[(4 * g + k) * 32 + col1] = c1[k];
+        }
+        if (lane < 16) inv[lane * COOP_TILES + tl] = 255;
+        const uint32_t cnt = ho[t] >> 16;
+        const uint32_t r = (hr[t * 4 + (e >> 2)] >> (8 * (e & 3))) & 255u;
+        if (lane < 16 && (uint32_t)lane < cnt) inv[r * COOP_TILES + tl] = (uint8_t)lane;   // same wave: ordered behind the 255s
+    };
+    // this wave's two tiles of a round: base + 2 wave + {0, 1}; the next round's operands are requested before this
+    // round's products are summed, so a round costs MFMAs + two barriers, not a memory latency
+    AB cur[2], nxt[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (wave * 2 + q < nt) cur[q] = fetch(wave * 2 + q);
+    for (int base = 0; base < nt; base += COOP_TILES) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = base + COOP_TILES + wave * 2 + q;
+            if (t < nt) nxt[q] = fetch(t);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = base + wave * 2 + q;
+            if (t < nt) products(cur[q], t, wave * 2 + q);
+        }
+        __syncthreads();
+        if (tid < 512) {   // ordered sum over the tiles of this round
+            const int ntl = min(COOP_TILES, nt - base);
+            const uint4 w0 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES), w1 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES + 16);
+            const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+            float pv[COOP_TILES];
+#pragma unroll
+            for (int tl = 0; tl < COOP_TILES; ++tl) {
+                const uint32_t i = (wd[tl >> 2] >> (8 * (tl & 3))) & 255u;
+                // absent (or past the end of the list): + 0.0f, which leaves the sum unchanged (the sum is never -0)
+                pv[tl] = (tl < ntl && i != 255u) ? P[(size_t)tl * 512 + i * 32 + och] : 0.0f;
+            }
+#pragma unroll
+            for (int tl = 0; tl < COOP_TILES; ++tl) acc = acc + pv[tl];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) cur[q] = nxt[q];
+    }
+    if (tid < 512) {
+        const int grow = blk * 16 + orow;
+        if (grow < n) {
+            float v = acc;
+            if (J.res) v = v + J.res[(size_t)grow * 32 + och];
+            if (relu) v = v > 0.f ? v : 0.f;
+            J.out[(size_t)grow * 32 + och] = v;
+        }
+    }
+}
+
 static int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
 {
     Prof &p = ctx->prof;
@@ -436,6 +553,20 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         lds_attr_set = true;
+    }
+    static int use_coop = -1;
+    if (use_coop < 0) { const char *e = getenv("GAUSPCC_CONV_COOP"); use_coop = e ? atoi(e) != 0 : 1; }
+    if (T.R == 16 && use_coop) {
+        static bool coop_attr_set = false;
+        if (!coop_attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343)));
+            coop_attr_set = true;
+        }
+        if (T.K > 343) return fail(GPCC_ERR_ARG, "kernel size > 7 is not supported");
+        k_sparse_conv_coop<<<dim3((unsigned)T.nblk, (unsigned)njobs), 64 * COOP_WAVES, coop_lds_bytes(T.K), st>>>(jobs, T, (int)n, relu);
+        LAUNCH_CHECK();
+        if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+        return GPCC_OK;
     }
     dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
     const size_t lds_bytes = (size_t)CONV_WAVES * conv_lds_wave_floats(T.R) * 4;

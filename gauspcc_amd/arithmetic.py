@@ -5,6 +5,13 @@ same argument order, same tensor types, same byte format -- backed by libgauspcc
     calculate_cdf(mean, scale, Q, min_value, max_value) -> Tensor (n, max-min+2) float32
     arithmetic_encode(sym, cdf, chunk_size, N, Lp)      -> (Tensor uint8, Tensor int32[chunks])
     arithmetic_decode(cdf, bytes, cnt, chunk_size, N, Lp) -> Tensor int16 (N)
+
+plus the two fused calls the `encodings_cuda` mirror uses (no reference counterpart: they replace the
+calculate_cdf -> arithmetic_encode / arithmetic_decode pair of encoder_gaussian / decoder_gaussian and never
+materialise the (n, max-min+2) float table):
+
+    encode_gaussian(x, mean, scale, Q, chunk_size)                    -> (min, max, Tensor uint8, Tensor int32[chunks])
+    decode_gaussian(mean, scale, Q, min, max, bytes, cnt, chunk_size) -> Tensor float32 (n)
 """
 import ctypes as C
 
@@ -58,4 +65,34 @@ def arithmetic_decode(cdf, in_cache_all, in_cnt_all, chunk_size, N, Lp):
     out = torch.zeros(int(N), dtype=torch.int16, device=cdf.device)
     _lib.check(_lib.lib().gsac_decode(runtime.context(cdf.device), cdf.data_ptr(), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
                                       int(N), int(Lp), out.data_ptr(), runtime.stream_ptr(cdf.device)))
+    return out
+
+
+def encode_gaussian(x, mean, scale, Q, chunk_size):
+    """round(x / Q) -> symbols -> chunked range coder with the Gaussian CDF entries evaluated on the fly.
+    Byte-identical to calculate_cdf + arithmetic_encode (encodings_cuda.py:336-371)."""
+    for t, nm in ((x, "x"), (mean, "mean"), (scale, "scale"), (Q, "Q")):
+        _chk(t, nm)
+    n = int(x.shape[0])
+    mn, mx = C.c_float(), C.c_float()
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode_gaussian(runtime.context(x.device), x.float().data_ptr(), mean.float().data_ptr(), scale.float().data_ptr(),
+                                               Q.float().data_ptr(), n, int(chunk_size), C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb),
+                                               C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
+    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
+    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    return mn.value, mx.value, torch.from_numpy(out).to(x.device), torch.from_numpy(cnt).to(x.device)
+
+
+def decode_gaussian(mean, scale, Q, min_value, max_value, in_cache_all, in_cnt_all, chunk_size):
+    """Inverse of encode_gaussian: (sym + min) * Q, float32 on mean.device (encodings_cuda.py:399-433)."""
+    for t, nm in ((mean, "mean"), (scale, "scale"), (Q, "Q")):
+        _chk(t, nm)
+    data = np.ascontiguousarray(in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False))
+    cnt = np.ascontiguousarray(in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False))
+    n = int(mean.shape[0])
+    out = torch.empty(n, dtype=torch.float32, device=mean.device)
+    _lib.check(_lib.lib().gsac_decode_gaussian(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(), n,
+                                               float(min_value), float(max_value), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
+                                               out.data_ptr(), runtime.stream_ptr(mean.device)))
     return out

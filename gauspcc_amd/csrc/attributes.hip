@@ -21,35 +21,58 @@ namespace {
 constexpr int TB = 256;
 
 // ------------------------------------------------------------------ calculate_cdf
+// lower[idx][i] of arithmetic.calculate_cdf (arithmetic_kernel.cu:7-28) -- ONE definition, used by the table kernel and by
+// the fused coder below, so a stream coded without the table is byte-identical to one coded with it
+__device__ __forceinline__ float gaussian_cdf_entry(float mean, float scale, float q, int min_value, int i)
+{
+    const float sc = (float)fmax((double)scale, 1e-9);                            // max(scale[idx], 1e-9)
+    const float sample = (float)(((double)(min_value + i) - 0.5) * (double)q);    // (min + i - 0.5) * Q
+    const float arg = -(sample - mean) / (sc * sqrtf(2.0f));
+    return (float)(0.5 * (double)erfcf(arg));
+}
+
 __global__ __launch_bounds__(TB) void k_gaussian_cdf(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ Q, int64_t n,
                                                      int min_value, int lp, float *__restrict__ lower)
 {
     const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (t >= n * lp) return;
     const int64_t idx = t / lp;
-    const int i = (int)(t - idx * lp);
-    const float sc = (float)fmax((double)scale[idx], 1e-9);                            // max(scale[idx], 1e-9)
-    const float sample = (float)(((double)(min_value + i) - 0.5) * (double)Q[idx]);    // (min + i - 0.5) * Q
-    const float arg = -(sample - mean[idx]) / (sc * sqrtf(2.0f));
-    lower[t] = (float)(0.5 * (double)erfcf(arg));
+    lower[t] = gaussian_cdf_entry(mean[idx], scale[idx], Q[idx], min_value, (int)(t - idx * lp));
 }
+
+// Row sources of the coder: a float table row, a uint16 table row (torchac's *_int16_normalized_cdf), or the Gaussian
+// parameters of the element -- the table-free path of encoder_gaussian / decoder_gaussian (the reference writes and
+// re-reads n x (max - min + 2) floats per slice; here the two entries an encoded symbol needs, or the <= 64 entries a
+// decoding wave compares, are evaluated in registers).
+struct GaussTable { const float *mean, *scale, *q; int min_value; };
+struct GaussRow { float mean, scale, q; int min_value; };
+template <typename CT> struct RowOf { typedef const CT *type; };
+template <> struct RowOf<GaussTable> { typedef GaussRow type; };
+__device__ __forceinline__ const float *row_of(const float *t, int64_t idx, int lp) { return t + idx * lp; }
+__device__ __forceinline__ const uint16_t *row_of(const uint16_t *t, int64_t idx, int lp) { return t + idx * lp; }
+__device__ __forceinline__ GaussRow row_of(const GaussTable &t, int64_t idx, int) { return GaussRow{t.mean[idx], t.scale[idx], t.q[idx], t.min_value}; }
 
 // ------------------------------------------------------------------ encode pre-pass
 // CDF entry -> integer: float rows are integerised on the fly (arithmetic_kernel.cu:124-125 == kit/op.py:67-79),
 // uint16 rows (torchac's *_int16_normalized_cdf) are used as they are
 __device__ __forceinline__ uint32_t cdf_int(const float *row, int m, float scale) { return (uint32_t)((int)__builtin_rintf(row[m] * scale) + m); }
 __device__ __forceinline__ uint32_t cdf_int(const uint16_t *row, int m, float) { return row[m]; }
+__device__ __forceinline__ uint32_t cdf_int(const GaussRow &row, int m, float scale)
+{
+    return (uint32_t)((int)__builtin_rintf(gaussian_cdf_entry(row.mean, row.scale, row.q, row.min_value, m) * scale) + m);
+}
 
 template <typename CT>
-__global__ __launch_bounds__(TB) void k_hac_pack(const CT *__restrict__ cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
+__global__ __launch_bounds__(TB) void k_hac_pack(const CT cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
                                                  uint32_t *__restrict__ lohi)
 {
     const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (r >= n) return;
     const float scale = (float)(65536 - (lp - 1));
     const int s = sym[r];
-    const uint32_t lo = cdf_int(cdf + r * lp, s, scale);
-    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf_int(cdf + r * lp, s + 1, scale);
+    const auto row = row_of(cdf, r, lp);
+    const uint32_t lo = cdf_int(row, s, scale);
+    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf_int(row, s + 1, scale);
     const uint32_t c = (uint32_t)(r / chunk), t = (uint32_t)(r - (int64_t)c * chunk);
     lohi[(size_t)t * nch + c] = (lo & 0xFFFFu) | ((hi - 1u) << 16);
 }
@@ -88,7 +111,7 @@ struct WaveBits {  // every lane holds the same reader state (wave-uniform addre
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
 template <typename CT>
-__global__ __launch_bounds__(64) void k_hac_decode(const CT *__restrict__ cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
+__global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
                                                    const uint32_t *__restrict__ cnt_cum, int16_t *__restrict__ sym, int64_t n, int lp, int chunk)
 {
     const int c = blockIdx.x, lane = threadIdx.x;
@@ -105,12 +128,12 @@ __global__ __launch_bounds__(64) void k_hac_decode(const CT *__restrict__ cdf, c
         // prefetch the first segment of the next four rows (rows do not depend on decoded symbols)
         uint32_t pre[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf_int(cdf + (base + i0 + u) * lp, lane, scale) : 0u;
+        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf_int(row_of(cdf, base + i0 + u, lp), lane, scale) : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u;
             if (i >= cn) break;
-            const CT *row = cdf + (base + i) * lp;
+            const auto row = row_of(cdf, base + i, lp);
             const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
             const uint32_t x = value - low;
             int s;
@@ -273,25 +296,27 @@ extern "C" int gsac_calculate_cdf(gpcc_ctx *ctx, const float *mean, const float 
     return GPCC_OK;
 }
 
-static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, const void *cdf, bool cdf_is_u16, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
-                           int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+template <typename CT>
+static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, CT cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+                           int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream, bool keep_arena = false)
 {
-    if (!ctx || !sym || !cdf || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (!ctx || !sym || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out) return fail(GPCC_ERR_ARG, "null argument");
     if (n <= 0 || chunk_size <= 0 || lp < 2) return fail(GPCC_ERR_ARG, "bad size");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)cdiv(n, chunk_size);
     const uint32_t sstride = rc_scratch_stride((uint32_t)std::min<int64_t>(chunk_size, n));
-    GP_TRY(ctx->arena.reserve((size_t)nch * chunk_size * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + ((size_t)4 << 20)));
-    ctx->arena.reset();
+    if (!keep_arena) {
+        GP_TRY(ctx->arena.reserve((size_t)nch * chunk_size * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + ((size_t)4 << 20)));
+        ctx->arena.reset();
+    }
     std::vector<RcChunk> chunks((size_t)nch);
     for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(chunk_size, n - (int64_t)c * chunk_size), 0, 0, 0};
     TAKE(lohi, uint32_t, (int64_t)nch * chunk_size); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
     TAKE(scratch, uint8_t, (size_t)nch * sstride); TAKE(payload, uint8_t, (size_t)nch * sstride);
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (cdf_is_u16) k_hac_pack<uint16_t><<<(unsigned)cdiv(n, TB), TB, 0, st>>>((const uint16_t *)cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
-    else k_hac_pack<float><<<(unsigned)cdiv(n, TB), TB, 0, st>>>((const float *)cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
+    k_hac_pack<CT><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(cdf, sym, n, lp, chunk_size, (uint32_t)nch, lohi);
     LAUNCH_CHECK();
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
@@ -313,19 +338,22 @@ static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, const void *cdf, 
 extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
                            int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
-    return gsac_encode_impl(ctx, sym, cdf, false, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+    if (!cdf) return fail(GPCC_ERR_ARG, "null argument");
+    return gsac_encode_impl<const float *>(ctx, sym, cdf, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
 }
 
 extern "C" int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym, const uint16_t *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
                                int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
-    return gsac_encode_impl(ctx, sym, cdf, true, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+    if (!cdf) return fail(GPCC_ERR_ARG, "null argument");
+    return gsac_encode_impl<const uint16_t *>(ctx, sym, cdf, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
 }
 
-static int gsac_decode_impl(gpcc_ctx *ctx, const void *cdf, bool cdf_is_u16, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
-                           int16_t *sym_out, void *stream)
+template <typename CT>
+static int gsac_decode_impl(gpcc_ctx *ctx, CT cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+                           int16_t *sym_out, void *stream, bool keep_arena = false)
 {
-    if (!ctx || !cdf || !bytes || !cnt || !sym_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (!ctx || !bytes || !cnt || !sym_out) return fail(GPCC_ERR_ARG, "null argument");
     if (n <= 0 || chunk_size <= 0 || lp < 2) return fail(GPCC_ERR_ARG, "bad size");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -336,15 +364,16 @@ static int gsac_decode_impl(gpcc_ctx *ctx, const void *cdf, bool cdf_is_u16, con
         cum[(size_t)c + 1] = cum[(size_t)c] + (uint32_t)cnt[c];
     }
     if ((int64_t)cum[(size_t)nch] > nbytes) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
-    GP_TRY(ctx->arena.reserve((size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
-    ctx->arena.reset();
+    if (!keep_arena) {
+        GP_TRY(ctx->arena.reserve((size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
+        ctx->arena.reset();
+    }
     TAKE(db, uint8_t, nbytes + 16); TAKE(dcnt, int32_t, nch); TAKE(dcum, uint32_t, nch + 1);
     HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dcnt, cnt, 4 * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dcum, cum.data(), 4 * ((size_t)nch + 1), hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (cdf_is_u16) k_hac_decode<uint16_t><<<(unsigned)nch, 64, 0, st>>>((const uint16_t *)cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
-    else k_hac_decode<float><<<(unsigned)nch, 64, 0, st>>>((const float *)cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
+    k_hac_decode<CT><<<(unsigned)nch, 64, 0, st>>>(cdf, db, dcnt, dcum, sym_out, n, lp, chunk_size);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
@@ -353,13 +382,98 @@ static int gsac_decode_impl(gpcc_ctx *ctx, const void *cdf, bool cdf_is_u16, con
 extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
                            int16_t *sym_out, void *stream)
 {
-    return gsac_decode_impl(ctx, cdf, false, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
+    if (!cdf) return fail(GPCC_ERR_ARG, "null argument");
+    return gsac_decode_impl<const float *>(ctx, cdf, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
 }
 
 extern "C" int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
                                int16_t *sym_out, void *stream)
 {
-    return gsac_decode_impl(ctx, cdf, true, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
+    if (!cdf) return fail(GPCC_ERR_ARG, "null argument");
+    return gsac_decode_impl<const uint16_t *>(ctx, cdf, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
+}
+
+// ------------------------------------------------------------------ fused Gaussian coder (no CDF table)
+namespace {
+// x_int = round(x / Q) (torch.round: half to even), its min / max over the slice (encodings_cuda.py:343-345)
+__global__ __launch_bounds__(TB) void k_quantise_minmax(const float *__restrict__ x, const float *__restrict__ q, int64_t n, int32_t *__restrict__ xi, int32_t *__restrict__ mm)
+{
+    int mn = INT32_MAX, mx = INT32_MIN;
+    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TB) {
+        const int v = (int)__builtin_rintf(x[i] / q[i]);
+        xi[i] = v;
+        mn = min(mn, v); mx = max(mx, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+    __shared__ int red[TB / 64][2];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = mn; red[threadIdx.x >> 6][1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TB / 64; ++w) { mn = min(mn, red[w][0]); mx = max(mx, red[w][1]); }
+        atomicMin(&mm[0], mn); atomicMax(&mm[1], mx);
+    }
+}
+__global__ __launch_bounds__(TB) void k_to_symbols(const int32_t *__restrict__ xi, int64_t n, int min_value, int16_t *__restrict__ sym)
+{
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) sym[i] = (int16_t)(xi[i] - min_value);
+}
+// x = (sym + min) * Q (encodings_cuda.py:431-432)
+__global__ __launch_bounds__(TB) void k_from_symbols(const int16_t *__restrict__ sym, const float *__restrict__ q, int64_t n, float min_value, float *__restrict__ x)
+{
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) x[i] = ((float)sym[i] + min_value) * q[i];
+}
+}  // namespace
+
+extern "C" int gsac_encode_gaussian(gpcc_ctx *ctx, const float *x, const float *mean, const float *scale, const float *Q, int64_t n, int chunk_size,
+                                    float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out,
+                                    int64_t *nchunks_out, void *stream)
+{
+    if (!ctx || !x || !mean || !scale || !Q || !min_out || !max_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    const uint32_t sstride = rc_scratch_stride((uint32_t)std::min<int64_t>(chunk_size, n));
+    GP_TRY(ctx->arena.reserve((size_t)n * 8 + (size_t)nch * chunk_size * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(xi, int32_t, n); TAKE(sym, int16_t, n); TAKE(mm, int32_t, 2);
+    const int32_t init[2] = {INT32_MAX, INT32_MIN};
+    HIP_TRY(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, st));
+    k_quantise_minmax<<<(unsigned)std::min<int64_t>(cdiv(n, TB), 512), TB, 0, st>>>(x, Q, n, xi, mm);
+    LAUNCH_CHECK();
+    int32_t hmm[2];
+    HIP_TRY(hipMemcpyAsync(hmm, mm, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int lp = hmm[1] - hmm[0] + 2;
+    if (lp > 32767) return fail(GPCC_ERR_RANGE, "quantised values span %d levels (int16 symbols)", lp - 1);
+    k_to_symbols<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(xi, n, hmm[0], sym);
+    LAUNCH_CHECK();
+    *min_out = (float)hmm[0]; *max_out = (float)hmm[1];
+    return gsac_encode_impl<GaussTable>(ctx, sym, GaussTable{mean, scale, Q, hmm[0]}, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream, true);
+}
+
+extern "C" int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, int64_t n, float min_value, float max_value,
+                                    const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out, void *stream)
+{
+    if (!ctx || !mean || !scale || !Q || !x_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    const int mn = (int)min_value, mx = (int)max_value;
+    const int lp = mx - mn + 2;
+    if (lp < 2 || lp > 32767) return fail(GPCC_ERR_FORMAT, "bad symbol range [%d, %d]", mn, mx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    GP_TRY(ctx->arena.reserve((size_t)n * 2 + (size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(sym, int16_t, n);
+    GP_TRY(gsac_decode_impl<GaussTable>(ctx, GaussTable{mean, scale, Q, mn}, bytes, nbytes, cnt, chunk_size, n, lp, sym, stream, true));
+    k_from_symbols<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(sym, Q, n, min_value, x_out);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
 }
 
 extern "C" int gsge_forward(gpcc_ctx *ctx, const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,

@@ -4,6 +4,11 @@ gauspcc_amd.arithmetic instead of the CUDA `arithmetic` extension.
 
     encoder_gaussian(_chunk) / decoder_gaussian(_chunk)   :317-433
     encoder / decoder (Bernoulli, one global p)            :435-492
+
+encoder_gaussian / decoder_gaussian go through the fused gsac_encode_gaussian / gsac_decode_gaussian: the reference
+writes and re-reads an (n, max-min+2) float table per slice (36 MB for a 3000-anchor feature slice, 334 slices per
+million anchors); here the CDF entries are evaluated inside the coder.  Same `.b` bytes either way
+(tests/test_gpu_attributes.py::test_fused_gaussian_matches_table_path).
 """
 import numpy as np
 import torch
@@ -35,18 +40,13 @@ def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
     assert len(x.shape) == 1
     if not isinstance(Q, torch.Tensor):
         Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
-    x_int_round = torch.round(x / Q)
-    max_value = x_int_round.max()
-    min_value = x_int_round.min()
-    lower = arithmetic.calculate_cdf(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value)
-    x_int_round_idx = (x_int_round - min_value).to(torch.int16)
-    byte_stream_torch, cnt_torch = arithmetic.arithmetic_encode(x_int_round_idx.contiguous(), lower, chunk_size_cuda,
-                                                                int(lower.shape[0]), int(lower.shape[1]))
+    min_value, max_value, byte_stream_torch, cnt_torch = arithmetic.encode_gaussian(x.contiguous(), mean.contiguous(), scale.contiguous(),
+                                                                                     Q.contiguous(), chunk_size_cuda)
     cnt_bytes = cnt_torch.cpu().numpy().tobytes()
     byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
     with open(file_name, 'wb') as fout:
-        fout.write(min_value.to(torch.float32).cpu().numpy().tobytes())
-        fout.write(max_value.to(torch.float32).cpu().numpy().tobytes())
+        fout.write(np.float32(min_value).tobytes())
+        fout.write(np.float32(max_value).tobytes())
         fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
         fout.write(cnt_bytes)
         fout.write(byte_stream_bytes)
@@ -76,16 +76,13 @@ def decoder_gaussian(mean, scale, Q, file_name='tmp.b'):
     if not isinstance(Q, torch.Tensor):
         Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
     with open(file_name, 'rb') as fin:
-        min_value = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy(), device=mean.device)
-        max_value = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy(), device=mean.device)
+        min_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+        max_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
         len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
-        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy(), device=mean.device)
-        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy(), device=mean.device)
-    lower = arithmetic.calculate_cdf(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value)
-    sym_out = arithmetic.arithmetic_decode(lower, byte_stream_torch, cnt_torch, chunk_size_cuda,
-                                           int(lower.shape[0]), int(lower.shape[1])).to(mean.device).to(torch.float32)
-    x = sym_out + min_value
-    return x * Q
+        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy())
+        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy())
+    return arithmetic.decode_gaussian(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value, byte_stream_torch, cnt_torch,
+                                      chunk_size_cuda)
 
 
 def _bernoulli_cdf(p1: torch.Tensor, n: int, device):

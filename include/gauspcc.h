@@ -177,6 +177,20 @@ GPCC_API int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym_dev, const uint16
 GPCC_API int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
                              int64_t n, int lp, int16_t *sym_out_dev, void *stream);
 
+/* encoder_gaussian / decoder_gaussian in one call each, WITHOUT the (n, max-min+2) float CDF table of
+ * arithmetic.calculate_cdf (src/gs_compress/HAC/utils/encodings_cuda.py:336-371, 399-433):
+ *   encode: x_int = round(x / Q), min/max over the slice, the two CDF entries of every symbol evaluated on the fly,
+ *           the chunked coder -> (min, max, bytes, cnt) = what the reference writes into the `.b` file;
+ *   decode: the <= 64 entries a decoding wave compares evaluated on the fly; x = (sym + min) * Q.
+ * Byte-identical to gsac_calculate_cdf + gsac_encode (same entry formula, same integerisation).
+ * x / mean / scale / Q device (n); bytes / cnt host; min / max are the float values the file stores. */
+GPCC_API int gsac_encode_gaussian(gpcc_ctx *ctx, const float *x_dev, const float *mean_dev, const float *scale_dev, const float *q_dev, int64_t n,
+                                  int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out,
+                                  const int32_t **cnt_out, int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean_dev, const float *scale_dev, const float *q_dev, int64_t n, float min_value,
+                                  float max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out_dev,
+                                  void *stream);
+
 /* _gridencoder.grid_encode_forward (inputs (N,D) in [0,1], embeddings (sO,F), offsets (L+1), resolutions (L),
  * outputs (L,N,F), ..., Rb, binary_vxl, min_level_id)   gridencoder.zip!gridencoder/src/gridencoder.h:12-22,
  * gridencoder.cu:100-361 (forward only; dy_dx / backward are training-side and out of scope).  All device. */

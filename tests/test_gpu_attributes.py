@@ -129,3 +129,30 @@ def test_torchac_interface_bytes_match_oracle(torch_cuda, orc):
     b3 = torchac.encode_float_cdf(torch.tensor(cdf).view(60, 100, lp), torch.tensor(sym).view(60, 100))
     assert b3 == ref
     assert torchac.decode_float_cdf(torch.tensor(cdf).view(60, 100, lp), b3).shape == (60, 100)
+
+
+@pytest.mark.parametrize("n,chunk", [(30000, 10000), (4097, 1000)])
+def test_fused_gaussian_matches_table_path(torch_cuda, n, chunk):
+    """gsac_encode_gaussian / gsac_decode_gaussian (CDF entries evaluated inside the coder) produce the bytes of
+    calculate_cdf + arithmetic_encode and decode what arithmetic_decode decodes (encodings_cuda.py:336-371, 399-433)."""
+    torch = torch_cuda
+    from gauspcc_amd import arithmetic
+
+    g = torch.Generator(device="cpu").manual_seed(n)
+    mean = (torch.randn(n, generator=g) * 2).cuda()
+    scale = (torch.rand(n, generator=g) * 3 + 0.05).cuda()
+    scale[:7] = 0.0                                             # clamped to 1e-9 inside the CDF
+    q = (torch.rand(n, generator=g) * 0.5 + 0.75).cuda()
+    x = (mean + torch.randn(n, generator=g).cuda() * scale).contiguous()
+    mn, mx, b, cnt = arithmetic.encode_gaussian(x, mean, scale, q, chunk)
+    xi = torch.round(x / q)
+    assert mn == float(xi.min()) and mx == float(xi.max())
+    lower = arithmetic.calculate_cdf(mean, scale, q, xi.min(), xi.max())
+    sym = (xi - xi.min()).to(torch.int16).contiguous()
+    b2, cnt2 = arithmetic.arithmetic_encode(sym, lower, chunk, n, int(lower.shape[1]))
+    assert torch.equal(cnt.cpu(), cnt2.cpu())
+    assert torch.equal(b.cpu(), b2.cpu())                       # same `.b` payload without ever writing the table
+    dec = arithmetic.decode_gaussian(mean, scale, q, mn, mx, b, cnt, chunk)
+    assert torch.equal(dec, xi * q)
+    dec2 = arithmetic.arithmetic_decode(lower, b, cnt, chunk, n, int(lower.shape[1])).to(torch.float32)
+    assert torch.equal((dec2 + xi.min()) * q, dec)

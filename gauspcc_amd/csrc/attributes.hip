@@ -393,6 +393,54 @@ extern "C" int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf, const uint8_t
     return gsac_decode_impl<const uint16_t *>(ctx, cdf, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
 }
 
+// ------------------------------------------------------------------ mlp_grid (a16): Linear - ReLU - Linear
+// HAC's context MLP (scene/gaussian_model.py:258-262: Linear(96, 100) - ReLU - Linear(100, 175)) on the hash-grid
+// features of a slice of anchors.  Encoder and decoder must obtain bit-identical means / scales / step sizes from it,
+// so the arithmetic is specified, as for the geometry heads: acc = bias; for k ascending: acc = fmaf(x[k], W[c][k], acc).
+// 16 rows per 256-thread block: the rows and their hidden activations live in LDS, every thread walks the k chain of
+// its outputs; the two weight matrices (38 KB + 70 KB) stay in L1/L2.
+namespace {
+constexpr int MLP_ROWS = 16;
+__global__ __launch_bounds__(TB) void k_mlp2(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                             const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, int din, int dh, int dout,
+                                             float *__restrict__ y)
+{
+    extern __shared__ float sm[];
+    float *xs = sm, *hs = sm + MLP_ROWS * din;
+    const int64_t row0 = (int64_t)blockIdx.x * MLP_ROWS;
+    const int rows = (int)min((int64_t)MLP_ROWS, n - row0);
+    for (int i = threadIdx.x; i < rows * din; i += TB) xs[i] = x[row0 * din + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * dh; i += TB) {
+        const int r = i / dh, c = i - r * dh;
+        const float *w = w1 + (size_t)c * din, *xr = xs + r * din;
+        float acc = b1[c];
+        for (int k = 0; k < din; ++k) acc = __builtin_fmaf(xr[k], w[k], acc);
+        hs[i] = acc > 0.0f ? acc : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * dout; i += TB) {
+        const int r = i / dout, c = i - r * dout;
+        const float *w = w2 + (size_t)c * dh, *hr = hs + r * dh;
+        float acc = b2[c];
+        for (int k = 0; k < dh; ++k) acc = __builtin_fmaf(hr[k], w[k], acc);
+        y[(row0 + r) * dout + c] = acc;
+    }
+}
+}  // namespace
+
+extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh,
+                          int dout, float *y, void *stream)
+{
+    if (!ctx || !x || !w1 || !b1 || !w2 || !b2 || !y) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0) return GPCC_OK;
+    if (din <= 0 || dh <= 0 || dout <= 0 || (size_t)MLP_ROWS * (size_t)(din + dh) * 4 > 64 * 1024) return fail(GPCC_ERR_ARG, "mlp2: unsupported layer sizes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    k_mlp2<<<(unsigned)cdiv(n, MLP_ROWS), TB, (size_t)MLP_ROWS * (size_t)(din + dh) * 4, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, din, dh, dout, y);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
 // ------------------------------------------------------------------ fused Gaussian coder (no CDF table)
 namespace {
 // x_int = round(x / Q) (torch.round: half to even), its min / max over the slice (encodings_cuda.py:343-345)

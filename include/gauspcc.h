@@ -191,6 +191,13 @@ GPCC_API int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean_dev, const fl
                                   float max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out_dev,
                                   void *stream);
 
+/* GaussianModel.mlp_grid = nn.Sequential(Linear(din, dh), ReLU, Linear(dh, dout)) (src/gs_compress/HAC/scene/gaussian_model.py:258-262,
+ * called through get_grid_mlp at :1152-1153 and :1281-1282): y = W2 relu(W1 x + b1) + b2 for n rows.
+ * w1 (dh, din), w2 (dout, dh) row-major as nn.Linear stores them; all pointers device.  Specified fp32 order
+ * (bias, then fmaf over k ascending), so the encoder and the decoder see the same context parameters. */
+GPCC_API int gshac_mlp2(gpcc_ctx *ctx, const float *x_dev, const float *w1_dev, const float *b1_dev, const float *w2_dev, const float *b2_dev,
+                        int64_t n, int din, int dh, int dout, float *y_dev, void *stream);
+
 /* _gridencoder.grid_encode_forward (inputs (N,D) in [0,1], embeddings (sO,F), offsets (L+1), resolutions (L),
  * outputs (L,N,F), ..., Rb, binary_vxl, min_level_id)   gridencoder.zip!gridencoder/src/gridencoder.h:12-22,
  * gridencoder.cu:100-361 (forward only; dy_dx / backward are training-side and out of scope).  All device. */

@@ -59,6 +59,7 @@ def lib():
         L.orc_hac_encode.argtypes = [vp, i32, vp, i64, i32, vp, i64, vp]
         L.orc_hac_decode.argtypes = [vp, i32, vp, vp, i64, i32, vp]
         L.orc_grid_forward.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp]
+        L.orc_mlp2.argtypes = [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]
         L.orc_raster_forward.restype = i64
         L.orc_raster_forward.argtypes = [i32, vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_float, C.c_float, vp, vp]
         _LIB = L
@@ -282,6 +283,18 @@ def hac_decode(cdf: np.ndarray, data: np.ndarray, cnt: np.ndarray, chunk: int = 
     out = np.empty(cdf.shape[0], dtype=np.int16)
     lib().orc_hac_decode(_p(cdf), cdf.shape[1], _p(data), _p(cnt), cdf.shape[0], chunk, _p(out))
     return out
+
+
+def mlp2(x, w1, b1, w2, b2) -> np.ndarray:
+    """mlp_grid (HAC/scene/gaussian_model.py:258-262): Linear - ReLU - Linear in the normative fp32 order."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    w1, b1, w2, b2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (w1, b1, w2, b2))
+    n, din = x.shape
+    dh, dout = w1.shape[0], w2.shape[0]
+    assert dh <= 1024
+    y = np.empty((n, dout), dtype=np.float32)
+    lib().orc_mlp2(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), C.c_int64(n), din, dh, dout, _p(y))
+    return y
 
 
 def grid_forward(inputs, emb, offsets, resolutions, rb=128, binary_vxl=None, min_level_id=None):

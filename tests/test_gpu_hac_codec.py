@@ -1,0 +1,142 @@
+"""GPU tests of the HAC attribute loop: gshac_mlp2 against the oracle, and
+conduct_encoding -> conduct_decoding on a model object that exposes what the reference's GaussianModel exposes
+(src/gs_compress/HAC/scene/gaussian_model.py:1090-1366)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X")
+    return torch
+
+
+@pytest.mark.parametrize("n,din,dh,dout", [(3000, 96, 100, 175), (17, 8, 5, 3), (4099, 48, 64, 97)])
+def test_mlp2_matches_oracle_bit_for_bit(torch_cuda, orc, n, din, dh, dout):
+    torch = torch_cuda
+    from gauspcc_amd import hac_codec
+
+    rng = np.random.RandomState(n)
+    x = rng.randn(n, din).astype(np.float32)
+    w1 = (rng.randn(dh, din) / np.sqrt(din)).astype(np.float32); b1 = rng.randn(dh).astype(np.float32) * 0.1
+    w2 = (rng.randn(dout, dh) / np.sqrt(dh)).astype(np.float32); b2 = rng.randn(dout).astype(np.float32) * 0.1
+    y = hac_codec.mlp2(*(torch.tensor(a).cuda() for a in (x, w1, b1, w2, b2))).cpu().numpy()
+    ref = orc.mlp2(x, w1, b1, w2, b2)
+    assert np.array_equal(y, ref)                                   # specified fp32 order: bit-identical
+    t = torch.relu(torch.tensor(x) @ torch.tensor(w1).T + torch.tensor(b1)) @ torch.tensor(w2).T + torch.tensor(b2)
+    np.testing.assert_allclose(y, t.numpy(), rtol=2e-5, atol=2e-5)  # and it is the MLP torch computes
+
+
+class _Model:
+    """The slice of GaussianModel that conduct_encoding / conduct_decoding touch (HAC/scene/gaussian_model.py)."""
+
+    def __init__(self, torch, n, feat_dim=50, n_offsets=10, seed=0):
+        from gauspcc_amd.gridencoder import mix_3D2D_encoding
+
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        dev = torch.device("cuda", 0)
+        self.feat_dim, self.n_offsets, self.voxel_size = feat_dim, n_offsets, 0.01
+        self.decoded_version = False
+        self.ste_binary, self.use_2D, self.n_features_per_level = True, True, 2
+        # unique voxels inside a 2.5 m box
+        vox = torch.unique(torch.randint(-120, 120, (n, 3), generator=g), dim=0)
+        self._anchor = (vox.float() * self.voxel_size).to(dev)
+        n = self._anchor.shape[0]
+        self._anchor_feat = (torch.randn(n, feat_dim, generator=g) * 0.7).to(dev)
+        self._offset = (torch.randn(n, n_offsets, 3, generator=g) * 0.3).to(dev)
+        self._scaling = (torch.randn(n, 6, generator=g) * 0.5 - 3.0).to(dev)
+        self._mask = (torch.randn(n, n_offsets, 1, generator=g) * 4.0).to(dev)      # logits; some anchors end up fully masked
+        self.x_bound_min = torch.tensor([[-1.3, -1.3, -1.3]], device=dev)
+        self.x_bound_max = torch.tensor([[1.3, 1.3, 1.3]], device=dev)
+        self.encoding_xyz = mix_3D2D_encoding(n_features=2, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                                              log2_hashmap_size=13, resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=15,
+                                              ste_binary=True, ste_multistep=False, add_noise=False, Q=1).to(dev)
+        for p in self.encoding_xyz.parameters():
+            p.data = torch.randn(p.shape, generator=g).to(dev)                      # signs matter (STE_binary)
+        self.mlp_grid = torch.nn.Sequential(torch.nn.Linear(self.encoding_xyz.output_dim, feat_dim * 2), torch.nn.ReLU(True),
+                                            torch.nn.Linear(feat_dim * 2, (feat_dim + 6 + 3 * n_offsets) * 2 + 3)).to(dev)
+
+    # accessors, as in the reference (:347-405)
+    @property
+    def get_scaling(self):
+        import torch
+        return self._scaling if self.decoded_version else 1.0 * torch.exp(self._scaling)
+
+    @property
+    def get_mask(self):
+        import torch
+        if self.decoded_version:
+            return self._mask
+        s = torch.sigmoid(self._mask)
+        return ((s > 0.01).float() - s).detach() + s
+
+    @property
+    def get_mask_anchor(self):
+        import torch
+        return (torch.sum(self.get_mask, dim=1)[:, 0]) > 0
+
+    @property
+    def get_anchor(self):
+        import torch
+        return self._anchor if self.decoded_version else torch.round(self._anchor / self.voxel_size) * self.voxel_size
+
+    @property
+    def get_grid_mlp(self):
+        return self.mlp_grid
+
+    def get_encoding_params(self):
+        import torch
+        e = self.encoding_xyz
+        p = torch.cat([e.encoding_xyz.params, e.encoding_xy.params, e.encoding_xz.params, e.encoding_yz.params], dim=0)
+        return (p >= 0) * (+1.0) + (p < 0) * (-1.0)                                 # STE_binary (:283-286)
+
+    def calc_interp_feat(self, x):
+        return self.encoding_xyz((x - self.x_bound_min) / (self.x_bound_max - self.x_bound_min))
+
+
+def test_conduct_encoding_decoding_roundtrip(torch_cuda, tmp_path):
+    torch = torch_cuda
+    from gauspcc_amd import hac_codec
+
+    enc = _Model(torch, 7000, seed=5)
+    patched, log = hac_codec.conduct_encoding(enc, str(tmp_path), ckpt_path="synthetic")
+    n_full, n, mb = patched
+    assert mb == 3000 and n_full == enc._anchor.shape[0] and n == int(enc.get_mask_anchor.sum())
+    steps = -(-n // mb)
+    files = set(os.listdir(tmp_path))
+    want = {"xyz_pcc.bin", "hash.b", "masks.b"} | {f"{a}_{s}_0.b" for a in ("feat", "scaling", "offsets") for s in range(steps)}
+    assert want <= files, sorted(want - files)
+    assert "Encoded sizes in MB" in log
+
+    # a fresh model with the SAME networks / hash tables (they travel as model weights) but no attributes
+    dec = _Model(torch, 10, seed=99)
+    dec.encoding_xyz, dec.mlp_grid = enc.encoding_xyz, enc.mlp_grid
+    dec.x_bound_min, dec.x_bound_max = enc.x_bound_min, enc.x_bound_max
+    dec._anchor_feat = torch.zeros(1, enc.feat_dim, device="cuda")
+    msg = hac_codec.conduct_decoding(dec, str(tmp_path), patched, ckpt_path="synthetic")
+    assert msg.startswith("\nDecTime")
+
+    # what the decoder must reproduce: the encoder's inputs, quantised with the context's step sizes
+    keep = enc.get_mask_anchor
+    a_int = torch.round(enc.get_anchor[keep] / enc.voxel_size)
+    order = hac_codec.calculate_morton_order(a_int)
+    anchor = a_int[order] * enc.voxel_size
+    assert torch.equal(dec._anchor.data, anchor)
+    c = hac_codec._context(enc, anchor)
+    feat = enc._anchor_feat[keep][order]
+    assert torch.equal(dec._anchor_feat.data, hac_codec.ste_multistep(feat, c["Q_feat"], feat.mean()))
+    scaling = enc.get_scaling[keep][order]
+    assert torch.equal(dec._scaling.data, hac_codec.ste_multistep(scaling, c["Q_scaling"], scaling.mean()))
+    mask = enc.get_mask[keep][order]
+    assert torch.equal(dec._mask.data, mask)
+    offs = enc._offset[keep][order].reshape(n, -1)
+    q = hac_codec.ste_multistep(offs, c["Q_offsets"], offs.mean())
+    q = q * mask.repeat(1, 1, 3).view(n, -1)
+    assert torch.equal(dec._offset.data.reshape(n, -1), q)

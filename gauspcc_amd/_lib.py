@@ -41,7 +41,7 @@ EXPORTS = [
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get",
-    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_encode_gaussian", "gsac_decode_gaussian", "gshac_mlp2", "gsge_forward", "gsr_visible_filter", "gsr_forward",
+    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_encode_gaussian", "gsac_decode_gaussian", "gshac_mlp2", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
 ]
 
 
@@ -88,6 +88,7 @@ def lib():
     f32 = C.c_float
     L.gsr_visible_filter.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp]
     L.gsr_forward.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp, C.POINTER(i64), vp]
+    L.gsnn_generate.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp]
     _lib = L
     return L
 

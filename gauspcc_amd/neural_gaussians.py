@@ -1,0 +1,68 @@
+"""generate_neural_gaussians of HAC (src/gs_compress/HAC/gaussian_renderer/__init__.py:25-172; the same function in
+HAC-plus / TC-GS / CAT-3DGS) for RD evaluation -- SURVEY.md §8(f) row 2: anchors -> the Gaussians the rasteriser draws.
+
+    from gauspcc_amd.neural_gaussians import generate_neural_gaussians
+    xyz, color, opacity, scaling, rot, time_sub = generate_neural_gaussians(viewpoint_camera, pc, visible_mask)
+
+Inference only (`is_training=False`): the training branches add noise and rate terms and need autograd.  The model `pc`
+is used through the attributes the reference uses.  When `pc.decoded_version` is false the attributes are first quantised
+with the context model's step sizes exactly as the reference does (:103-114); everything after that -- view vectors,
+feature bank, the three MLPs, masking, assembly -- is ONE call into libgauspcc (gsnn_generate: two kernels and a scan
+instead of ~40 PyTorch kernels and an (n K, 22) concatenate / mask / split).
+"""
+import ctypes as C
+import time
+
+import torch
+
+from . import _lib, runtime
+from .hac_codec import _context, ste_multistep
+
+
+def _linears(seq):
+    mods = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    if len(mods) != 2:
+        raise TypeError("expected nn.Sequential(Linear, ReLU, Linear, ...) as built in HAC/scene/gaussian_model.py:229-256")
+    return [t.detach().float().contiguous() for t in (mods[0].weight, mods[0].bias, mods[1].weight, mods[1].bias)]
+
+
+@torch.no_grad()
+def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_training=False, step=0):
+    if is_training:
+        raise NotImplementedError("gauspcc_amd.generate_neural_gaussians is the inference path (RD evaluation); training needs autograd")
+    time_sub = 0
+    if visible_mask is None:
+        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
+    anchor = pc.get_anchor[visible_mask]
+    feat = pc._anchor_feat[visible_mask]
+    grid_offsets = pc._offset[visible_mask]
+    grid_scaling = pc.get_scaling[visible_mask]
+    binary_grid_masks = pc.get_mask[visible_mask]
+    if not pc.decoded_version:      # quantise as the encoder would (:103-114)
+        torch.cuda.synchronize(); t1 = time.time()
+        c = _context(pc, anchor)
+        feat = ste_multistep(feat, c["Q_feat"], pc._anchor_feat.mean())
+        grid_scaling = ste_multistep(grid_scaling, c["Q_scaling"], pc.get_scaling.mean())
+        grid_offsets = ste_multistep(grid_offsets.reshape(anchor.shape[0], -1), c["Q_offsets"], pc._offset.mean()).view_as(grid_offsets)
+        torch.cuda.synchronize(); time_sub = time.time() - t1
+    n, K, F = anchor.shape[0], pc.n_offsets, pc.feat_dim
+    dev = anchor.device
+    tensors = []
+    if getattr(pc, "use_feat_bank", False):
+        tensors += _linears(pc.get_featurebank_mlp)
+    else:
+        tensors += [None] * 4
+    tensors += _linears(pc.get_opacity_mlp) + _linears(pc.get_cov_mlp) + _linears(pc.get_color_mlp)
+    ptrs = (C.c_void_p * 16)(*[None if t is None else t.data_ptr() for t in tensors])
+    f32 = lambda t: t.detach().float().contiguous()
+    anchor, feat, grid_offsets, grid_scaling = f32(anchor), f32(feat), f32(grid_offsets), f32(grid_scaling)
+    mask = f32(binary_grid_masks).view(n, K)
+    cam = f32(viewpoint_camera.camera_center).view(3)
+    xyz = torch.empty(n * K, 3, device=dev); color = torch.empty(n * K, 3, device=dev); opacity = torch.empty(n * K, 1, device=dev)
+    scaling = torch.empty(n * K, 3, device=dev); rot = torch.empty(n * K, 4, device=dev)
+    m = C.c_int64()
+    _lib.check(_lib.lib().gsnn_generate(runtime.context(dev), n, F, K, anchor.data_ptr(), feat.data_ptr(), grid_offsets.data_ptr(), grid_scaling.data_ptr(),
+                                        mask.data_ptr(), cam.data_ptr(), ptrs, xyz.data_ptr(), color.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
+                                        rot.data_ptr(), C.byref(m), runtime.stream_ptr(dev)))
+    m = m.value
+    return xyz[:m], color[:m], opacity[:m], scaling[:m], rot[:m], time_sub

@@ -205,6 +205,18 @@ GPCC_API int gsge_forward(gpcc_ctx *ctx, const float *inputs_dev, const float *e
                           const int32_t *resolutions_dev, float *outputs_dev, int64_t n, int num_dim, int n_features, int n_levels,
                           int rb, const uint8_t *binary_vxl_dev, const int32_t *min_level_id_dev, void *stream);
 
+/* ================= generate_neural_gaussians, inference path =================
+ * src/gs_compress/HAC/gaussian_renderer/__init__.py:25-172 after attribute quantisation (:103-114, done by the caller):
+ * view direction / distance (:116-118), optional feature bank (:121-132), opacity / colour / covariance MLPs on
+ * [feat | view | dist] (:134-152), masking by neural opacity > 0 (:136-141, 160-162) and the assembly of position,
+ * scale and rotation (:165-171).  n visible anchors, feat_dim in {32, 50}, K = n_offsets.
+ * mlp: 16 device pointers = {w1, b1, w2, b2} of mlp_feature_bank (all four NULL when use_feat_bank is off), mlp_opacity,
+ * mlp_cov, mlp_color (nn.Linear layouts; gaussian_model.py:229-256).  mask (n, K) in {0, 1}; cam_center (3) device.
+ * Outputs have room for n*K Gaussians; *count_out of them are written (anchor-major, the reference's order). */
+GPCC_API int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
+                           const float *scaling, const float *mask, const float *cam_center, const float *const *mlp, float *xyz_out,
+                           float *color_out, float *opacity_out, float *scale_out, float *rot_out, int64_t *count_out, void *stream);
+
 /* ================= Gaussian splat rasteriser, forward only (a20) =================
  * diff_gaussian_rasterization (Scaffold-GS fork; zip missing from the reference tree).  Mirrors the C++ API the
  * reference's viewer calls: CudaRasterizer::Rasterizer::visible_filter / ::forward,

@@ -15,7 +15,7 @@ def test_library_exports_every_declared_symbol():
     from gauspcc_amd import _lib
 
     header = open(os.path.join(ROOT, "include", "gauspcc.h")).read()
-    declared = sorted(set(re.findall(r"GPCC_API\s+[\w\s\*]*?\b(g(?:pcc|sac|sge|sr|shac)_\w+)\s*\(", header)))
+    declared = sorted(set(re.findall(r"GPCC_API\s+[\w\s\*]*?\b(g(?:pcc|sac|sge|sr|shac|snn)_\w+)\s*\(", header)))
     assert len(declared) >= 15
     assert sorted(_lib.EXPORTS) == declared
     so = ctypes.CDLL(_lib.LIB_PATH)

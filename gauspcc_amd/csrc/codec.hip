@@ -330,7 +330,18 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     };
     TAKE(dbytes, uint8_t, nbytes + 16);
     HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, st));
-    GP_TRY(ctx->hstage.reserve(4096 + 16 * (size_t)bn));
+    // chunk descriptors of every level are staged in pinned memory that is written once (no reuse, so no sync before
+    // a level's table may be overwritten): chunked containers know all level sizes from the header
+    size_t desc_total = 0;
+    for (int g = 0; g + 1 < L; ++g) {
+        const int64_t ncg = v1 ? lvl_n[g + 1] : 0;
+        const int clog = rc_level_chunk_log2(ncg, chunk_log2, version);
+        desc_total += 4 * (size_t)(chunk_log2 ? cdiv(std::max<int64_t>(ncg, 1), (int64_t)1 << clog) : 1);
+    }
+    const size_t desc_off = (4096 + 16 * (size_t)bn + 63) & ~(size_t)63;
+    GP_TRY(ctx->hstage.reserve(desc_off + sizeof(RcChunk) * desc_total + 64));
+    RcChunk *hdesc = reinterpret_cast<RcChunk *>(ctx->hstage.p + desc_off);
+    size_t desc_used = 0;
     Level cur;
     GP_TRY(alloc_level(&cur, bn, L));
     {
@@ -357,7 +368,6 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     ConvTiles tilesP;
     GP_TRY(conv_tiles_build(ctx, st, nbrP, bn, K, &tilesP, pairs_dev));
     int64_t coded = 0;
-    std::vector<RcChunk> chunks;
     // Arena discipline: level g allocates [child arrays | child neighbour map | chunk table] (kept: they are
     // level g+1's parent data) and then its work buffers, which are rewound at the end of the level.
     for (int g = 0; g + 1 < L; ++g) {
@@ -385,7 +395,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const int clog = rc_level_chunk_log2(nc, chunk_log2, version);   // this level's chunk size
         const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
         const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
-        chunks.assign((size_t)4 * nch, RcChunk{});
+        if (desc_used + (size_t)4 * nch > desc_total) return fail(GPCC_ERR_FORMAT, "level %d: chunk tables exceed the header's level sizes", g + 1);
+        RcChunk *chunks = hdesc + desc_used;
+        desc_used += (size_t)4 * nch;
         for (int s = 0; s < 4; ++s) {
             const int si = 4 * g + s;
             const int64_t off = s_off[si], len = s_len[si];
@@ -404,10 +416,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             }
         }
         TAKE(dchunks, RcChunk, 4 * nch);
-        // pageable source -> the runtime stages it before returning, so `chunks` may be reused next level
-        HIP_TRY(hipMemcpyAsync(dchunks, chunks.data(), sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (v1 && htotal[1 + g] != (uint32_t)nc) return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)nc, htotal[1 + g]);
+        HIP_TRY(hipMemcpyAsync(dchunks, chunks, sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));   // pinned, write-once: no sync
         const size_t mk = ctx->arena.mark();
         const int64_t np = cur.n;
         TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
@@ -444,6 +453,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int64_t npts = htotal[0];
+    // the header's level sizes against what the decoded occupancy expanded to (the copies were queued level by level;
+    // the expansion is bounded by the header, so a wrong header produced garbage, not out-of-bounds accesses)
+    if (v1)
+        for (int g = 0; g + 1 < L; ++g)
+            if (htotal[1 + g] != (uint32_t)lvl_n[g + 1])
+                return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)lvl_n[g + 1], htotal[1 + g]);
     if (v1 && npts != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)npts, (long long)npts_hdr);
     TAKE(xyz, int32_t, 3 * std::max<int64_t>(npts, 1));
     GP_TRY(leaves_reference_order(ctx, st, &cur, xyz, npts));

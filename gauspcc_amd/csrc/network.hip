@@ -115,6 +115,15 @@ __global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__
     idx[b] = (uint32_t)b;
 }
 
+// CONV_HDR_PAD zeroed tiles behind the list, whose length lives on the device
+__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc)
+{
+    const uint32_t t = *total;
+    for (int i = threadIdx.x; i < CONV_HDR_PAD * 16; i += 64) tj[(size_t)t * 16 + i] = 0;
+    for (int i = threadIdx.x; i < CONV_HDR_PAD * 4; i += 64) tr4[(size_t)t * 4 + i] = 0;
+    for (int i = threadIdx.x; i < CONV_HDR_PAD; i += 64) toc[t + i] = 0;
+}
+
 template <int R>
 static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
 {
@@ -126,17 +135,24 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, nullptr, nullptr, nullptr, pairs_dev);
     LAUNCH_CHECK();
     GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
+    // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the
+    // host ever learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run
+    // ahead).  Taller blocks are sized exactly: one sync.
+    constexpr bool BOUNDED = R == 16;
+    int64_t cap;
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    const int64_t cap = (int64_t)total + CONV_HDR_PAD;  // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
+    if (BOUNDED) cap = nblk * K + CONV_HDR_PAD;
+    else {
+        HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        cap = (int64_t)total + CONV_HDR_PAD;  // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
+    }
     TAKE(tj, int32_t, cap * 16);
     TAKE(tr, uint8_t, cap * 16);
     TAKE(toc, uint32_t, cap);
     T->tj = tj; T->tr = tr; T->toc = toc;
-    HIP_TRY(hipMemsetAsync(tj + (size_t)total * 16, 0, (size_t)CONV_HDR_PAD * 64, st));
-    HIP_TRY(hipMemsetAsync(tr + (size_t)total * 16, 0, (size_t)CONV_HDR_PAD * 16, st));
-    HIP_TRY(hipMemsetAsync(toc + total, 0, (size_t)CONV_HDR_PAD * 4, st));
+    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc);
+    LAUNCH_CHECK();
     k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
     // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling).  When all

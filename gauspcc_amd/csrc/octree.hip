@@ -240,7 +240,7 @@ __global__ __launch_bounds__(TB) void k_popc(const uint8_t *__restrict__ occ, in
 }
 
 __global__ __launch_bounds__(TB) void k_expand(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart,
-                                               int64_t n, uint64_t *__restrict__ rkey_c, uint32_t *__restrict__ parent_c)
+                                               int64_t n, uint64_t *__restrict__ rkey_c, uint32_t *__restrict__ parent_c, int64_t nc_cap)
 {
     int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     int64_t p = t >> 3;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(TB) void k_expand(const uint64_t *__restrict__ rkey
     const uint32_t o = occ[p];
     if (!((o >> q) & 1u)) return;
     const uint32_t idx = cstart[p] + (uint32_t)__popc(o & ((1u << q) - 1u));
+    if ((int64_t)idx >= nc_cap) return;   // a header that understates the level: the caller reports it at its next sync
     const uint64_t k = rkey[p];
     rkey_c[idx] = rkey3(2 * rk_x(k) + (q & 1), 2 * rk_y(k) + ((q >> 1) & 1), 2 * rk_z(k) + ((q >> 2) & 1));
     parent_c[idx] = (uint32_t)p;
@@ -262,7 +263,10 @@ int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t
     GP_TRY(exclusive_scan_u32(ctx, st, par->cstart, par->cstart, n, par->cstart + n));
     if (total_dev) HIP_TRY(hipMemcpyAsync(total_dev, par->cstart + n, 4, hipMemcpyDeviceToDevice, st));
     if (chi) {
-        k_expand<<<nblk(n * 8), TB, 0, st>>>(par->rkey, par->occ, par->cstart, n, chi->rkey, chi->parent);
+        // the child arrays were sized from the container header, which is verified only at the caller's next sync: keep
+        // every parent index valid (0) where a lying header leaves children unwritten
+        HIP_TRY(hipMemsetAsync(chi->parent, 0, 4 * (size_t)chi->n, st));
+        k_expand<<<nblk(n * 8), TB, 0, st>>>(par->rkey, par->occ, par->cstart, n, chi->rkey, chi->parent, chi->n);
         LAUNCH_CHECK();
     }
     return GPCC_OK;

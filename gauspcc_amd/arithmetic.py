@@ -12,6 +12,7 @@ materialise the (n, max-min+2) float table):
 
     encode_gaussian(x, mean, scale, Q, chunk_size)                    -> (min, max, Tensor uint8, Tensor int32[chunks])
     decode_gaussian(mean, scale, Q, min, max, bytes, cnt, chunk_size) -> Tensor float32 (n)
+    encode_gaussian_slices / decode_gaussian_slices: the same for every slice of an attribute in one call
 """
 import ctypes as C
 
@@ -95,4 +96,35 @@ def decode_gaussian(mean, scale, Q, min_value, max_value, in_cache_all, in_cnt_a
     _lib.check(_lib.lib().gsac_decode_gaussian(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(), n,
                                                float(min_value), float(max_value), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
                                                out.data_ptr(), runtime.stream_ptr(mean.device)))
+    return out
+
+
+def encode_gaussian_slices(x, mean, scale, Q, slice_start, chunk_size):
+    """All slices [slice_start[s], slice_start[s+1]) of an attribute in one call (gsac_encode_gaussian_slices).
+    Returns (mins, maxs, bytes, cnt) as numpy arrays: float32 (nslices) x 2, uint8, int32 (chunks, slice by slice)."""
+    for t, nm in ((x, "x"), (mean, "mean"), (scale, "scale"), (Q, "Q")):
+        _chk(t, nm)
+    ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
+    ns = ss.size - 1
+    mins, maxs = np.empty(ns, dtype=np.float32), np.empty(ns, dtype=np.float32)
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode_gaussian_slices(runtime.context(x.device), x.float().data_ptr(), mean.float().data_ptr(), scale.float().data_ptr(),
+                                                      Q.float().data_ptr(), ss.ctypes.data, ns, int(chunk_size), mins.ctypes.data, maxs.ctypes.data,
+                                                      C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
+    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
+    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    return mins, maxs, out, cnt
+
+
+def decode_gaussian_slices(mean, scale, Q, slice_start, mins, maxs, data, cnt, chunk_size):
+    """Inverse of encode_gaussian_slices; data / cnt are the concatenated payloads / chunk byte counts (numpy)."""
+    for t, nm in ((mean, "mean"), (scale, "scale"), (Q, "Q")):
+        _chk(t, nm)
+    ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
+    mins = np.ascontiguousarray(mins, dtype=np.float32); maxs = np.ascontiguousarray(maxs, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    out = torch.empty(int(ss[-1]), dtype=torch.float32, device=mean.device)
+    _lib.check(_lib.lib().gsac_decode_gaussian_slices(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(),
+                                                      ss.ctypes.data, ss.size - 1, mins.ctypes.data, maxs.ctypes.data, data.ctypes.data, data.size,
+                                                      cnt.ctypes.data, int(chunk_size), out.data_ptr(), runtime.stream_ptr(mean.device)))
     return out

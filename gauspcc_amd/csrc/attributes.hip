@@ -110,17 +110,16 @@ struct WaveBits {  // every lane holds the same reader state (wave-uniform addre
 
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
-template <typename CT>
-__global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
-                                                   const uint32_t *__restrict__ cnt_cum, int16_t *__restrict__ sym, int64_t n, int lp, int chunk)
+// One wave decodes one chunk: `cn` symbols whose rows are base .. base+cn-1 of `cdf`; out(row, symbol) stores the result.
+template <typename CT, typename OUT>
+__device__ __forceinline__ void hac_decode_chunk(const CT &cdf, const uint8_t *__restrict__ chunk_bytes, uint32_t chunk_nbytes, int64_t base, int cn, int lp,
+                                                 OUT out)
 {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int64_t base = (int64_t)c * chunk;
-    const int cn = (int)min((int64_t)chunk, n - base);
+    const int lane = threadIdx.x;
     const float scale = (float)(65536 - (lp - 1));
     const int max_symbol = lp - 2;
     WaveBits in;
-    in.init(bytes + cnt_cum[c], (uint32_t)cnt[c]);
+    in.init(chunk_bytes, chunk_nbytes);
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = in.take(32);
     const int nseg = (lp - 1 + 63) / 64;  // indices 0 .. lp-2 are searched
@@ -160,7 +159,7 @@ __global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *
                 lo = (uint32_t)((span * (uint64_t)cdf_int(row, s, scale)) >> 16);
                 hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)cdf_int(row, s + 1, scale)) >> 16);
             }
-            if (lane == 0) sym[base + i] = (int16_t)s;
+            if (lane == 0) out(base + i, s);
             high = (low - 1u) + hi;
             low = low + lo;
             const int n1 = clz32(low ^ high);
@@ -171,6 +170,30 @@ __global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *
             value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
         }
     }
+}
+
+template <typename CT>
+__global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *__restrict__ bytes, const int32_t *__restrict__ cnt,
+                                                   const uint32_t *__restrict__ cnt_cum, int16_t *__restrict__ sym, int64_t n, int lp, int chunk)
+{
+    const int c = blockIdx.x;
+    const int64_t base = (int64_t)c * chunk;
+    hac_decode_chunk(cdf, bytes + cnt_cum[c], (uint32_t)cnt[c], base, (int)min((int64_t)chunk, n - base), lp,
+                     [&](int64_t r, int s) { sym[r] = (int16_t)s; });
+}
+
+// The same for MANY slices at once (every 3000-anchor slice of an attribute has its own symbol range [min, max], hence
+// its own alphabet): one wave per chunk of any slice, CDF entries from the element's Gaussian parameters, the decoded
+// value (sym + min) * Q written directly (encodings_cuda.py:431-432).
+struct SliceChunk { int64_t base; int32_t n, slice; uint32_t byte_off, nbytes; };
+__global__ __launch_bounds__(64) void k_hac_decode_slices(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ q,
+                                                          const SliceChunk *__restrict__ chunks, const int32_t *__restrict__ smin,
+                                                          const int32_t *__restrict__ slp, const uint8_t *__restrict__ bytes, float *__restrict__ x)
+{
+    const SliceChunk ch = chunks[blockIdx.x];
+    const int mn = smin[ch.slice];
+    hac_decode_chunk(GaussTable{mean, scale, q, mn}, bytes + ch.byte_off, ch.nbytes, ch.base, ch.n, slp[ch.slice],
+                     [&](int64_t r, int s) { x[r] = ((float)s + (float)mn) * q[r]; });
 }
 
 // ------------------------------------------------------------------ hash-grid forward
@@ -519,6 +542,177 @@ extern "C" int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean, const floa
     TAKE(sym, int16_t, n);
     GP_TRY(gsac_decode_impl<GaussTable>(ctx, GaussTable{mean, scale, Q, mn}, bytes, nbytes, cnt, chunk_size, n, lp, sym, stream, true));
     k_from_symbols<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(sym, Q, n, min_value, x_out);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}
+
+// ------------------------------------------------------------------ all slices of an attribute in one call
+namespace {
+constexpr int SLICE_PARTS = 8;   // blocks per slice in the min / max pass
+
+__device__ __forceinline__ int slice_of(const int64_t *__restrict__ start, int nslices, int64_t r)
+{
+    int lo = 0, hi = nslices;           // start[lo] <= r < start[hi]
+    while (lo + 1 < hi) { const int m = (lo + hi) >> 1; if (start[m] <= r) lo = m; else hi = m; }
+    return lo;
+}
+
+// x_int = round(x / Q) and the min / max of every slice: block (part, slice)
+__global__ __launch_bounds__(TB) void k_quantise_minmax_slices(const float *__restrict__ x, const float *__restrict__ q, const int64_t *__restrict__ start,
+                                                               int32_t *__restrict__ xi, int32_t *__restrict__ mm)
+{
+    const int s = blockIdx.y;
+    const int64_t a = start[s], b = start[s + 1], len = b - a;
+    const int64_t lo = a + len * blockIdx.x / SLICE_PARTS, hi = a + len * (blockIdx.x + 1) / SLICE_PARTS;
+    int mn = INT32_MAX, mx = INT32_MIN;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += TB) {
+        const int v = (int)__builtin_rintf(x[i] / q[i]);
+        xi[i] = v;
+        mn = min(mn, v); mx = max(mx, v);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { mn = min(mn, __shfl_xor(mn, d, 64)); mx = max(mx, __shfl_xor(mx, d, 64)); }
+    __shared__ int red[TB / 64][2];
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = mn; red[threadIdx.x >> 6][1] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < TB / 64; ++w) { mn = min(mn, red[w][0]); mx = max(mx, red[w][1]); }
+        if (hi > lo) { atomicMin(&mm[2 * s], mn); atomicMax(&mm[2 * s + 1], mx); }
+    }
+}
+
+// (symbol, Gaussian parameters) -> the coder's two integers, in the chunk-interleaved layout of the element's slice
+__global__ __launch_bounds__(TB) void k_hac_pack_slices(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ q,
+                                                        const int32_t *__restrict__ xi, int64_t n, const int64_t *__restrict__ start, int nslices,
+                                                        const int32_t *__restrict__ mm, const int64_t *__restrict__ lohi_base,
+                                                        const int32_t *__restrict__ slice_nch, int chunk, uint32_t *__restrict__ lohi)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    const int sl = slice_of(start, nslices, r);
+    const int mn = mm[2 * sl], lp = mm[2 * sl + 1] - mn + 2;
+    const float sc = (float)(65536 - (lp - 1));
+    const int s = xi[r] - mn;
+    const GaussRow row{mean[r], scale[r], q[r], mn};
+    const uint32_t lo = cdf_int(row, s, sc);
+    const uint32_t hi = s == lp - 2 ? 0x10000u : cdf_int(row, s + 1, sc);
+    const int64_t e = r - start[sl];
+    const int64_t c = e / chunk, t = e - c * chunk;
+    lohi[lohi_base[sl] + t * slice_nch[sl] + c] = (lo & 0xFFFFu) | ((hi - 1u) << 16);
+}
+}  // namespace
+
+extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const float *mean, const float *scale, const float *Q, const int64_t *slice_start,
+                                           int nslices, int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out,
+                                           const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    if (!ctx || !x || !mean || !scale || !Q || !slice_start || !min_out || !max_out || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out)
+        return fail(GPCC_ERR_ARG, "null argument");
+    if (nslices <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    for (int s = 0; s < nslices; ++s)
+        if (slice_start[s + 1] <= slice_start[s]) return fail(GPCC_ERR_ARG, "slice %d is empty", s);
+    if (slice_start[0] != 0) return fail(GPCC_ERR_ARG, "slices must start at element 0");
+    const int64_t n = slice_start[nslices];
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    // chunk descriptors: slice by slice, the chunks of a slice interleaved among themselves
+    std::vector<RcChunk> chunks;
+    std::vector<int64_t> lbase((size_t)nslices);
+    std::vector<int32_t> snch((size_t)nslices);
+    int64_t slots = 0;
+    uint32_t max_syms = 1;
+    for (int s = 0; s < nslices; ++s) {
+        const int64_t len = slice_start[s + 1] - slice_start[s];
+        const int nch = (int)cdiv(len, chunk_size);
+        lbase[(size_t)s] = slots; snch[(size_t)s] = nch;
+        for (int c = 0; c < nch; ++c) {
+            const uint32_t cn = (uint32_t)std::min<int64_t>(chunk_size, len - (int64_t)c * chunk_size);
+            chunks.push_back(RcChunk{(uint32_t)(slots + c), (uint32_t)nch, cn, 0, 0, 0});
+            max_syms = std::max(max_syms, cn);
+        }
+        slots += (int64_t)nch * chunk_size;
+    }
+    if (slots >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many symbols in one call");
+    const int nch = (int)chunks.size();
+    const uint32_t sstride = rc_scratch_stride(max_syms);
+    GP_TRY(ctx->arena.reserve((size_t)n * 4 + (size_t)slots * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + (size_t)nslices * 32 + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(xi, int32_t, n); TAKE(mm, int32_t, 2 * nslices); TAKE(dstart, int64_t, nslices + 1); TAKE(dlbase, int64_t, nslices); TAKE(dsnch, int32_t, nslices);
+    TAKE(lohi, uint32_t, slots); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
+    TAKE(scratch, uint8_t, (size_t)nch * sstride); TAKE(payload, uint8_t, (size_t)nch * sstride);
+    std::vector<int32_t> init((size_t)2 * nslices);
+    for (int s = 0; s < nslices; ++s) { init[(size_t)2 * s] = INT32_MAX; init[(size_t)2 * s + 1] = INT32_MIN; }
+    HIP_TRY(hipMemcpyAsync(mm, init.data(), 8 * (size_t)nslices, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dstart, slice_start, 8 * ((size_t)nslices + 1), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dlbase, lbase.data(), 8 * (size_t)nslices, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dsnch, snch.data(), 4 * (size_t)nslices, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of scope before the stream drains otherwise
+    k_quantise_minmax_slices<<<dim3(SLICE_PARTS, (unsigned)nslices), TB, 0, st>>>(x, Q, dstart, xi, mm);
+    LAUNCH_CHECK();
+    k_hac_pack_slices<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(mean, scale, Q, xi, n, dstart, nslices, mm, dlbase, dsnch, chunk_size, lohi);
+    LAUNCH_CHECK();
+    GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
+    GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
+    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nch, payload));
+    GP_TRY(ctx->hstage.reserve(4 * (size_t)nch + 8 * (size_t)nslices + 64));
+    uint32_t *hcnt = reinterpret_cast<uint32_t *>(ctx->hstage.p);
+    int32_t *hmm = reinterpret_cast<int32_t *>(hcnt + nch + 1);
+    HIP_TRY(hipMemcpyAsync(hcnt, dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hcnt + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hmm, mm, 8 * (size_t)nslices, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int s = 0; s < nslices; ++s) {
+        if (hmm[2 * s + 1] - hmm[2 * s] + 2 > 32767) return fail(GPCC_ERR_RANGE, "slice %d: quantised values span %d levels (int16 symbols)", s, hmm[2 * s + 1] - hmm[2 * s] + 1);
+        min_out[s] = (float)hmm[2 * s]; max_out[s] = (float)hmm[2 * s + 1];
+    }
+    const size_t total = hcnt[nch];
+    GP_TRY(ctx->hbytes.reserve(total + 16));
+    if (total) HIP_TRY(hipMemcpyAsync(ctx->hbytes.p, payload, total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *bytes_out = ctx->hbytes.p; *nbytes_out = (int64_t)total;
+    *cnt_out = reinterpret_cast<const int32_t *>(hcnt); *nchunks_out = nch;
+    return GPCC_OK;
+}
+
+extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, const int64_t *slice_start, int nslices,
+                                           const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt,
+                                           int chunk_size, float *x_out, void *stream)
+{
+    if (!ctx || !mean || !scale || !Q || !slice_start || !min_value || !max_value || !bytes || !cnt || !x_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (nslices <= 0 || chunk_size <= 0 || slice_start[0] != 0) return fail(GPCC_ERR_ARG, "bad size");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<SliceChunk> chunks;
+    std::vector<int32_t> smin((size_t)nslices), slp((size_t)nslices);
+    uint64_t off = 0;
+    for (int s = 0; s < nslices; ++s) {
+        const int64_t len = slice_start[s + 1] - slice_start[s];
+        if (len <= 0) return fail(GPCC_ERR_ARG, "slice %d is empty", s);
+        const int mn = (int)min_value[s], lp = (int)max_value[s] - mn + 2;
+        if (lp < 2 || lp > 32767) return fail(GPCC_ERR_FORMAT, "slice %d: bad symbol range", s);
+        smin[(size_t)s] = mn; slp[(size_t)s] = lp;
+        const int nch = (int)cdiv(len, chunk_size);
+        for (int c = 0; c < nch; ++c) {
+            const int32_t cb = cnt[chunks.size()];
+            if (cb < 0) return fail(GPCC_ERR_FORMAT, "negative chunk size");
+            chunks.push_back(SliceChunk{slice_start[s] + (int64_t)c * chunk_size, (int32_t)std::min<int64_t>(chunk_size, len - (int64_t)c * chunk_size), s,
+                                        (uint32_t)off, (uint32_t)cb});
+            off += (uint32_t)cb;
+        }
+    }
+    if ((int64_t)off > nbytes || off >= ((uint64_t)1 << 32)) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
+    const size_t nch = chunks.size();
+    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(SliceChunk) * nch + 8 * (size_t)nslices + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(db, uint8_t, nbytes + 16); TAKE(dch, SliceChunk, nch); TAKE(dmin, int32_t, nslices); TAKE(dlp, int32_t, nslices);
+    HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(SliceChunk) * nch, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dmin, smin.data(), 4 * (size_t)nslices, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dlp, slp.data(), 4 * (size_t)nslices, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    k_hac_decode_slices<<<(unsigned)nch, 64, 0, st>>>(mean, scale, Q, dch, dmin, dlp, db, x_out);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;

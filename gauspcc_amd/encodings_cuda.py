@@ -120,3 +120,59 @@ def decoder(N_len, file_name='tmp.b', device='cuda'):
     output_cdf = _bernoulli_cdf(prob_1.to(device), N_len, device)
     return arithmetic.arithmetic_decode(output_cdf, byte_stream_torch, cnt_torch, chunk_size_cuda,
                                         int(output_cdf.shape[0]), int(output_cdf.shape[1]))
+
+
+# ---------------------------------------------------------------- all slices of an attribute at once
+def encoder_gaussian_slices(x, mean, scale, Q, slice_start, file_names, chunk_size=1000_0000):
+    """encoder_gaussian_chunk for MANY slices in one device call: slice s = elements [slice_start[s], slice_start[s+1]) goes
+    to file_names[s] (a `*.b` name; as in encoder_gaussian_chunk the file written is `*_0.b`) with its own min / max.
+    Same files as calling encoder_gaussian_chunk slice by slice.  Empty slices write nothing.  Returns the bit count per slice."""
+    ss = np.asarray(slice_start, dtype=np.int64)
+    lens = np.diff(ss)
+    assert lens.max(initial=0) <= chunk_size, "slices longer than chunk_size are split by encoder_gaussian_chunk; use it for those"
+    keep = np.nonzero(lens > 0)[0]
+    bits = [0] * len(lens)
+    if keep.size == 0:
+        return bits
+    sel = torch.cat([torch.arange(int(ss[i]), int(ss[i + 1]), device=x.device) for i in keep]) if keep.size != len(lens) else None
+    pick = (lambda t: t.contiguous()) if sel is None else (lambda t: t[sel].contiguous())
+    cs = np.concatenate([[0], np.cumsum(lens[keep])])
+    mins, maxs, data, cnt = arithmetic.encode_gaussian_slices(pick(x), pick(mean), pick(scale), pick(Q), cs, chunk_size_cuda)
+    nch = [-(-int(l) // chunk_size_cuda) for l in lens[keep]]
+    c0 = b0 = 0
+    for j, i in enumerate(keep):
+        c = cnt[c0:c0 + nch[j]]
+        nb = int(c.sum())
+        fn = file_names[i].replace('.b', '_0.b')
+        with open(fn, 'wb') as fout:
+            fout.write(np.float32(mins[j]).tobytes())
+            fout.write(np.float32(maxs[j]).tobytes())
+            fout.write(np.array([4 * len(c)]).astype(np.int32).tobytes())
+            fout.write(c.tobytes())
+            fout.write(data[b0:b0 + nb].tobytes())
+        bits[i] = (nb + 4 * len(c)) * 8 + 32 * 3
+        c0 += nch[j]; b0 += nb
+    return bits
+
+
+def decoder_gaussian_slices(mean, scale, Q, slice_start, file_names):
+    """Inverse of encoder_gaussian_slices: reads the per-slice files, decodes every chunk of every slice concurrently.
+    Returns the decoded values of all (non-empty) slices concatenated in slice order."""
+    ss = np.asarray(slice_start, dtype=np.int64)
+    lens = np.diff(ss)
+    keep = np.nonzero(lens > 0)[0]
+    if keep.size == 0:
+        return torch.empty(0, dtype=torch.float32, device=mean.device)
+    mins, maxs, cnts, datas = [], [], [], []
+    for i in keep:
+        with open(file_names[i].replace('.b', '_0.b'), 'rb') as fin:
+            mins.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+            maxs.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+            len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+            cnts.append(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32))
+            datas.append(np.frombuffer(fin.read(), dtype=np.uint8))
+    sel = torch.cat([torch.arange(int(ss[i]), int(ss[i + 1]), device=mean.device) for i in keep]) if keep.size != len(lens) else None
+    pick = (lambda t: t.contiguous()) if sel is None else (lambda t: t[sel].contiguous())
+    cs = np.concatenate([[0], np.cumsum(lens[keep])])
+    return arithmetic.decode_gaussian_slices(pick(mean), pick(scale), pick(Q), cs, np.array(mins), np.array(maxs), np.concatenate(datas),
+                                             np.concatenate(cnts), chunk_size_cuda)

@@ -19,7 +19,9 @@ Same files under `pre_path_name` (xyz_pcc.bin, feat_{s}_0.b, scaling_{s}_0.b, of
     bits        encoder / decoder (one global Bernoulli p)                     gsac_encode / gsac_decode
 
 The context MLP runs ONCE over all anchors instead of once per 3000-anchor slice (rows are independent, so the slices of
-the result are the per-slice results); the slices only decide which elements share a `.b` file and its min / max.
+the result are the per-slice results), and all slices of an attribute are coded in ONE device call
+(gsac_encode_gaussian_slices / gsac_decode_gaussian_slices): the slices only decide which elements share a `.b` file and
+its min / max.  Per million anchors the reference issues ~1000 coder calls, each a serial chain of 10000-symbol chunks.
 """
 import os
 import time
@@ -27,7 +29,7 @@ import time
 import torch
 
 from . import _lib, runtime
-from .encodings_cuda import decoder, decoder_gaussian_chunk, encoder, encoder_gaussian_chunk
+from .encodings_cuda import decoder, decoder_gaussian_slices, encoder, encoder_gaussian_slices
 from .pcc_utils import calculate_morton_order, compress_point_cloud, decompress_point_cloud
 
 bit2MB_scale = 8 * 1024 * 1024     # HAC/scene/gaussian_model.py:30
@@ -122,36 +124,28 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
     n_off = self.n_offsets
     c = _context(self, _anchor)
     feat_mean, scaling_mean, offsets_mean = _feat.mean(), _scaling.mean(), _grid_offsets.mean()
-    bit_feat_list, bit_scaling_list, bit_offsets_list = [], [], []
     hash_b_name = os.path.join(pre_path_name, 'hash.b')
     masks_b_name = os.path.join(pre_path_name, 'masks.b')
-    for s in range(steps):
-        a, b = s * MAX_BATCH_SIZE, min((s + 1) * MAX_BATCH_SIZE, N)
-        feat_b_name = os.path.join(pre_path_name, 'feat.b').replace('.b', f'_{s}.b')
-        scaling_b_name = os.path.join(pre_path_name, 'scaling.b').replace('.b', f'_{s}.b')
-        offsets_b_name = os.path.join(pre_path_name, 'offsets.b').replace('.b', f'_{s}.b')
+    names = lambda stem: [os.path.join(pre_path_name, f'{stem}.b').replace('.b', f'_{s}.b') for s in range(steps)]
+    bounds = [min(s * MAX_BATCH_SIZE, N) for s in range(steps + 1)]
 
-        Q = c["Q_feat"][a:b].reshape(-1)
-        feat = ste_multistep(_feat[a:b].reshape(-1), Q, feat_mean)
-        torch.cuda.synchronize(); t0 = time.time()
-        bit_feat_list.append(encoder_gaussian_chunk(feat, c["mean"][a:b].reshape(-1), c["scale"][a:b].reshape(-1), Q, file_name=feat_b_name))
-        torch.cuda.synchronize(); t_codec += time.time() - t0
+    torch.cuda.synchronize(); t0 = time.time()
+    Q = c["Q_feat"].reshape(-1)
+    feat = ste_multistep(_feat.reshape(-1), Q, feat_mean)
+    bit_feat_list = encoder_gaussian_slices(feat, c["mean"].reshape(-1), c["scale"].reshape(-1), Q, [b * self.feat_dim for b in bounds], names('feat'))
 
-        Q = c["Q_scaling"][a:b].reshape(-1)
-        scaling = ste_multistep(_scaling[a:b].reshape(-1), Q, scaling_mean)
-        torch.cuda.synchronize(); t0 = time.time()
-        bit_scaling_list.append(encoder_gaussian_chunk(scaling, c["mean_scaling"][a:b].reshape(-1), c["scale_scaling"][a:b].reshape(-1), Q,
-                                                       file_name=scaling_b_name))
-        torch.cuda.synchronize(); t_codec += time.time() - t0
+    Q = c["Q_scaling"].reshape(-1)
+    scaling = ste_multistep(_scaling.reshape(-1), Q, scaling_mean)
+    bit_scaling_list = encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds], names('scaling'))
 
-        mask = _mask[a:b].repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)      # [N_num*K*3]
-        Q = c["Q_offsets"][a:b].reshape(-1)
-        offsets = ste_multistep(_grid_offsets[a:b].reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
-        offsets[~mask] = 0.0
-        torch.cuda.synchronize(); t0 = time.time()
-        bit_offsets_list.append(encoder_gaussian_chunk(offsets[mask], c["mean_offsets"][a:b].reshape(-1)[mask], c["scale_offsets"][a:b].reshape(-1)[mask],
-                                                       Q[mask], file_name=offsets_b_name))
-        torch.cuda.synchronize(); t_codec += time.time() - t0
+    mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
+    Q = c["Q_offsets"].reshape(-1)
+    offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
+    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()           # masked elements up to each anchor
+    off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+    bit_offsets_list = encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask],
+                                               off_bounds, names('offsets'))
+    torch.cuda.synchronize(); t_codec += time.time() - t0
 
     bit_anchor = bits_xyz
     bit_feat, bit_scaling, bit_offsets = sum(bit_feat_list), sum(bit_scaling_list), sum(bit_offsets_list)
@@ -207,28 +201,20 @@ def conduct_decoding(self, pre_path_name, patched_infos, ckpt_path=None):
     N = anchor_decoded.shape[0]
 
     c = _context(self, anchor_decoded)
-    feat_list, scaling_list, offsets_list = [], [], []
-    for s in range(steps):
-        a, b = s * max_batch, min((s + 1) * max_batch, N)
-        n_num = b - a
-        feat_b_name = os.path.join(pre_path_name, 'feat.b').replace('.b', f'_{s}.b')
-        scaling_b_name = os.path.join(pre_path_name, 'scaling.b').replace('.b', f'_{s}.b')
-        offsets_b_name = os.path.join(pre_path_name, 'offsets.b').replace('.b', f'_{s}.b')
-        feat_list.append(decoder_gaussian_chunk(c["mean"][a:b].reshape(-1), c["scale"][a:b].reshape(-1), c["Q_feat"][a:b].reshape(-1),
-                                                file_name=feat_b_name).view(n_num, self.feat_dim))
-        scaling_list.append(decoder_gaussian_chunk(c["mean_scaling"][a:b].reshape(-1), c["scale_scaling"][a:b].reshape(-1), c["Q_scaling"][a:b].reshape(-1),
-                                                   file_name=scaling_b_name).view(n_num, 6))
-        masks_tmp = masks_decoded[a:b].repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
-        mo = c["mean_offsets"][a:b].reshape(-1)
-        offsets_decoded = torch.zeros_like(mo)
-        if bool(masks_tmp.any()):
-            offsets_decoded[masks_tmp] = decoder_gaussian_chunk(mo[masks_tmp], c["scale_offsets"][a:b].reshape(-1)[masks_tmp],
-                                                                c["Q_offsets"][a:b].reshape(-1)[masks_tmp], file_name=offsets_b_name)
-        offsets_list.append(offsets_decoded.view(n_num, n_off, 3))
+    names = lambda stem: [os.path.join(pre_path_name, f'{stem}.b').replace('.b', f'_{s}.b') for s in range(steps)]
+    bounds = [min(s * max_batch, N) for s in range(steps + 1)]
+    feat_decoded = decoder_gaussian_slices(c["mean"].reshape(-1), c["scale"].reshape(-1), c["Q_feat"].reshape(-1),
+                                           [b * self.feat_dim for b in bounds], names('feat')).view(N, self.feat_dim)
+    scaling_decoded = decoder_gaussian_slices(c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), c["Q_scaling"].reshape(-1),
+                                              [b * 6 for b in bounds], names('scaling')).view(N, 6)
+    mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
+    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
+    off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+    mo = c["mean_offsets"].reshape(-1)
+    offsets_decoded = torch.zeros_like(mo)
+    offsets_decoded[mask] = decoder_gaussian_slices(mo[mask], c["scale_offsets"].reshape(-1)[mask], c["Q_offsets"].reshape(-1)[mask], off_bounds, names('offsets'))
+    offsets_decoded = offsets_decoded.view(N, n_off, 3)
 
-    feat_decoded = torch.cat(feat_list, dim=0)
-    scaling_decoded = torch.cat(scaling_list, dim=0)
-    offsets_decoded = torch.cat(offsets_list, dim=0)
     torch.cuda.synchronize(); t2 = time.time()
     print('decoding time:', t2 - t1)
 

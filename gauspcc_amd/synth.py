@@ -133,3 +133,84 @@ def synthetic_state_dict(channels: int = 32, kernel_size: int = 5, seed: int = 7
             sd[f"pred_head_s{s}_emb.weight"] = nrm((2 ** (1, 2, 4)[s - 1], C))
     sd["fog.conv.kernel"] = np.ones((8, 1, 1), dtype=np.float32)
     return sd
+
+
+class SyntheticGaussianModel:
+    """The slice of HAC's GaussianModel that conduct_encoding / conduct_decoding / generate_neural_gaussians touch
+    (src/gs_compress/HAC/scene/gaussian_model.py:111-430), filled with seeded random tensors and randomly initialised
+    MLPs -- the reference ships no trained scene.  Anchors come from synthetic_cloud (voxel units x voxel_size)."""
+
+    def __init__(self, n_anchors, feat_dim=50, n_offsets=10, seed=0, voxel_size=0.001, use_feat_bank=False, device="cuda:0"):
+        import torch
+        from .gridencoder import mix_3D2D_encoding
+
+        nn = torch.nn
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        dev = torch.device(device)
+        self.feat_dim, self.n_offsets, self.voxel_size = feat_dim, n_offsets, voxel_size
+        self.decoded_version, self.ste_binary, self.use_2D, self.n_features_per_level = False, True, True, 2
+        self.use_feat_bank = use_feat_bank
+        vox = torch.tensor(synthetic_cloud(n_anchors, seed=seed + 1, extent_log2=12)).float()
+        vox = vox - vox.mean(dim=0).round()
+        self._anchor = (vox * voxel_size).to(dev)
+        n = self._anchor.shape[0]
+        self._anchor_feat = (torch.randn(n, feat_dim, generator=g) * 0.7).to(dev)
+        self._offset = (torch.randn(n, n_offsets, 3, generator=g) * 0.3).to(dev)
+        self._scaling = (torch.randn(n, 6, generator=g) * 0.5 - 4.5).to(dev)
+        self._mask = (torch.randn(n, n_offsets, 1, generator=g) * 4.0).to(dev)   # logits: some anchors end up fully masked
+        lo, hi = self._anchor.min(dim=0).values, self._anchor.max(dim=0).values
+        pad = (hi - lo) * 0.05 + 1e-3
+        self.x_bound_min, self.x_bound_max = (lo - pad).view(1, 3), (hi + pad).view(1, 3)
+        self.encoding_xyz = mix_3D2D_encoding(n_features=2, resolutions_list=(18, 24, 33, 44, 59, 80, 108, 148, 201, 275, 376, 514),
+                                              log2_hashmap_size=13, resolutions_list_2D=(130, 258, 514, 1026), log2_hashmap_size_2D=15,
+                                              ste_binary=True, ste_multistep=False, add_noise=False, Q=1).to(dev)
+        for p in self.encoding_xyz.parameters():
+            p.data = torch.randn(p.shape, generator=g).to(dev)                   # only the signs matter (STE_binary)
+        torch.manual_seed(seed)
+        F, K = feat_dim, n_offsets
+        self.mlp_grid = nn.Sequential(nn.Linear(self.encoding_xyz.output_dim, F * 2), nn.ReLU(True), nn.Linear(F * 2, (F + 6 + 3 * K) * 2 + 3)).to(dev)
+        self.mlp_opacity = nn.Sequential(nn.Linear(F + 4, F), nn.ReLU(True), nn.Linear(F, K), nn.Tanh()).to(dev)
+        self.mlp_cov = nn.Sequential(nn.Linear(F + 4, F), nn.ReLU(True), nn.Linear(F, 7 * K)).to(dev)
+        self.mlp_color = nn.Sequential(nn.Linear(F + 4, F), nn.ReLU(True), nn.Linear(F, 3 * K), nn.Sigmoid()).to(dev)
+        if use_feat_bank:
+            self.mlp_feature_bank = nn.Sequential(nn.Linear(4, F), nn.ReLU(True), nn.Linear(F, 3), nn.Softmax(dim=1)).to(dev)
+        self.rotation_activation = torch.nn.functional.normalize
+
+    # accessors as in the reference (:347-405)
+    @property
+    def get_scaling(self):
+        import torch
+        return self._scaling if self.decoded_version else 1.0 * torch.exp(self._scaling)
+
+    @property
+    def get_mask(self):
+        import torch
+        if self.decoded_version:
+            return self._mask
+        s = torch.sigmoid(self._mask)
+        return ((s > 0.01).float() - s).detach() + s
+
+    @property
+    def get_mask_anchor(self):
+        import torch
+        return (torch.sum(self.get_mask, dim=1)[:, 0]) > 0
+
+    @property
+    def get_anchor(self):
+        import torch
+        return self._anchor if self.decoded_version else torch.round(self._anchor / self.voxel_size) * self.voxel_size
+
+    get_grid_mlp = property(lambda self: self.mlp_grid)
+    get_opacity_mlp = property(lambda self: self.mlp_opacity)
+    get_cov_mlp = property(lambda self: self.mlp_cov)
+    get_color_mlp = property(lambda self: self.mlp_color)
+    get_featurebank_mlp = property(lambda self: self.mlp_feature_bank)
+
+    def get_encoding_params(self):
+        import torch
+        e = self.encoding_xyz
+        p = torch.cat([e.encoding_xyz.params, e.encoding_xy.params, e.encoding_xz.params, e.encoding_yz.params], dim=0)
+        return (p >= 0) * (+1.0) + (p < 0) * (-1.0)                              # STE_binary (:283-286)
+
+    def calc_interp_feat(self, x):
+        return self.encoding_xyz((x - self.x_bound_min) / (self.x_bound_max - self.x_bound_min))

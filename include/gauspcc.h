@@ -191,6 +191,19 @@ GPCC_API int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean_dev, const fl
                                   float max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out_dev,
                                   void *stream);
 
+/* The same for every slice of an attribute in ONE call: conduct_encoding / conduct_decoding code each 3000-anchor
+ * slice into its own `.b` file (own min / max, hence own alphabet; HAC/scene/gaussian_model.py:1123-1206, 1262-1311) --
+ * 334 slices x 3 attributes per million anchors, each a serial chain of 10000-symbol chunks.  Here all chunks of all
+ * slices are coded concurrently.  slice_start (nslices + 1, host): element ranges, slice_start[0] = 0.
+ * encode: min_out / max_out (nslices, host); cnt lists the chunks slice by slice (ceil(len / chunk_size) each), bytes
+ * are their payloads in that order -- the caller cuts them into the per-slice files.  decode: the reverse. */
+GPCC_API int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x_dev, const float *mean_dev, const float *scale_dev, const float *q_dev,
+                                         const int64_t *slice_start, int nslices, int chunk_size, float *min_out, float *max_out,
+                                         const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean_dev, const float *scale_dev, const float *q_dev, const int64_t *slice_start,
+                                         int nslices, const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes,
+                                         const int32_t *cnt, int chunk_size, float *x_out_dev, void *stream);
+
 /* GaussianModel.mlp_grid = nn.Sequential(Linear(din, dh), ReLU, Linear(dh, dout)) (src/gs_compress/HAC/scene/gaussian_model.py:258-262,
  * called through get_grid_mlp at :1152-1153 and :1281-1282): y = W2 relu(W1 x + b1) + b2 for n rows.
  * w1 (dh, din), w2 (dout, dh) row-major as nn.Linear stores them; all pointers device.  Specified fp32 order

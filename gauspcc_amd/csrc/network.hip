@@ -20,16 +20,16 @@
 #include "octree.hpp"
 #include "primitives.hpp"
 #include "rangecoder.hpp"
-#include "conv_loop_gfx950.inc"   // generated: tools/gen_conv_loop.py
+#ifndef CONV_LOOP_INC
+#define CONV_LOOP_INC "conv_loop_gfx950.inc"   // generated: tools/gen_conv_loop.py (tools/build_variants.sh substitutes ablations)
+#endif
+#include CONV_LOOP_INC
 
 namespace gpcc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CONV_WAVES = 4;
-#ifndef CONV_EXP
-#define CONV_EXP 0   // developer experiments (tools/build_variants.sh): 1 no LDS accumulate, 2 no weight loads, 4 no gathers
-#endif
 constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
 // LDS floats per wave: R accumulator rows + 1 dummy row, then the 32-slot tile-header ring (512 + 128 + 32 dwords)
 __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + 672; }
@@ -189,8 +189,6 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 
 // ------------------------------------------------------------------ convolution
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
-// ds_add_f32 without return: IEEE fp32 add performed by the LDS, in the wave's program order
-__device__ __forceinline__ void lds_add(float *p, float v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 // ASM = true: the tile loop is the hand-scheduled gfx950 instruction stream of conv_loop_gfx950.inc (row offsets are
 // 32-bit there: n < 2^25).  ASM = false: the same loop in HIP C++ (any n; also the readable statement of the schedule).
@@ -226,23 +224,12 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
     const int32_t *hr = hdr + 512 + g;      // + slot * 4
     const int32_t *ho = hdr + 640;          // + slot
     struct AB { float4 a0, a1, b00, b01, b10, b11; };
-#if CONV_EXP
-    const float4 XB0 = ld4(wf), XB1 = ld4(wf + 256);
-#endif
     auto load_ab = [&](int j, uint32_t o) -> AB {
         const float *p = in + (size_t)(uint32_t)j * 32;
         const float *w = wf + (size_t)o * 1024;
         AB r;
-#if CONV_EXP & 4
-        r.a0 = XB0; r.a1 = XB1; r.a0.x += (float)j;
-#else
         r.a0 = ld4(p); r.a1 = ld4(p + 16);
-#endif
-#if CONV_EXP & 2
-        r.b00 = XB0; r.b01 = XB1; r.b10 = XB0; r.b11 = XB1; r.b00.x += (float)o;
-#else
         r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
-#endif
         return r;
     };
     // Per tile: 16 MFMAs build the tile's 16 x 32 partial products from a ZERO accumulator (an fma chain over
@@ -260,7 +247,6 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
 #define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
     auto step = [&](const AB &v, const PT &p, PT &q) {
         f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-#if !(CONV_EXP & 1)
         float s0[4], s1[4];
         int row[4];
 #pragma unroll
@@ -269,29 +255,22 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
             s0[k] = acc[row[k] + col0];
             s1[k] = acc[row[k] + col1];
         }
-#endif
         MF(c0, v.a0.x, v.b00.x); MF(c1, v.a0.x, v.b10.x);
         MF(c0, v.a0.y, v.b00.y); MF(c1, v.a0.y, v.b10.y);
         MF(c0, v.a0.z, v.b00.z); MF(c1, v.a0.z, v.b10.z);
         __builtin_amdgcn_sched_barrier(0);
-#if !(CONV_EXP & 1)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             acc[row[k] + col0] = s0[k] + p.c0[k];
             acc[row[k] + col1] = s1[k] + p.c1[k];
         }
-#endif
         MF(c0, v.a0.w, v.b00.w); MF(c1, v.a0.w, v.b10.w);
         MF(c0, v.a1.x, v.b01.x); MF(c1, v.a1.x, v.b11.x);
         __builtin_amdgcn_sched_barrier(0);
         MF(c0, v.a1.y, v.b01.y); MF(c1, v.a1.y, v.b11.y);
         MF(c0, v.a1.z, v.b01.z); MF(c1, v.a1.z, v.b11.z);
         MF(c0, v.a1.w, v.b01.w); MF(c1, v.a1.w, v.b11.w);
-#if CONV_EXP & 1
-        q.c0 = c0 + p.c0; q.c1 = c1 + p.c1;
-#else
         q.c0 = c0; q.c1 = c1;
-#endif
     };
 #undef MF
     auto accumulate = [&](const PT &p) {

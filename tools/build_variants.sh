@@ -1,15 +1,18 @@
 #!/bin/bash
-# Build experiment variants of libgauspcc.so (network.hip compiled with -DCONV_EXP=<mask>) into gauspcc_amd/variants/.
-# Usage: tools/build_variants.sh 1 2 4 7 ...   then   GAUSPCC_LIB=gauspcc_amd/variants/libgauspcc_exp1.so python tools/enc_only.py
+# Ablation builds of the conv tile loop: tools/gen_conv_loop.py with CONV_ASM_EXP=<mask> (1 no LDS sums, 2 no weight loads,
+# 4 no gathers) into gauspcc_amd/variants/, one libgauspcc_a<mask>.so each.  The results are WRONG on purpose; time them with
+#   GAUSPCC_LIB=gauspcc_amd/variants/libgauspcc_a7.so python tools/enc_only.py
+# Usage: tools/build_variants.sh 1 2 4 6 7
 set -e
 cd "$(dirname "$0")/../gauspcc_amd/csrc"
 mkdir -p ../variants
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fvisibility=hidden -Wno-unused-result"
 for v in "$@"; do
-  /opt/rocm/bin/hipcc $FLAGS -DCONV_EXP=$v $EXTRA -c network.hip -o ../variants/network_exp$v.o &
+  CONV_ASM_EXP=$v CONV_ASM_OUT=$PWD/../variants/conv_loop_a$v.inc python3 ../../tools/gen_conv_loop.py > /dev/null
+  /opt/rocm/bin/hipcc $FLAGS -DCONV_LOOP_INC="\"../variants/conv_loop_a$v.inc\"" -c network.hip -o ../variants/network_a$v.o &
 done
 wait
 for v in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_exp$v.so primitives.o octree.o ../variants/network_exp$v.o rangecoder.o codec.o api.o attributes.o rasterizer.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_a$v.so primitives.o octree.o ../variants/network_a$v.o rangecoder.o codec.o api.o attributes.o rasterizer.o neural_gaussians.o
 done
 ls -la ../variants/*.so

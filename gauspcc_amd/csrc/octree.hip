@@ -324,6 +324,7 @@ __global__ __launch_bounds__(TB) void k_nbr_child(const uint64_t *__restrict__ r
         const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
         const uint32_t oc = occ_p[pn];
         if ((oc >> tq) & 1u) res = (int32_t)(cstart_p[pn] + (uint32_t)__popc(oc & ((1u << tq) - 1u)));
+        if ((int64_t)res >= nc) res = -1;   // only when a container header understates the level (reported at the decoder's final sync)
     }
     out1.p[(int64_t)o * out1.stride + i] = res >= 0 ? res + out1.voff : -1;
     if (out2.p) out2.p[(int64_t)o * out2.stride + i] = res >= 0 ? res + out2.voff : -1;

@@ -286,6 +286,19 @@ def test_codec_rejects_bad_input(gh, dev_model_k5):
     for cut in (1, 7, len(data) // 2, len(data) - 1):
         with pytest.raises(GpccError):
             gh.decode(dev_model_k5, data[:cut])
+    # a header whose level sizes do not match the coded occupancy (the device expands into arrays sized from the header
+    # and verifies at its final sync): an error, never an out-of-bounds access
+    assert data[:2] == b"\xff\xff" and data[2] == 2
+    L = data[6]
+    for lvl, delta in ((L - 1, +3), (L - 1, -3), (L - 2, +1), (2, -1)):
+        bad = bytearray(data)
+        off = 8 + 4 * lvl
+        v = int.from_bytes(bad[off:off + 4], "little") + delta
+        bad[off:off + 4] = v.to_bytes(4, "little")
+        with pytest.raises(GpccError):
+            gh.decode(dev_model_k5, bytes(bad))
+    dec, _, _ = gh.decode(dev_model_k5, data)      # and the context is still usable afterwards
+    assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts))
 
 
 def test_plugin_api_roundtrip(gh, tmp_path):

@@ -406,7 +406,11 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
 // order as the wave-serial kernel, so the results are bit-identical; the chain per block drops from ~125 tile
 // latencies to 4 rounds.
 constexpr int COOP_TILES = 32;
-constexpr int COOP_WAVES = 16;
+#ifndef COOP_WAVES_N
+#define COOP_WAVES_N 16
+#endif
+constexpr int COOP_WAVES = COOP_WAVES_N;
+constexpr int COOP_TPW = COOP_TILES / COOP_WAVES;   // tiles per wave and round
 // LDS: products [32][16][32] f32, row->entry map [16][32] u8, then the block's tile headers (K tiles: 16 + 4 + 1 dwords each)
 static inline size_t coop_lds_bytes(int K) { return (size_t)COOP_TILES * 16 * 32 * 4 + 16 * COOP_TILES + (size_t)K * 84; }
 
@@ -433,8 +437,10 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     __syncthreads();
     const float *__restrict__ in = J.in + 4 * g;
     const float *__restrict__ wf = J.w + lane * 4;
-    const int orow = tid >> 5, och = tid & 31;     // phase B: threads 0..511 own one output element each
-    float acc = 0.0f;
+    constexpr int COOP_EPT = 512 / (64 * COOP_WAVES) > 0 ? 512 / (64 * COOP_WAVES) : 1;   // output elements per thread in phase B
+    float acc[COOP_EPT];
+#pragma unroll
+    for (int u = 0; u < COOP_EPT; ++u) acc[u] = 0.0f;
     struct AB { float4 a0, a1, b00, b01, b10, b11; };
     auto fetch = [&](int t) -> AB {   // gathered rows + weight fragment of tile t of this block (t < nt)
         const float *p = in + (size_t)(uint32_t)hj[t * 16 + e] * 32;
@@ -470,44 +476,51 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     };
     // this wave's two tiles of a round: base + 2 wave + {0, 1}; the next round's operands are requested before this
     // round's products are summed, so a round costs MFMAs + two barriers, not a memory latency
-    AB cur[2], nxt[2];
+    AB cur[COOP_TPW], nxt[COOP_TPW];
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-        if (wave * 2 + q < nt) cur[q] = fetch(wave * 2 + q);
+    for (int q = 0; q < COOP_TPW; ++q)
+        if (wave * COOP_TPW + q < nt) cur[q] = fetch(wave * COOP_TPW + q);
     for (int base = 0; base < nt; base += COOP_TILES) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int t = base + COOP_TILES + wave * 2 + q;
+        for (int q = 0; q < COOP_TPW; ++q) {
+            const int t = base + COOP_TILES + wave * COOP_TPW + q;
             if (t < nt) nxt[q] = fetch(t);
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int t = base + wave * 2 + q;
-            if (t < nt) products(cur[q], t, wave * 2 + q);
+        for (int q = 0; q < COOP_TPW; ++q) {
+            const int t = base + wave * COOP_TPW + q;
+            if (t < nt) products(cur[q], t, wave * COOP_TPW + q);
         }
         __syncthreads();
-        if (tid < 512) {   // ordered sum over the tiles of this round
-            const int ntl = min(COOP_TILES, nt - base);
-            const uint4 w0 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES), w1 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES + 16);
-            const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-            float pv[COOP_TILES];
 #pragma unroll
-            for (int tl = 0; tl < COOP_TILES; ++tl) {
-                const uint32_t i = (wd[tl >> 2] >> (8 * (tl & 3))) & 255u;
-                // absent (or past the end of the list): + 0.0f, which leaves the sum unchanged (the sum is never -0)
-                pv[tl] = (tl < ntl && i != 255u) ? P[(size_t)tl * 512 + i * 32 + och] : 0.0f;
+        for (int u = 0; u < COOP_EPT; ++u) {   // ordered sum over the tiles of this round, one output element at a time
+            const int el = tid + u * 64 * COOP_WAVES;
+            if (el < 512) {
+                const int orow = el >> 5, och = el & 31;
+                const int ntl = min(COOP_TILES, nt - base);
+                const uint4 w0 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES), w1 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES + 16);
+                const uint32_t wd[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                float pv[COOP_TILES];
+#pragma unroll
+                for (int tl = 0; tl < COOP_TILES; ++tl) {
+                    const uint32_t i = (wd[tl >> 2] >> (8 * (tl & 3))) & 255u;
+                    // absent (or past the end of the list): + 0.0f, which leaves the sum unchanged (the sum is never -0)
+                    pv[tl] = (tl < ntl && i != 255u) ? P[(size_t)tl * 512 + i * 32 + och] : 0.0f;
+                }
+#pragma unroll
+                for (int tl = 0; tl < COOP_TILES; ++tl) acc[u] = acc[u] + pv[tl];
             }
-#pragma unroll
-            for (int tl = 0; tl < COOP_TILES; ++tl) acc = acc + pv[tl];
         }
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 2; ++q) cur[q] = nxt[q];
+        for (int q = 0; q < COOP_TPW; ++q) cur[q] = nxt[q];
     }
-    if (tid < 512) {
-        const int grow = blk * 16 + orow;
-        if (grow < n) {
-            float v = acc;
+#pragma unroll
+    for (int u = 0; u < COOP_EPT; ++u) {
+        const int el = tid + u * 64 * COOP_WAVES;
+        const int grow = blk * 16 + (el >> 5), och = el & 31;
+        if (el < 512 && grow < n) {
+            float v = acc[u];
             if (J.res) v = v + J.res[(size_t)grow * 32 + och];
             if (relu) v = v > 0.f ? v : 0.f;
             J.out[(size_t)grow * 32 + och] = v;

@@ -38,7 +38,7 @@ __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) *
 template <int R, bool FILL>
 __global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *__restrict__ nbrT, int n, int K, int nblk, uint32_t *__restrict__ per_block,
                                                                 int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc,
-                                                                unsigned long long *__restrict__ pairs)
+                                                                uint32_t *__restrict__ pairs_per_block)
 {
     constexpr int Q = (R + 63) / 64;  // rows per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,44 +46,71 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *_
     if (blk >= nblk) return;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     uint32_t t = FILL ? per_block[blk] : 0u, npairs = 0;
-    for (int o = 0; o < K; ++o) {
-        int j[Q];
-        uint64_t b[Q];
-        uint32_t cnt = 0;
+    // the map is streamed once per pass: OB offsets' worth of loads are issued before the first ballot, so a wave pays one
+    // memory latency per OB offsets instead of one per offset
+    constexpr int OB = 4;
+    for (int o0 = 0; o0 < K; o0 += OB) {
+        int jj[OB][Q];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int lr = q * 64 + lane, row = blk * R + lr;
-            j[q] = (lr < R && row < n) ? nbrT[(size_t)o * n + row] : -1;
-            b[q] = __ballot(j[q] >= 0);
-            cnt += (uint32_t)__popcll(b[q]);
-        }
-        if (cnt == 0) continue;
-        const uint32_t nt = (cnt + 15u) >> 4;
-        if (FILL) {
-            uint32_t base = 0;
+        for (int u = 0; u < OB; ++u)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                if (j[q] >= 0) {
-                    const uint32_t p = base + (uint32_t)__popcll(b[q] & lt);
-                    tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = j[q];
-                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane);
+                const int lr = q * 64 + lane, row = blk * R + lr;
+                jj[u][q] = (o0 + u < K && lr < R && row < n) ? nbrT[(size_t)(o0 + u) * n + row] : -1;
+            }
+#pragma unroll
+        for (int u = 0; u < OB; ++u) {
+            const int o = o0 + u;
+            if (o >= K) break;
+            int j[Q];
+            uint64_t b[Q];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                j[q] = jj[u][q];
+                b[q] = __ballot(j[q] >= 0);
+                cnt += (uint32_t)__popcll(b[q]);
+            }
+            if (cnt == 0) continue;
+            const uint32_t nt = (cnt + 15u) >> 4;
+            if (FILL) {
+                uint32_t base = 0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    if (j[q] >= 0) {
+                        const uint32_t p = base + (uint32_t)__popcll(b[q] & lt);
+                        tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = j[q];
+                        tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane);
+                    }
+                    base += (uint32_t)__popcll(b[q]);
                 }
-                base += (uint32_t)__popcll(b[q]);
+                if ((uint32_t)lane < nt * 16u - cnt) {
+                    const uint32_t p = cnt + (uint32_t)lane;
+                    tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;
+                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)R;
+                }
+                if ((uint32_t)lane < nt) toc[t + lane] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)lane) << 16);
             }
-            if ((uint32_t)lane < nt * 16u - cnt) {
-                const uint32_t p = cnt + (uint32_t)lane;
-                tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;
-                tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)R;
-            }
-            if ((uint32_t)lane < nt) toc[t + lane] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)lane) << 16);
+            t += nt;
+            npairs += cnt;
         }
-        t += nt;
-        npairs += cnt;
     }
     if (!FILL && lane == 0) {
         per_block[blk] = t;
-        if (pairs && npairs) atomicAdd(pairs, (unsigned long long)npairs);
+        if (pairs_per_block) pairs_per_block[blk] = npairs;   // summed by k_sum_pairs (one hot atomic per block cost 0.2 ms)
     }
+}
+
+__global__ __launch_bounds__(256) void k_sum_pairs(const uint32_t *__restrict__ v, int n, unsigned long long *__restrict__ out)
+{
+    unsigned long long s = 0;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    __shared__ unsigned long long red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out += red[0] + red[1] + red[2] + red[3];
 }
 
 int conv_pick_rows(int64_t n)
@@ -132,8 +159,11 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     TAKE(first, uint32_t, nblk + 1);
     T->first = first;
     const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
-    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, nullptr, nullptr, nullptr, pairs_dev);
+    uint32_t *bpairs = nullptr;
+    if (pairs_dev) { TAKE(bp, uint32_t, nblk); bpairs = bp; }
+    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, nullptr, nullptr, nullptr, bpairs);
     LAUNCH_CHECK();
+    if (pairs_dev) { k_sum_pairs<<<1, 256, 0, st>>>(bpairs, (int)nblk, pairs_dev); LAUNCH_CHECK(); }
     GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
     // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the
     // host ever learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run

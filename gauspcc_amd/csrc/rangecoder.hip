@@ -145,9 +145,10 @@ template <int LP>
 __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                   int nchunks, uint8_t *__restrict__ sym)
 {
-    constexpr int RS = LP == 3 ? 1 : LP == 5 ? 4 : 16;      // row stride in uint16
-    constexpr int DEPTH = LP == 17 ? 4 : 8;                 // rows in flight per lane (multiple of 4)
-    struct Row { uint32_t w[LP == 3 ? 1 : LP == 5 ? 2 : 8]; };
+    static_assert(LP == 3 || LP == 5, "17-entry rows are decoded by k_rc_decode17");
+    constexpr int RS = LP == 3 ? 1 : 4;                     // row stride in uint16
+    constexpr int DEPTH = 8;                                // rows in flight per lane (multiple of 4)
+    struct Row { uint32_t w[LP == 3 ? 1 : 2]; };
     const int c = blockIdx.x * 64 + threadIdx.x;
     RcChunk ch = {0, 0, 0, 0, 0, 0};
     if (c < nchunks) ch = chunks[c];
@@ -169,11 +170,7 @@ __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ c
         rowp += rstep;
         Row r;
         if (LP == 3) r.w[0] = row[0];
-        else if (LP == 5) { const uint2 q = *reinterpret_cast<const uint2 *>(row); r.w[0] = q.x; r.w[1] = q.y; }
-        else {
-            const uint4 q0 = reinterpret_cast<const uint4 *>(row)[0], q1 = reinterpret_cast<const uint4 *>(row)[1];
-            r.w[0] = q0.x; r.w[1] = q0.y; r.w[2] = q0.z; r.w[3] = q0.w; r.w[4] = q1.x; r.w[5] = q1.y; r.w[6] = q1.z; r.w[7] = q1.w;
-        }
+        else { const uint2 q = *reinterpret_cast<const uint2 *>(row); r.w[0] = q.x; r.w[1] = q.y; }
         return r;
     };
     Row ring[DEPTH];
@@ -196,35 +193,11 @@ __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ c
                 const bool ge = t1 <= x;
                 s = ge; lo = ge ? t1 : 0u;
                 hi = ge ? dd + 1u : t1;  // span == 2^32 wraps to 0: high = low - 1 + 2^32 (mod 2^32), as the reference
-            } else if (LP == 5) {
+            } else {
                 const uint32_t t1 = scale_d(dd, rw.w[0] & 0xFFFFu), t2 = scale_d(dd, rw.w[0] >> 16), t3 = scale_d(dd, rw.w[1] & 0xFFFFu);
                 s = (uint32_t)(t1 <= x) + (uint32_t)(t2 <= x) + (uint32_t)(t3 <= x);
                 lo = s == 0 ? 0u : s == 1 ? t1 : s == 2 ? t2 : t3;
                 hi = s == 0 ? t1 : s == 1 ? t2 : s == 2 ? t3 : dd + 1u;
-            } else {
-                // v[k], k = 1..15, sits in half (k-1)&1 of word (k-1)>>1.  Binary search with register selects.
-                auto V = [&](int k) -> uint32_t { return ((k - 1) & 1) ? rw.w[(k - 1) >> 1] >> 16 : rw.w[(k - 1) >> 1] & 0xFFFFu; };
-                const bool b8 = scale_d(dd, V(8)) <= x;
-                const uint32_t m4 = b8 ? V(12) : V(4);
-                const bool b4 = scale_d(dd, m4) <= x;
-                const uint32_t m2 = b8 ? (b4 ? V(14) : V(10)) : (b4 ? V(6) : V(2));
-                const bool b2 = scale_d(dd, m2) <= x;
-                const uint32_t base = (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u);  // s in {base, base+1}
-                // candidates: v[base] (0 when base == 0), v[base+1], v[base+2] (span when base + 2 == 16):
-                // v[base] / v[base+2] are the two halves around word base>>1 ... pick words, then halves
-                uint32_t wa = 0, wb = 0;   // wa holds v[base] in its high half (base >= 2), wb = {v[base+1], v[base+2]}
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if ((uint32_t)q + 1u == (base >> 1)) wa = rw.w[q];
-                    if ((uint32_t)q == (base >> 1)) wb = rw.w[q];
-                }
-                const uint32_t cm1 = wa >> 16, c0 = wb & 0xFFFFu, cp1 = wb >> 16;
-                const uint32_t tm1 = base ? scale_d(dd, cm1) : 0u, t0 = scale_d(dd, c0);
-                const uint32_t tp1 = base + 2u == 16u ? dd + 1u : scale_d(dd, cp1);
-                const bool b1 = t0 <= x;
-                s = base + (uint32_t)b1;
-                lo = b1 ? t0 : tm1;
-                hi = b1 ? tp1 : t0;
             }
             pack |= s << (8 * (d & 3));
             if ((d & 3) == 3) {
@@ -256,6 +229,81 @@ __global__ __launch_bounds__(64) void k_rc_decode(const uint16_t *__restrict__ c
     }
 }
 
+// 17-entry rows (the 16-way last stage): a 16-lane group per chunk, lane k holds CDF entry k.  The symbol search of the
+// lane-per-chunk kernel is four dependent scale-and-compare rounds (the longest part of its 160 instructions per symbol);
+// here every lane scales its own entry, one ballot gives the symbol (the scaled bounds are monotone, so the lanes with
+// t <= x form a prefix) and two lane reads give its bounds.  The interval update then runs redundantly on the 16 lanes.
+// Four chunks per wave; the rows of consecutive chunks are adjacent in memory (chunk-interleaved layout).
+__global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
+                                                    int nchunks, uint8_t *__restrict__ sym)
+{
+    constexpr int DEPTH = 8;
+    static_assert(DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
+    const int lane = threadIdx.x, grp = lane >> 4, k = lane & 15;
+    const int c = blockIdx.x * 4 + grp;
+    RcChunk ch = {0, 0, 0, 0, 0, 0};
+    if (c < nchunks) ch = chunks[c];
+    uint32_t nmax = ch.n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    if (nmax == 0) return;
+    BitWin in;
+    in.init(bytes + ch.byte_off, ch.nbytes);
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t value = in.take32();
+    in.fetch();
+    // compact row: v[1..15] at [0..14]; lane 0 stands for v[0] = 0 and reads the unused slot 15
+    const uint16_t *rowp = cdf + (size_t)ch.first * 16 + (k ? k - 1 : 15);
+    const size_t rstep = (size_t)ch.stride * 16;
+    uint32_t ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { ring[d] = *rowp; rowp += rstep; }
+    const bool wide = (ch.out & 3u) == 0u;
+    uint32_t pack = 0;
+    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint32_t i = i0 + (uint32_t)d;
+            const uint32_t v = ring[d];
+            ring[d] = *rowp; rowp += rstep;
+            const uint32_t dd = high - low;   // span - 1
+            const uint32_t x = value - low;
+            const uint32_t t = k ? scale_d(dd, v) : 0u;
+            const uint64_t bal = __ballot(t <= x);
+            const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
+            const uint32_t s = (uint32_t)__popc(bits) - 1u;
+            const uint32_t lo = (uint32_t)__shfl((int)t, (grp << 4) + (int)s);
+            const uint32_t nx = (uint32_t)__shfl((int)t, (grp << 4) + (int)min(s + 1u, 15u));
+            const uint32_t hi = s == 15u ? dd + 1u : nx;
+            pack |= s << (8 * (d & 3));
+            if ((d & 3) == 3) {
+                if (k == 0) {
+                    if (wide && i < ch.n) *reinterpret_cast<uint32_t *>(sym + ch.out + i - 3u) = pack;
+                    else if (i - 3u < ch.n) {
+#pragma unroll
+                        for (uint32_t q = 0; q < 4; ++q)
+                            if (i - 3u + q < ch.n) sym[ch.out + i - 3u + q] = (uint8_t)(pack >> (8 * q));
+                    }
+                }
+                pack = 0;
+            }
+            high = (low - 1u) + hi;
+            low = low + lo;
+            const uint32_t n1 = (uint32_t)clz32(low ^ high) & 31u;
+            const uint32_t l1 = low << n1, h1 = ~((~high) << n1);
+            const uint32_t n2 = (uint32_t)min(min(clz32(~(l1 << 1)), clz32(h1 << 1)), 31);
+            const uint32_t flip = n2 ? 0x80000000u : 0u;
+            const uint32_t kk = n1 + n2;
+            low = (l1 << n2) & ~flip;
+            high = ~((~h1) << n2) | flip;
+            value = (((value << n1) << n2) | in.take(kk)) ^ flip;
+            in.fetch();
+        }
+    }
+}
+
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt)
 {
     if (nchunks <= 0) return GPCC_OK;
@@ -279,7 +327,7 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
     switch (lp) {
     case 3: k_rc_decode<3><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;
     case 5: k_rc_decode<5><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;
-    case 17: k_rc_decode<17><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;
+    case 17: k_rc_decode17<<<(unsigned)cdiv(nchunks, 4), 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;
     default: return fail(GPCC_ERR_ARG, "rc_decode: Lp must be 3, 5 or 17");
     }
     LAUNCH_CHECK();

@@ -105,6 +105,21 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB1 + s], (size_t)C);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW2 + s], (size_t)STAGE_M[s] * C);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB2 + s], (size_t)STAGE_M[s]);
+    for (int s = 0; s < 4; ++s) {   // MFMA fragments of the heads: B[k][c] = W[c][k] through the conv fragment layout
+        off.push_back(h.size());
+        const size_t b = h.size();
+        h.resize(b + HEAD_FRAG_FLOATS, 0.0f);
+        std::vector<float> wt((size_t)C * C), fr((size_t)C * C);
+        for (int c = 0; c < C; ++c) for (int k = 0; k < C; ++k) wt[(size_t)k * C + c] = t[GPCC_T_HW1 + s][(size_t)c * C + k];
+        conv_weight_fragments(wt.data(), 1, fr.data());
+        std::copy(fr.begin(), fr.end(), h.begin() + b);
+        std::fill(wt.begin(), wt.end(), 0.0f);
+        for (int j = 0; j < STAGE_M[s]; ++j) for (int k = 0; k < C; ++k) wt[(size_t)k * C + j] = t[GPCC_T_HW2 + s][(size_t)j * C + k];
+        conv_weight_fragments(wt.data(), 1, fr.data());
+        std::copy(fr.begin(), fr.begin() + 512, h.begin() + b + 1024);          // output half 0 = columns 0..15
+        std::copy(t[GPCC_T_HB1 + s], t[GPCC_T_HB1 + s] + C, h.begin() + b + 1536);
+        std::copy(t[GPCC_T_HB2 + s], t[GPCC_T_HB2 + s] + STAGE_M[s], h.begin() + b + 1568);
+    }
     static const int semb_rows[3] = {2, 4, 16};
     for (int s = 0; s < 3; ++s) push_rows_phys(t[GPCC_T_SEMB + s], semb_rows[s]);
     gpcc_model *m = new gpcc_model();
@@ -119,6 +134,7 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     for (int s = 0; s < 4; ++s) m->hb1[s] = m->slab + off[i++];
     for (int s = 0; s < 4; ++s) m->hw2[s] = m->slab + off[i++];
     for (int s = 0; s < 4; ++s) m->hb2[s] = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hfrag[s] = m->slab + off[i++];
     for (int s = 0; s < 3; ++s) m->semb[s] = m->slab + off[i++];
     *out = m;
     return GPCC_OK;

@@ -774,45 +774,11 @@ __device__ __forceinline__ float dev_exp(float x)
     return __int_as_float(bits);
 }
 
+// softmax -> cdf -> integerise -> the mode's output, for node i with logits z (max mx); shared by both head kernels
 template <int M, int MODE>
-__global__ __launch_bounds__(TB) void k_head(HeadArgs a)
+__device__ __forceinline__ void head_tail(const HeadArgs &a, int64_t i, const float (&z)[M], float mx)
 {
-    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= a.n) return;
-    float x[32];
-    {
-        const float4 *__restrict__ px = reinterpret_cast<const float4 *>(a.x + (size_t)i * 32);
-        float raw[32];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            float4 v = px[g];
-            raw[4 * g] = v.x; raw[4 * g + 1] = v.y; raw[4 * g + 2] = v.z; raw[4 * g + 3] = v.w;
-        }
-#pragma unroll
-        for (int c = 0; c < 32; ++c) x[c] = MODE == 2 ? raw[c] : raw[phys_of(c)];
-    }
-    const float *__restrict__ W1 = a.w1;
-    const float *__restrict__ B1 = a.b1;
-    const float *__restrict__ W2 = a.w2;
-    const float *__restrict__ B2 = a.b2;
-    float hdn[32];
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        float acc = B1[c];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(x[k], W1[c * 32 + k], acc);
-        hdn[c] = acc > 0.0f ? acc : 0.0f;
-    }
-    float z[M], e[M];
-    float mx = -__builtin_inff();
-#pragma unroll
-    for (int j = 0; j < M; ++j) {
-        float acc = B2[j];
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(hdn[k], W2[j * 32 + k], acc);
-        z[j] = acc;
-        mx = acc > mx ? acc : mx;
-    }
+    float e[M];
     float s = 0.0f;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
@@ -877,9 +843,120 @@ __global__ __launch_bounds__(TB) void k_head(HeadArgs a)
     }
 }
 
+template <int M, int MODE>
+__global__ __launch_bounds__(TB) void k_head(HeadArgs a)
+{
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= a.n) return;
+    float x[32];
+    {
+        const float4 *__restrict__ px = reinterpret_cast<const float4 *>(a.x + (size_t)i * 32);
+        float raw[32];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            float4 v = px[g];
+            raw[4 * g] = v.x; raw[4 * g + 1] = v.y; raw[4 * g + 2] = v.z; raw[4 * g + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) x[c] = MODE == 2 ? raw[c] : raw[phys_of(c)];
+    }
+    const float *__restrict__ W1 = a.w1;
+    const float *__restrict__ B1 = a.b1;
+    const float *__restrict__ W2 = a.w2;
+    const float *__restrict__ B2 = a.b2;
+    float hdn[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        float acc = B1[c];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(x[k], W1[c * 32 + k], acc);
+        hdn[c] = acc > 0.0f ? acc : 0.0f;
+    }
+    float z[M];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+        float acc = B2[j];
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = __builtin_fmaf(hdn[k], W2[j * 32 + k], acc);
+        z[j] = acc;
+        mx = acc > mx ? acc : mx;
+    }
+    head_tail<M, MODE>(a, i, z, mx);
+}
+
+// Encode / decode heads on the matrix pipe.  The scalar kernel above spends 90 % of its cycles waiting (weights stream
+// through the scalar cache, 1800 mostly dependent instructions per wave); here a wave takes 64 nodes as four 16-row
+// tiles: hidden = relu(b1 + x W1^T) is 16 MFMAs per tile (bias as the initial accumulator, k ascending -- the chain the
+// oracle runs), the 16 x 32 hidden tile turns from the accumulator layout into the A-operand layout through wave-
+// private LDS, logits = b2 + hidden W2^T is 8 more, and the logits go through LDS to one lane per node for the
+// sequential softmax / CDF tail.  Weights live in 24 VGPRs for the whole wave.
+template <int M, int MODE>
+__global__ __launch_bounds__(TB) void k_head_mfma(HeadArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sm[(TB / 64) * (512 + 1024)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *hbuf = sm + wave * (512 + 1024), *zbuf = hbuf + 512;
+    const int e = lane & 15, g = lane >> 4;
+    const int64_t nb = ((int64_t)blockIdx.x * (TB / 64) + wave) * 64;
+    if (nb >= a.n) return;
+    const float4 *__restrict__ fr = reinterpret_cast<const float4 *>(a.frag) + lane;
+    // [half][q][lane][4]: k-step kk = 4 q + r of output half `half`
+    const float4 w10a = fr[0], w10b = fr[64], w11a = fr[128], w11b = fr[192], w2a = fr[256], w2b = fr[320];
+    const float b1lo = a.frag[1536 + e], b1hi = a.frag[1536 + 16 + e], b2e = a.frag[1568 + e];
+#define MF(c, x, w) c = __builtin_amdgcn_mfma_f32_16x16x4f32(x, w, c, 0, 0, 0)
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) {
+        const int64_t row = min(nb + 16 * t4 + e, a.n - 1);
+        const float *px = a.x + row * 32 + 4 * g;       // physical channel order: logical k = 4 kk + g sits at 4 g + kk / 16 + 4 g + (kk - 4)
+        const float4 a0 = ld4(px), a1 = ld4(px + 16);
+        f32x4 c0 = {b1lo, b1lo, b1lo, b1lo}, c1 = {b1hi, b1hi, b1hi, b1hi};
+        MF(c0, a0.x, w10a.x); MF(c1, a0.x, w11a.x);
+        MF(c0, a0.y, w10a.y); MF(c1, a0.y, w11a.y);
+        MF(c0, a0.z, w10a.z); MF(c1, a0.z, w11a.z);
+        MF(c0, a0.w, w10a.w); MF(c1, a0.w, w11a.w);
+        MF(c0, a1.x, w10b.x); MF(c1, a1.x, w11b.x);
+        MF(c0, a1.y, w10b.y); MF(c1, a1.y, w11b.y);
+        MF(c0, a1.z, w10b.z); MF(c1, a1.z, w11b.z);
+        MF(c0, a1.w, w10b.w); MF(c1, a1.w, w11b.w);
+        // relu; hidden[row][c] -> hbuf[row][c & 3][c >> 2] so that lane (e, g) finds its eight k-steps contiguous
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float h0 = c0[i] > 0.0f ? c0[i] : 0.0f, h1 = c1[i] > 0.0f ? c1[i] : 0.0f;
+            hbuf[(4 * g + i) * 32 + (e & 3) * 8 + (e >> 2)] = h0;            // c = e
+            hbuf[(4 * g + i) * 32 + (e & 3) * 8 + 4 + (e >> 2)] = h1;        // c = 16 + e
+        }
+        const float4 h0 = *reinterpret_cast<const float4 *>(hbuf + e * 32 + g * 8), h1 = *reinterpret_cast<const float4 *>(hbuf + e * 32 + g * 8 + 4);
+        f32x4 z = {b2e, b2e, b2e, b2e};
+        MF(z, h0.x, w2a.x); MF(z, h0.y, w2a.y); MF(z, h0.z, w2a.z); MF(z, h0.w, w2a.w);
+        MF(z, h1.x, w2b.x); MF(z, h1.y, w2b.y); MF(z, h1.z, w2b.z); MF(z, h1.w, w2b.w);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zbuf[(16 * t4 + 4 * g + i) * 16 + e] = z[i];
+    }
+#undef MF
+    const int64_t i = nb + lane;
+    if (i >= a.n) return;
+    float z[M];
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int j = 0; j < M; ++j) { z[j] = zbuf[lane * 16 + j]; mx = z[j] > mx ? z[j] : mx; }
+    head_tail<M, MODE>(a, i, z, mx);
+}
+
 template <int MODE>
 static int head_launch(hipStream_t st, const HeadArgs &a)
 {
+    if (MODE != 2 && a.frag) {
+        const unsigned g = (unsigned)cdiv(a.n, TB);   // 64 nodes per wave
+        switch (a.stage_m) {
+        case 2: k_head_mfma<2, MODE><<<g, TB, 0, st>>>(a); break;
+        case 4: k_head_mfma<4, MODE><<<g, TB, 0, st>>>(a); break;
+        case 16: k_head_mfma<16, MODE><<<g, TB, 0, st>>>(a); break;
+        default: return fail(GPCC_ERR_ARG, "head width must be 2, 4 or 16");
+        }
+        LAUNCH_CHECK();
+        return GPCC_OK;
+    }
     const unsigned g = nblk(a.n);
     switch (a.stage_m) {
     case 2: k_head<2, MODE><<<g, TB, 0, st>>>(a); break;

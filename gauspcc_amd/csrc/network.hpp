@@ -18,6 +18,7 @@ struct gpcc_model {
     const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order
     const float *temb = nullptr;        // (8, 32) physical
     const float *hw1[4] = {0}, *hb1[4] = {0}, *hw2[4] = {0}, *hb2[4] = {0};  // upstream layouts (logical)
+    const float *hfrag[4] = {0};        // per head: W1 as 2 x 512 B-fragment floats, W2 (columns padded to 16) as 512, b1 (32), b2 padded (16)
     const float *semb[3] = {0};         // ({2,4,16}, 32) physical
 };
 
@@ -100,9 +101,11 @@ int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint
 //         mode 1: decode -> compact cdf row (interior values only, rc_row_stride u16) at row pos
 //         mode 2: test   -> prob (n,m) and cdf (n,Lp) in input order, x in LOGICAL channel order
 // pos = rc_interleaved(m2r[i], chunk_log2, nch): raster rank -> chunk-interleaved slot of the stream
+constexpr int HEAD_FRAG_FLOATS = 1024 + 512 + 32 + 16;
 struct HeadArgs {
     const float *x; int64_t n; int stage_m;
     const float *w1, *b1, *w2, *b2;
+    const float *frag;   // modes 0 / 1: the head's MFMA fragments (gpcc_model::hfrag); mode 2 uses w1 .. b2
     const uint32_t *m2r; const uint8_t *occ; int stage;
     uint32_t *lohi; uint16_t *cdf; float *prob; int mode;
     int chunk_log2; uint32_t nch;

@@ -301,39 +301,60 @@ int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbr
     return GPCC_OK;
 }
 
-// child (i) x offset (o): the target voxel's parent is one of the 27 neighbours of i's parent
-// (already in the parent's map), its octant bit says whether it exists and the parent's child
-// start + popcount of the lower octant bits says where (children are stored octant-ascending).
-__global__ __launch_bounds__(TB) void k_nbr_child(const uint64_t *__restrict__ rkey_c, const uint32_t *__restrict__ parent_c, int64_t nc,
+// Child map from the parent's map.  The voxel at kernel offset o from child i lies in one of the (2 PR + 1)^3 parent cells
+// around i's parent (PR = (r + 1) / 2: 27 cells for k = 3 and 5, all of them in the parent's map); its octant bit in that
+// cell's occupancy says whether it exists, the cell's child start + popcount of the lower octant bits says where
+// (children are stored octant-ascending).  One wave takes 64 consecutive children -- their parents are a contiguous
+// run of at most 64 nodes -- stages the cells of those parents in LDS (one gather of map entry, occupancy and child start
+// per cell instead of one per child x offset), then every lane walks the k^3 offsets of its child: writes are one
+// coalesced row segment per offset.
+struct NbrCell { uint32_t cstart, occ; };
+__global__ __launch_bounds__(64) void k_nbr_child(const uint64_t *__restrict__ rkey_c, const uint32_t *__restrict__ parent_c, int64_t nc,
                                                   NbrView in, const uint8_t *__restrict__ occ_p,
                                                   const uint32_t *__restrict__ cstart_p, int k, NbrView out1, NbrView out2)
 {
-    const int r = k / 2;
-    const int o = blockIdx.y;
-    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= nc) return;
-    const int dx = o % k - r, dy = (o / k) % k - r, dz = o / (k * k) - r;
-    const uint64_t kc = rkey_c[i];
-    const int tx = (int)(rk_x(kc) & 1) + dx, ty = (int)(rk_y(kc) & 1) + dy, tz = (int)(rk_z(kc) & 1) + dz;
-    const int px = tx >> 1, py = ty >> 1, pz = tz >> 1;  // floor: -1, 0 or 1 (k <= 5); up to +-2 for k = 7
-    const int po = (px + r) + k * (py + r) + k * k * (pz + r);
-    int32_t pn = in.p[(int64_t)po * in.stride + parent_c[i]];
-    int32_t res = -1;
-    if (pn >= 0) {
-        pn -= in.voff;
-        const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-        const uint32_t oc = occ_p[pn];
-        if ((oc >> tq) & 1u) res = (int32_t)(cstart_p[pn] + (uint32_t)__popc(oc & ((1u << tq) - 1u)));
-        if ((int64_t)res >= nc) res = -1;   // only when a container header understates the level (reported at the decoder's final sync)
+    extern __shared__ NbrCell cells[];
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * 64, i = min(c0 + lane, nc - 1);
+    const int r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
+    const uint32_t my_parent = parent_c[i];
+    const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)parent_c[c0]);
+    const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)parent_c[min(c0 + 63, nc - 1)]);
+    const int ncell = (int)(p_hi - p_lo + 1u) * NP;
+    for (int idx = lane; idx < ncell; idx += 64) {
+        const uint32_t p = p_lo + (uint32_t)(idx / NP);
+        const int q = idx % NP;
+        const int px = q % PW - PR, py = (q / PW) % PW - PR, pz = q / (PW * PW) - PR;
+        const int po = (px + r) + k * (py + r) + k * k * (pz + r);
+        int32_t pn = in.p[(int64_t)po * in.stride + p];
+        NbrCell c = {0u, 0u};
+        if (pn >= 0) { pn -= in.voff; c.cstart = cstart_p[pn]; c.occ = occ_p[pn]; }
+        cells[idx] = c;
     }
-    out1.p[(int64_t)o * out1.stride + i] = res >= 0 ? res + out1.voff : -1;
-    if (out2.p) out2.p[(int64_t)o * out2.stride + i] = res >= 0 ? res + out2.voff : -1;
+    __syncthreads();
+    if (c0 + lane >= nc) return;
+    const uint64_t kc = rkey_c[i];
+    const int cx = (int)(rk_x(kc) & 1), cy = (int)(rk_y(kc) & 1), cz = (int)(rk_z(kc) & 1);
+    const NbrCell *mine = cells + (size_t)(my_parent - p_lo) * NP;
+    int o = 0;
+    for (int dz = -r; dz <= r; ++dz)
+        for (int dy = -r; dy <= r; ++dy)
+            for (int dx = -r; dx <= r; ++dx, ++o) {
+                const int tx = cx + dx, ty = cy + dy, tz = cz + dz;
+                const int q = ((tx >> 1) + PR) + PW * ((ty >> 1) + PR) + PW * PW * ((tz >> 1) + PR);   // floor halves: the parent cell
+                const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
+                const NbrCell c = mine[q];
+                int32_t res = (c.occ >> tq) & 1u ? (int32_t)(c.cstart + (uint32_t)__popc(c.occ & ((1u << tq) - 1u))) : -1;
+                if ((int64_t)res >= nc) res = -1;   // only when a container header understates the level (reported at the decoder's final sync)
+                out1.p[(int64_t)o * out1.stride + i] = res >= 0 ? res + out1.voff : -1;
+                if (out2.p) out2.p[(int64_t)o * out2.stride + i] = res >= 0 ? res + out2.voff : -1;
+            }
 }
 
 int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in, const Level *chi, int k, NbrView out1, NbrView out2)
 {
-    const int K = k * k * k;
-    k_nbr_child<<<dim3(nblk(chi->n), (unsigned)K), TB, 0, st>>>(chi->rkey, chi->parent, chi->n, in, par->occ, par->cstart, k, out1, out2);
+    const int PW = 2 * ((k / 2 + 1) / 2) + 1;   // parent cells per axis around a child's parent
+    k_nbr_child<<<(unsigned)cdiv(chi->n, 64), 64, (size_t)64 * PW * PW * PW * sizeof(NbrCell), st>>>(chi->rkey, chi->parent, chi->n, in, par->occ, par->cstart, k, out1, out2);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

@@ -63,8 +63,10 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, hipStream_t st)
 {
     ctx->arena.reset();
+    HostTrace ht;
     Tree T;
     GP_TRY(tree_build(ctx, st, xyz, n, &T));
+    ht.mark("enc tree built");
     const int L = T.L, K = m->K;
     int64_t coded = 0, nmax = 0;
     for (int d = 0; d < L; ++d) { nmax = std::max(nmax, T.lv[d].n); if (d) coded += T.lv[d].n; }
@@ -115,9 +117,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 lohi_base += 4 * slots(lv->n);
             }
         }
+        ht.mark("enc maps queued");
         ConvTiles tilesP, tilesC;
         GP_TRY(conv_tiles_build(ctx, st, nbrPs, nP, K, &tilesP, pairs_dev));
         GP_TRY(conv_tiles_build(ctx, st, nbrCs, nC, K, &tilesC, pairs_dev + 1));
+        ht.mark("enc tiles built");
         TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
         GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF));
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
@@ -202,7 +206,9 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * MAXLV, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + off_bx, base_xyz, 12 * (size_t)base->n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + off_bo, base_occ, (size_t)base->n, hipMemcpyDeviceToHost, st));
+    ht.mark("enc all queued");
     HIP_TRY(hipStreamSynchronize(st));
+    ht.mark("enc coded (sync)");
     const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
     if (nchunks) total_payload = hcnt[nchunks];
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, reinterpret_cast<const unsigned long long *>(hs + off_pairs), 2));
@@ -242,6 +248,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         }
         HIP_TRY(hipStreamSynchronize(st));
     }
+    ht.mark("enc payload d2h");
     if (pos != fsize) return fail(GPCC_ERR_HIP, "internal: container size mismatch (%zu vs %zu)", pos, fsize);
     *bytes_out = out; *nbytes_out = (int64_t)pos;
     if (stats) {
@@ -260,6 +267,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
                 uint16_t *posq_out, gpcc_stats *stats, hipStream_t st)
 {
     ctx->arena.reset();
+    HostTrace ht;
     const int K = m->K;
     int64_t pos = 0;
     int chunk_log2 = 0, L = -1, version = 0;
@@ -350,7 +358,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         for (int64_t i = 0; i < bn; ++i) { hr[i] = bnodes[(size_t)i].rk; ho[i] = bnodes[(size_t)i].occ; }
         HIP_TRY(hipMemcpyAsync(cur.rkey, hr, 8 * (size_t)bn, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(cur.occ, ho, (size_t)bn, hipMemcpyHostToDevice, st));
+        ht.mark("dec parse+h2d queued");
         HIP_TRY(hipStreamSynchronize(st));  // staging is reused below
+        ht.mark("dec base sync");
     }
     GP_TRY(level_raster_rank(ctx, st, &cur, hb));
     TAKE(dtotal, uint32_t, 4);
@@ -447,11 +457,13 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         ctx->arena.rewind(mk);
         coded += nc;
         cur = chi; nbrP = nbrC; tilesP = tilesC;
+        ht.mark("dec level queued", g + 1, nc);
     }
     // ---- leaves
     GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
     HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    ht.mark("dec levels done (sync)");
     const int64_t npts = htotal[0];
     // the header's level sizes against what the decoded occupancy expanded to (the copies were queued level by level;
     // the expansion is bounded by the header, so a wrong header produced garbage, not out-of-bounds accesses)
@@ -465,7 +477,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     unsigned long long hpairs[MAXLV];
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    ht.mark("dec leaves done (sync)");
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, hpairs, L));
+    ht.mark("dec prof collect");
     *xyz_out = xyz; *n_out = npts;
     if (stats) {
         memset(stats, 0, sizeof *stats);

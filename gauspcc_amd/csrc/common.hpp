@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -95,7 +96,7 @@ template <typename T> struct HostBuf {
 
 namespace gpcc {
 // HIP-event timing of the dominant kernel (k_sparse_conv), on the stream it is launched on.
-struct ConvRec { int e0, e1, level, njobs; };
+struct ConvRec { int e0, e1, level, njobs, R, H; long long n, nblk; };
 struct Prof {
     bool on = false;
     std::vector<hipEvent_t> pool;
@@ -103,6 +104,25 @@ struct Prof {
     std::vector<ConvRec> recs;
     double conv_ms = 0.0;
     int64_t conv_launches = 0, conv_pair_jobs = 0;
+};
+}  // namespace gpcc
+
+namespace gpcc {
+// GAUSPCC_HOST_TRACE=1: host-side phase times of encode / decode on stderr (where the CPU thread is when the GPU idles)
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    HostTrace() : on(getenv("GAUSPCC_HOST_TRACE") && atoi(getenv("GAUSPCC_HOST_TRACE")) > 0) { t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char *what, long long a = -1, long long b = -1)
+    {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[host] %-22s %8.3f ms  (+%.3f)", what, std::chrono::duration<double, std::milli>(t - t0).count(), std::chrono::duration<double, std::milli>(t - last).count());
+        if (a >= 0) fprintf(stderr, "  %lld", a);
+        if (b >= 0) fprintf(stderr, " %lld", b);
+        fputc('\n', stderr);
+        last = t;
+    }
 };
 }  // namespace gpcc
 

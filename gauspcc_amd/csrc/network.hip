@@ -30,13 +30,17 @@ namespace gpcc {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CONV_WAVES = 4;
+#ifndef CONV_SC_WAVES_N
+#define CONV_SC_WAVES_N 4
+#endif
+constexpr int SC_WAVES = CONV_SC_WAVES_N;   // waves per workgroup of k_sparse_conv (every wave works alone on its own block)
 constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
 // LDS floats per wave: R accumulator rows + 1 dummy row, then the 32-slot tile-header ring (512 + 128 + 32 dwords)
 __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + 672; }
 
 // ------------------------------------------------------------------ tile list
 template <int R, bool FILL>
-__global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *__restrict__ nbrT, int n, int K, int nblk, uint32_t *__restrict__ per_block,
+__global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *__restrict__ nbrT, int n, int K, int nblk, int H, uint32_t *__restrict__ per_block,
                                                                 int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc,
                                                                 uint32_t *__restrict__ pairs_per_block)
 {
@@ -55,8 +59,8 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *_
         for (int u = 0; u < OB; ++u)
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
-                const int lr = q * 64 + lane, row = blk * R + lr;
-                jj[u][q] = (o0 + u < K && lr < R && row < n) ? nbrT[(size_t)(o0 + u) * n + row] : -1;
+                const int lr = q * 64 + lane, row = blk * H + lr;
+                jj[u][q] = (o0 + u < K && lr < H && row < n) ? nbrT[(size_t)(o0 + u) * n + row] : -1;
             }
 #pragma unroll
         for (int u = 0; u < OB; ++u) {
@@ -134,6 +138,21 @@ int conv_pick_rows(int64_t n)
     return 16;
 }
 
+// A launch runs nblk single-wave blocks on a fixed number of wave slots (LDS and registers allow 1 wave per SIMD for the
+// 255-row class, 2 below); with a handful of blocks per slot the last round is mostly idle slots
+// (3.06 blocks per slot take as long as 4).  The rows are therefore cut into slots x k equal blocks, k the smallest
+// number of rounds the class allows -- slightly lower blocks, every round full.
+int conv_pick_height(int64_t n, int R)
+{
+    static int balance = -1;
+    if (balance < 0) { const char *e = getenv("GAUSPCC_CONV_BALANCE"); balance = e ? atoi(e) : 0; }
+    if (!balance || R <= 16) return R;
+    const int64_t slots = 1024 * (int64_t)(R >= 255 ? 1 : 2);
+    const int64_t k = cdiv(n, slots * R);
+    const int64_t H = cdiv(n, slots * k);
+    return (int)std::min<int64_t>(R, std::max<int64_t>(H, 16));
+}
+
 __global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__ first, int nblk, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
@@ -143,9 +162,11 @@ __global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__
 }
 
 // CONV_HDR_PAD zeroed tiles behind the list, whose length lives on the device
-__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc)
+__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc,
+                                                   uint32_t *__restrict__ ctr)
 {
     const uint32_t t = *total;
+    if (threadIdx.x < 2) ctr[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD * 16; i += 64) tj[(size_t)t * 16 + i] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD * 4; i += 64) tr4[(size_t)t * 4 + i] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD; i += 64) toc[t + i] = 0;
@@ -154,14 +175,15 @@ __global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ t
 template <int R>
 static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
 {
-    const int64_t nblk = cdiv(n, R);
-    T->nblk = nblk; T->R = R; T->K = K;
+    const int H = conv_pick_height(n, R);
+    const int64_t nblk = cdiv(n, H);
+    T->nblk = nblk; T->R = R; T->H = H; T->K = K;
     TAKE(first, uint32_t, nblk + 1);
     T->first = first;
     const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
     uint32_t *bpairs = nullptr;
     if (pairs_dev) { TAKE(bp, uint32_t, nblk); bpairs = bp; }
-    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, nullptr, nullptr, nullptr, bpairs);
+    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, H, first, nullptr, nullptr, nullptr, bpairs);
     LAUNCH_CHECK();
     if (pairs_dev) { k_sum_pairs<<<1, 256, 0, st>>>(bpairs, (int)nblk, pairs_dev); LAUNCH_CHECK(); }
     GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
@@ -180,10 +202,11 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     TAKE(tj, int32_t, cap * 16);
     TAKE(tr, uint8_t, cap * 16);
     TAKE(toc, uint32_t, cap);
-    T->tj = tj; T->tr = tr; T->toc = toc;
-    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc);
+    TAKE(ctr, uint32_t, 2);
+    T->tj = tj; T->tr = tr; T->toc = toc; T->ctr = ctr;
+    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc, ctr);
     LAUNCH_CHECK();
-    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, first, tj, tr, toc, nullptr);
+    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, H, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
     // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling).  When all
     // blocks are resident at once (<= 8 waves on each of 256 CUs) the order cannot matter: identity, no sort.
@@ -220,20 +243,47 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 // ------------------------------------------------------------------ convolution
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
+#ifdef CONV_TIMING
+// developer build (tools/conv_timing.sh): shader-clock stamps around the phases of every wave, summed per launch
+__device__ unsigned long long g_conv_timing[12];
+#define CT_STAMP(v) const long long v = clock64()
+#else
+#define CT_STAMP(v)
+#endif
+
 // ASM = true: the tile loop is the hand-scheduled gfx950 instruction stream of conv_loop_gfx950.inc (row offsets are
 // 32-bit there: n < 2^25).  ASM = false: the same loop in HIP C++ (any n; also the readable statement of the schedule).
 template <int R, int DIST, bool ASM>
-__global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu)
+__global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs, int persist)
 {
     constexpr int CONV_LDS_WAVE = conv_lds_wave_floats(R);  // R rows + 1 dummy row for padding entries + the tile-header ring
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const ConvJob J = jobs.job[blockIdx.y];
     const int lane = threadIdx.x & 63;
     // everything derived from the wave index is wave-uniform: keep it in SGPRs (scalar loads for the tile
     // headers, scalar address arithmetic for the weight fragments)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = blockIdx.x * CONV_WAVES + wave;
-    if (slot >= (int)T.nblk) return;  // no block-wide barrier below: every wave works on its own LDS slice
+    // Work items are (block, job) pairs, w = slot * njobs + job with slot running over the blocks longest first.
+    // persist = 0: one item per wave (w from the grid position).  persist = 1: the grid is exactly the waves the chip
+    // holds at once and every wave draws items from T.ctr[0] until they run out -- a SIMD never waits for the other
+    // three waves of a workgroup to finish before it gets new work, and there is no workgroup launch between blocks.
+    // No block-wide barrier anywhere: every wave works on its own LDS slice.
+    const uint32_t total = (uint32_t)T.nblk * (uint32_t)njobs;
+    auto draw = [&]() -> uint32_t {
+        uint32_t v = 0;
+        if (lane == 0) v = atomicAdd(T.ctr, 1u);
+        return v;
+    };
+    uint32_t w = persist ? (uint32_t)__builtin_amdgcn_readfirstlane((int)draw()) : (uint32_t)(blockIdx.x * SC_WAVES + wave);
+    while (w < total) {
+    CT_STAMP(ct0);
+#ifdef CONV_TIMING
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const uint32_t job = w % (uint32_t)njobs, slot = w / (uint32_t)njobs;
+    ConvJob J = jobs.job[0];
+    if (job == 1) J = jobs.job[1];
+    if (job == 2) J = jobs.job[2];
+    if (job == 3) J = jobs.job[3];
     const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);
     float *acc = lds + wave * CONV_LDS_WAVE;
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
@@ -335,6 +385,7 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
             sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
             so[0] = (int32_t)(c0 & 0xFFFFu); so[16] = (int32_t)(c1 & 0xFFFFu);
         }
+        CT_STAMP(ct1);
         if constexpr (ASM) {
             uint32_t su, st0, st1;
             const uint32_t acc_lds = __builtin_amdgcn_groupstaticsize() + (uint32_t)(wave * CONV_LDS_WAVE * 4);
@@ -396,9 +447,17 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
         }
         accumulate(prev);
         }
+#ifdef CONV_TIMING
+        const long long ct2 = clock64();
+        if (lane == 0) { atomicAdd(&g_conv_timing[0], (unsigned long long)(ct1 - ct0)); atomicAdd(&g_conv_timing[1], (unsigned long long)(ct2 - ct1)); atomicAdd(&g_conv_timing[3], (unsigned long long)nt); }
+#endif
     }
+    CT_STAMP(ct3);
+    uint32_t w_next = 0;
+    if (persist) w_next = draw();   // the next item's number arrives while the epilogue runs
     // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
-    const int row0 = blk * R;
+    const int row0 = blk * T.H;
+    const int nrow8 = T.H * 8;
     const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res);
     float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out);
     // residual rows are fetched in batches ahead of the LDS reads (one wait per batch instead of one per row group)
@@ -412,13 +471,13 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
             const int idx = (it0 + b) * 64 + lane;
             const int grow = row0 + (idx >> 3);
             rr[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (res4 && it0 + b < NIT && idx < R * 8 && grow < n) rr[b] = res4[(size_t)grow * 8 + (idx & 7)];
+            if (res4 && it0 + b < NIT && idx < nrow8 && grow < n) rr[b] = res4[(size_t)grow * 8 + (idx & 7)];
         }
 #pragma unroll
         for (int b = 0; b < EB; ++b) {
             const int idx = (it0 + b) * 64 + lane;
             const int grow = row0 + (idx >> 3);
-            if (it0 + b < NIT && idx < R * 8 && grow < n) {
+            if (it0 + b < NIT && idx < nrow8 && grow < n) {
                 float4 v = acc4[idx];
                 if (res4) { const float4 r = rr[b]; v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
                 if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
@@ -426,6 +485,23 @@ __global__ __launch_bounds__(64 * CONV_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3
             }
         }
     }
+#ifdef CONV_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long ct4 = clock64();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0) {
+        atomicAdd(&g_conv_timing[2], (unsigned long long)(ct4 - ct3)); atomicAdd(&g_conv_timing[4], 1ull); atomicAdd(&g_conv_timing[5], (unsigned long long)(ct4 - ct0));
+        atomicAdd(&g_conv_timing[6], rt1 - rt0); atomicMin(&g_conv_timing[7], rt0); atomicMax(&g_conv_timing[8], rt1); atomicMax(&g_conv_timing[9], rt1 - rt0);
+    }
+#endif
+    if (!persist) break;
+    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);
+    }
+#ifdef CONV_TIMING
+    if (lane == 0) { const unsigned long long rt = __builtin_amdgcn_s_memrealtime(); atomicMin(&g_conv_timing[10], rt); atomicMax(&g_conv_timing[11], rt); }
+#endif
+    // the last wave to leave puts the two counters back to zero for the next launch on this tile list
+    if (persist && lane == 0 && atomicAdd(T.ctr + 1, 1u) == gridDim.x * SC_WAVES - 1u) { T.ctr[0] = 0; T.ctr[1] = 0; }
 }
 
 // Small levels (16-row blocks: every (block, offset) pair is exactly one tile, a block's list is a serial chain of up to
@@ -576,17 +652,17 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     if (n <= 0) return GPCC_OK;
     if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
     const bool prof = ctx && ctx->prof.on;
-    ConvRec rec = {0, 0, level, njobs};
+    ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk};
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
     static int dist = -1, use_asm = -1;
     if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
     if (use_asm < 0) { const char *e = getenv("GAUSPCC_CONV_ASM"); use_asm = e ? atoi(e) != 0 : 1; }
     static bool lds_attr_set = false;
     if (!lds_attr_set) {  // 128-row blocks need more LDS per workgroup than the 64 KiB default cap
-        const int bytes = CONV_WAVES * conv_lds_wave_floats(128) * 4;
+        const int bytes = SC_WAVES * conv_lds_wave_floats(128) * 4;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(255) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, CONV_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -606,10 +682,26 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
         return GPCC_OK;
     }
-    dim3 grid((unsigned)cdiv(T.nblk, CONV_WAVES), (unsigned)njobs);
-    const size_t lds_bytes = (size_t)CONV_WAVES * conv_lds_wave_floats(T.R) * 4;
+    // work items = blocks x jobs.  More items than the chip holds waves: persistent launch, exactly the resident waves,
+    // each drawing items from the tile list's counter (GAUSPCC_CONV_PERSIST=0: one item per wave, as for small launches)
+    static int persist_on = -1, n_cu = 0;
+    if (persist_on < 0) {
+        const char *e = getenv("GAUSPCC_CONV_PERSIST");
+        persist_on = e ? atoi(e) : 0;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
+    }
+    const int64_t items = T.nblk * njobs;
+    const int wg_per_cu = T.R >= 255 ? 1 : 2;   // what LDS (255 / 128 rows) and registers (186-220 VGPRs) let a CU hold
+    const int64_t resident = (int64_t)n_cu * wg_per_cu;
+    const int persist = persist_on && T.ctr && items > resident * SC_WAVES ? 1 : 0;
+    dim3 grid((unsigned)(persist ? resident : cdiv(items, SC_WAVES)), 1u);
+    const size_t lds_bytes = (size_t)SC_WAVES * conv_lds_wave_floats(T.R) * 4;
     const bool asm_ok = use_asm && dist == 1 && n < ((int64_t)1 << 25);   // the asm loop addresses rows with 32-bit byte offsets
-#define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * CONV_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu)
+#define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs, persist)
     switch (T.R) {
     case 16: if (asm_ok) CONV_LAUNCH(16, 1, true); else CONV_LAUNCH(16, 1, false); break;
     case 32: if (asm_ok) CONV_LAUNCH(32, 1, true); else CONV_LAUNCH(32, 1, false); break;
@@ -626,15 +718,33 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
 #undef CONV_LAUNCH
     LAUNCH_CHECK();
     if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+#ifdef CONV_TIMING
+    if (prof) {
+        unsigned long long h[12], z[12] = {0};
+        z[7] = ~0ull; z[10] = ~0ull;
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof.pool[(size_t)rec.e0], ctx->prof.pool[(size_t)rec.e1]));
+        HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_timing), sizeof h));
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof z));
+        const double waves = (double)h[4], tiles = (double)h[3];
+        fprintf(stderr, "[conv] R %3d H %3d jobs %d n %8lld blocks %6.0f tiles %9.0f  %.1f us | per wave: setup %.0f loop %.0f epilogue %.0f total %.0f cyc | loop %.0f cyc/tile | clock %.0f MHz | span %.1f us, wave time / 1024 slots %.1f us, longest block %.1f us, first wave exit at %.1f us, last at %.1f us\n",
+                T.R, T.H, njobs, (long long)n, waves, tiles, ms * 1e3, h[0] / waves, h[1] / waves, h[2] / waves, h[5] / waves, h[1] / tiles, 100.0 * h[5] / (double)h[6],
+                (h[8] - h[7]) / 100.0, h[6] / 100.0 / 1024.0, h[9] / 100.0, (h[10] - h[7]) / 100.0, (h[11] - h[7]) / 100.0);
+    }
+#endif
     return GPCC_OK;
 }
 
 int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
 {
     Prof &p = ctx->prof;
+    static int log = -1;
+    if (log < 0) { const char *e = getenv("GAUSPCC_CONV_LOG"); log = e ? atoi(e) : 0; }
     for (const ConvRec &r : p.recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
+        if (log) fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3);
         p.conv_ms += ms;
         p.conv_launches += 1;
         if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs;

@@ -15,7 +15,7 @@ struct gpcc_model {
     int C = 32, k = 5, K = 125;
     float *slab = nullptr;         // one allocation
     const float *prior_emb = nullptr;   // (256, 32) physical order
-    const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order
+    const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order, followed by the same in the transposed (A-fragment) order
     const float *temb = nullptr;        // (8, 32) physical
     const float *hw1[4] = {0}, *hb1[4] = {0}, *hw2[4] = {0}, *hb2[4] = {0};  // upstream layouts (logical)
     const float *hfrag[4] = {0};        // per head: W1 as 2 x 512 B-fragment floats, W2 (columns padded to 16) as 512, b1 (32), b2 padded (16)
@@ -47,11 +47,27 @@ inline void conv_weight_fragments(const float *W, int K, float *out)
                         out[((((size_t)o * 2 + hh) * 2 + q) * 64 + lane) * 4 + r] = W[((size_t)o * 32 + (4 * (4 * q + r) + (lane >> 4))) * 32 + 16 * hh + (lane & 15)];
 }
 
+// The same kernel as the A operand of the TRANSPOSED product D^T = W^T X^T (the asm tile loop): MFMA row m of output half
+// hh is logical output channel 16*hh + 4*(m%4) + m/4, so that the four accumulator registers of lane (g = lane/16, e) are
+// four physically consecutive channels of tile row e -- one 16-byte LDS access per half instead of four 4-byte ones.
+// [o][half][q][lane][r] = W[o][4*(4q + r) + lane/16][16*half + 4*((lane%16)%4) + (lane%16)/4]
+inline void conv_weight_fragments_t(const float *W, int K, float *out)
+{
+    for (int o = 0; o < K; ++o)
+        for (int hh = 0; hh < 2; ++hh)
+            for (int q = 0; q < 2; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = lane & 15;
+                        out[((((size_t)o * 2 + hh) * 2 + q) * 64 + lane) * 4 + r] = W[((size_t)o * 32 + (4 * (4 * q + r) + (lane >> 4))) * 32 + 16 * hh + 4 * (m & 3) + (m >> 2)];
+                    }
+}
+
 constexpr int STAGE_M[4] = {2, 2, 4, 16};
 
 struct ConvJob {
     const float *in;   // (n,32) physical
-    const float *w;    // B-fragment order
+    const float *w;    // K x 1024 floats in B-fragment order, then K x 1024 in the transposed order (conv_weight_fragments_t)
     const float *res;  // nullable, physical
     float *out;        // physical
 };
@@ -70,11 +86,14 @@ struct ConvTiles {
     uint32_t *toc = nullptr;   // [tiles]     offset | valid entries << 16
     uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
     uint32_t *order = nullptr; // [nblk]      blocks sorted by tile count, longest first (dispatch order)
+    uint32_t *ctr = nullptr;   // [2]         work counter / exit counter of the persistent launches (zero between launches)
     int64_t nblk = 0;
-    int R = CONV_R_MAX;
+    int R = CONV_R_MAX;        // capacity class of the blocks (LDS rows per wave; selects the kernel)
+    int H = CONV_R_MAX;        // rows per block, <= R: chosen so that the blocks fill the chip's wave slots a whole number of times
     int K = 0;                 // kernel offsets
 };
 int conv_pick_rows(int64_t n);  // policy (env GAUSPCC_CONV_R overrides)
+int conv_pick_height(int64_t n, int R);  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
 static inline int64_t conv_blocks_capacity(int64_t n) { return cdiv(n, 16) + 1; }
 // Build the tile list of a level (or of several concatenated levels) from its dense neighbour map.
 // Two passes over the map (count, fill) with one stream sync in between to size the arrays exactly

@@ -40,6 +40,7 @@ V = dict(
 CLOBBER_V = list(range(16, 168))
 NSTEP = 4                              # lcm(D + 1, 2)
 WINDOW = 6 * (D - 1)                   # tile loads that may stay in flight across a step start
+LGKM_YOUNGER = int(os.environ.get("CONV_ASM_LGKM", "4"))   # LDS operations that may stay in flight across a step start
 
 
 def vr(base, n=1):
@@ -162,17 +163,20 @@ def staging_store(label, younger_loads):
 def step_wait(du, label):
     """The loads of the last D - 1 steps may stay in flight; everything older (this tile's) must have landed.  For D
     steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside that window as well."""
+    # LDS completes in order: the header reads this step needs are older than the 4 sum writes that close the previous step
+    # (and than its staging writes, if any), so those may still be in flight
+    lg = 0 if EXP & 1 else LGKM_YOUNGER
     if not 1 <= du <= D:
-        return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)"]
+        return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt({lg})"]
     return ["s_and_b32 %[t0], %[u], 15",
             "s_cmp_eq_u32 %[t0], 0",
             f"s_cbranch_scc0 {label}_wa%=",
             "s_cmp_eq_u32 %[u], 0",
             f"s_cbranch_scc1 {label}_wa%=",
-            f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt(0)",
+            f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt({lg})",
             f"s_branch {label}_wb%=",
             f"{label}_wa%=:",
-            f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)",
+            f"s_waitcnt vmcnt({WINDOW}) lgkmcnt({lg})",
             f"{label}_wb%=:"]
 
 
@@ -240,6 +244,7 @@ def build():
         f"ds_read_b32 v{L['on']}, v{L['ho']} offset:{4 * D}",
         f"ds_read_b32 v{L['r4nn']}, v{L['hr']} offset:16",
         "s_mov_b32 %[u], 0",
+        "s_waitcnt lgkmcnt(0)",        # the steps only wait for LDS operations older than a previous step's sum writes
         "conv_loop%=:",
     ]
     for du in range(NSTEP):

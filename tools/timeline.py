@@ -38,6 +38,11 @@ def report(name, seg):
 
 report("encode", seg[:cut])
 dec = seg[cut:]
-# drop anything after the decode (next step / teardown): decode ends with the last k_expand
-last = max(i for i, r in enumerate(dec) if "k_expand" in r[2] or "k_level" in r[2])
+# drop anything after the decode (teardown): cut at the first gap longer than 20 ms
+last = len(dec) - 1
+for i in range(len(dec) - 1):
+    if dec[i + 1][0] - dec[i][1] > 20e6:
+        last = i
+        break
 report("decode", dec[: last + 1])
+print(f"== gap between the encode's last kernel and the decode's first: {(dec[0][0] - seg[cut - 1][1]) / 1e6:.2f} ms")

@@ -35,8 +35,12 @@ constexpr int CONV_WAVES = 4;
 #endif
 constexpr int SC_WAVES = CONV_SC_WAVES_N;   // waves per workgroup of k_sparse_conv (every wave works alone on its own block)
 constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
-// LDS floats per wave: R accumulator rows + 1 dummy row, then the 32-slot tile-header ring (512 + 128 + 32 dwords)
-__host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + 672; }
+// LDS floats per wave: slot 0 = the dummy row (padding entries, tiles past the end of a list), slots 1..R = the block's rows,
+// then the tile-header ring: 32 slots + 4 mirror slots (copies of slots 0..3, so that the asm loop reaches the slots of
+// four consecutive tiles by immediate offsets): neighbour rows 36 x 16 dwords | output slots 33 x 4 dwords (16 bytes a
+// tile) | kernel offsets 36 dwords
+constexpr int HDR_R = 576, HDR_O = 712, HDR_DWORDS = 752;
+__host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + HDR_DWORDS; }
 
 // ------------------------------------------------------------------ tile list
 template <int R, bool FILL>
@@ -84,14 +88,14 @@ __global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *_
                     if (j[q] >= 0) {
                         const uint32_t p = base + (uint32_t)__popcll(b[q] & lt);
                         tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = j[q];
-                        tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane);
+                        tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane + 1);   // LDS slot: row + 1
                     }
                     base += (uint32_t)__popcll(b[q]);
                 }
                 if ((uint32_t)lane < nt * 16u - cnt) {
                     const uint32_t p = cnt + (uint32_t)lane;
                     tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;
-                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)R;
+                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;   // the dummy slot
                 }
                 if ((uint32_t)lane < nt) toc[t + lane] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)lane) << 16);
             }
@@ -245,7 +249,7 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 
 #ifdef CONV_TIMING
 // developer build (tools/conv_timing.sh): shader-clock stamps around the phases of every wave, summed per launch
-__device__ unsigned long long g_conv_timing[12];
+__device__ unsigned long long g_conv_timing[16];
 #define CT_STAMP(v) const long long v = clock64()
 #else
 #define CT_STAMP(v)
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     int32_t *hdr = reinterpret_cast<int32_t *>(acc + (R + 1) * 32);
 #pragma unroll
     for (int it = 0; it < (R * 8 + 63) / 64; ++it)
-        if (it * 64 + lane < R * 8) acc4[it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (it * 64 + lane < R * 8) acc4[8 + it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // slots 1..R
     const int e = lane & 15, g = lane >> 4;
     // column of this lane inside an accumulator row (physical order) for output halves 0 / 1
     const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
@@ -301,8 +305,8 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     const float *__restrict__ in = J.in + 4 * g;
     const float *__restrict__ wf = J.w + lane * 4;
     const int32_t *hj = hdr + e;            // + slot * 16
-    const int32_t *hr = hdr + 512 + g;      // + slot * 4
-    const int32_t *ho = hdr + 640;          // + slot
+    const int32_t *hr = hdr + HDR_R + g;    // + slot * 4
+    const int32_t *ho = hdr + HDR_O;        // + slot
     struct AB { float4 a0, a1, b00, b01, b10, b11; };
     auto load_ab = [&](int j, uint32_t o) -> AB {
         const float *p = in + (size_t)(uint32_t)j * 32;
@@ -370,31 +374,47 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
         // last tile work on the headers that follow in memory (the next block's, or the zeroed padding of the
         // list) and accumulate into the dummy LDS row.
         constexpr int RING = DIST + 1;
-        constexpr uint32_t DUMMY4 = (uint32_t)R * 0x01010101u;
+        constexpr uint32_t DUMMY4 = 0u;   // four times the dummy slot
         const uint32_t nt = t1 - t0;
         const int4 *__restrict__ gtj = reinterpret_cast<const int4 *>(T.tj + (size_t)t0 * 16) + lane;
         const uint32_t *__restrict__ gtr = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16) + lane;
         const uint32_t *__restrict__ gto = T.toc + t0 + (lane & 15);
         int4 *sj = reinterpret_cast<int4 *>(hdr) + lane;   // + (batch & 1) * 64
-        int32_t *sr = hdr + 512 + lane;                    // + (batch & 1) * 64
-        int32_t *so = hdr + 640 + (lane & 15);             // + (batch & 1) * 16
-        {   // batches 0 and 1 straight into the ring
+        int32_t *sr = hdr + HDR_R + lane;                  // + (batch & 1) * 64
+        int32_t *so = hdr + HDR_O + (lane & 15);           // + (batch & 1) * 16
+        {   // batches 0 and 1 straight into the ring (and slots 0..3 into their mirrors behind slot 31)
             const int4 a0 = gtj[0], a1 = gtj[64];
             const uint32_t b0 = gtr[0], b1 = gtr[64], c0 = gto[0], c1 = gto[16];
             sj[0] = a0; sj[64] = a1;
             sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
             so[0] = (int32_t)(c0 & 0xFFFFu); so[16] = (int32_t)(c1 & 0xFFFFu);
+            if (lane < 16) sj[128] = a0;
+            if (lane < 4) sr[128] = (int32_t)b0;
+            if ((lane & 15) < 4) so[32] = (int32_t)(c0 & 0xFFFFu);
         }
         CT_STAMP(ct1);
         if constexpr (ASM) {
             uint32_t su, st0, st1;
             const uint32_t acc_lds = __builtin_amdgcn_groupstaticsize() + (uint32_t)(wave * CONV_LDS_WAVE * 4);
             const uint32_t hdr_lds = acc_lds + (uint32_t)((R + 1) * 128);
+#ifdef CONV_LOOP_STAMPS
+            uint32_t sw0, sw1, sw2, sw3;
+            asm volatile(CONV_LOOP_ASM
+                         : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1), [w0] "=&s"(sw0), [w1] "=&s"(sw1), [w2] "=&s"(sw2), [w3] "=&s"(sw3)
+                         : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                           [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                         : CONV_LOOP_CLOBBERS);
+            if (lane == 0) {
+                atomicAdd(&g_conv_timing[12], (unsigned long long)sw0); atomicAdd(&g_conv_timing[13], (unsigned long long)sw1);
+                atomicAdd(&g_conv_timing[14], (unsigned long long)sw2); atomicAdd(&g_conv_timing[15], (unsigned long long)sw3);
+            }
+#else
             asm volatile(CONV_LOOP_ASM
                          : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
-                         : [in] "s"(J.in), [w] "s"(J.w), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
-                           [nt] "s"(nt), [dummy] "s"(DUMMY4), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                         : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                           [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
                          : CONV_LOOP_CLOBBERS);
+#endif
         } else {
         int4 st_j = make_int4(0, 0, 0, 0);
         uint32_t st_r = 0, st_o = 0;
@@ -455,33 +475,53 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     CT_STAMP(ct3);
     uint32_t w_next = 0;
     if (persist) w_next = draw();   // the next item's number arrives while the epilogue runs
-    // epilogue: accumulator rows are already in the physical channel order -> straight 16-byte copies
-    const int row0 = blk * T.H;
-    const int nrow8 = T.H * 8;
-    const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res);
-    float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out);
-    // residual rows are fetched in batches ahead of the LDS reads (one wait per batch instead of one per row group)
-    constexpr int NIT = (R * 8 + 63) / 64;
-    constexpr int EB = NIT < 8 ? NIT : 8;
+    // epilogue: the block's rows are contiguous in the output and already in the physical channel order -> straight 16-byte
+    // copies, 64 rows (512 float4, 8 per lane) per batch.  Every branch is wave-uniform; only the last batch of a block
+    // (and the last block of a level) is predicated.  Residual rows of a batch are all requested before the first is used.
+    {
+        const int row0 = blk * T.H;
+        const int nvec = min(T.H, n - row0) * 8;   // float4 elements of this block
+        const bool has_res = J.res != nullptr;
+        const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8 + lane;
+        float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8 + lane;
+        const float4 *src = acc4 + 8 + lane;        // slot 1 = row 0
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+        for (int base = 0; base < nvec; base += 512) {
+            float4 v[8], r[8];
+            if (base + 512 <= nvec) {
+                if (has_res) {
 #pragma unroll
-    for (int it0 = 0; it0 < NIT; it0 += EB) {
-        float4 rr[EB];
+                    for (int b = 0; b < 8; ++b) r[b] = res4[base + 64 * b];
+                }
 #pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            const int idx = (it0 + b) * 64 + lane;
-            const int grow = row0 + (idx >> 3);
-            rr[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (res4 && it0 + b < NIT && idx < nrow8 && grow < n) rr[b] = res4[(size_t)grow * 8 + (idx & 7)];
-        }
+                for (int b = 0; b < 8; ++b) v[b] = src[base + 64 * b];
+                if (has_res) {
 #pragma unroll
-        for (int b = 0; b < EB; ++b) {
-            const int idx = (it0 + b) * 64 + lane;
-            const int grow = row0 + (idx >> 3);
-            if (it0 + b < NIT && idx < nrow8 && grow < n) {
-                float4 v = acc4[idx];
-                if (res4) { const float4 r = rr[b]; v.x = v.x + r.x; v.y = v.y + r.y; v.z = v.z + r.z; v.w = v.w + r.w; }
-                if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-                out4[(size_t)grow * 8 + (idx & 7)] = v;
+                    for (int b = 0; b < 8; ++b) { v[b].x = v[b].x + r[b].x; v[b].y = v[b].y + r[b].y; v[b].z = v[b].z + r[b].z; v[b].w = v[b].w + r[b].w; }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int b = 0; b < 8; ++b) { v[b].x = v[b].x > 0.f ? v[b].x : 0.f; v[b].y = v[b].y > 0.f ? v[b].y : 0.f; v[b].z = v[b].z > 0.f ? v[b].z : 0.f; v[b].w = v[b].w > 0.f ? v[b].w : 0.f; }
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) out4[base + 64 * b] = v[b];
+            } else {
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool ok = base + 64 * b + lane < nvec;
+                    r[b] = has_res && ok ? res4[base + 64 * b] : zero4;
+                }
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const bool ok = base + 64 * b + lane < nvec;
+                    if (ok) {
+                        float4 t = src[base + 64 * b];
+                        if (has_res) { t.x = t.x + r[b].x; t.y = t.y + r[b].y; t.z = t.z + r[b].z; t.w = t.w + r[b].w; }
+                        if (relu) { t.x = t.x > 0.f ? t.x : 0.f; t.y = t.y > 0.f ? t.y : 0.f; t.z = t.z > 0.f ? t.z : 0.f; t.w = t.w > 0.f ? t.w : 0.f; }
+                        out4[base + 64 * b] = t;
+                    }
+                }
             }
         }
     }
@@ -578,7 +618,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
         if (lane < 16) inv[lane * COOP_TILES + tl] = 255;
         const uint32_t cnt = ho[t] >> 16;
         const uint32_t r = (hr[t * 4 + (e >> 2)] >> (8 * (e & 3))) & 255u;
-        if (lane < 16 && (uint32_t)lane < cnt) inv[r * COOP_TILES + tl] = (uint8_t)lane;   // same wave: ordered behind the 255s
+        if (lane < 16 && (uint32_t)lane < cnt) inv[(r - 1u) * COOP_TILES + tl] = (uint8_t)lane;   // tr holds row + 1; same wave: ordered behind the 255s
     };
     // this wave's two tiles of a round: base + 2 wave + {0, 1}; the next round's operands are requested before this
     // round's products are summed, so a round costs MFMAs + two barriers, not a memory latency
@@ -720,7 +760,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
 #ifdef CONV_TIMING
     if (prof) {
-        unsigned long long h[12], z[12] = {0};
+        unsigned long long h[16], z[16] = {0};
         z[7] = ~0ull; z[10] = ~0ull;
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0.f;
@@ -731,6 +771,9 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         fprintf(stderr, "[conv] R %3d H %3d jobs %d n %8lld blocks %6.0f tiles %9.0f  %.1f us | per wave: setup %.0f loop %.0f epilogue %.0f total %.0f cyc | loop %.0f cyc/tile | clock %.0f MHz | span %.1f us, wave time / 1024 slots %.1f us, longest block %.1f us, first wave exit at %.1f us, last at %.1f us\n",
                 T.R, T.H, njobs, (long long)n, waves, tiles, ms * 1e3, h[0] / waves, h[1] / waves, h[2] / waves, h[5] / waves, h[1] / tiles, 100.0 * h[5] / (double)h[6],
                 (h[8] - h[7]) / 100.0, h[6] / 100.0 / 1024.0, h[9] / 100.0, (h[10] - h[7]) / 100.0, (h[11] - h[7]) / 100.0);
+        if (h[12] + h[13] + h[14] + h[15])
+            fprintf(stderr, "[conv]    per tile: step-start wait %.0f, first pair + VALU burst + LDS issue %.0f, second pair + loads issue %.0f, remaining 12 MFMAs %.0f cycles\n",
+                    h[12] / tiles, h[13] / tiles, h[14] / tiles, h[15] / tiles);
     }
 #endif
     return GPCC_OK;

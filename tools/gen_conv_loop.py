@@ -1,120 +1,127 @@
 #!/usr/bin/env python3
-"""Generate gauspcc_amd/csrc/conv_loop_gfx950.inc: the hand-scheduled tile loops of k_sparse_conv (gfx950 ISA,
-each used as one inline-asm block).  The schedule is written down here once, with symbolic register names, so that
-the unrolled copies of a step (register rings) cannot drift apart.
+"""Generate gauspcc_amd/csrc/conv_loop_gfx950.inc: the hand-scheduled tile loop of k_sparse_conv (gfx950 ISA, used as
+one inline-asm block).  The schedule is written down here once, with symbolic register names, so that the unrolled
+copies of a step (register rings) cannot drift apart.
 
-One wave owns R rows x all 32 output channels: 16 MFMAs per tile (two accumulator quads).  (A column-split variant
--- two waves sharing 255 rows, 8 MFMAs per tile each, 20 % better tile fill -- was built and measured 20 % SLOWER:
-the loop is bound by L1 / issue work per tile, which the split doubles; it is not kept.)
+What shapes the schedule (tools/ubench/mfma_shadow.hip, measured on MI355X): v_mfma_f32_16x16x4_f32 runs on the SIMD's
+fp32 lanes -- a VALU instruction does NOT execute in the shadow of an fp32 MFMA, it costs its 4 cycles on top of the
+MFMA's 32, plus ~10 cycles every time the instruction stream switches from MFMAs to VALU work and back, from the same
+wave or another one on the SIMD.  Scalar instructions, LDS and global-memory instructions do overlap.  So the step is
+built to need as few VALU instructions as possible, all of them in ONE burst:
 
-Per step (one tile = 16 (output row, neighbour row) pairs of one kernel offset) the v_mfma_f32_16x16x4_f32 are issued
-back to back from a ZERO accumulator; everything else is slotted into the shadow of the matrix pipe (an MFMA occupies
-it for 32 cycles, a wave can issue ~5 other instructions meanwhile):
-    gathered rows (A) and weight fragment (B) of the tile D = 3 steps ahead -- a tile waits for the slowest of its 16
-        gathered rows, and with ~1/n_bar of all gathers being first touches of a row, nearly every tile contains an HBM
-        miss.  vmcnt retires in order, so a step waits with vmcnt(6 (D-1)): the loads of the last D-1 steps stay in
-        flight, this tile's (issued D steps ago) have landed
-    header words from the wave's LDS ring: neighbour rows + offset of tile u+D+1, output rows of tile u+2
-    LDS addresses of the PREVIOUS tile's 4 output rows, their running sums read, previous products added, written back
-    loop bookkeeping / header staging (three wide loads every 16 tiles, moved into the ring 8 tiles later)
-LDS operations of a wave execute in program order, so consecutive tiles may share output rows.
-Registers v16.. are fixed here (declared as clobbers), the rest is the compiler's; 2 waves/SIMD allow 256 per wave.
-Register tuples start on even registers (gfx90a+ requirement).
+  * the product is computed transposed, D^T = W^T X^T: the weights are the MFMA A operand (pre-swizzled fragments,
+    conv_weight_fragments_t), the 16 gathered neighbour rows the B operand.  Lane (g = lane/16, e = lane%16) then holds
+    four physically consecutive output channels of tile row e in each accumulator quad: the running sums of a tile are
+    two 16-byte LDS reads and writes per lane and four v_pk_add_f32 (was 4 + 4 two-dword accesses, 8 v_add_f32 and
+    8 address computations for the four rows a lane used to touch);
+  * one row byte per lane (tr holds the LDS slot = row + 1, slot 0 is the dummy row); slot address and "tile exists"
+    in one v_mad_u32_u24 with a scalar multiplier of 128 or 0;
+  * the ring positions of a step's header reads are immediate offsets from three pointers that move once per four
+    steps (the ring carries four mirror slots behind slot 31 for that);
+  * loop bookkeeping and the header staging control flow are scalar.
+Per step: 16 MFMAs from a ZERO accumulator + 7 VALU (+3 per four steps); the rest is LDS / global-memory issue.
+
+One wave owns R rows x all 32 output channels.  Per step (one tile = 16 (output row, neighbour row) pairs of one kernel
+offset):
+    gathered rows (X) and weight fragment (W) of the tile D = 3 steps ahead; vmcnt retires in order, so a step waits
+        with vmcnt(6 (D-1)): the loads of the last D-1 steps stay in flight, this tile's (issued D steps ago) have landed
+    header words from the wave's LDS ring: neighbour rows + offset of tile u+D+1, output slot of tile u+1
+    the PREVIOUS tile's products are added to its rows' running sums (read from LDS during the previous step) and
+        written back; then this tile's rows are read -- LDS operations of a wave execute in program order, so
+        consecutive tiles may share output rows
+    header staging: three wide loads every 16 tiles, moved into the ring 8 tiles later
+Registers v16.. are fixed here (declared as clobbers), the rest is the compiler's.  Register tuples start on even
+registers (gfx90a+ requirement).
 """
 import os
 
 EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers
-D = 3                                            # issue distance of the tile loads (steps); A and B rings = D + 1 sets
+D = 3                                            # issue distance of the tile loads (steps); X and W rings = D + 1 sets
 
 V = dict(
-    A=(16, 24, 32, 40),                # 4 sets x 8 regs
-    B=(48, 64, 80, 96),                # 4 sets x 16 regs
-    C=(112, 120),                      # c0 = C..C+3, c1 = C+4..C+7
-    jn=128, on=129, r4nn=130, r4nxt=131, r4cur=132, r4prev=133,
-    ao=134, bo=135, t0=136, wof=137,
-    ra=138,                            # 138..141
-    s=142,                             # 142..149
-    stj=150, str=154, sto=155,
-    accb=156, hj=157, hr=158, ho=159, goff=160, loff=161, dummy=162, sgr=163, sgo=164, swj=165, swr=166, swo=167,
+    X=(16, 24, 32, 40),                # gathered rows: 4 sets x 8 regs
+    W=(48, 64, 80, 96),                # weight fragments: 4 sets x 16 regs
+    C=(112, 120),                      # products: c0 = C..C+3, c1 = C+4..C+7
+    S=(128, 136),                      # running sums of the tile's rows: 2 sets x 8 regs
+    jn=144, on=145, rb=146, ao=147, bo=148,
+    ra=(149, 150),                     # LDS address of this lane's 16 bytes in the tile row's slot
+    t0=151,
+    stj=152, str=156, sto=157,         # staged header batch
+    accb=158, hjb=159, hrb=160, hob=161, goff=162, loff=163,
+    hjp=164, hrp=165, hop=166,
+    sgr=167, sgo=168, swj=169, swr=170, swo=171, swjm=172, swrm=173, swom=174,
 )
-CLOBBER_V = list(range(16, 168))
+CLOBBER_V = list(range(16, 175))
 NSTEP = 4                              # lcm(D + 1, 2)
 WINDOW = 6 * (D - 1)                   # tile loads that may stay in flight across a step start
-LGKM_YOUNGER = int(os.environ.get("CONV_ASM_LGKM", "4"))   # LDS operations that may stay in flight across a step start
+# byte offsets inside the header ring (must match network.hip: HDR_R, HDR_O)
+RING_R = 2304                          # 36 slots x 64 B of neighbour rows before it
+RING_O = 2848                          # 33 slots x 16 B of output slots (padded to 544) before it
 
 
 def vr(base, n=1):
     return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
 
 
-def mfma(c, a, b, first):
-    return f"v_mfma_f32_16x16x4_f32 {vr(c, 4)}, v{a}, v{b}, {'0' if first else vr(c, 4)}"
+def mfma(c, w, x, first):
+    return f"v_mfma_f32_16x16x4_f32 {vr(c, 4)}, v{w}, v{x}, {'0' if first else vr(c, 4)}"
 
 
-def loads_a(aset):
-    A = V["A"][aset]
-    o = [f"global_load_dwordx4 {vr(A, 4)}, v{V['ao']}, %[in]",
-         f"global_load_dwordx4 {vr(A + 4, 4)}, v{V['ao']}, %[in] offset:64"]
+def loads_x(xset):
+    X = V["X"][xset]
+    o = [f"global_load_dwordx4 {vr(X, 4)}, v{V['ao']}, %[in]",
+         f"global_load_dwordx4 {vr(X + 4, 4)}, v{V['ao']}, %[in] offset:64"]
     return ["s_nop 0"] * 2 if EXP & 4 else o
 
 
-def loads_b(bset):
-    B = V["B"][bset]
-    nb = 4
-    o = [f"global_load_dwordx4 {vr(B + 4 * i, 4)}, v{V['bo']}, %[w]" + (f" offset:{1024 * i}" if i else "") for i in range(nb)]
-    return ["s_nop 0"] * nb if EXP & 2 else o
+def loads_w(wset):
+    W = V["W"][wset]
+    o = [f"global_load_dwordx4 {vr(W + 4 * i, 4)}, v{V['bo']}, %[w]" + (f" offset:{1024 * i}" if i else "") for i in range(4)]
+    return ["s_nop 0"] * 4 if EXP & 2 else o
 
 
-def addr_a():
+def addr_x():
     return [f"v_lshl_add_u32 v{V['ao']}, v{V['jn']}, 7, v{V['goff']}"]
 
 
-def addr_b():
-    return [f"v_lshl_add_u32 v{V['bo']}, v{V['on']}, 12, v{V['wof']}"]
+def addr_w():
+    return [f"v_lshl_add_u32 v{V['bo']}, v{V['on']}, 12, v{V['loff']}"]
 
 
-def row_addr(r4, ks):
-    o = []
-    for k in ks:
-        o.append(f"v_bfe_u32 v{V['t0']}, v{r4}, {8 * k}, 8")
-        o.append(f"v_lshl_add_u32 v{V['ra'] + k}, v{V['t0']}, 7, v{V['accb']}")
-    return o
-
-
-def sum_reads(ks):
+def sum_adds(sset, cp):
     if EXP & 1:
         return []
-    return [f"ds_read2_b32 {vr(V['s'] + 2 * k, 2)}, v{V['ra'] + k} offset1:16" for k in ks]
+    S = V["S"][sset]
+    return [f"v_pk_add_f32 {vr(S + 2 * i, 2)}, {vr(S + 2 * i, 2)}, {vr(cp + 2 * i, 2)}" for i in range(4)]
 
 
-def sum_adds_writes(cp):
+def sum_writes(sset):
     if EXP & 1:
         return []
-    o = []
-    for k in range(4):
-        o.append(f"v_add_f32 v{V['s'] + 2 * k}, v{V['s'] + 2 * k}, v{cp + k}")
-        o.append(f"v_add_f32 v{V['s'] + 2 * k + 1}, v{V['s'] + 2 * k + 1}, v{cp + 4 + k}")
-        o.append(f"ds_write2_b32 v{V['ra'] + k}, v{V['s'] + 2 * k}, v{V['s'] + 2 * k + 1} offset1:16")
-    return o
+    S, ra = V["S"][sset], V["ra"][sset]
+    return [f"ds_write_b128 v{ra}, {vr(S, 4)}", f"ds_write_b128 v{ra}, {vr(S + 4, 4)} offset:64"]
 
 
-def r4_rotate():
-    return [f"v_mov_b32 v{V['r4prev']}, v{V['r4cur']}", f"v_mov_b32 v{V['r4cur']}, v{V['r4nxt']}"]
-
-
-def r4_validate(du):
-    # r4nxt <- tile u+du+1 exists ? its rows (read from the ring in the previous step) : the dummy row
-    return [f"s_add_u32 %[t0], %[u], {du + 1}", "s_cmp_lt_u32 %[t0], %[nt]", "s_cselect_b64 vcc, -1, 0",
-            f"v_cndmask_b32 v{V['r4nxt']}, v{V['dummy']}, v{V['r4nn']}, vcc"]
+def sum_reads(sset):
+    if EXP & 1:
+        return []
+    S, ra = V["S"][sset], V["ra"][sset]
+    return [f"ds_read_b128 {vr(S, 4)}, v{ra}", f"ds_read_b128 {vr(S + 4, 4)}, v{ra} offset:64"]
 
 
 def header_reads(du):
-    # neighbour rows + offset of tile u+du+D+1 (its loads are issued in the next step), output rows of tile u+du+2
-    return [f"s_add_u32 %[t0], %[u], {du + D + 1}", "s_and_b32 %[t0], %[t0], 31",
-            f"v_lshl_add_u32 v{V['t0']}, %[t0], 6, v{V['hj']}", f"ds_read_b32 v{V['jn']}, v{V['t0']}",
-            f"v_lshl_add_u32 v{V['t0']}, %[t0], 2, v{V['ho']}", f"ds_read_b32 v{V['on']}, v{V['t0']}",
-            f"s_add_u32 %[t0], %[u], {du + 2}", "s_and_b32 %[t0], %[t0], 31",
-            f"v_lshl_add_u32 v{V['t0']}, %[t0], 4, v{V['hr']}", f"ds_read_b32 v{V['r4nn']}, v{V['t0']}"]
+    # neighbour rows + offset of tile u+du+D+1 (its loads are issued in the next step), output slot of tile u+du+1
+    return [f"ds_read_b32 v{V['jn']}, v{V['hjp']} offset:{64 * (D + 1 + du)}",
+            f"ds_read_b32 v{V['on']}, v{V['hop']} offset:{4 * (D + 1 + du)}",
+            f"ds_read_u8 v{V['rb']}, v{V['hrp']} offset:{16 * (1 + du)}"]
+
+
+def ring_pointers():
+    # ring position of tile u (u % 4 == 0): the four steps of an iteration reach slots su+1 .. su+7 <= 35 by immediate offsets
+    return ["s_and_b32 %[t0], %[u], 31",
+            f"v_lshl_add_u32 v{V['hjp']}, %[t0], 6, v{V['hjb']}",
+            f"v_lshl_add_u32 v{V['hrp']}, %[t0], 4, v{V['hrb']}",
+            f"v_lshl_add_u32 v{V['hop']}, %[t0], 2, v{V['hob']}"]
 
 
 def staging_fetch(label):
@@ -138,7 +145,8 @@ def staging_fetch(label):
 
 
 def staging_store(label, younger_loads):
-    # ... and moved into the ring eight steps later -- the half of the ring it replaces was last read before step u
+    # ... and moved into the ring eight steps later -- the half of the ring it replaces was last read before step u.
+    # Slots 0..3 are mirrored behind slot 31 (the lanes that do not hold them repeat their own write).
     return [
         "s_and_b32 %[t0], %[u], 15",
         "s_cmp_eq_u32 %[t0], 8",
@@ -156,53 +164,92 @@ def staging_store(label, younger_loads):
         f"ds_write_b32 v{V['t0']}, v{V['str']}",
         f"v_lshl_add_u32 v{V['t0']}, %[t1], 6, v{V['swo']}",
         f"ds_write_b32 v{V['t0']}, v{V['sto']}",
+        "s_cmp_eq_u32 %[t1], 0",
+        f"s_cbranch_scc0 {label}_nostore%=",
+        f"ds_write_b128 v{V['swjm']}, {vr(V['stj'], 4)}",
+        f"ds_write_b32 v{V['swrm']}, v{V['str']}",
+        f"ds_write_b32 v{V['swom']}, v{V['sto']}",
         f"{label}_nostore%=:",
     ]
 
 
 def step_wait(du, label):
     """The loads of the last D - 1 steps may stay in flight; everything older (this tile's) must have landed.  For D
-    steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside that window as well."""
-    # LDS completes in order: the header reads this step needs are older than the 4 sum writes that close the previous step
-    # (and than its staging writes, if any), so those may still be in flight
-    lg = 0 if EXP & 1 else LGKM_YOUNGER
+    steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside that window as well.
+    Every LDS operation of the previous step was issued behind its first MFMA pair: long done."""
     if not 1 <= du <= D:
-        return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt({lg})"]
+        return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)"]
     return ["s_and_b32 %[t0], %[u], 15",
             "s_cmp_eq_u32 %[t0], 0",
             f"s_cbranch_scc0 {label}_wa%=",
             "s_cmp_eq_u32 %[u], 0",
             f"s_cbranch_scc1 {label}_wa%=",
-            f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt({lg})",
+            f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt(0)",
             f"s_branch {label}_wb%=",
             f"{label}_wa%=:",
-            f"s_waitcnt vmcnt({WINDOW}) lgkmcnt({lg})",
+            f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)",
             f"{label}_wb%=:"]
 
 
+STAMPS = ("sa", "sb", "sc", "sd")      # EXP & 8: s_memtime at four points of every step (developer timing build)
+
+
+STAMP_S = {f"{n}{p}": 60 + 2 * (4 * p + i) for p in (0, 1) for i, n in enumerate(STAMPS)}   # fixed SGPR pairs s[60:75]
+
+
+def stamp(name, par):
+    r = STAMP_S[f"{name}{par}"]
+    return [f"s_memtime s[{r}:{r + 1}]"] if EXP & 8 else []
+
+
+def stamp_collect(par):
+    """Differences of the previous step's stamps (all landed: the step start waited for lgkmcnt(0)) into the accumulators:
+    wait = sb - sa, burst = sc - sb, loads = sd - sc, rest = this step's sa - sd."""
+    if not EXP & 8:
+        return []
+    q = 1 - par
+    o = []
+    for acc, (hi, lo) in (("w0", ("sb", "sa")), ("w1", ("sc", "sb")), ("w2", ("sd", "sc"))):
+        o += [f"s_sub_u32 %[t0], s{STAMP_S[hi + str(q)]}, s{STAMP_S[lo + str(q)]}", f"s_add_u32 %[{acc}], %[{acc}], %[t0]"]
+    o += [f"s_sub_u32 %[t0], s{STAMP_S['sa' + str(par)]}, s{STAMP_S['sd' + str(q)]}", "s_add_u32 %[w3], %[w3], %[t0]"]
+    return o
+
+
 def step(du):
-    rset, cset = du % (D + 1), du % 2
-    A, B, CC, CP = V["A"][rset], V["B"][rset], V["C"][cset], V["C"][1 - cset]
+    rset, cur, prv = du % (D + 1), du % 2, 1 - du % 2
+    X, W, CC, CP = V["X"][rset], V["W"][rset], V["C"][cur], V["C"][prv]
     label = f"s{du}"
 
     def mf(kk, first=False):
-        return [mfma(CC, A + kk, B + kk, first), mfma(CC + 4, A + kk, B + 8 + kk, first)]
+        return [mfma(CC, W + kk, X + kk, first), mfma(CC + 4, W + 8 + kk, X + kk, first)]
 
     nset = (du + D) % (D + 1)          # the set consumed by the previous step receives tile u+du+D
-    la, lb = loads_a(nset), loads_b(nset)
-    o = [f"; ---- step: tile u+{du}: A/B set {rset}, C set {cset}"] + step_wait(du, label) + addr_a() + addr_b()
-    # all six tile loads in one burst behind the first MFMA pair (measured: spread one per pair 62.7, before the first
-    # pair 65.0, two per pair over three pairs 66.2, this 67.1 TFLOP/s on the encoder's sets)
-    o += mf(0, True) + la + lb + (staging_fetch(label) if du == 0 else [])
-    o += mf(1)
-    o += mf(2)
-    o += mf(3) + r4_rotate() + row_addr(V["r4prev"], range(4))
-    o += mf(4) + sum_reads(range(4))
-    o += mf(5) + r4_validate(du) + header_reads(du)
-    o += mf(6) + (staging_store(label, WINDOW + 6) if du == 0 else [])
-    # LDS returns in order: the 4 sum reads are older than the 3 header reads (and than any staging write)
-    o += [mfma(CC, A + 7, B + 7, False)] + ([] if EXP & 1 else ["s_waitcnt lgkmcnt(3)"]) + sum_adds_writes(CP)
-    o += [mfma(CC + 4, A + 7, B + 15, False)]
+    o = [f"; ---- step: tile u+{du}: X/W set {rset}, C/S set {cur}"] + stamp("sa", cur) + step_wait(du, label) + stamp("sb", cur) + stamp_collect(cur)
+    # slot multiplier of this tile: 128 if it exists, 0 (the dummy slot) past the end of the block's list
+    o += [f"s_add_u32 %[t0], %[u], {du}", "s_cmp_lt_u32 %[t0], %[nt]", "s_cselect_b32 %[t1], 128, 0"]
+    o += mf(0, True)
+    # the step's only VALU burst: previous tile's products onto its rows' sums, addresses of the loads and of this tile's slot
+    o += (ring_pointers() if du == 0 else [])
+    o += sum_adds(prv, CP) + addr_x() + addr_w()
+    o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
+    # memory instructions issue slowly (measured: ~20 cycles an LDS, ~13 a global load instruction, during which an in-order
+    # wave issues nothing else) but, unlike VALU work, they do overlap a running MFMA: one in front of each remaining MFMA
+    mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nset) + loads_w(nset)
+    rest = [m for kk in range(1, 8) for m in mf(kk)]
+    spread = os.environ.get("CONV_ASM_SPREAD", "1") != "0"
+    if not spread:
+        o += mem[:-6] + stamp("sc", cur) + rest[:2] + mem[-6:] + (staging_fetch(label) if du == 0 else []) + stamp("sd", cur)
+        o += rest[2:10] + (staging_store(label, WINDOW + 6) if du == 0 else []) + rest[10:]
+        return o
+    for i, m in enumerate(rest):
+        if i < len(mem):
+            o.append(mem[i])
+        if i == len(mem):
+            o += (staging_fetch(label) + staging_store(label, WINDOW + 6) if du == 0 else [])
+        if i == 7:
+            o += stamp("sc", cur)
+        o.append(m)
+    o += stamp("sd", cur)
     return o
 
 
@@ -211,40 +258,45 @@ def build():
     o = [
         "; ---- per-lane constants",
         f"v_and_b32 v{L['t0']}, 15, %[lane]",                       # e
-        f"v_lshrrev_b32 v{L['ra']}, 4, %[lane]",                    # g
-        f"v_and_b32 v{L['ra'] + 1}, 3, v{L['t0']}",
-        f"v_lshrrev_b32 v{L['ra'] + 2}, 2, v{L['t0']}",
-        f"v_lshl_add_u32 v{L['ra'] + 1}, v{L['ra'] + 1}, 2, v{L['ra'] + 2}",   # col0 = 4 (e & 3) + (e >> 2)
-        f"v_lshl_add_u32 v{L['accb']}, v{L['ra'] + 1}, 2, %[acc]",
-        f"v_lshl_add_u32 v{L['hj']}, v{L['t0']}, 2, %[hdr]",
-        f"v_lshl_add_u32 v{L['hr']}, v{L['ra']}, 2, %[hdr]",
-        f"v_add_u32 v{L['hr']}, 2048, v{L['hr']}",
-        f"v_mov_b32 v{L['ho']}, %[hdr]",
-        f"v_add_u32 v{L['ho']}, 2560, v{L['ho']}",
-        f"v_lshlrev_b32 v{L['goff']}, 4, v{L['ra']}",
+        f"v_lshrrev_b32 v{L['goff']}, 4, %[lane]",                  # g
+        f"v_lshlrev_b32 v{L['goff']}, 4, v{L['goff']}",             # 16 g: byte offset of this lane's channels in a row half
+        f"v_add_u32 v{L['accb']}, %[acc], v{L['goff']}",
+        f"v_lshl_add_u32 v{L['hjb']}, v{L['t0']}, 2, %[hdr]",
+        f"v_add_u32 v{L['hrb']}, %[hdr], v{L['t0']}",
+        f"v_add_u32 v{L['hrb']}, {RING_R}, v{L['hrb']}",
+        f"v_mov_b32 v{L['hob']}, %[hdr]",
+        f"v_add_u32 v{L['hob']}, {RING_O}, v{L['hob']}",
         f"v_lshlrev_b32 v{L['loff']}, 4, %[lane]",
-        f"v_mov_b32 v{L['wof']}, v{L['loff']}",
-        f"v_mov_b32 v{L['dummy']}, %[dummy]",
         f"v_lshlrev_b32 v{L['sgr']}, 2, %[lane]",
         f"v_lshlrev_b32 v{L['sgo']}, 2, v{L['t0']}",
         f"v_add_u32 v{L['swj']}, %[hdr], v{L['loff']}",
         f"v_add_u32 v{L['swr']}, %[hdr], v{L['sgr']}",
-        f"v_add_u32 v{L['swr']}, 2048, v{L['swr']}",
-        f"v_add_u32 v{L['swo']}, v{L['ho']}, v{L['sgo']}",
-        "; ---- pipeline prologue: A and B of tiles 0..D-1 in flight; headers j(D), o(D), r4(0), r4(1) in registers",
+        f"v_add_u32 v{L['swr']}, {RING_R}, v{L['swr']}",
+        f"v_add_u32 v{L['swo']}, v{L['hob']}, v{L['sgo']}",
+        # mirror slots 32..35 (= 0..3): lanes 0..15 hold them of the neighbour rows, lanes 0..3 slot 32 of the output slots,
+        # lanes with e < 4 of the offsets; everybody else repeats the regular write
+        f"v_add_u32 v{L['swjm']}, 2048, v{L['swj']}",
+        "v_cmp_gt_u32 vcc, 16, %[lane]",
+        f"v_cndmask_b32 v{L['swjm']}, v{L['swj']}, v{L['swjm']}, vcc",
+        f"v_add_u32 v{L['swrm']}, 512, v{L['swr']}",
+        "v_cmp_gt_u32 vcc, 4, %[lane]",
+        f"v_cndmask_b32 v{L['swrm']}, v{L['swr']}, v{L['swrm']}, vcc",
+        f"v_add_u32 v{L['swom']}, 128, v{L['swo']}",
+        f"v_cmp_gt_u32 vcc, 4, v{L['t0']}",
+        f"v_cndmask_b32 v{L['swom']}, v{L['swo']}, v{L['swom']}, vcc",
+        f"v_mov_b32 v{L['ra'][1]}, v{L['accb']}",                   # "previous tile" of step 0: the dummy slot
+        "; ---- pipeline prologue: X and W of tiles 0..D-1 in flight; headers j(D), o(D), slot(0) in registers",
         "s_waitcnt lgkmcnt(0)",
-        f"ds_read_b32 v{L['r4nxt']}, v{L['hr']}",
-        f"v_mov_b32 v{L['r4cur']}, v{L['dummy']}",
     ]
     for t in range(D):
-        o += [f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * t}", f"ds_read_b32 v{L['on']}, v{L['ho']} offset:{4 * t}", "s_waitcnt lgkmcnt(0)"]
-        o += addr_a() + addr_b() + loads_a(t) + loads_b(t)
+        o += [f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * t}", f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * t}", "s_waitcnt lgkmcnt(0)"]
+        o += addr_x() + addr_w() + loads_x(t) + loads_w(t)
     o += [
-        f"ds_read_b32 v{L['jn']}, v{L['hj']} offset:{64 * D}",
-        f"ds_read_b32 v{L['on']}, v{L['ho']} offset:{4 * D}",
-        f"ds_read_b32 v{L['r4nn']}, v{L['hr']} offset:16",
+        f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * D}",
+        f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * D}",
+        f"ds_read_u8 v{L['rb']}, v{L['hrb']}",
         "s_mov_b32 %[u], 0",
-        "s_waitcnt lgkmcnt(0)",        # the steps only wait for LDS operations older than a previous step's sum writes
+    ] + ([f"s_mov_b32 %[w{i}], 0" for i in range(4)] + [x for n in STAMPS for x in stamp(n, 1)] if EXP & 8 else []) + [
         "conv_loop%=:",
     ]
     for du in range(NSTEP):
@@ -256,9 +308,11 @@ def build():
         "s_cmp_lt_u32 %[u], %[nt]",
         "s_cbranch_scc1 conv_loop%=",
         "conv_drain%=:",
-        "; ---- drain: products of the last step (set 1's accumulators, rows r4cur)",
+        "; ---- drain: products of the last step (set 1) onto the sums read during it",
+        "s_waitcnt lgkmcnt(0)",
+        "s_nop 15",                    # MFMA result -> VALU read needs 11 wait states after an 8-pass MFMA; nothing else separates them here
     ]
-    o += row_addr(L["r4cur"], range(4)) + sum_reads(range(4)) + ["s_waitcnt lgkmcnt(0)"] + sum_adds_writes(V["C"][1])
+    o += sum_adds(1, V["C"][1]) + sum_writes(1)
     o += ["s_waitcnt vmcnt(0) lgkmcnt(0)"]
     return o
 
@@ -274,7 +328,10 @@ def main():
                 f.write('    "' + ln + '\\n" \\\n')
             f.write('    ""\n')
             print(f"{name}: {len(o)} lines")
-        f.write("#define CONV_LOOP_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + ', "vcc", "scc", "memory"\n')
+        f.write("#define CONV_LOOP_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + (", " + ", ".join(f'"s{i}"' for i in range(60, 76)) if EXP & 8 else "")
+                + ', "vcc", "scc", "memory"\n')
+        if EXP & 8:
+            f.write("#define CONV_LOOP_STAMPS 1\n")
     print(f"wrote {path}")
 
 

@@ -130,12 +130,13 @@ int conv_pick_rows(int64_t n)
         if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128 && forced != 255) forced = 0;
     }
     if (forced) return forced;
-    // the biggest levels: 255-row blocks at one wave per SIMD (4 x 35 KiB of LDS sums per CU) -- per-offset tiles fill
-    // ~20 % better, and the asm loop keeps the matrix pipe fed from a single wave (32-bit row offsets: n < 2^25)
+    // every level the cooperative kernel does not take: the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
+    // with the block height set by conv_pick_height -- up to 1024 blocks run as ONE round of equal blocks, one per SIMD
+    // (measured against 2-3 waves per SIMD on 32..128-row blocks: 34 k nodes 40 vs 56 us, 92 k 75 vs 88, 251 k 185 vs 199,
+    // 540 k 322 vs 377).  The asm loop addresses rows with 32-bit offsets: n < 2^25.
     static int64_t tall_min = -1;
-    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 768 * 1024; }
+    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 24 * 1024; }
     if (n >= tall_min && n < ((int64_t)1 << 25)) return 255;
-    // enough waves to cover the chip a few times over before growing the block height
     if (n >= 192 * 1024) return 128;
     if (n >= 96 * 1024) return 64;
     if (n >= 24 * 1024) return 32;
@@ -149,10 +150,13 @@ int conv_pick_rows(int64_t n)
 int conv_pick_height(int64_t n, int R)
 {
     static int balance = -1;
-    if (balance < 0) { const char *e = getenv("GAUSPCC_CONV_BALANCE"); balance = e ? atoi(e) : 0; }
+    if (balance < 0) { const char *e = getenv("GAUSPCC_CONV_BALANCE"); balance = e ? atoi(e) : 2; }
     if (!balance || R <= 16) return R;
     const int64_t slots = 1024 * (int64_t)(R >= 255 ? 1 : 2);
     const int64_t k = cdiv(n, slots * R);
+    // measured (MI355X, 1 M-point cloud): with the longest-first order a last round that is mostly full costs nothing
+    // (3.6 blocks per slot at 255 rows beat 4.0 at 231), a nearly empty one does (2.07 -> 3.0 rounds of 176 rows: -19 %)
+    if (balance == 2 && (double)(k * slots * R - n) < 0.2 * (double)(k * slots * R)) return R;
     const int64_t H = cdiv(n, slots * k);
     return (int)std::min<int64_t>(R, std::max<int64_t>(H, 16));
 }
@@ -166,11 +170,9 @@ __global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__
 }
 
 // CONV_HDR_PAD zeroed tiles behind the list, whose length lives on the device
-__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc,
-                                                   uint32_t *__restrict__ ctr)
+__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc)
 {
     const uint32_t t = *total;
-    if (threadIdx.x < 2) ctr[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD * 16; i += 64) tj[(size_t)t * 16 + i] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD * 4; i += 64) tr4[(size_t)t * 4 + i] = 0;
     for (int i = threadIdx.x; i < CONV_HDR_PAD; i += 64) toc[t + i] = 0;
@@ -206,9 +208,8 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     TAKE(tj, int32_t, cap * 16);
     TAKE(tr, uint8_t, cap * 16);
     TAKE(toc, uint32_t, cap);
-    TAKE(ctr, uint32_t, 2);
-    T->tj = tj; T->tr = tr; T->toc = toc; T->ctr = ctr;
-    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc, ctr);
+    T->tj = tj; T->tr = tr; T->toc = toc;
+    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc);
     LAUNCH_CHECK();
     k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, H, first, tj, tr, toc, nullptr);
     LAUNCH_CHECK();
@@ -258,7 +259,7 @@ __device__ unsigned long long g_conv_timing[16];
 // ASM = true: the tile loop is the hand-scheduled gfx950 instruction stream of conv_loop_gfx950.inc (row offsets are
 // 32-bit there: n < 2^25).  ASM = false: the same loop in HIP C++ (any n; also the readable statement of the schedule).
 template <int R, int DIST, bool ASM>
-__global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs, int persist)
+__global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
 {
     constexpr int CONV_LDS_WAVE = conv_lds_wave_floats(R);  // R rows + 1 dummy row for padding entries + the tile-header ring
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -266,19 +267,13 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     // everything derived from the wave index is wave-uniform: keep it in SGPRs (scalar loads for the tile
     // headers, scalar address arithmetic for the weight fragments)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // Work items are (block, job) pairs, w = slot * njobs + job with slot running over the blocks longest first.
-    // persist = 0: one item per wave (w from the grid position).  persist = 1: the grid is exactly the waves the chip
-    // holds at once and every wave draws items from T.ctr[0] until they run out -- a SIMD never waits for the other
-    // three waves of a workgroup to finish before it gets new work, and there is no workgroup launch between blocks.
-    // No block-wide barrier anywhere: every wave works on its own LDS slice.
+    // Work items are (block, job) pairs, one per wave: w = slot * njobs + job with slot running over the blocks longest
+    // first (neighbouring waves share a block's tile list across the jobs of a batched launch).  No block-wide barrier
+    // anywhere: every wave works on its own LDS slice.
     const uint32_t total = (uint32_t)T.nblk * (uint32_t)njobs;
-    auto draw = [&]() -> uint32_t {
-        uint32_t v = 0;
-        if (lane == 0) v = atomicAdd(T.ctr, 1u);
-        return v;
-    };
-    uint32_t w = persist ? (uint32_t)__builtin_amdgcn_readfirstlane((int)draw()) : (uint32_t)(blockIdx.x * SC_WAVES + wave);
-    while (w < total) {
+    const uint32_t w = (uint32_t)(blockIdx.x * SC_WAVES + wave);
+    if (w >= total) return;
+    {
     CT_STAMP(ct0);
 #ifdef CONV_TIMING
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
@@ -473,8 +468,6 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
 #endif
     }
     CT_STAMP(ct3);
-    uint32_t w_next = 0;
-    if (persist) w_next = draw();   // the next item's number arrives while the epilogue runs
     // epilogue: the block's rows are contiguous in the output and already in the physical channel order -> straight 16-byte
     // copies, 64 rows (512 float4, 8 per lane) per batch.  Every branch is wave-uniform; only the last batch of a block
     // (and the last block of a level) is predicated.  Residual rows of a batch are all requested before the first is used.
@@ -534,14 +527,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
         atomicAdd(&g_conv_timing[6], rt1 - rt0); atomicMin(&g_conv_timing[7], rt0); atomicMax(&g_conv_timing[8], rt1); atomicMax(&g_conv_timing[9], rt1 - rt0);
     }
 #endif
-    if (!persist) break;
-    w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w_next);
     }
-#ifdef CONV_TIMING
-    if (lane == 0) { const unsigned long long rt = __builtin_amdgcn_s_memrealtime(); atomicMin(&g_conv_timing[10], rt); atomicMax(&g_conv_timing[11], rt); }
-#endif
-    // the last wave to leave puts the two counters back to zero for the next launch on this tile list
-    if (persist && lane == 0 && atomicAdd(T.ctr + 1, 1u) == gridDim.x * SC_WAVES - 1u) { T.ctr[0] = 0; T.ctr[1] = 0; }
 }
 
 // Small levels (16-row blocks: every (block, offset) pair is exactly one tile, a block's list is a serial chain of up to
@@ -722,26 +708,10 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
         return GPCC_OK;
     }
-    // work items = blocks x jobs.  More items than the chip holds waves: persistent launch, exactly the resident waves,
-    // each drawing items from the tile list's counter (GAUSPCC_CONV_PERSIST=0: one item per wave, as for small launches)
-    static int persist_on = -1, n_cu = 0;
-    if (persist_on < 0) {
-        const char *e = getenv("GAUSPCC_CONV_PERSIST");
-        persist_on = e ? atoi(e) : 0;
-        int dev = 0;
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount;
-    }
-    const int64_t items = T.nblk * njobs;
-    const int wg_per_cu = T.R >= 255 ? 1 : 2;   // what LDS (255 / 128 rows) and registers (186-220 VGPRs) let a CU hold
-    const int64_t resident = (int64_t)n_cu * wg_per_cu;
-    const int persist = persist_on && T.ctr && items > resident * SC_WAVES ? 1 : 0;
-    dim3 grid((unsigned)(persist ? resident : cdiv(items, SC_WAVES)), 1u);
+    dim3 grid((unsigned)cdiv(T.nblk * njobs, SC_WAVES), 1u);   // work items = blocks x jobs, one per wave
     const size_t lds_bytes = (size_t)SC_WAVES * conv_lds_wave_floats(T.R) * 4;
     const bool asm_ok = use_asm && dist == 1 && n < ((int64_t)1 << 25);   // the asm loop addresses rows with 32-bit byte offsets
-#define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs, persist)
+#define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs)
     switch (T.R) {
     case 16: if (asm_ok) CONV_LAUNCH(16, 1, true); else CONV_LAUNCH(16, 1, false); break;
     case 32: if (asm_ok) CONV_LAUNCH(32, 1, true); else CONV_LAUNCH(32, 1, false); break;
@@ -761,16 +731,16 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
 #ifdef CONV_TIMING
     if (prof) {
         unsigned long long h[16], z[16] = {0};
-        z[7] = ~0ull; z[10] = ~0ull;
+        z[7] = ~0ull;
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->prof.pool[(size_t)rec.e0], ctx->prof.pool[(size_t)rec.e1]));
         HIP_TRY(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_conv_timing), sizeof h));
         HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_conv_timing), z, sizeof z));
         const double waves = (double)h[4], tiles = (double)h[3];
-        fprintf(stderr, "[conv] R %3d H %3d jobs %d n %8lld blocks %6.0f tiles %9.0f  %.1f us | per wave: setup %.0f loop %.0f epilogue %.0f total %.0f cyc | loop %.0f cyc/tile | clock %.0f MHz | span %.1f us, wave time / 1024 slots %.1f us, longest block %.1f us, first wave exit at %.1f us, last at %.1f us\n",
+        fprintf(stderr, "[conv] R %3d H %3d jobs %d n %8lld blocks %6.0f tiles %9.0f  %.1f us | per wave: setup %.0f loop %.0f epilogue %.0f total %.0f cyc | loop %.0f cyc/tile | clock %.0f MHz | span %.1f us, wave time / 1024 slots %.1f us, longest block %.1f us\n",
                 T.R, T.H, njobs, (long long)n, waves, tiles, ms * 1e3, h[0] / waves, h[1] / waves, h[2] / waves, h[5] / waves, h[1] / tiles, 100.0 * h[5] / (double)h[6],
-                (h[8] - h[7]) / 100.0, h[6] / 100.0 / 1024.0, h[9] / 100.0, (h[10] - h[7]) / 100.0, (h[11] - h[7]) / 100.0);
+                (h[8] - h[7]) / 100.0, h[6] / 100.0 / 1024.0, h[9] / 100.0);
         if (h[12] + h[13] + h[14] + h[15])
             fprintf(stderr, "[conv]    per tile: step-start wait %.0f, first pair + VALU burst + LDS issue %.0f, second pair + loads issue %.0f, remaining 12 MFMAs %.0f cycles\n",
                     h[12] / tiles, h[13] / tiles, h[14] / tiles, h[15] / tiles);

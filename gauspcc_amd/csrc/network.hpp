@@ -86,7 +86,6 @@ struct ConvTiles {
     uint32_t *toc = nullptr;   // [tiles]     offset | valid entries << 16
     uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
     uint32_t *order = nullptr; // [nblk]      blocks sorted by tile count, longest first (dispatch order)
-    uint32_t *ctr = nullptr;   // [2]         work counter / exit counter of the persistent launches (zero between launches)
     int64_t nblk = 0;
     int R = CONV_R_MAX;        // capacity class of the blocks (LDS rows per wave; selects the kernel)
     int H = CONV_R_MAX;        // rows per block, <= R: chosen so that the blocks fill the chip's wave slots a whole number of times

@@ -4,7 +4,8 @@ The block height (and with it the kernel: cooperative 16-row kernel, wave-serial
 HIP C++ loop) is picked from the level size, so a 10 k-point test cloud only ever meets the small-level kernels.  The
 policy is read once per process from the environment; each variant therefore runs in its own interpreter:
 GAUSPCC_CONV_R forces the block height, GAUSPCC_CONV_ASM=0 the C++ loop, GAUSPCC_CONV_COOP=0 the wave-serial kernel on
-16-row blocks."""
+16-row blocks, GAUSPCC_CONV_BALANCE the block-height rule (0: the class height, 1: always equal blocks, default 2: equal
+blocks when the last round would be mostly empty)."""
 import os
 import subprocess
 import sys
@@ -56,6 +57,9 @@ print("variant ok", pairs)
     {"GAUSPCC_CONV_R": "16", "GAUSPCC_CONV_COOP": "0"},
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_ASM": "0"},
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "0"},
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "1"},
+    {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_BALANCE": "1"},
 ], ids=lambda e: ",".join(f"{k[13:]}={v}" for k, v in e.items()))
 def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)

@@ -3,16 +3,15 @@
 // k_sparse_conv   submanifold 3-D convolution, C = 32, exact fp32 on v_mfma_f32_16x16x4_f32.
 //                 A submanifold conv on an octree level is ~90 % empty (7..25 of the 125 taps exist),
 //                 so the work is the list of (output row, neighbour row) PAIRS, not rows x offsets.
-//                 Each wave owns 128 consecutive Morton-ordered output rows (spatially compact) and
-//                 keeps their 128 x 32 fp32 accumulators in wave-private LDS (16 KiB).  Per kernel
-//                 offset the block's pairs were compacted (k_conv_tiles, once per level) into tiles
-//                 of 16 rows; per tile the wave gathers the 16 neighbour rows (A operand: one
-//                 contiguous 32-byte load per lane thanks to the physical channel order), loads the
-//                 pre-swizzled 4 KiB weight fragment of the offset (B operand), pulls the 16 x 32
-//                 partial sums out of LDS into the MFMA C registers, issues 16 MFMAs and puts the
-//                 result back.  Offsets are visited in ascending order and every output element is
-//                 one fma chain over (offset, k) -- exactly the oracle's order, so results are
-//                 bit-exact no matter how rows are packed into tiles.
+//                 Each wave owns up to 255 consecutive Morton-ordered output rows (spatially compact) and
+//                 keeps their fp32 sums in wave-private LDS.  Per kernel offset the block's pairs were
+//                 compacted (k_conv_tiles, once per level) into tiles of 16 rows; per tile the wave gathers
+//                 the 16 neighbour rows, loads the pre-swizzled 4 KiB weight fragment of the offset, issues
+//                 16 MFMAs from a zero accumulator and adds the 16 x 32 products to the rows' sums in LDS.
+//                 Offsets are visited in ascending order: acc = acc + (fma chain over k from 0) per offset,
+//                 exactly the oracle's order, so results are bit-exact no matter how rows are packed into
+//                 tiles.  The asm tile loop (conv_loop_gfx950.inc) computes the product transposed; see
+//                 tools/gen_conv_loop.py and DESIGN.md section 4 for why.
 //                 Bound: fp32 MFMA (2*32*32 flop per pair); gathers come from L2/MALL.
 // k_head          Linear-ReLU-Linear-softmax-cumsum-integerise, one node per lane, weights through
 //                 the scalar cache.  Negligible next to the convolutions.

@@ -37,6 +37,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);

@@ -118,13 +118,21 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             }
         }
         ht.mark("enc maps queued");
+        // the target set's tile list is built on the side stream beside the prior set's trunk
+        GP_TRY(ctx->side_init());
+        hipStream_t sd = ctx->side;
+        struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } side_guard{sd};
+        HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ConvTiles tilesP, tilesC;
         GP_TRY(conv_tiles_build(ctx, st, nbrPs, nP, K, &tilesP, pairs_dev));
-        GP_TRY(conv_tiles_build(ctx, st, nbrCs, nC, K, &tilesC, pairs_dev + 1));
-        ht.mark("enc tiles built");
         TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
         GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF));
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
+        HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
+        GP_TRY(conv_tiles_build(ctx, sd, nbrCs, nC, K, &tilesC, pairs_dev + 1));
+        HIP_TRY(hipEventRecord(ctx->ev_side, sd));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
+        ht.mark("enc tiles built");
         TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
         GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX));
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)
@@ -378,29 +386,47 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     ConvTiles tilesP;
     GP_TRY(conv_tiles_build(ctx, st, nbrP, bn, K, &tilesP, pairs_dev));
     int64_t coded = 0;
-    // Arena discipline: level g allocates [child arrays | child neighbour map | chunk table] (kept: they are
-    // level g+1's parent data) and then its work buffers, which are rewound at the end of the level.
+    // Two streams.  `st` carries the network of a level (18 convolutions, heads, range decoder).  The octree work that only
+    // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's neighbour map and
+    // tile list -- runs on the context's side stream beside the parent trunk's five convolutions and fills the idle tails
+    // of their launches.  ev_main: the parent level is complete on st; ev_side: the child's structure is ready.
+    GP_TRY(ctx->side_init());
+    hipStream_t sd = ctx->side;
+    struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } side_guard{sd};   // error returns leave nothing in flight
+    HIP_TRY(hipEventRecord(ctx->ev_main, st));
+    // Arena discipline: a level's child arrays, neighbour map, tile list and chunk table come from the bottom (kept: they are
+    // the next level's parent data), its feature buffers from the top (rewound at the end of the level).
     for (int g = 0; g + 1 < L; ++g) {
+        const size_t top_mk = ctx->arena.top_mark();
+        const int64_t np = cur.n;
+        // ---- st: parent trunk
+        TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
+        GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
+        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
+        // ---- side: the child level's structure
+        HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
         Level chi;
         int64_t nc = lvl_n[g + 1];
         if (!v1) {
-            GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
-            HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            GP_TRY(level_expand(ctx, sd, &cur, nullptr, dtotal));
+            HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, sd));
+            HIP_TRY(hipStreamSynchronize(sd));
             nc = htotal[0];
             lvl_n[g + 1] = nc;
         }
         if (nc <= 0 || nc > 8 * cur.n) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", g + 1);
         GP_TRY(alloc_level(&chi, nc, L - g - 1));
-        GP_TRY(level_expand(ctx, st, &cur, &chi, dtotal));
-        if (v1) {  // verify the header against the occupancy actually decoded (checked at the next sync)
-            HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, st));
+        GP_TRY(level_expand(ctx, sd, &cur, &chi, dtotal));
+        if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
+            HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
         }
-        GP_TRY(level_raster_rank(ctx, st, &chi, hb + g + 1));
+        GP_TRY(level_raster_rank(ctx, sd, &chi, hb + g + 1));
         TAKE(nbrC, int32_t, (int64_t)K * nc);
-        GP_TRY(nbr_child(ctx, st, &cur, nbrP, &chi, m->k, nbrC));
+        GP_TRY(nbr_child(ctx, sd, &cur, nbrP, &chi, m->k, nbrC));
         ConvTiles tilesC;
-        GP_TRY(conv_tiles_build(ctx, st, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
+        GP_TRY(conv_tiles_build(ctx, sd, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
+        HIP_TRY(hipEventRecord(ctx->ev_side, sd));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
         // chunk descriptors of this level's four streams
         const int clog = rc_level_chunk_log2(nc, chunk_log2, version);   // this level's chunk size
         const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
@@ -427,17 +453,13 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         TAKE(dchunks, RcChunk, 4 * nch);
         HIP_TRY(hipMemcpyAsync(dchunks, chunks, sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));   // pinned, write-once: no sync
-        const size_t mk = ctx->arena.mark();
-        const int64_t np = cur.n;
-        TAKE(pF, float, np * 32); TAKE(pA, float, np * 32); TAKE(pB, float, np * 32);
-        GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
-        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
-        TAKE(cX, float, nc * 32); TAKE(cA, float, nc * 32); TAKE(cB, float, nc * 32); TAKE(cU, float, nc * 32);
+        // ---- st: child trunk and the four stages
+        TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
         GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        TAKE(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? S : nc) * 16);  // interleaved rows + the decoder's look-ahead
+        TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? S : nc) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
-        for (int s = 0; s < 4; ++s) { TAKE(sy, uint8_t, nc); sym[s] = sy; }
+        for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc); sym[s] = sy; }
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
             if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
@@ -454,7 +476,8 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
         }
         GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ));
-        ctx->arena.rewind(mk);
+        HIP_TRY(hipEventRecord(ctx->ev_main, st));
+        ctx->arena.top_rewind(top_mk);
         coded += nc;
         cur = chi; nbrP = nbrC; tilesP = tilesC;
         ht.mark("dec level queued", g + 1, nc);

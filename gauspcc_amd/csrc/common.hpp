@@ -50,10 +50,11 @@ constexpr int CH = 32;             // channels the MFMA kernels are specialised 
 
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// Bump allocator over one hipMalloc'd slab; reset at the start of every API call.
+// Bump allocator over one hipMalloc'd slab; reset at the start of every API call.  Two ends: take() grows from the bottom
+// (data that outlives a step of the caller's loop), take_top() from the top (per-step work buffers, rewound by the caller).
 struct Arena {
     char *base = nullptr;
-    size_t cap = 0, off = 0;
+    size_t cap = 0, off = 0, top = 0;
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return GPCC_OK;
@@ -61,18 +62,27 @@ struct Arena {
         base = nullptr; cap = 0;
         size_t want = bytes + (bytes >> 3) + (1 << 20);
         HIP_TRY(hipMalloc((void **)&base, want));
-        cap = want;
+        cap = want; top = want & ~size_t(255);
         return GPCC_OK;
     }
-    void reset() { off = 0; }
+    void reset() { off = 0; top = cap & ~size_t(255); }
     template <typename T> T *take(size_t count)
     {
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
-        if (off + bytes > cap) return nullptr;
+        if (off + bytes > top) return nullptr;
         T *p = reinterpret_cast<T *>(base + off);
         off += bytes;
         return p;
     }
+    template <typename T> T *take_top(size_t count)
+    {
+        size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+        if (off + bytes > top) return nullptr;
+        top -= bytes;
+        return reinterpret_cast<T *>(base + top);
+    }
+    size_t top_mark() const { return top; }
+    void top_rewind(size_t m) { top = m; }
     size_t mark() const { return off; }
     void rewind(size_t m) { off = m; }
 };
@@ -133,7 +143,22 @@ struct gpcc_ctx {
     gpcc::HostBuf<uint8_t> hbytes;  // pinned output / staging bytes
     gpcc::HostBuf<uint8_t> hstage;  // pinned small staging (counts, flags, descriptors)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // second stream of the codec: octree / tile-list work of the next step runs beside the convolutions of this one
+    hipStream_t side = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    int side_init()
+    {
+        if (side) return GPCC_OK;
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        return GPCC_OK;
+    }
 };
+
+#define TAKE_TOP(var, T, count)                                                                    \
+    T *var = ctx->arena.take_top<T>((size_t)(count));                                              \
+    if (!var) return gpcc::fail(GPCC_ERR_NOMEM, "%s:%d workspace arena exhausted (%s x %lld)", __FILE__, __LINE__, #T, (long long)(count))
 
 #define TAKE(var, T, count)                                                                        \
     T *var = ctx->arena.take<T>((size_t)(count));                                                  \

@@ -51,7 +51,7 @@ V = dict(
     hjp=164, hrp=165, hop=166,
     sgr=167, sgo=168, swj=169, swr=170, swo=171, swjm=172, swrm=173, swom=174,
 )
-CLOBBER_V = list(range(16, 175))
+CLOBBER_V = list(range(16, 176))
 NSTEP = 4                              # lcm(D + 1, 2)
 WINDOW = 6 * (D - 1)                   # tile loads that may stay in flight across a step start
 # byte offsets inside the header ring (must match network.hip: HDR_R, HDR_O)
@@ -231,7 +231,10 @@ def step(du):
     # the step's only VALU burst: previous tile's products onto its rows' sums, addresses of the loads and of this tile's slot
     o += (ring_pointers() if du == 0 else [])
     o += sum_adds(prv, CP) + addr_x() + addr_w()
-    o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
+    if EXP & 16:   # developer experiment: every lane on its own conflict-free slot (wrong sums, LDS timing without bank conflicts)
+        o += [f"v_mov_b32 v{V['ra'][cur]}, v{V['t0'] + 24}"]
+    else:
+        o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
     # memory instructions issue slowly (measured: ~20 cycles an LDS, ~13 a global load instruction, during which an in-order
     # wave issues nothing else) but, unlike VALU work, they do overlap a running MFMA: one in front of each remaining MFMA
     mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nset) + loads_w(nset)
@@ -285,6 +288,10 @@ def build():
         f"v_cmp_gt_u32 vcc, 4, v{L['t0']}",
         f"v_cndmask_b32 v{L['swom']}, v{L['swo']}, v{L['swom']}, vcc",
         f"v_mov_b32 v{L['ra'][1]}, v{L['accb']}",                   # "previous tile" of step 0: the dummy slot
+    ] + ([f"v_and_b32 v{L['t0']}, 15, %[lane]", f"v_lshrrev_b32 v{L['t0'] + 24}, 1, v{L['t0']}", f"v_lshrrev_b32 v{L['ao']}, 4, %[lane]",
+           f"v_xor_b32 v{L['t0'] + 24}, v{L['t0'] + 24}, v{L['ao']}", f"v_and_b32 v{L['t0'] + 24}, 7, v{L['t0'] + 24}",
+           f"v_lshlrev_b32 v{L['t0'] + 24}, 4, v{L['t0'] + 24}", f"v_lshl_add_u32 v{L['t0'] + 24}, v{L['t0']}, 7, v{L['t0'] + 24}",
+           f"v_add_u32 v{L['t0'] + 24}, %[acc], v{L['t0'] + 24}"] if EXP & 16 else []) + [
         "; ---- pipeline prologue: X and W of tiles 0..D-1 in flight; headers j(D), o(D), slot(0) in registers",
         "s_waitcnt lgkmcnt(0)",
     ]

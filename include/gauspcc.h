@@ -2,7 +2,8 @@
  * gauspcc.h -- C ABI of libgauspcc.so, the MI355X (gfx950) implementation of the
  * GausPcc hot path.  Plain pointers and sizes only; every device pointer is a HIP
  * device address on the context's device, every `stream` is a hipStream_t passed
- * as void* (NULL = the legacy default stream).
+ * as void* (NULL = the legacy default stream).  gpcc_encode / gpcc_decode also use a second stream the
+ * context owns (event-fenced against `stream`); a context serves one call at a time.
  *
  * Each entry point cites the reference interface it replaces (paths relative to the
  * reference repository root).  All functions return 0 on success or a negative

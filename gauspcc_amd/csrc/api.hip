@@ -62,10 +62,22 @@ extern "C" int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out)
     return GPCC_OK;
 }
 
+// the runtime's blit path moved 12 MB in 220 us (54 GB/s) here; a plain grid of 16-byte copies does it in ~10
+__global__ __launch_bounds__(256) void k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int64_t n16)
+{
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 extern "C" int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst, const void *src, int64_t nbytes, void *stream)
 {
     if (!ctx || !dst || !src || nbytes < 0) return fail(GPCC_ERR_ARG, "bad argument");
     HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t n16 = nbytes / 16;
+    if (n16 > 0 && (reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) % 16 == 0) {
+        k_copy16<<<(unsigned)std::min<int64_t>(cdiv(n16, 256), 8192), 256, 0, (hipStream_t)stream>>>(static_cast<const uint4 *>(src), static_cast<uint4 *>(dst), n16);
+        LAUNCH_CHECK();
+        if (nbytes % 16) HIP_TRY(hipMemcpyAsync(static_cast<char *>(dst) + 16 * n16, static_cast<const char *>(src) + 16 * n16, (size_t)(nbytes % 16), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    } else
     HIP_TRY(hipMemcpyAsync(dst, src, (size_t)nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return GPCC_OK;
@@ -448,7 +460,7 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     GP_TRY(rc_pack_lohi(st, cdf_dev, lp, sym_dev, n, chunk_log2, lohi));
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
-    GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nch, payload));
+    GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nullptr, nch, payload));
     std::vector<uint32_t> hcnt((size_t)nch + 1);
     HIP_TRY(hipMemcpyAsync(hcnt.data(), dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hcnt.data() + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));

@@ -343,7 +343,7 @@ static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, CT cdf, int chunk
     LAUNCH_CHECK();
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
-    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nch, payload));
+    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nullptr, nch, payload));
     GP_TRY(ctx->hstage.reserve(4 * (size_t)nch + 64));
     uint32_t *hcnt = reinterpret_cast<uint32_t *>(ctx->hstage.p);
     HIP_TRY(hipMemcpyAsync(hcnt, dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
@@ -655,7 +655,7 @@ extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const 
     LAUNCH_CHECK();
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
-    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nch, payload));
+    GP_TRY(rc_compact_launch(st, scratch, sstride, dcnt, doff, nullptr, nch, payload));
     GP_TRY(ctx->hstage.reserve(4 * (size_t)nch + 8 * (size_t)nslices + 64));
     uint32_t *hcnt = reinterpret_cast<uint32_t *>(ctx->hstage.p);
     int32_t *hmm = reinterpret_cast<int32_t *>(hcnt + nch + 1);

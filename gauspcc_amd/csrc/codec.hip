@@ -161,10 +161,12 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     // ---- range coder over every chunk of every stream
     const int nstreams = 4 * (L - 1);
     std::vector<RcChunk> chunks;
+    std::vector<uint32_t> gaps;          // container bytes in front of a chunk's payload that are not payload: stream lengths + chunk tables
     std::vector<int> stream_first(nstreams + 1, 0);
     uint32_t max_syms = 1;
     {
         int64_t pre = 0; int si = 0;
+        uint32_t gap = 0;
         for (int d = 1; d < L; ++d) {
             const int64_t nc = T.lv[d].n;
             const int64_t S = chunk_log2 ? (int64_t)1 << clog(nc) : INT64_MAX;
@@ -172,8 +174,10 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 stream_first[si] = (int)chunks.size();
                 const int64_t base = pre + (int64_t)s * slots(nc);
                 const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(nc, S) : 1u;
+                gap += 4u + (chunk_log2 ? 2u * nch : 0u);
                 for (uint32_t c = 0; c < nch; ++c) {
                     const int64_t cn = chunk_log2 ? std::min<int64_t>(S, nc - (int64_t)c * S) : nc;
+                    gaps.push_back(gap);
                     chunks.push_back(RcChunk{(uint32_t)(base + c), nch, (uint32_t)cn, 0, 0, 0});
                     max_syms = std::max<uint32_t>(max_syms, (uint32_t)cn);
                 }
@@ -187,17 +191,22 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     TAKE(base_xyz, int32_t, 3 * base->n);
     TAKE(base_occ, uint8_t, base->n);
     GP_TRY(level_to_raster(ctx, st, base, base_xyz, base_occ));
-    // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ]
+    // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ | gaps]
     const size_t off_desc = 0, off_cnt = off_desc + sizeof(RcChunk) * (size_t)std::max(nchunks, 1);
     const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * MAXLV, off_bo = off_bx + 12 * (size_t)base->n;
-    GP_TRY(ctx->hstage.reserve(off_bo + (size_t)base->n + 64));
+    const size_t off_gap = (off_bo + (size_t)base->n + 63) & ~(size_t)63;
+    GP_TRY(ctx->hstage.reserve(off_gap + 4 * (size_t)std::max(nchunks, 1) + 64));
+    const uint32_t gap_total = gaps.empty() ? 0u : gaps.back();
     uint8_t *hs = ctx->hstage.p;
     uint32_t total_payload = 0;
     uint8_t *payload_dev = nullptr;
     if (nchunks) {
         memcpy(hs + off_desc, chunks.data(), sizeof(RcChunk) * (size_t)nchunks);
+        memcpy(hs + off_gap, gaps.data(), 4 * (size_t)nchunks);
         const uint32_t stride = rc_scratch_stride(max_syms);
         TAKE(dchunks, RcChunk, nchunks);
+        TAKE(dgap, uint32_t, nchunks);
+        HIP_TRY(hipMemcpyAsync(dgap, hs + off_gap, 4 * (size_t)nchunks, hipMemcpyHostToDevice, st));
         TAKE(dcnt, uint32_t, nchunks + 1);
         TAKE(doff, uint32_t, nchunks + 1);
         TAKE(scratch, uint8_t, (size_t)nchunks * stride);
@@ -206,9 +215,10 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt + 4 * (size_t)nchunks, doff + nchunks, 4, hipMemcpyDeviceToHost, st));
-        // worst case payload = all scratch; compact into a buffer of that size, copy back only the used part
-        TAKE(payload, uint8_t, (size_t)nchunks * stride);
-        GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nchunks, payload));
+        // worst case payload = all scratch; compact into a buffer of that size -- every chunk at its final distance from the
+        // first stream's length field -- and copy back only the used part, in one piece
+        TAKE(payload, uint8_t, (size_t)nchunks * stride + gap_total);
+        GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload));
         payload_dev = payload;
     }
     HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * MAXLV, hipMemcpyDeviceToHost, st));
@@ -237,24 +247,31 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     memcpy(out + pos, hs + off_bx, 12 * (size_t)base->n); pos += 12 * (size_t)base->n;
     memcpy(out + pos, hs + off_bo, (size_t)base->n); pos += (size_t)base->n;
     out[pos] = (uint8_t)nstreams; out[pos + 1] = (uint8_t)(nstreams >> 8); pos += 2;
-    // payload bytes come straight from the device into their final place, stream by stream
+    // the payload comes straight from the device into its final place in one copy; the stream lengths and chunk tables
+    // are then written into the gaps it left
     {
-        size_t src = 0;
+        const size_t pos0 = pos, body = (size_t)total_payload + gap_total;
+        if (body) HIP_TRY(hipMemcpyAsync(out + pos0, payload_dev, body, hipMemcpyDeviceToHost, st));
+        for (int si = 0; si < nstreams; ++si) {
+            const int c0 = stream_first[si], c1 = stream_first[si + 1];
+            size_t plen = 0;
+            for (int c = c0; c < c1; ++c) plen += hcnt[c];
+            for (int c = c0; c < c1; ++c) if (chunk_log2 && hcnt[c] > 0xFFFF) return fail(GPCC_ERR_ARG, "chunk byte count overflows uint16");
+            pos += 4 + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0) + plen;
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        size_t p = pos0;
         for (int si = 0; si < nstreams; ++si) {
             const int c0 = stream_first[si], c1 = stream_first[si + 1];
             size_t plen = 0;
             for (int c = c0; c < c1; ++c) plen += hcnt[c];
             const size_t slen = plen + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0);
-            put32(out + pos, (uint32_t)slen); pos += 4;
+            put32(out + p, (uint32_t)slen); p += 4;
             if (chunk_log2)
-                for (int c = c0; c < c1; ++c) {
-                    if (hcnt[c] > 0xFFFF) return fail(GPCC_ERR_ARG, "chunk byte count overflows uint16");
-                    out[pos] = (uint8_t)hcnt[c]; out[pos + 1] = (uint8_t)(hcnt[c] >> 8); pos += 2;
-                }
-            if (plen) HIP_TRY(hipMemcpyAsync(out + pos, payload_dev + src, plen, hipMemcpyDeviceToHost, st));
-            pos += plen; src += plen;
+                for (int c = c0; c < c1; ++c) { out[p] = (uint8_t)hcnt[c]; out[p + 1] = (uint8_t)(hcnt[c] >> 8); p += 2; }
+            p += plen;
         }
-        HIP_TRY(hipStreamSynchronize(st));
+        if (p != pos) return fail(GPCC_ERR_HIP, "internal: container layout mismatch");
     }
     ht.mark("enc payload d2h");
     if (pos != fsize) return fail(GPCC_ERR_HIP, "internal: container size mismatch (%zu vs %zu)", pos, fsize);

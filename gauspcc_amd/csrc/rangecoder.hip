@@ -87,13 +87,15 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
 }
 
 // gather the per-chunk scratch rows into one contiguous payload; one block per chunk
+// (gap, optional: bytes the container puts in front of chunk c on top of the chunk bytes before it -- stream headers and
+// chunk tables -- so that the payload lands in its final place and leaves the device in one copy)
 __global__ __launch_bounds__(256) void k_rc_compact(const uint8_t *__restrict__ scratch, uint32_t stride, const uint32_t *__restrict__ cnt,
-                                                    const uint32_t *__restrict__ off, uint8_t *__restrict__ payload)
+                                                    const uint32_t *__restrict__ off, const uint32_t *__restrict__ gap, uint8_t *__restrict__ payload)
 {
     const int c = blockIdx.x;
     const uint32_t n = cnt[c];
     const uint8_t *src = scratch + (size_t)c * stride;
-    uint8_t *dst = payload + off[c];
+    uint8_t *dst = payload + off[c] + (gap ? gap[c] : 0u);
     for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
@@ -312,10 +314,10 @@ int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks
     return GPCC_OK;
 }
 
-int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, int nchunks, uint8_t *payload)
+int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload)
 {
     if (nchunks <= 0) return GPCC_OK;
-    k_rc_compact<<<(unsigned)nchunks, 256, 0, st>>>(scratch, stride, cnt, off, payload);
+    k_rc_compact<<<(unsigned)nchunks, 256, 0, st>>>(scratch, stride, cnt, off, gap, payload);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

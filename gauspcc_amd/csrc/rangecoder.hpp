@@ -46,7 +46,7 @@ static inline int rc_level_chunk_log2(int64_t n, int chunk_log2, int version)
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);
-int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, int nchunks, uint8_t *payload);
+int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload);
 // cdf: compact interleaved rows (rc_row_stride uint16 per row)
 int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym);
 // full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words

@@ -28,6 +28,11 @@ def report(name, seg):
     print("   idle by gap size:", {k: f"{v/1e6:.2f}ms" for k, v in hist.items()})
     for g, a, b in sorted(gaps, reverse=True)[:8]:
         print(f"   gap {g/1e3:8.1f} us  after {a[:50]}  before {b[:50]}")
+    big = sorted(range(len(gaps)), key=lambda i: -gaps[i][0])[:3]
+    for i in sorted(big):
+        print(f"   around the {gaps[i][0]/1e3:.0f} us gap (t = {(seg[i][1] - seg[0][0])/1e3:.0f} us after the first kernel):")
+        for s_, e_, n_ in seg[max(0, i - 3): i + 5]:
+            print(f"      {(s_ - seg[0][0])/1e3:9.1f} us  +{(e_ - s_)/1e3:7.1f}  {n_[:60]}")
     agg = collections.defaultdict(lambda: [0, 0])
     for s, e, n in seg:
         agg[n][0] += 1

@@ -127,7 +127,9 @@ def save_ply_ascii_geo(coords, filedir):
 def _decode_bytes(data: bytes, model, device):
     ctx = runtime.context(device)
     px, n, pq, st = C.c_void_p(), C.c_int64(), C.c_uint16(), _lib.Stats()
-    buf = (C.c_char * len(data)).from_buffer_copy(data)
+    if not isinstance(data, bytes):
+        data = bytes(data)
+    buf = C.c_char_p(data)   # the bytes object's own storage: the library only reads it
     _lib.check(_lib.lib().gpcc_decode(ctx, model.handle, C.cast(buf, C.c_void_p), len(data), C.byref(px), C.byref(n), C.byref(pq),
                                       C.byref(st), runtime.stream_ptr(device)))
     out = torch.empty((n.value, 3), dtype=torch.int32, device=device)

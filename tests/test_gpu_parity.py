@@ -236,6 +236,19 @@ def test_codec_bitstream_identical_to_oracle(gh, orc, k, chunk_log2, dev_model_k
     assert float(posq) == 1.0
 
 
+def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_model_k5):
+    """A cloud whose fine levels leave the cooperative 16-row kernel: 255-row class blocks with level-dependent heights,
+    several blocks per wave slot in the encoder's batched sets, tile lists sized through a stream sync, the second
+    stream busy beside the trunks -- still the oracle's bytes, and the oracle's points back."""
+    pts = _cloud(150_000, seed=11)
+    data, st = gh.encode(dev_model_k5, pts, 10)
+    ref = orc.encode(synth_model_k5, pts, chunk_log2=10)
+    assert data == ref
+    assert max(st.level_nodes[: st.num_levels]) > 100_000
+    dec, _, _ = gh.decode(dev_model_k5, data)
+    assert np.array_equal(dec, orc.decode(synth_model_k5, ref)[0])
+
+
 def test_ideal_bits_estimator_and_coder_overhead(gh, orc, dev_model_k5, synth_model_k5):
     """a14: the reference's bpp estimator (network_ue_4stage_conv.py:100-182), sum clamp(-log2(p_gt + 1e-10), 0, 50),
     accumulated on the device beside the coder; the actual range-coder payload must sit within a small

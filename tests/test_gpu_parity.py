@@ -348,6 +348,18 @@ def test_full_size_roundtrip_1m(gh, dev_model_k5):
     assert st.level_nodes[0] < 64
 
 
+def test_roundtrip_sizes_back_to_back(gh, dev_model_k5):
+    """One context, clouds of very different sizes one after the other (the workspace arena is reused and regrown, the
+    second stream and its events are reused, small levels run without host syncs): every decode returns its cloud."""
+    rng = np.random.RandomState(4)
+    sizes = [300_000, 7, 40_000, 1_000, 120_000, 64, 500_000, 3_000, 90_000, 250_000, 20, 33_000]
+    for i, n in enumerate(sizes):
+        pts = _cloud(n, seed=100 + i, negative=bool(rng.randint(2)))
+        data, st = gh.encode(dev_model_k5, pts, 10 if i % 3 else 0)
+        dec, _, _ = gh.decode(dev_model_k5, data)
+        assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts)), (i, n)
+
+
 def test_cli_compress_decompress_roundtrip(gh, tmp_path):
     """python -m gauspcc_amd.cli.compress / .decompress over a folder: .bin per file, CSV with an avg row,
     PLYs holding exactly the quantised input geometry (reference CLIs: compress_ue_4stage_conv.py, decompress_ue_4stage_conv.py)."""

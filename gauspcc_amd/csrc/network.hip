@@ -129,12 +129,12 @@ int conv_pick_rows(int64_t n)
         if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128 && forced != 255) forced = 0;
     }
     if (forced) return forced;
-    // every level the cooperative kernel does not take: the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
+    // every level the cooperative kernel does not take (it wins below ~12 k nodes): the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
     // with the block height set by conv_pick_height -- up to 1024 blocks run as ONE round of equal blocks, one per SIMD
     // (measured against 2-3 waves per SIMD on 32..128-row blocks: 34 k nodes 40 vs 56 us, 92 k 75 vs 88, 251 k 185 vs 199,
     // 540 k 322 vs 377).  The asm loop addresses rows with 32-bit offsets: n < 2^25.
     static int64_t tall_min = -1;
-    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 24 * 1024; }
+    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 12 * 1024; }
     if (n >= tall_min && n < ((int64_t)1 << 25)) return 255;
     if (n >= 192 * 1024) return 128;
     if (n >= 96 * 1024) return 64;
@@ -195,7 +195,7 @@ static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT
     // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the
     // host ever learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run
     // ahead).  Taller blocks are sized exactly: one sync.
-    constexpr bool BOUNDED = R == 16;
+    const bool BOUNDED = H <= 16;
     int64_t cap;
     uint32_t total = 0;
     if (BOUNDED) cap = nblk * K + CONV_HDR_PAD;

@@ -49,7 +49,7 @@ extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)
     if (!ctx) return fail(GPCC_ERR_ARG, "null argument");
     ctx->prof.on = on != 0;
     ctx->prof.conv_ms = 0.0; ctx->prof.conv_launches = 0; ctx->prof.conv_pair_jobs = 0;
-    ctx->prof.recs.clear(); ctx->prof.used = 0;
+    ctx->prof.recs.clear(); ctx->prof.used = 0; ctx->prof.chain_open = false;
     return GPCC_OK;
 }
 

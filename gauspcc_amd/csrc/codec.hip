@@ -32,11 +32,13 @@ int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int
         cb.job[0] = ConvJob{in, m->conv[ci], res, out};
         return sparse_conv(ctx, level, st, cb, 1, tiles, n, 1);
     };
+    GP_TRY(conv_chain_begin(ctx, st));
     GP_TRY(one(t.x, conv0, nullptr, t.a));
     GP_TRY(one(t.a, conv0 + 1, nullptr, t.b));
     GP_TRY(one(t.b, conv0 + 2, t.a, t.x));
     GP_TRY(one(t.x, conv0 + 3, nullptr, t.b));
     GP_TRY(one(t.b, conv0 + 4, t.x, t.a));
+    GP_TRY(conv_chain_end(ctx, st));
     return GPCC_OK;
 }
 
@@ -481,10 +483,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             const float *xin = cA;
             if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
+            GP_TRY(conv_chain_begin(ctx, st));
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 1));
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
+            GP_TRY(conv_chain_end(ctx, st));
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];

@@ -105,10 +105,14 @@ template <typename T> struct HostBuf {
 }  // namespace gpcc
 
 namespace gpcc {
-// HIP-event timing of the dominant kernel (k_sparse_conv), on the stream it is launched on.
-struct ConvRec { int e0, e1, level, njobs, R, H; long long n, nblk; };
+// HIP-event timing of the dominant kernel (k_sparse_conv), on the stream it is launched on.  Convolutions that are
+// enqueued back to back with nothing between them (a trunk's five, a stage's two) share ONE pair of events: an event
+// costs ~3 us of stream time, and one pair per launch slowed a decode by 1.5 ms.
+struct ConvRec { int e0, e1, level, njobs, R, H; long long n, nblk; int launches; };
 struct Prof {
     bool on = false;
+    bool chain_open = false;   // between conv_chain_begin and conv_chain_end: sparse_conv records no events of its own
+    ConvRec chain = {};
     std::vector<hipEvent_t> pool;
     int used = 0;
     std::vector<ConvRec> recs;

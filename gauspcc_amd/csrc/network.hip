@@ -676,8 +676,10 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
 {
     if (n <= 0) return GPCC_OK;
     if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
-    const bool prof = ctx && ctx->prof.on;
-    ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk};
+    const bool chained = ctx && ctx->prof.on && ctx->prof.chain_open;
+    const bool prof = ctx && ctx->prof.on && !chained;
+    ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk, 1};
+    if (chained) { ConvRec &c = ctx->prof.chain; c.level = level; c.njobs = njobs; c.R = T.R; c.H = T.H; c.n = (long long)n; c.nblk = (long long)T.nblk; c.launches += 1; }
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
     static int dist = -1, use_asm = -1;
     if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
@@ -748,18 +750,43 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     return GPCC_OK;
 }
 
+// a run of convolutions on the same level with nothing else enqueued between them: one pair of events for all
+int conv_chain_begin(gpcc_ctx *ctx, hipStream_t st)
+{
+    if (!ctx || !ctx->prof.on) return GPCC_OK;
+#ifdef CONV_TIMING
+    return GPCC_OK;   // the developer timing build reads its counters back after every launch
+#endif
+    ctx->prof.chain = ConvRec{};
+    GP_TRY(prof_event(ctx, st, &ctx->prof.chain.e0));
+    ctx->prof.chain_open = true;
+    return GPCC_OK;
+}
+
+int conv_chain_end(gpcc_ctx *ctx, hipStream_t st)
+{
+    if (!ctx || !ctx->prof.on || !ctx->prof.chain_open) return GPCC_OK;
+    ctx->prof.chain_open = false;
+    GP_TRY(prof_event(ctx, st, &ctx->prof.chain.e1));
+    if (ctx->prof.chain.launches > 0) ctx->prof.recs.push_back(ctx->prof.chain);
+    return GPCC_OK;
+}
+
 int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
 {
     Prof &p = ctx->prof;
+    p.chain_open = false;
     static int log = -1;
     if (log < 0) { const char *e = getenv("GAUSPCC_CONV_LOG"); log = e ? atoi(e) : 0; }
     for (const ConvRec &r : p.recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
-        if (log) fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3);
+        if (log)
+            for (int q = 0; q < r.launches; ++q)
+                fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3 / r.launches);
         p.conv_ms += ms;
-        p.conv_launches += 1;
-        if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs;
+        p.conv_launches += r.launches;
+        if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs * r.launches;
     }
     p.recs.clear();
     p.used = 0;

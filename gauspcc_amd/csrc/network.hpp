@@ -103,6 +103,9 @@ int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t
 // out = conv(in) (+res) (relu); up to 4 independent jobs on the same tile list in one launch
 // ctx/level: when ctx->prof.on the launch is bracketed by HIP events tagged with `level` (bench.py roofline)
 int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs, int njobs, const ConvTiles &T, int64_t n, int relu);
+// profiling only: the sparse_conv calls between the two share one pair of timing events (same level, nothing else enqueued between)
+int conv_chain_begin(gpcc_ctx *ctx, hipStream_t st);
+int conv_chain_end(gpcc_ctx *ctx, hipStream_t st);
 // fold the recorded events into ctx->prof (call after the stream is synchronised); pairs[level] = present neighbours
 int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs_per_level, int nlevels);
 

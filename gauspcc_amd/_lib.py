@@ -23,7 +23,7 @@ class Stats(C.Structure):
         ("num_points", C.c_int64),
         ("num_bytes", C.c_int64),
         ("num_levels", C.c_int32),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
         ("level_nodes", C.c_int64 * 24),
         ("coded_nodes", C.c_int64),
         ("conv_pairs", C.c_int64),

@@ -66,6 +66,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
 {
     ctx->arena.reset();
     HostTrace ht;
+    const bool want_bits = stats && (stats->flags & GPCC_STATS_IDEAL_BITS);   // the reference's bpp estimator (a14): on request only
     Tree T;
     GP_TRY(tree_build(ctx, st, xyz, n, &T));
     ht.mark("enc tree built");
@@ -156,7 +157,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
-            ha.bits = stats ? reinterpret_cast<double *>(pairs_dev + 8) : nullptr;   // slots 8..23 of the zeroed counter block
+            ha.bits = want_bits ? reinterpret_cast<double *>(pairs_dev + 8) : nullptr;   // slots 8..23 of the zeroed counter block
             GP_TRY(head_cdf(st, ha));
         }
     }

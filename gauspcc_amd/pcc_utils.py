@@ -50,9 +50,10 @@ def calculate_morton_order(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
+def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ, ideal_bits: bool = False):
     ctx = runtime.context(xyz_int32.device)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
+    st.flags = 1 if ideal_bits else 0   # GPCC_STATS_IDEAL_BITS: the bpp estimator next to the coder (diagnostic, ~4 % of an encode)
     _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
                                       C.byref(pb), C.byref(nb), C.byref(st), runtime.stream_ptr(xyz_int32.device)))
     data = C.string_at(pb, nb.value)

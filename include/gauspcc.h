@@ -68,16 +68,17 @@ GPCC_API int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, con
                       gpcc_model **out);
 GPCC_API void gpcc_model_destroy(gpcc_model *m);
 
+#define GPCC_STATS_IDEAL_BITS 1
 typedef struct {
     int64_t num_points;
     int64_t num_bytes;
     int32_t num_levels;        /* stored levels L (base + coded) */
-    int32_t reserved;
+    int32_t flags;             /* IN: GPCC_STATS_IDEAL_BITS asks gpcc_encode for ideal_bits (costs ~4 % of an encode); OUT: 0 */
     int64_t level_nodes[24];   /* nodes per stored level, base first */
     int64_t coded_nodes;       /* sum of nodes over coded levels */
     int64_t conv_pairs;        /* sum over all 18*levels convs of (output node, present neighbour) pairs */
     double device_ms;          /* wall time between the syncs that bracket the call */
-    double ideal_bits;         /* encode only: sum over coded symbols of clamp(-log2(p_gt + 1e-10), 0, 50), the reference's
+    double ideal_bits;         /* encode only, when requested through flags: sum over coded symbols of clamp(-log2(p_gt + 1e-10), 0, 50), the reference's
                                   bpp estimator before the division by N (network_ue_4stage_conv.py:100-182, a14) */
 } gpcc_stats;
 

@@ -77,11 +77,11 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int) -> np.ndarray:
     return out.cpu().numpy()
 
 
-def encode(model, xyz: np.ndarray, chunk_log2=10, posq=1):
+def encode(model, xyz: np.ndarray, chunk_log2=10, posq=1, ideal_bits=False):
     from gauspcc_amd.pcc_utils import _encode_to_bytes
 
     x = torch.tensor(np.ascontiguousarray(xyz, dtype=np.int32), device=dev())
-    return _encode_to_bytes(x, model, chunk_log2, posq)
+    return _encode_to_bytes(x, model, chunk_log2, posq, ideal_bits)
 
 
 def decode(model, data: bytes):

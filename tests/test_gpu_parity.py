@@ -254,7 +254,7 @@ def test_ideal_bits_estimator_and_coder_overhead(gh, orc, dev_model_k5, synth_mo
     accumulated on the device beside the coder; the actual range-coder payload must sit within a small
     overhead of it (the estimator prices the float p, the coder the 16-bit integerised CDF)."""
     pts = _cloud(20_000, seed=5)
-    data, st = gh.encode(dev_model_k5, pts, 0)
+    data, st = gh.encode(dev_model_k5, pts, 0, ideal_bits=True)
     orc.encode(synth_model_k5, pts, chunk_log2=0)
     ref_bits = orc.ideal_bits()
     assert ref_bits > 0

@@ -144,7 +144,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(v1, float, nC * 32); TAKE(v2, float, nC * 32);
         float *u[4] = {cA, u1, u2, u3};
         float *v[4] = {cX, cB, v1, v2};
-        for (int s = 1; s < 4; ++s) GP_TRY(stage_input_gt(st, cA, m->semb[s - 1], occC, s, nC, u[s]));
+        {
+            const float *const embs[3] = {m->semb[0], m->semb[1], m->semb[2]};
+            float *const outs[3] = {u1, u2, u3};
+            GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs));
+        }
         ConvBatch cb = {};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 1));

@@ -831,19 +831,24 @@ int child_features(hipStream_t st, const float *F, const uint32_t *parent, const
     return GPCC_OK;
 }
 
-__global__ __launch_bounds__(TB) void k_stage_input_gt(const float4 *__restrict__ X, const float4 *__restrict__ emb, const uint8_t *__restrict__ occ,
-                                                       int stage, int64_t n, float4 *__restrict__ out)
+// the encoder's three stage inputs in one pass over X (one read of the trunk output instead of three)
+__global__ __launch_bounds__(TB) void k_stage_inputs_gt(const float4 *__restrict__ X, const float4 *__restrict__ e1, const float4 *__restrict__ e2, const float4 *__restrict__ e3,
+                                                        const uint8_t *__restrict__ occ, int64_t n, float4 *__restrict__ o1, float4 *__restrict__ o2, float4 *__restrict__ o3)
 {
     int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     int64_t i = t >> 3;
     if (i >= n) return;
     const uint32_t o = occ[i];
-    const uint32_t prev = stage == 1 ? (o >> 7) & 1u : stage == 2 ? (o >> 6) & 3u : (o >> 4) & 15u;  // pcc_utils.py:121,128,136
-    out[t] = add4(X[t], emb[prev * 8 + (t & 7)]);
+    const float4 x = X[t];
+    const int c = (int)(t & 7);
+    o1[t] = add4(x, e1[((o >> 7) & 1u) * 8 + c]);    // pcc_utils.py:121,128,136
+    o2[t] = add4(x, e2[((o >> 6) & 3u) * 8 + c]);
+    o3[t] = add4(x, e3[((o >> 4) & 15u) * 8 + c]);
 }
-int stage_input_gt(hipStream_t st, const float *X, const float *emb, const uint8_t *occ, int stage, int64_t n, float *out)
+int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3])
 {
-    k_stage_input_gt<<<nblk(n * 8), TB, 0, st>>>((const float4 *)X, (const float4 *)emb, occ, stage, n, (float4 *)out);
+    k_stage_inputs_gt<<<nblk(n * 8), TB, 0, st>>>((const float4 *)X, (const float4 *)emb[0], (const float4 *)emb[1], (const float4 *)emb[2], occ, n,
+                                                  (float4 *)out[0], (float4 *)out[1], (float4 *)out[2]);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

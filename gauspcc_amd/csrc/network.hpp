@@ -114,7 +114,7 @@ int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, f
 // X[i] = F[parent[i]] + Emb8[octant(i)]                    (kit/nn.py:77-98,108-117)
 int child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out);
 // stage input X + Emb_s[prev bits]; prev from ground-truth occupancy (encode) ...
-int stage_input_gt(hipStream_t st, const float *X, const float *emb, const uint8_t *occ, int stage, int64_t n, float *out);
+int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3]);   // stages 1..3 in one pass
 // ... or from the symbols decoded so far (raster order, looked up through m2r)
 int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out);
 

@@ -42,6 +42,12 @@ def report(name, seg):
 
 
 report("encode", seg[:cut])
+import os
+if os.environ.get("TL_WINDOW"):   # every kernel of the encode inside [a, b] us after its first kernel
+    a, b = (float(v) * 1e3 for v in os.environ["TL_WINDOW"].split(","))
+    for s_, e_, n_ in seg[:cut]:
+        if a <= s_ - seg[0][0] <= b:
+            print(f"      {(s_ - seg[0][0])/1e3:9.1f} us  +{(e_ - s_)/1e3:7.1f}  {n_[:70]}")
 dec = seg[cut:]
 # drop anything after the decode (teardown): cut at the first gap longer than 20 ms
 last = len(dec) - 1

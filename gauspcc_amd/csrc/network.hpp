@@ -73,12 +73,12 @@ struct ConvJob {
 };
 struct ConvBatch { ConvJob job[4]; };
 
-// Compacted work list of one level: every wave owns R consecutive (Morton-ordered) output rows;
+// Compacted work list of one level: every wave owns H consecutive (Morton-ordered) output rows;
 // for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of
 // 16 rows (one v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per level, used by all
-// 5 / 13 convolutions that run on that level.  R (16, 32, 64, 96 or 128) is picked per level: tall blocks
-// pack tiles better, short blocks give more waves and shorter serial chains on small levels.
-// (Measured on MI355X, 1M-point cloud: 255-row blocks at 1 wave/SIMD lose to 128-row blocks at 2.)
+// 5 / 13 convolutions that run on that level.  R is the capacity class (LDS rows per wave, selects the kernel:
+// 16 = the cooperative kernel, 255 = the wave-serial kernel at one wave per SIMD; 32 / 64 / 96 / 128 remain for the
+// variant tests), H <= R the block height picked per level (conv_pick_rows / conv_pick_height).
 constexpr int CONV_R_MAX = 255;
 struct ConvTiles {
     int32_t *tj = nullptr;     // [tiles][16] neighbour row (padding: 0, a valid row whose result is discarded)

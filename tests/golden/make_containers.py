@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/containers.npz: bitstreams of THIS implementation's oracle for a fixed small cloud and the
+seeded synthetic weights (gauspcc_amd.synth), one per container layout.  Unlike the other fixtures these are not derived
+from the reference (its coder and sparse-conv packages are absent); they pin the container format and
+the normative numerics across rounds -- a change that alters a single byte of a stream fails tests/test_containers.py
+until this script is re-run on purpose.  Usage: python tests/golden/make_containers.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from gauspcc_amd.model import tensor_table  # noqa: E402
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+orc.build()
+pts = synthetic_cloud(700, seed=2024)
+out = {"points": pts}
+for k in (5, 3):
+    m = orc.Model(tensor_table(synthetic_state_dict(32, k), 32, k), 32, k)
+    for cl in (0, 6, 10):
+        out[f"k{k}_chunk{cl}"] = np.frombuffer(orc.encode(m, pts, chunk_log2=cl), dtype=np.uint8)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "containers.npz"), **out)
+print({k: v.shape for k, v in out.items()})

@@ -37,6 +37,29 @@ def test_stored_headers(fixture):
         assert fixture[f"k5_chunk{cl}"][:4].tolist() == [0xFF, 0xFF, 2, cl]
 
 
+def _as_version1(stream: bytes) -> bytes:
+    """Version 1 cut every level into 2^chunk_log2-symbol chunks; for chunk_log2 <= 7 version 2 does the same, so the
+    chunk_log2 = 6 stream with the version byte set to 1 IS the version-1 stream of the same cloud."""
+    assert stream[:4] == bytes([0xFF, 0xFF, 2, 6])
+    return stream[:2] + bytes([1]) + stream[3:]
+
+
+def test_oracle_reads_version1(orc, fixture, synth_model_k5):
+    dec, _ = orc.decode(synth_model_k5, _as_version1(fixture["k5_chunk6"].tobytes()))
+    assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+
+
+@pytest.mark.gpu
+def test_device_reads_version1(fixture):
+    from gauspcc_amd import runtime
+    from gauspcc_amd.synth import synthetic_state_dict
+    from tests import gpu_helpers as gh
+
+    model = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
+    dec, _, _ = gh.decode(model, _as_version1(fixture["k5_chunk6"].tobytes()))
+    assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,cl", CASES)
 def test_device_reproduces_stored_stream(fixture, k, cl):

@@ -314,6 +314,39 @@ def test_codec_rejects_bad_input(gh, dev_model_k5):
     assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts))
 
 
+def test_corrupted_containers_never_crash(gh, dev_model_k5):
+    """Bit flips, randomised payload runs, truncations and perturbed header bytes: the decoder either reports an error or
+    returns some cloud, and the context decodes the intact stream afterwards (bounded expansion, clamped neighbour
+    indices, header verification at the final sync -- the small levels run without host syncs)."""
+    from gauspcc_amd._lib import GpccError
+
+    pts = _cloud(20_000, seed=3)
+    rng = np.random.RandomState(0)
+    for cl in (10, 0):
+        data, _ = gh.encode(dev_model_k5, pts, cl)
+        outcomes = {"decoded": 0, "error": 0}
+        for it in range(24):
+            b = bytearray(data)
+            mode = it % 4
+            if mode == 0:
+                b[rng.randint(len(b))] ^= 1 << rng.randint(8)
+            elif mode == 1:
+                i = rng.randint(len(b) // 2, len(b) - 64)
+                b[i:i + 32] = rng.randint(0, 256, 32).astype(np.uint8).tobytes()
+            elif mode == 2:
+                b = b[: rng.randint(8, len(b))]
+            else:
+                b[rng.randint(0, 80)] = rng.randint(256)
+            try:
+                gh.decode(dev_model_k5, bytes(b))
+                outcomes["decoded"] += 1
+            except GpccError:
+                outcomes["error"] += 1
+        assert outcomes["error"] > 0
+        dec, _, _ = gh.decode(dev_model_k5, data)
+        assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts))
+
+
 def test_plugin_api_roundtrip(gh, tmp_path):
     """compress_point_cloud / decompress_point_cloud with the reference's call pattern
     (HAC/scene/gaussian_model.py:1107-1114, 1251-1256)."""

@@ -63,7 +63,7 @@ def main():
 
     from gauspcc_amd import _lib, runtime
     from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed
-    from gauspcc_amd.pcc_utils import _decode_bytes, _encode_to_bytes
+    from gauspcc_amd.pcc_utils import _decode_bytes, _encode_view
     from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
 
     k = args.kernel_size
@@ -83,7 +83,7 @@ def main():
 
     def step():
         t0 = time.perf_counter()
-        data, st = _encode_to_bytes(x, model, args.chunk_log2, 1)
+        data, st = _encode_view(x, model, args.chunk_log2, 1)   # the bitstream stays in the library's pinned host buffer
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         dec, _, _ = _decode_bytes(data, model, device)

@@ -295,8 +295,9 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     return GPCC_OK;
 }
 
+// out_user / out_cap: optional caller-owned device buffer for the points (capacity in points); else a context-owned one
 int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t nbytes, const int32_t **xyz_out, int64_t *n_out,
-                uint16_t *posq_out, gpcc_stats *stats, hipStream_t st)
+                uint16_t *posq_out, gpcc_stats *stats, hipStream_t st, int32_t *out_user, int64_t out_cap)
 {
     ctx->arena.reset();
     HostTrace ht;
@@ -521,7 +522,13 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (htotal[1 + g] != (uint32_t)lvl_n[g + 1])
                 return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)lvl_n[g + 1], htotal[1 + g]);
     if (v1 && npts != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)npts, (long long)npts_hdr);
-    TAKE(xyz, int32_t, 3 * std::max<int64_t>(npts, 1));
+    int32_t *xyz = out_user;
+    if (out_user) {
+        if (npts > out_cap) return fail(GPCC_ERR_ARG, "decoded %lld points, the output buffer holds %lld", (long long)npts, (long long)out_cap);
+    } else {
+        TAKE(own, int32_t, 3 * std::max<int64_t>(npts, 1));
+        xyz = own;
+    }
     GP_TRY(leaves_reference_order(ctx, st, &cur, xyz, npts));
     unsigned long long hpairs[MAXLV];
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
@@ -566,10 +573,9 @@ extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xy
     return rc;
 }
 
-extern "C" int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes, const int32_t **xyz_dev_out,
-                           int64_t *n_out, uint16_t *posq_f16_out, gpcc_stats *stats, void *stream)
+static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes, const int32_t **xyz_dev_out,
+                        int64_t *n_out, uint16_t *posq_f16_out, gpcc_stats *stats, void *stream, int32_t *out_user, int64_t out_cap)
 {
-    if (!ctx || !m || !bytes || !xyz_dev_out || !n_out || !posq_f16_out) return fail(GPCC_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const auto t0 = std::chrono::steady_clock::now();
@@ -583,13 +589,29 @@ extern "C" int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *by
         want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * m->K + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
     }
     int rc = GPCC_OK;
+    const int32_t *xyz = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
-        rc = decode_body(ctx, m, bytes, nbytes, xyz_dev_out, n_out, posq_f16_out, stats, st);
+        rc = decode_body(ctx, m, bytes, nbytes, &xyz, n_out, posq_f16_out, stats, st, out_user, out_cap);
         if (rc != GPCC_ERR_NOMEM) break;
         HIP_TRY(hipStreamSynchronize(st));
         want *= 2;
     }
+    if (rc == GPCC_OK && xyz_dev_out) *xyz_dev_out = xyz;
     if (rc == GPCC_OK && stats) stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
+}
+
+extern "C" int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes, const int32_t **xyz_dev_out,
+                           int64_t *n_out, uint16_t *posq_f16_out, gpcc_stats *stats, void *stream)
+{
+    if (!ctx || !m || !bytes || !xyz_dev_out || !n_out || !posq_f16_out) return fail(GPCC_ERR_ARG, "null argument");
+    return decode_entry(ctx, m, bytes, nbytes, xyz_dev_out, n_out, posq_f16_out, stats, stream, nullptr, 0);
+}
+
+extern "C" int gpcc_decode_to(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes, int32_t *xyz_dev, int64_t capacity_points,
+                              int64_t *n_out, uint16_t *posq_f16_out, gpcc_stats *stats, void *stream)
+{
+    if (!ctx || !m || !bytes || !xyz_dev || capacity_points < 0 || !n_out || !posq_f16_out) return fail(GPCC_ERR_ARG, "null argument");
+    return decode_entry(ctx, m, bytes, nbytes, nullptr, n_out, posq_f16_out, stats, stream, xyz_dev, capacity_points);
 }

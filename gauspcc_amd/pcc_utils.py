@@ -94,7 +94,7 @@ def compress_point_cloud(
 
     torch.cuda.synchronize(device)
     enc_time_start = time.time()
-    data, st = _encode_to_bytes(xyz, model, chunk_log2, posQ)
+    data, st = _encode_view(xyz, model, chunk_log2, posQ)   # the context's pinned output buffer, written to the file as it is
     torch.cuda.synchronize(device)
     enc_time_end = time.time()
 
@@ -125,13 +125,42 @@ def save_ply_ascii_geo(coords, filedir):
             f.write(f"{p[0]} {p[1]} {p[2]}\n")
 
 
-def _decode_bytes(data: bytes, model, device):
+def _encode_view(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
+    """gpcc_encode without the copy into a Python bytes object: a ctypes byte array over the context's pinned output buffer,
+    valid until the next encode on this context (write it to a file, or hand it to _decode_bytes)."""
+    ctx = runtime.context(xyz_int32.device)
+    pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
+    _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
+                                      C.byref(pb), C.byref(nb), C.byref(st), runtime.stream_ptr(xyz_int32.device)))
+    return (C.c_ubyte * nb.value).from_address(pb.value), st
+
+
+def _header_points(head: bytes):
+    """Point count from a chunked container's header (FF FF | version | chunk_log2 | posQ | L | 0 | u32 n[L] | u32 N), else None."""
+    if len(head) >= 12 and head[0] == 0xFF and head[1] == 0xFF and 1 <= head[6] <= 21 and len(head) >= 12 + 4 * head[6]:
+        return int.from_bytes(head[8 + 4 * head[6]: 12 + 4 * head[6]], "little")
+    return None
+
+
+def _decode_bytes(data, model, device):
+    """data: bytes, or a ctypes byte array (e.g. from _encode_view).  The chunked containers announce their point count,
+    so the output tensor is allocated up front and the library writes the points straight into it."""
     ctx = runtime.context(device)
-    px, n, pq, st = C.c_void_p(), C.c_int64(), C.c_uint16(), _lib.Stats()
-    if not isinstance(data, bytes):
-        data = bytes(data)
-    buf = C.c_char_p(data)   # the bytes object's own storage: the library only reads it
-    _lib.check(_lib.lib().gpcc_decode(ctx, model.handle, C.cast(buf, C.c_void_p), len(data), C.byref(px), C.byref(n), C.byref(pq),
+    n, pq, st = C.c_int64(), C.c_uint16(), _lib.Stats()
+    if isinstance(data, C.Array):
+        ptr, nbytes, head = C.c_void_p(C.addressof(data)), len(data), bytes(data[:96])
+    else:
+        if not isinstance(data, bytes):
+            data = bytes(data)
+        ptr, nbytes, head = C.cast(C.c_char_p(data), C.c_void_p), len(data), data[:96]   # the bytes object's own storage: only read
+    npts = _header_points(head)
+    if npts is not None and 0 < npts < (1 << 31):
+        out = torch.empty((npts, 3), dtype=torch.int32, device=device)
+        _lib.check(_lib.lib().gpcc_decode_to(ctx, model.handle, ptr, nbytes, out.data_ptr(), npts, C.byref(n), C.byref(pq),
+                                             C.byref(st), runtime.stream_ptr(device)))
+        return out[: n.value], runtime.bits_f16(pq.value), st
+    px = C.c_void_p()
+    _lib.check(_lib.lib().gpcc_decode(ctx, model.handle, ptr, nbytes, C.byref(px), C.byref(n), C.byref(pq),
                                       C.byref(st), runtime.stream_ptr(device)))
     out = torch.empty((n.value, 3), dtype=torch.int32, device=device)
     if n.value:

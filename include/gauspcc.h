@@ -101,6 +101,13 @@ GPCC_API int gpcc_decode(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *byte
                 const int32_t **xyz_dev_out, int64_t *n_out, uint16_t *posq_f16_out,
                 gpcc_stats *stats, void *stream);
 
+/* The same into a caller-owned DEVICE buffer of capacity_points x 3 int32 (the chunked containers carry the point count
+ * in their header -- u32 at byte 8 + 4 L, L = byte 6 -- so a caller can size it before the call); fails with
+ * GPCC_ERR_ARG when the cloud does not fit.  Saves the copy out of the context's buffer. */
+GPCC_API int gpcc_decode_to(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes, int64_t nbytes,
+                int32_t *xyz_dev, int64_t capacity_points, int64_t *n_out, uint16_t *posq_f16_out,
+                gpcc_stats *stats, void *stream);
+
 /* Live timing of the dominant kernel (the sparse convolution): while enabled, every launch is
  * bracketed by HIP events on the stream it runs on.  conv_pair_jobs = sum over launches of
  * (output node, present neighbour) pairs x jobs in the launch; algorithmic flops = 2*C*C*conv_pair_jobs. */

@@ -33,6 +33,28 @@ if ROOT not in sys.path:
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
 
 
+def launcher_selftest(args, rank, world):
+    """The rank-side skeleton of a multi-GPU run without a GPU (gloo): process group from the launcher's environment, the
+    stats all_gather and the MAX of the elapsed time, one JSON line from rank 0.  Covers `bench.py --gpus N` starting its
+    own ranks (tests/test_dist_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+
+    from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed
+
+    dist.init_process_group("gloo")
+    cpu = torch.device("cpu")
+    mine = SceneStats(num_points=args.points, num_bytes=100 + rank, enc_s=0.01 * (rank + 1), dec_s=0.02, coded_nodes=scene_seed(1234, rank),
+                      conv_pairs=1, levels=3, status=0)
+    scenes = collate_stats([mine], cpu)
+    elapsed = max_over_ranks(1.0 + rank, cpu)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": len(scenes), "seeds": [s.coded_nodes for s in scenes],
+                          "max_elapsed": elapsed, "value": args.points * world / elapsed / 1e6}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,6 +64,7 @@ def main():
     ap.add_argument("--kernel-size", type=int, default=5)
     ap.add_argument("--chunk-log2", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=250_000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
     args = ap.parse_args()
 
     import torch
@@ -49,8 +72,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU), BEFORE anything
+        # here touches the GPU; this parent only relays the ranks' output (rank 0's JSON line) and their exit code
+        from gauspcc_amd.dist import launch_ranks
+
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    if args.selftest_launcher:
+        return launcher_selftest(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)

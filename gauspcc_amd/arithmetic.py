@@ -29,6 +29,13 @@ def _chk(t, name):
         raise RuntimeError(f"{name} must be contiguous")          # CHECK_CONTIGUOUS (include/utils.h:4)
 
 
+def _f32(*ts):
+    """float32 contiguous views / copies of the arguments, as a tuple the CALLER keeps alive until the library call has
+    returned: `t.float().data_ptr()` on a non-fp32 tensor takes the address of a temporary that the caching allocator hands
+    to the next conversion (several arguments would alias one block)."""
+    return tuple(t.detach().to(torch.float32).contiguous() for t in ts)
+
+
 def calculate_cdf(mean, scale, Q, min_value, max_value):
     for t, nm in ((mean, "mean"), (scale, "scale"), (Q, "Q")):
         _chk(t, nm)
@@ -36,7 +43,8 @@ def calculate_cdf(mean, scale, Q, min_value, max_value):
     n = mean.shape[0]
     lower = torch.zeros((n, mx - mn + 2), dtype=torch.float32, device=mean.device)
     if n:
-        _lib.check(_lib.lib().gsac_calculate_cdf(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(),
+        m32, s32, q32 = _f32(mean, scale, Q)
+        _lib.check(_lib.lib().gsac_calculate_cdf(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(),
                                                   n, mn, mx, lower.data_ptr(), runtime.stream_ptr(mean.device)))
     return lower
 
@@ -47,8 +55,8 @@ def arithmetic_encode(sym, cdf, chunk_size, N, Lp):
         raise RuntimeError(f"Expected sym to have 1 dimension, but got {sym.dim()}")
     if cdf.dim() != 2:
         raise RuntimeError(f"Expected cdf to have 2 dimensions, but got {cdf.dim()}")
-    sym = sym.to(torch.int16)
-    cdf = cdf.to(torch.float32)
+    sym = sym.to(torch.int16).contiguous()
+    cdf = cdf.to(torch.float32).contiguous()
     pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
     _lib.check(_lib.lib().gsac_encode(runtime.context(sym.device), sym.data_ptr(), cdf.data_ptr(), int(chunk_size), int(N), int(Lp),
                                       C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(sym.device)))
@@ -59,7 +67,7 @@ def arithmetic_encode(sym, cdf, chunk_size, N, Lp):
 
 def arithmetic_decode(cdf, in_cache_all, in_cnt_all, chunk_size, N, Lp):
     _chk(cdf, "cdf")
-    cdf = cdf.to(torch.float32)
+    cdf = cdf.to(torch.float32).contiguous()
     data = in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False)
     cnt = in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False)
     data = np.ascontiguousarray(data); cnt = np.ascontiguousarray(cnt)
@@ -77,8 +85,9 @@ def encode_gaussian(x, mean, scale, Q, chunk_size):
     n = int(x.shape[0])
     mn, mx = C.c_float(), C.c_float()
     pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().gsac_encode_gaussian(runtime.context(x.device), x.float().data_ptr(), mean.float().data_ptr(), scale.float().data_ptr(),
-                                               Q.float().data_ptr(), n, int(chunk_size), C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb),
+    x32, m32, s32, q32 = _f32(x, mean, scale, Q)
+    _lib.check(_lib.lib().gsac_encode_gaussian(runtime.context(x.device), x32.data_ptr(), m32.data_ptr(), s32.data_ptr(),
+                                               q32.data_ptr(), n, int(chunk_size), C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb),
                                                C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
     out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
     cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
@@ -93,7 +102,8 @@ def decode_gaussian(mean, scale, Q, min_value, max_value, in_cache_all, in_cnt_a
     cnt = np.ascontiguousarray(in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False))
     n = int(mean.shape[0])
     out = torch.empty(n, dtype=torch.float32, device=mean.device)
-    _lib.check(_lib.lib().gsac_decode_gaussian(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(), n,
+    m32, s32, q32 = _f32(mean, scale, Q)
+    _lib.check(_lib.lib().gsac_decode_gaussian(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(), n,
                                                float(min_value), float(max_value), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
                                                out.data_ptr(), runtime.stream_ptr(mean.device)))
     return out
@@ -108,8 +118,9 @@ def encode_gaussian_slices(x, mean, scale, Q, slice_start, chunk_size):
     ns = ss.size - 1
     mins, maxs = np.empty(ns, dtype=np.float32), np.empty(ns, dtype=np.float32)
     pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().gsac_encode_gaussian_slices(runtime.context(x.device), x.float().data_ptr(), mean.float().data_ptr(), scale.float().data_ptr(),
-                                                      Q.float().data_ptr(), ss.ctypes.data, ns, int(chunk_size), mins.ctypes.data, maxs.ctypes.data,
+    x32, m32, s32, q32 = _f32(x, mean, scale, Q)
+    _lib.check(_lib.lib().gsac_encode_gaussian_slices(runtime.context(x.device), x32.data_ptr(), m32.data_ptr(), s32.data_ptr(),
+                                                      q32.data_ptr(), ss.ctypes.data, ns, int(chunk_size), mins.ctypes.data, maxs.ctypes.data,
                                                       C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
     out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
     cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
@@ -124,7 +135,8 @@ def decode_gaussian_slices(mean, scale, Q, slice_start, mins, maxs, data, cnt, c
     mins = np.ascontiguousarray(mins, dtype=np.float32); maxs = np.ascontiguousarray(maxs, dtype=np.float32)
     data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
     out = torch.empty(int(ss[-1]), dtype=torch.float32, device=mean.device)
-    _lib.check(_lib.lib().gsac_decode_gaussian_slices(runtime.context(mean.device), mean.float().data_ptr(), scale.float().data_ptr(), Q.float().data_ptr(),
+    m32, s32, q32 = _f32(mean, scale, Q)
+    _lib.check(_lib.lib().gsac_decode_gaussian_slices(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(),
                                                       ss.ctypes.data, ss.size - 1, mins.ctypes.data, maxs.ctypes.data, data.ctypes.data, data.size,
                                                       cnt.ctypes.data, int(chunk_size), out.data_ptr(), runtime.stream_ptr(mean.device)))
     return out

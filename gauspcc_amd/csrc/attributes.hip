@@ -381,12 +381,17 @@ static int gsac_decode_impl(gpcc_ctx *ctx, CT cdf, const uint8_t *bytes, int64_t
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)cdiv(n, chunk_size);
+    if (nbytes < 0 || nbytes >= ((int64_t)1 << 32)) return fail(GPCC_ERR_FORMAT, "byte stream must be shorter than 4 GiB");
     std::vector<uint32_t> cum((size_t)nch + 1, 0);
-    for (int c = 0; c < nch; ++c) {
-        if (cnt[c] < 0) return fail(GPCC_ERR_FORMAT, "negative chunk size");
-        cum[(size_t)c + 1] = cum[(size_t)c] + (uint32_t)cnt[c];
+    {
+        uint64_t run = 0;   // the counts come from a file: summed in 64 bits, checked chunk by chunk (a wrapped 32-bit sum would pass)
+        for (int c = 0; c < nch; ++c) {
+            if (cnt[c] < 0) return fail(GPCC_ERR_FORMAT, "negative chunk size");
+            run += (uint64_t)cnt[c];
+            if (run > (uint64_t)nbytes) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
+            cum[(size_t)c + 1] = (uint32_t)run;
+        }
     }
-    if ((int64_t)cum[(size_t)nch] > nbytes) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
     if (!keep_arena) {
         GP_TRY(ctx->arena.reserve((size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
         ctx->arena.reset();
@@ -531,9 +536,13 @@ extern "C" int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean, const floa
 {
     if (!ctx || !mean || !scale || !Q || !x_out) return fail(GPCC_ERR_ARG, "null argument");
     if (n <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    // min / max are floats read from a `.b` file: NaN, infinities and values that do not fit an int are format errors
+    if (!(min_value >= -1.0e9f && min_value <= 1.0e9f) || !(max_value >= -1.0e9f && max_value <= 1.0e9f))
+        return fail(GPCC_ERR_FORMAT, "bad symbol range [%g, %g]", (double)min_value, (double)max_value);
     const int mn = (int)min_value, mx = (int)max_value;
-    const int lp = mx - mn + 2;
-    if (lp < 2 || lp > 32767) return fail(GPCC_ERR_FORMAT, "bad symbol range [%d, %d]", mn, mx);
+    const int64_t lp64 = (int64_t)mx - mn + 2;
+    if (lp64 < 2 || lp64 > 32767) return fail(GPCC_ERR_FORMAT, "bad symbol range [%d, %d]", mn, mx);
+    const int lp = (int)lp64;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int nch = (int)cdiv(n, chunk_size);
@@ -690,8 +699,12 @@ extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, con
     for (int s = 0; s < nslices; ++s) {
         const int64_t len = slice_start[s + 1] - slice_start[s];
         if (len <= 0) return fail(GPCC_ERR_ARG, "slice %d is empty", s);
-        const int mn = (int)min_value[s], lp = (int)max_value[s] - mn + 2;
-        if (lp < 2 || lp > 32767) return fail(GPCC_ERR_FORMAT, "slice %d: bad symbol range", s);
+        if (!(min_value[s] >= -1.0e9f && min_value[s] <= 1.0e9f) || !(max_value[s] >= -1.0e9f && max_value[s] <= 1.0e9f))
+            return fail(GPCC_ERR_FORMAT, "slice %d: bad symbol range", s);
+        const int mn = (int)min_value[s];
+        const int64_t lp64 = (int64_t)(int)max_value[s] - mn + 2;
+        if (lp64 < 2 || lp64 > 32767) return fail(GPCC_ERR_FORMAT, "slice %d: bad symbol range", s);
+        const int lp = (int)lp64;
         smin[(size_t)s] = mn; slp[(size_t)s] = lp;
         const int nch = (int)cdiv(len, chunk_size);
         for (int c = 0; c < nch; ++c) {
@@ -700,9 +713,9 @@ extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, con
             chunks.push_back(SliceChunk{slice_start[s] + (int64_t)c * chunk_size, (int32_t)std::min<int64_t>(chunk_size, len - (int64_t)c * chunk_size), s,
                                         (uint32_t)off, (uint32_t)cb});
             off += (uint32_t)cb;
+            if ((int64_t)off > nbytes || off >= ((uint64_t)1 << 32)) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
         }
     }
-    if ((int64_t)off > nbytes || off >= ((uint64_t)1 << 32)) return fail(GPCC_ERR_FORMAT, "chunk sizes exceed the byte stream");
     const size_t nch = chunks.size();
     GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(SliceChunk) * nch + 8 * (size_t)nslices + ((size_t)4 << 20)));
     ctx->arena.reset();

@@ -3,6 +3,10 @@ section 8e), nothing is exchanged on the data path, and one all_gather collates 
 per-scene bitstream statistics.  Works over any torch.distributed backend: RCCL
 ("nccl") on the MI355X node, gloo in the CPU tests.
 """
+import os
+import socket
+import subprocess
+import sys
 from dataclasses import dataclass
 
 import torch
@@ -73,3 +77,23 @@ def max_over_ranks(seconds: float, device, group=None) -> float:
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script: str, argv, nproc: int, port: int = 0) -> int:
+    """Start `nproc` ranks of `script` on this node, one per GPU, the way the driver does:
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv`.
+    Called by a parent that has NOT touched the GPU (an exec / fork from a process with an initialised HIP runtime takes the
+    box down); the children are ordinary subprocesses whose stdout / stderr pass straight through (rank 0 prints the JSON
+    line), and the launcher's exit code is returned."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port or free_port()), script] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool: RCCL needs it
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)

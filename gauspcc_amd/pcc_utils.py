@@ -126,8 +126,10 @@ def save_ply_ascii_geo(coords, filedir):
 
 
 def _encode_view(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
-    """gpcc_encode without the copy into a Python bytes object: a ctypes byte array over the context's pinned output buffer,
-    valid until the next encode on this context (write it to a file, or hand it to _decode_bytes)."""
+    """gpcc_encode without the copy into a Python bytes object: a ctypes byte array over the context's pinned output buffer.
+    The view is valid only until the NEXT call of any kind that writes that buffer on this context: gpcc_encode, gpcc_rc_encode
+    and every gsac_encode* (the attribute coders of arithmetic.py / encodings_cuda.py share it).  Write it to a file or hand
+    it to _decode_bytes first; _encode_to_bytes returns an owned copy."""
     ctx = runtime.context(xyz_int32.device)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
     _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
@@ -136,9 +138,15 @@ def _encode_view(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
 
 
 def _header_points(head: bytes):
-    """Point count from a chunked container's header (FF FF | version | chunk_log2 | posQ | L | 0 | u32 n[L] | u32 N), else None."""
+    """Point count from a chunked container's header (FF FF | version | chunk_log2 | posQ | L | 0 | u32 n[L] | u32 N), else None.
+    The header is untrusted: a count that the last level cannot expand to (more than 8 children per node, or fewer than one)
+    is reported as None, and the caller takes the path on which the library sizes the output from what it decoded."""
     if len(head) >= 12 and head[0] == 0xFF and head[1] == 0xFF and 1 <= head[6] <= 21 and len(head) >= 12 + 4 * head[6]:
-        return int.from_bytes(head[8 + 4 * head[6]: 12 + 4 * head[6]], "little")
+        L = head[6]
+        npts = int.from_bytes(head[8 + 4 * L: 12 + 4 * L], "little")
+        last = int.from_bytes(head[8 + 4 * (L - 1): 8 + 4 * L], "little")
+        if last <= npts <= 8 * last:
+            return npts
     return None
 
 

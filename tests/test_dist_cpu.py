@@ -1,7 +1,10 @@
 """world_size-2 gloo test of the N>1 path: scene sharding + stats all_gather + MAX timing
 (the same code bench.py runs over RCCL)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.multiprocessing as mp
@@ -48,3 +51,28 @@ def test_scene_sharding_and_stats_allgather_gloo():
     assert pts == [1000, 1002, 1004, 1001, 1003]       # ordered by (rank, local index)
     assert [r[4] for r in res[0][2]][0] == 2 ** 40     # int64-sized counters survive the float64 transport
     assert res[0][3] == res[1][3] == 2.0               # MAX over ranks
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two ranks through torch.distributed.run
+    (before touching any GPU), relays rank 0's JSON line and the exit code.  Here on gloo, without a GPU."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "1000", "--selftest-launcher"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout     # one JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["seeds"] == [1234, 1235] and out["max_elapsed"] == 2.0
+
+
+def test_bench_relays_a_failing_rank():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    # without --selftest-launcher the ranks need a GPU: on this box they exit non-zero, and so must the parent
+    if torch.cuda.is_available():
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "1000", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0

@@ -182,3 +182,55 @@ def test_gaussian_slices_write_the_per_slice_files(torch_cuda, tmp_path):
             assert open(a[s].replace(".b", "_0.b"), "rb").read() == open(b[s].replace(".b", "_0.b"), "rb").read()
     dec = ec.decoder_gaussian_slices(mean, scale, q, bounds, b)         # reads the files of the slice-by-slice encoder
     assert torch.equal(dec, torch.round(x / q) * q)
+
+
+def test_b_files_equal_oracle_written_files(torch_cuda, orc, tmp_path):
+    """a19: the `.b` containers (HAC/utils/encodings_cuda.py:366-376, 455-464) as whole files.  Expected files are put
+    together here from the ORACLE coder's output: Bernoulli `f32 p | i32 len | cnt | payload` from the exact float CDF
+    [0, 1 - p, 1]; Gaussian `f32 min | f32 max | i32 len | cnt | payload` from the CDF table the device computed (erfc comes
+    from two math libraries, which may round a table entry differently; the table itself is checked in
+    test_calculate_cdf_matches_oracle)."""
+    torch = torch_cuda
+    from gauspcc_amd import arithmetic
+    from gauspcc_amd import encodings_cuda as ec
+
+    g = torch.Generator(device="cpu").manual_seed(21)
+    # Bernoulli: masks-like input (n, K, 1) of {0, 1}; two chunks of 10000 and a ragged third
+    x = (torch.rand(2345, 10, 1, generator=g) < 0.27).float().cuda()
+    bits = ec.encoder(x, file_name=str(tmp_path / "masks.b"))
+    xs = x.view(-1).cpu().numpy()
+    p1 = np.float32((x.view(-1).sum() / x.numel()).item())              # the float32 the reference stores (:440, 456)
+    cdf = np.empty((xs.size, 3), np.float32)
+    cdf[:, 0], cdf[:, 1], cdf[:, 2] = 0.0, np.float32(1) - p1, 1.0      # :445-448: [0, 1 - p, 1] in float32
+    payload, cnt = orc.hac_encode(xs.astype(np.int16), cdf, 10000)
+    want = p1.tobytes() + np.array([4 * len(cnt)], np.int32).tobytes() + cnt.astype(np.int32).tobytes() + payload.tobytes()
+    got = (tmp_path / "masks.b").read_bytes()
+    assert got == want
+    assert bits == (len(payload) + 4 * len(cnt)) * 8 + 64
+    assert np.array_equal(ec.decoder(xs.size, file_name=str(tmp_path / "masks.b")).cpu().numpy(), xs.astype(np.int16))
+    # Gaussian
+    n = 23456
+    mean = (torch.randn(n, generator=g) * 2).cuda(); scale = (torch.rand(n, generator=g) * 3 + 0.05).cuda()
+    q = (torch.rand(n, generator=g) * 0.5 + 0.75).cuda()
+    xq = torch.round((mean + torch.randn(n, generator=g).cuda() * scale) / q) * q
+    bits = ec.encoder_gaussian(xq, mean, scale, q, file_name=str(tmp_path / "feat.b"))
+    xi = torch.round(xq / q)
+    mn, mx = float(xi.min()), float(xi.max())
+    lower = arithmetic.calculate_cdf(mean, scale, q, mn, mx).cpu().numpy()
+    payload, cnt = orc.hac_encode((xi - mn).to(torch.int16).cpu().numpy(), lower, 10000)
+    want = np.float32(mn).tobytes() + np.float32(mx).tobytes() + np.array([4 * len(cnt)], np.int32).tobytes() + cnt.astype(np.int32).tobytes() + payload.tobytes()
+    assert (tmp_path / "feat.b").read_bytes() == want
+    assert bits == (len(payload) + 4 * len(cnt)) * 8 + 96
+    assert torch.equal(ec.decoder_gaussian(mean, scale, q, file_name=str(tmp_path / "feat.b")), xq)
+
+
+def test_psnr_matches_reference_golden(torch_cuda, golden_dir):
+    """a21: the product's psnr (gauspcc_amd/rasterizer.py; HAC/utils/image_utils.py:17-19) on the device against the values
+    the reference function gave for the same images (tests/golden/image.npz, make_golden.py)."""
+    torch = torch_cuda
+    from gauspcc_amd.rasterizer import psnr
+
+    z = np.load(f"{golden_dir}/image.npz")
+    got = psnr(torch.tensor(z["a"]).cuda(), torch.tensor(z["b"]).cuda())
+    assert got.shape == tuple(z["psnr"].shape) and got.is_cuda
+    np.testing.assert_allclose(got.cpu().numpy(), z["psnr"], rtol=1e-5)

@@ -249,6 +249,21 @@ def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_m
     assert np.array_equal(dec, orc.decode(synth_model_k5, ref)[0])
 
 
+def test_codec_bitstream_identical_to_oracle_1m(gh, orc, dev_model_k5, synth_model_k5):
+    """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v2.  The device
+    writes the oracle's bytes and decodes to the oracle's points in the oracle's order (the oracle needs ~15 s of the box's
+    host cores for each direction)."""
+    pts = _cloud(1_000_000, seed=1234)
+    data, st = gh.encode(dev_model_k5, pts, 10)
+    ref = orc.encode(synth_model_k5, pts, chunk_log2=10)
+    assert len(data) == len(ref)
+    assert data == ref
+    assert st.num_points == 1_000_000 and st.coded_nodes > 2_500_000
+    dec, _, _ = gh.decode(dev_model_k5, data)
+    odec, _ = orc.decode(synth_model_k5, ref, cap_pts=1_000_000)
+    assert np.array_equal(dec, odec)
+
+
 def test_ideal_bits_estimator_and_coder_overhead(gh, orc, dev_model_k5, synth_model_k5):
     """a14: the reference's bpp estimator (network_ue_4stage_conv.py:100-182), sum clamp(-log2(p_gt + 1e-10), 0, 50),
     accumulated on the device beside the coder; the actual range-coder payload must sit within a small

@@ -138,6 +138,14 @@ def main():
     _lib.check(L.gpcc_profile_get(ctx, C.byref(prof)))
     _lib.check(L.gpcc_profile_enable(ctx, 0))
 
+    # size of the same cloud in the reference's container layout (one coder stream per level and stage, chunk_log2 = 0):
+    # what the chunked default costs in bytes, outside the timed region
+    bytes_v0 = None
+    if args.chunk_log2 and rank == 0:
+        v0, _ = _encode_view(x, model, 0, 1)
+        bytes_v0 = len(v0)
+        data, st = _encode_view(x, model, args.chunk_log2, 1)   # the view above shares the context's buffer: restore `data`
+
     # correctness of what was just timed: decoded geometry == input geometry (as sets; bit-identical)
     d = dec.cpu().numpy()
     ok = d.shape == pts.shape and np.array_equal(d[np.lexsort((d[:, 0], d[:, 1], d[:, 2]))], pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))])
@@ -189,6 +197,15 @@ def main():
             "enc_ms": round(float(allstats[:, 1].mean()) * 1e3, 3),
             "dec_ms": round(float(allstats[:, 2].mean()) * 1e3, 3),
             "bpp": round(float(allstats[:, 0].mean()) * 8 / args.points, 4),
+            # The chunked container pays a fixed number of bytes per chunk (u16 count + coder flush) for its parallel decode.
+            # The seeded random weights code ~22 bpp; a trained model at a few bpp shrinks the payload, not this overhead, so
+            # it is also quoted against a 4 bpp payload (HAC-class rates).  chunk_log2 = 0 writes bytes_v0 exactly.
+            "container_bytes": len(data),
+            "bytes_v0": bytes_v0,
+            "bpp_v0": None if bytes_v0 is None else round(bytes_v0 * 8 / args.points, 4),
+            "chunk_overhead_bytes": None if bytes_v0 is None else len(data) - bytes_v0,
+            "chunk_overhead_frac": None if bytes_v0 is None else round((len(data) - bytes_v0) / bytes_v0, 5),
+            "chunk_overhead_frac_at_4bpp": None if bytes_v0 is None else round((len(data) - bytes_v0) / (4.0 * args.points / 8), 5),
             "coded_nodes": int(allstats[0, 3]),
             "roundtrip_bit_identical": True,
             "roofline": {

@@ -36,12 +36,20 @@ def list_inputs(input_glob, num_samples=-1):
     return files[:num_samples] if num_samples > 0 else files
 
 
-def quantise(xyz, is_data_pre_quantized, posQ):
-    """:90-95 -- torch.round is round-half-even, as is np.rint."""
-    xyz = np.asarray(xyz, dtype=np.float64)
-    if not is_data_pre_quantized:
-        xyz = xyz / 0.001 + 131072
-    return np.rint(xyz / posQ).astype(np.int32)
+def quantise(xyz, is_data_pre_quantized, posQ, device=None):
+    """:89-94 on the device (gpcc_voxelise), in the dtype the reader produced (float32 for KITTI .bin, float64 for the text
+    and PLY readers) as the reference's numpy / torch expressions do; coincident voxels merge, as the reference's sparse
+    tensor construction merges them.  Returns an (M,3) int32 tensor on the device."""
+    import torch
+
+    from .. import pcc_utils
+
+    a = np.asarray(xyz)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
+    device = device or torch.device("cuda", torch.cuda.current_device())
+    q = pcc_utils.voxelise(torch.from_numpy(np.ascontiguousarray(a)).to(device), bool(is_data_pre_quantized), posQ)
+    return torch.unique(q, dim=0)
 
 
 def write_results_csv(rows, csvfile, with_avg):
@@ -79,9 +87,9 @@ def main(argv=None):
     csvfile = os.path.join(args.resultdir, args.prefix + "_data" + str(len(files)) + ".csv")
     for path, pts in zip(files, xyz_ls):
         name = os.path.split(path)[-1]
-        xyz = np.unique(quantise(pts, args.is_data_pre_quantized, args.posQ), axis=0)   # coincident voxels merge, as the reference's hash build does
+        xyz = quantise(pts, args.is_data_pre_quantized, args.posQ, device)
         n_in = len(pts)
-        r = pcc_utils.compress_point_cloud(torch.tensor(xyz), args.ckpt, os.path.join(args.output_folder, name + ".bin"), channels=args.channels,
+        r = pcc_utils.compress_point_cloud(xyz, args.ckpt, os.path.join(args.output_folder, name + ".bin"), channels=args.channels,
                                            kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
         rows.append({"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in})
         write_results_csv(rows, csvfile, with_avg=False)

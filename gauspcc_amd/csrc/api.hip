@@ -251,7 +251,40 @@ int raster_order_t(gpcc_ctx *ctx, hipStream_t st, const T *x, int64_t n, int64_t
     return GPCC_OK;
 }
 
+// a1: out = int32(rint(((x / d1) + add) / d2)) evaluated in the array's own type T, one IEEE operation after the other
+// (division correctly rounded; -ffp-contract=off keeps the add out of an fma), as numpy / torch on the CPU evaluate
+// `xyz / 0.001 + 131072` and `torch.round(xyz / posQ).int()`; values that do not fit an int32 saturate
+template <typename T>
+__global__ __launch_bounds__(TB) void k_voxelise(const T *__restrict__ x, int64_t n3, T d1, T add, T d2, int flags, int32_t *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n3) return;
+    T t = x[i];
+    if (flags & 1) { t = t / d1; t = t + add; }
+    if (flags & 2) t = t / d2;
+    const double r = rint((double)t);    // exact for float and double; round-half-even like torch.round
+    out[i] = r >= 2147483647.0 ? INT32_MAX : (r <= -2147483648.0 ? INT32_MIN : (int32_t)r);
+}
+
 }  // namespace
+
+extern "C" int gpcc_voxelise(gpcc_ctx *ctx, const void *xyz, int dtype, int64_t n, double d1, double add, double d2, int flags, int32_t *out, void *stream)
+{
+    if (!ctx || !xyz || !out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n < 0) return fail(GPCC_ERR_ARG, "negative point count");
+    if (n == 0) return GPCC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n3 = 3 * n;
+    const unsigned grid = (unsigned)cdiv(n3, TB);
+    switch (dtype) {
+    case GPCC_F32: k_voxelise<float><<<grid, TB, 0, st>>>((const float *)xyz, n3, (float)d1, (float)add, (float)d2, flags, out); break;
+    case GPCC_F64: k_voxelise<double><<<grid, TB, 0, st>>>((const double *)xyz, n3, d1, add, d2, flags, out); break;
+    default: return fail(GPCC_ERR_ARG, "gpcc_voxelise: dtype must be GPCC_F32 or GPCC_F64");
+    }
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
 
 extern "C" int gpcc_raster_order(gpcc_ctx *ctx, const void *xyz, int dtype, int64_t n, int64_t *perm, void *stream)
 {
@@ -348,7 +381,7 @@ extern "C" int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, i
             if (T.lv[d].n > cap_nodes) return fail(GPCC_ERR_ARG, "level %d has %lld nodes, capacity %lld", d, (long long)T.lv[d].n, (long long)cap_nodes);
             size_t mk = ctx->arena.mark();
             TAKE(dx, int32_t, 3 * T.lv[d].n); TAKE(dox, uint8_t, T.lv[d].n);
-            GP_TRY(level_to_raster(ctx, st, &T.lv[d], dx, dox));
+            GP_TRY(level_to_raster(ctx, st, &T.lv[d], T.bias, dx, dox));
             HIP_TRY(hipMemcpyAsync(coords_out_host[d], dx, 12 * (size_t)T.lv[d].n, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(occ_out_host[d], dox, (size_t)T.lv[d].n, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

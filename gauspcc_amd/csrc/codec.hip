@@ -197,7 +197,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     const Level *base = &T.lv[0];
     TAKE(base_xyz, int32_t, 3 * base->n);
     TAKE(base_occ, uint8_t, base->n);
-    GP_TRY(level_to_raster(ctx, st, base, base_xyz, base_occ));
+    GP_TRY(level_to_raster(ctx, st, base, T.bias, base_xyz, base_occ));
     // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ | gaps]
     const size_t off_desc = 0, off_cnt = off_desc + sizeof(RcChunk) * (size_t)std::max(nchunks, 1);
     const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * MAXLV, off_bo = off_bx + 12 * (size_t)base->n;
@@ -343,14 +343,25 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     }
 #undef NEED
     // ---- base level -> Morton order on the host (< 64 nodes)
-    const int bias = CB >> L;
+    // internal frame (octree.hpp: Tree::bias): 2^20 when the whole cloud lies inside (-2^20, 2^20), else the base level's own
+    // minimum per axis -- in leaf units a multiple of 2^L, which is all the tree needs
+    int64_t bias_base[3] = {CB >> L, CB >> L, CB >> L}, bias_leaf[3] = {CB, CB, CB};
+    {
+        int64_t lo[3] = {INT64_MAX, INT64_MAX, INT64_MAX}, hi[3] = {INT64_MIN, INT64_MIN, INT64_MIN};
+        for (int64_t i = 0; i < bn; ++i)
+            for (int a = 0; a < 3; ++a) { const int64_t c = (int32_t)get32(bxyz + 12 * i + 4 * a); lo[a] = std::min(lo[a], c); hi[a] = std::max(hi[a], c); }
+        bool inside = true;
+        for (int a = 0; a < 3; ++a) inside = inside && lo[a] + (int64_t)(CB >> L) >= 0 && hi[a] + (int64_t)(CB >> L) < ((int64_t)1 << (21 - L));
+        if (!inside)
+            for (int a = 0; a < 3; ++a) { bias_base[a] = -lo[a]; bias_leaf[a] = -lo[a] * ((int64_t)1 << L); }
+    }
     struct BN { uint64_t mk, rk; uint8_t occ; };
     std::vector<BN> bnodes((size_t)bn);
     uint32_t mn[3] = {~0u, ~0u, ~0u}, mx[3] = {0, 0, 0};
     for (int64_t i = 0; i < bn; ++i) {
         uint32_t b[3];
         for (int a = 0; a < 3; ++a) {
-            const int64_t c = (int32_t)get32(bxyz + 12 * i + 4 * a) + (int64_t)bias;
+            const int64_t c = (int32_t)get32(bxyz + 12 * i + 4 * a) + bias_base[a];
             if (c < 0 || c >= ((int64_t)1 << (21 - L))) return fail(GPCC_ERR_FORMAT, "base coordinate out of range");
             b[a] = (uint32_t)c; mn[a] = std::min(mn[a], b[a]); mx[a] = std::max(mx[a], b[a]);
         }
@@ -529,7 +540,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(own, int32_t, 3 * std::max<int64_t>(npts, 1));
         xyz = own;
     }
-    GP_TRY(leaves_reference_order(ctx, st, &cur, xyz, npts));
+    GP_TRY(leaves_reference_order(ctx, st, &cur, bias_leaf, xyz, npts));
     unsigned long long hpairs[MAXLV];
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -44,11 +44,11 @@ __global__ __launch_bounds__(TB) void k_bbox(const int32_t *__restrict__ xyz, in
     }
 }
 
-__global__ __launch_bounds__(TB) void k_leaf_keys(const int32_t *__restrict__ xyz, int64_t n, uint64_t *__restrict__ mkey)
+__global__ __launch_bounds__(TB) void k_leaf_keys(const int32_t *__restrict__ xyz, int64_t n, Bias3 b, uint64_t *__restrict__ mkey)
 {
     int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    mkey[i] = morton3((uint32_t)(xyz[3 * i] + CB), (uint32_t)(xyz[3 * i + 1] + CB), (uint32_t)(xyz[3 * i + 2] + CB));
+    mkey[i] = morton3((uint32_t)((int64_t)xyz[3 * i] + b.v[0]), (uint32_t)((int64_t)xyz[3 * i + 1] + b.v[1]), (uint32_t)((int64_t)xyz[3 * i + 2] + b.v[2]));
 }
 
 // counts[l] (l = 0..21): number of sorted leaves whose highest differing Morton triple vs the
@@ -152,7 +152,31 @@ int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level)
 }
 
 // ------------------------------------------------------------------ encode-side tree build
-static inline int bitlen(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+static inline int bitlen(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
+
+int tree_pick_bias(const int32_t mn[3], const int32_t mx[3], int64_t bias[3])
+{
+    bool inside = true;
+    int64_t ext = 0;
+    for (int a = 0; a < 3; ++a) {
+        inside = inside && mn[a] >= -CLIM && mx[a] < CLIM;
+        ext = std::max<int64_t>(ext, (int64_t)mx[a] - (int64_t)mn[a]);
+    }
+    if (inside) { bias[0] = bias[1] = bias[2] = CB; return GPCC_OK; }
+    // Anywhere in int32: the tree has at most max(1, bitlen(extent)) levels (a level whose cells are wider than half the
+    // extent has at most 27 nodes, and the FOG loop stops below 64), so an origin that is a multiple of A = 2^that keeps
+    // every floor-halving exact.  Internal coordinates then lie in [0, A + extent] and must fit 21 bits: extent < 2^20.
+    const int hbE = std::max(1, bitlen((uint64_t)ext));
+    if (hbE > 20)
+        return fail(GPCC_ERR_RANGE, "coordinate out of range: a cloud that leaves (-2^20, 2^20) must have an extent below 2^20 (it spans %lld)", (long long)ext);
+    const int64_t A = (int64_t)1 << hbE;
+    for (int a = 0; a < 3; ++a) {
+        const int64_t m = mn[a];
+        const int64_t fl = (m >= 0 ? m / A : -((-m + A - 1) / A)) * A;   // floor to a multiple of A
+        bias[a] = -fl;
+    }
+    return GPCC_OK;
+}
 
 static int level_alloc(gpcc_ctx *ctx, Level *lv, int64_t n, int lvl)
 {
@@ -178,15 +202,13 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tre
     HIP_TRY(hipMemcpyAsync(hb32, dsmall, 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     int hb = 1;
-    for (int a = 0; a < 3; ++a) {
-        if (hb32[a] < -CLIM || hb32[3 + a] >= CLIM) return fail(GPCC_ERR_RANGE, "coordinate out of range: axis %d spans [%d, %d], limit |c| < 2^20-8", a, hb32[a], hb32[3 + a]);
-        hb = std::max(hb, bitlen((uint32_t)(hb32[a] + CB) ^ (uint32_t)(hb32[3 + a] + CB)));
-    }
+    GP_TRY(tree_pick_bias(hb32, hb32 + 3, T->bias));
+    for (int a = 0; a < 3; ++a) hb = std::max(hb, bitlen((uint64_t)((int64_t)hb32[a] + T->bias[a]) ^ (uint64_t)((int64_t)hb32[3 + a] + T->bias[a])));
     T->hb = hb; T->npts = n;
     // sorted Morton keys of the leaves
     TAKE(mk0, uint64_t, n);
     TAKE(mk1, uint64_t, n);
-    k_leaf_keys<<<nblk(n), TB, 0, st>>>(xyz, n, mk0);
+    k_leaf_keys<<<nblk(n), TB, 0, st>>>(xyz, n, Bias3{{T->bias[0], T->bias[1], T->bias[2]}}, mk0);
     LAUNCH_CHECK();
     uint64_t *ka = mk0, *kb = mk1;
     GP_TRY(radix_sort_u64(ctx, st, &ka, &kb, nullptr, nullptr, n, 3 * hb));
@@ -388,7 +410,7 @@ __global__ __launch_bounds__(TB) void k_popc_raster(const uint8_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(TB) void k_leaves_out(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m,
-                                                   const uint32_t *__restrict__ start_r, int64_t n, int32_t *__restrict__ xyz)
+                                                   const uint32_t *__restrict__ start_r, int64_t n, Bias3 b, int32_t *__restrict__ xyz)
 {
     int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     int64_t r = t >> 3;
@@ -399,12 +421,12 @@ __global__ __launch_bounds__(TB) void k_leaves_out(const uint64_t *__restrict__ 
     if (!((o >> q) & 1u)) return;
     const int64_t idx = (int64_t)start_r[r] + __popc(o & ((1u << q) - 1u));
     const uint64_t k = rkey[m];
-    xyz[3 * idx] = (int32_t)(2 * rk_x(k) + (q & 1)) - CB;
-    xyz[3 * idx + 1] = (int32_t)(2 * rk_y(k) + ((q >> 1) & 1)) - CB;
-    xyz[3 * idx + 2] = (int32_t)(2 * rk_z(k) + ((q >> 2) & 1)) - CB;
+    xyz[3 * idx] = (int32_t)((int64_t)(2 * rk_x(k) + (q & 1)) - b.v[0]);
+    xyz[3 * idx + 1] = (int32_t)((int64_t)(2 * rk_y(k) + ((q >> 1) & 1)) - b.v[1]);
+    xyz[3 * idx + 2] = (int32_t)((int64_t)(2 * rk_z(k) + ((q >> 2) & 1)) - b.v[2]);
 }
 
-int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int32_t *xyz_out, int64_t npts)
+int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, const int64_t bias[3], int32_t *xyz_out, int64_t npts)
 {
     if (last->lvl != 1) return fail(GPCC_ERR_ARG, "leaves_reference_order: level is not the parents of the leaves");
     const int64_t n = last->n;
@@ -413,7 +435,7 @@ int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int
     k_popc_raster<<<nblk(n), TB, 0, st>>>(last->occ, last->r2m, n, cnt);
     LAUNCH_CHECK();
     GP_TRY(exclusive_scan_u32(ctx, st, cnt, cnt, n, nullptr));
-    k_leaves_out<<<nblk(n * 8), TB, 0, st>>>(last->rkey, last->occ, last->r2m, cnt, n, xyz_out);
+    k_leaves_out<<<nblk(n * 8), TB, 0, st>>>(last->rkey, last->occ, last->r2m, cnt, n, Bias3{{bias[0], bias[1], bias[2]}}, xyz_out);
     LAUNCH_CHECK();
     ctx->arena.rewind(mk);
     (void)npts;
@@ -421,21 +443,22 @@ int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int
 }
 
 __global__ __launch_bounds__(TB) void k_level_to_raster(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ m2r,
-                                                        int64_t n, int bias, int32_t *__restrict__ xyz, uint8_t *__restrict__ occ_out)
+                                                        int64_t n, Bias3 b, int32_t *__restrict__ xyz, uint8_t *__restrict__ occ_out)
 {
     int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
     const uint32_t r = m2r[i];
     const uint64_t k = rkey[i];
-    xyz[3 * (int64_t)r] = (int32_t)rk_x(k) - bias;
-    xyz[3 * (int64_t)r + 1] = (int32_t)rk_y(k) - bias;
-    xyz[3 * (int64_t)r + 2] = (int32_t)rk_z(k) - bias;
+    xyz[3 * (int64_t)r] = (int32_t)((int64_t)rk_x(k) - b.v[0]);
+    xyz[3 * (int64_t)r + 1] = (int32_t)((int64_t)rk_y(k) - b.v[1]);
+    xyz[3 * (int64_t)r + 2] = (int32_t)((int64_t)rk_z(k) - b.v[2]);
     occ_out[r] = occ[i];
 }
 
-int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int32_t *xyz_out_dev, uint8_t *occ_out_dev)
+int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, const int64_t bias[3], int32_t *xyz_out_dev, uint8_t *occ_out_dev)
 {
-    k_level_to_raster<<<nblk(lv->n), TB, 0, st>>>(lv->rkey, lv->occ, lv->m2r, lv->n, CB >> lv->lvl, xyz_out_dev, occ_out_dev);
+    // the bias is a multiple of 2^L >= 2^lvl: the arithmetic shift is exact
+    k_level_to_raster<<<nblk(lv->n), TB, 0, st>>>(lv->rkey, lv->occ, lv->m2r, lv->n, Bias3{{bias[0] >> lv->lvl, bias[1] >> lv->lvl, bias[2] >> lv->lvl}}, xyz_out_dev, occ_out_dev);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

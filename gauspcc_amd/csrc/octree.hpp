@@ -42,8 +42,9 @@ __host__ __device__ __forceinline__ uint32_t rk_x(uint64_t k) { return (uint32_t
 __host__ __device__ __forceinline__ uint32_t rk_y(uint64_t k) { return (uint32_t)((k >> 21) & 0x1FFFFF); }
 __host__ __device__ __forceinline__ uint32_t rk_z(uint64_t k) { return (uint32_t)((k >> 42) & 0x1FFFFF); }
 
-// One stored level, Morton order.  Biased coordinate b = c + (2^20 >> lvl) where lvl is the
-// number of halvings from the input resolution.
+// One stored level, Morton order.  Internal (biased) coordinate b = (c + Tree::bias[axis]) >> lvl >= 0, lvl = the number of
+// halvings from the input resolution; the bias is a multiple of 2^L per axis, so b = floor(c / 2^lvl) + (bias >> lvl)
+// exactly and the tree is the reference's tree of the absolute coordinates.
 struct Level {
     int64_t n = 0;
     int lvl = 0;            // halvings from the leaves (leaves = 0)
@@ -61,7 +62,14 @@ struct Tree {
     Level lv[MAXLV];
     int64_t npts = 0;
     uint64_t *leaf_mkey = nullptr;  // (npts) sorted Morton keys of the input points
+    // Origin of the internal 21-bit coordinate frame, per axis: internal = c + bias.  2^20 for clouds inside (-2^20, 2^20);
+    // otherwise minus the cloud's minimum rounded down to a multiple of 2^ceil_log2(extent) (>= 2^L), which keeps every
+    // level's floor-halving exact -- only the EXTENT has to fit, the position is any int32.
+    int64_t bias[3] = {CB, CB, CB};
 };
+struct Bias3 { int64_t v[3]; };
+// bias of a cloud from its bounding box (codec and oracle agree on the tree, not on the bias: any multiple of 2^L serves)
+int tree_pick_bias(const int32_t mn[3], const int32_t mx[3], int64_t bias_out[3]);
 
 // encode side: build every level bottom-up from the raw points (one bbox sync + one counts sync)
 int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz_dev, int64_t n, Tree *T);
@@ -85,8 +93,8 @@ int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in,
 int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev);
 
 // leaves of the last level in the reference's decoder order (parents in raster order, octants ascending)
-int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, int32_t *xyz_out, int64_t npts);
+int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, const int64_t bias[3], int32_t *xyz_out, int64_t npts);
 // copy a level to host-visible buffers in raster order: coords (n,3) int32 (un-biased), occ (n)
-int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int32_t *xyz_out_dev, uint8_t *occ_out_dev);
+int level_to_raster(gpcc_ctx *ctx, hipStream_t st, const Level *lv, const int64_t bias[3], int32_t *xyz_out_dev, uint8_t *occ_out_dev);
 
 }  // namespace gpcc

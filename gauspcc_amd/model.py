@@ -20,13 +20,28 @@ def _np(v):
     return np.ascontiguousarray(np.asarray(v, dtype=np.float32))
 
 
-def tensor_table(state_dict: dict, channels: int = 32, kernel_size: int = 5, flip_offsets: bool = False):
-    """Return the 39 float32 arrays in C-ABI order, shape-checked.
+def conv_offset_layout(w: np.ndarray, kernel_size: int, flip_offsets: bool = False, offset_order: str = "xyz") -> np.ndarray:
+    """A (k^3, Cin, Cout) conv kernel as stored by the checkpoint -> this library's enumeration of the k^3 offsets
+    (slice o = (dx+r) + k (dy+r) + k^2 (dz+r), x fastest; pinned against a dense F.conv3d in tests/test_oracle_independent.py).
 
-    flip_offsets reverses the kernel-offset axis of every conv kernel; torchsparse's
-    weight-slice <-> (dx,dy,dz) map cannot be verified here, so
-    a user with an upstream checkpoint can try both.
-    """
+    torchsparse's weight-slice <-> (dx,dy,dz) map cannot be verified here (the package is absent), so the
+    two ambiguities a user with an upstream checkpoint may meet are loader options:
+      offset_order="zyx"  the checkpoint enumerates z fastest (slice = (dz+r) + k (dy+r) + k^2 (dx+r)): a (k,k,k) axis
+                          transpose (x <-> z);
+      flip_offsets=True   the checkpoint's slice o belongs to the offset -delta (out[i] += in[i - delta] @ W[o]): the
+                          reversed enumeration (equivalent to mirroring all three axes)."""
+    k = kernel_size
+    if offset_order not in ("xyz", "zyx"):
+        raise ValueError("offset_order must be 'xyz' or 'zyx'")
+    if offset_order == "zyx":
+        w = w.reshape(k, k, k, *w.shape[1:]).transpose(2, 1, 0, 3, 4).reshape(w.shape)
+    if flip_offsets:
+        w = w[::-1]
+    return np.ascontiguousarray(w)
+
+
+def tensor_table(state_dict: dict, channels: int = 32, kernel_size: int = 5, flip_offsets: bool = False, offset_order: str = "xyz"):
+    """Return the 39 float32 arrays in C-ABI order, shape-checked.  flip_offsets / offset_order: conv_offset_layout."""
     C, K = channels, kernel_size ** 3
     sd = {k[7:] if k.startswith("module.") else k: v for k, v in state_dict.items()}
 
@@ -40,8 +55,7 @@ def tensor_table(state_dict: dict, channels: int = 32, kernel_size: int = 5, fli
 
     t = [get("prior_embedding.weight", (256, C))]
     for key in CONV_KEYS:
-        w = get(key, (K, C, C))
-        t.append(np.ascontiguousarray(w[::-1]) if flip_offsets else w)
+        t.append(conv_offset_layout(get(key, (K, C, C)), kernel_size, flip_offsets, offset_order))
     t.append(get("target_embedding.target_res_embedding.weight", (8, C)))
     t += [get(f"pred_head_s{s}.0.weight", (C, C)) for s in range(4)]
     t += [get(f"pred_head_s{s}.0.bias", (C,)) for s in range(4)]
@@ -67,7 +81,14 @@ def load_state_dict(ckpt_path, channels: int = 32, kernel_size: int = 5):
             return {k: z[k] for k in z.files}
     import torch
 
-    sd = torch.load(p, map_location="cpu")
-    if isinstance(sd, dict) and "state_dict" in sd:
+    # upstream saves `net.state_dict()` (src/ai_pcc/GausPcgc/train.py:212-228) and loads it with
+    # torch.load(ckpt_path, map_location=device) (pcc_utils.py:66, 267); tensors only, so weights_only loading suffices
+    try:
+        sd = torch.load(p, map_location="cpu", weights_only=True)
+    except Exception:
+        sd = torch.load(p, map_location="cpu", weights_only=False)
+    if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]
+    if not isinstance(sd, dict):
+        raise ValueError(f"{p}: expected a state dict, got {type(sd).__name__}")
     return sd

@@ -50,6 +50,25 @@ def calculate_morton_order(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def voxelise(xyz: torch.Tensor, is_data_pre_quantized: bool = True, posQ=1) -> torch.Tensor:
+    """The quantisation in front of the codec, on the device and in the tensor's own dtype
+    (compress_ue_4stage_conv.py:89-94): `xyz / 0.001 + 131072` unless the data is pre-quantised, then
+    `torch.round(xyz / posQ).int()`.  xyz: (N,3) float32 / float64 tensor on the MI355X -> (N,3) int32 on the same device.
+    (HAC's `torch.round(anchor / voxel_size)`, gaussian_model.py:1107, is voxelise(anchor / voxel_size).)"""
+    assert len(xyz.shape) == 2 and xyz.shape[1] == 3
+    if not xyz.is_cuda:
+        raise RuntimeError("gauspcc_amd.voxelise needs a tensor on the MI355X (no CPU path)")
+    x = xyz.detach()
+    if x.dtype not in (torch.float32, torch.float64):
+        x = x.to(torch.float64 if x.dtype == torch.int64 else torch.float32)
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    flags = (0 if is_data_pre_quantized else 1) | 2
+    _lib.check(_lib.lib().gpcc_voxelise(runtime.context(x.device), x.data_ptr(), _DTYPES[x.dtype], x.shape[0], 0.001, 131072.0, float(posQ), flags,
+                                        out.data_ptr(), runtime.stream_ptr(x.device)))
+    return out
+
+
 def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ, ideal_bits: bool = False):
     ctx = runtime.context(xyz_int32.device)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()

@@ -37,10 +37,10 @@ def stream_ptr(device=None):
 class Model:
     """Weights resident on one device (gpcc_model)."""
 
-    def __init__(self, state_dict, channels=32, kernel_size=5, device=None, flip_offsets=False):
+    def __init__(self, state_dict, channels=32, kernel_size=5, device=None, flip_offsets=False, offset_order="xyz"):
         self.device = _device_index(device)
         self.channels, self.kernel_size = channels, kernel_size
-        tensors = tensor_table(state_dict, channels, kernel_size, flip_offsets)
+        tensors = tensor_table(state_dict, channels, kernel_size, flip_offsets, offset_order)
         self._keep = tensors
         ptrs = (C.c_void_p * len(tensors))(*[t.ctypes.data for t in tensors])
         self.handle = C.c_void_p()
@@ -55,15 +55,25 @@ class Model:
             pass
 
 
-def get_model(ckpt_path, channels=32, kernel_size=5, device=None) -> Model:
+def get_model(ckpt_path, channels=32, kernel_size=5, device=None, flip_offsets=None, offset_order=None) -> Model:
     """The reference rebuilds and reloads the network on every call (pcc_utils.py:65-67);
-    here a model is uploaded once per (checkpoint, device) and reused."""
+    here a model is uploaded once per (checkpoint, device, offset layout) and reused.  `ckpt_path` is what the reference's
+    functions take -- a torch checkpoint of `net.state_dict()` -- or an .npz / a dict with the same keys / 'synthetic[:seed]'
+    / a Model.  The conv-kernel offset layout of the checkpoint (model.conv_offset_layout) comes from the arguments or, for
+    callers that only pass a path through compress_point_cloud, from GAUSPCC_OFFSET_ORDER (xyz | zyx) and
+    GAUSPCC_FLIP_OFFSETS (0 | 1)."""
+    import os
+
     idx = _device_index(device)
     if isinstance(ckpt_path, Model):
         return ckpt_path
-    key = (id(ckpt_path) if isinstance(ckpt_path, dict) else str(ckpt_path), channels, kernel_size, idx)
+    if offset_order is None:
+        offset_order = os.environ.get("GAUSPCC_OFFSET_ORDER", "xyz")
+    if flip_offsets is None:
+        flip_offsets = os.environ.get("GAUSPCC_FLIP_OFFSETS", "0") not in ("", "0")
+    key = (id(ckpt_path) if isinstance(ckpt_path, dict) else str(ckpt_path), channels, kernel_size, idx, bool(flip_offsets), offset_order)
     if key not in _MODELS:
-        _MODELS[key] = Model(load_state_dict(ckpt_path, channels, kernel_size), channels, kernel_size, idx)
+        _MODELS[key] = Model(load_state_dict(ckpt_path, channels, kernel_size), channels, kernel_size, idx, bool(flip_offsets), offset_order)
     return _MODELS[key]
 
 

@@ -25,7 +25,7 @@ typedef enum {
     GPCC_OK = 0,
     GPCC_ERR_HIP = -1,        /* a HIP runtime call failed */
     GPCC_ERR_ARG = -2,        /* bad argument */
-    GPCC_ERR_RANGE = -3,      /* coordinate outside [-2^20+8, 2^20-8) */
+    GPCC_ERR_RANGE = -3,      /* the cloud leaves (-2^20, 2^20) AND its extent is 2^20 or more (any int32 position is fine) */
     GPCC_ERR_DUPLICATE = -4,  /* duplicate point (the reference silently corrupts occupancy here) */
     GPCC_ERR_FORMAT = -5,     /* malformed / truncated bitstream */
     GPCC_ERR_NOMEM = -6
@@ -47,6 +47,16 @@ GPCC_API void gpcc_ctx_destroy(gpcc_ctx *ctx);
  * (M = max over all axes + 1), i.e. the (z,y,x) raster order; stable for equal keys. */
 GPCC_API int gpcc_raster_order(gpcc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n,
                       int64_t *perm_out_dev, void *stream);
+
+/* ---- a1  voxelise (caller side)     src/ai_pcc/GausPcgc/compress_ue_4stage_conv.py:89-94: `xyz / 0.001 + 131072` (when the
+ * data is not pre-quantised) then `torch.round(xyz / posQ).int()`; HAC/scene/gaussian_model.py:1107: `round(anchor / voxel)`.
+ * out[i] = int32(rint(((x[i] / d1) + add) / d2)) over the 3n coordinates, evaluated in the array's OWN dtype (GPCC_F32 or
+ * GPCC_F64) one correctly rounded operation at a time, as the reference's numpy / torch-CPU expressions are; flags bit 0
+ * enables the `/ d1 + add` step, bit 1 the `/ d2` step.  xyz_dev (n,3) and out_dev (n,3) int32 are device pointers. */
+#define GPCC_VOX_SCALE 1
+#define GPCC_VOX_POSQ 2
+GPCC_API int gpcc_voxelise(gpcc_ctx *ctx, const void *xyz_dev, int dtype, int64_t n, double d1, double add, double d2, int flags,
+                  int32_t *out_dev, void *stream);
 
 /* ---- Network(channels, kernel_size).load_state_dict     pcc_utils.py:65-67, 266-268
  * tensors: GPCC_T_COUNT host pointers to contiguous float32 arrays, upstream layouts

@@ -45,6 +45,75 @@ def _cloud(n, seed=1234, negative=False):
     return synthetic_cloud(n, seed=seed, negative=negative)
 
 
+# ---------------------------------------------------------------- a1 voxelise
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("pre,posq", [(True, 1), (False, 16), (False, 1), (True, 3)])
+def test_voxelise_matches_numpy_in_the_same_dtype(gh, dtype, pre, posq):
+    """compress_ue_4stage_conv.py:89-94 evaluated by numpy in the array's own dtype (how the reference evaluates it: numpy for
+    `/ 0.001 + 131072`, torch-CPU for `round(xyz / posQ).int()`) == gpcc_voxelise, bit for bit."""
+    import torch
+    from gauspcc_amd.pcc_utils import voxelise
+
+    rng = np.random.RandomState(int(posq) + 7 * int(pre))
+    x = (rng.randn(200_000, 3) * (300.0 if pre else 40.0)).astype(dtype)
+    x[:6] = np.array([[0.5, 1.5, 2.5], [-0.5, -1.5, -2.5], [0.0, 0.016, -0.016], [1e-3, 2e-3, 3e-3], [7.0005, -7.0005, 0.0015], [123.4565, 0.0, -0.0]], dtype)
+    t = x if pre else (x / dtype(0.001) + dtype(131072))                 # numpy: stays in x.dtype
+    want = np.rint(t / dtype(posq)).astype(np.int32)
+    got = voxelise(torch.tensor(x).cuda(), pre, posq)
+    assert got.dtype == torch.int32 and got.is_cuda
+    assert np.array_equal(got.cpu().numpy(), want)
+    # and what torch itself computes on the CPU for the second step
+    assert np.array_equal(torch.round(torch.tensor(t) / posq).int().numpy(), want)
+
+
+def test_cli_quantise_on_device(gh):
+    from gauspcc_amd.cli import compress
+
+    q = compress.quantise(np.array([[0.5, 1.5, 2.5], [0.5, 1.5, 2.5], [0.4, 1.6, 2.4]]), True, 1)
+    assert q.is_cuda and q.cpu().tolist() == [[0, 2, 2]]                 # round-half-even; coincident voxels merge
+    assert compress.quantise(np.array([[0.0, 0.016, -0.016]]), False, 16).cpu().tolist() == [[8192, 8193, 8191]]
+    assert compress.quantise(np.array([[0.0, 0.016, -0.016]], np.float32), False, 16).cpu().tolist() == [[8192, 8193, 8191]]
+
+
+# ---------------------------------------------------------------- any int32 position (origin shift)
+@pytest.mark.parametrize("shift,aligned", [((3 << 28, -(1 << 30), (1 << 29) + (1 << 21)), True), ((2 ** 31 - 70_000, -2 ** 31 + 17, 123_456_789), False)])
+def test_codec_far_coordinates(gh, orc, dev_model_k3, synth_model_k3, shift, aligned):
+    """The reference codes any int32 voxel (torchsparse coordinates, pcc_utils.py:73); only the EXTENT has to fit the 21-bit
+    internal frame.  Device bytes == oracle bytes; translating a cloud by a multiple of 2^21 changes nothing but the base
+    coordinates of the container."""
+    pts = _cloud(20_000, seed=21)
+    far = (pts.astype(np.int64) + np.array(shift, np.int64)).astype(np.int32)
+    data, st = gh.encode(dev_model_k3, far, 10)
+    ref = orc.encode(synth_model_k3, far, chunk_log2=10)
+    assert data == ref
+    dec, _, _ = gh.decode(dev_model_k3, data)
+    assert np.array_equal(dec, orc.decode(synth_model_k3, ref)[0])
+    assert np.array_equal(_sorted_rows(dec), _sorted_rows(far))
+    tree = gh.build_octree(far)
+    otree = orc.tree_build(far)
+    assert len(tree) == len(otree) and all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(tree, otree))
+    if aligned:
+        near, _ = gh.encode(dev_model_k3, pts, 0)
+        farb, _ = gh.encode(dev_model_k3, far, 0)
+        bn = int(np.frombuffer(near[2:6], np.int32)[0])
+        L = (near[6 + 13 * bn] | near[7 + 13 * bn] << 8) // 4 + 1
+        a = np.frombuffer(near[6:6 + 12 * bn], np.int32).reshape(-1, 3).astype(np.int64)
+        b = np.frombuffer(farb[6:6 + 12 * bn], np.int32).reshape(-1, 3).astype(np.int64)
+        assert np.array_equal(b - a, np.tile(np.array(shift, np.int64) >> L, (bn, 1)))
+        assert near[6 + 12 * bn:] == farb[6 + 12 * bn:]             # occupancy and every coded stream unchanged
+
+
+def test_codec_rejects_wide_far_cloud(gh, dev_model_k3):
+    from gauspcc_amd._lib import GpccError
+
+    with pytest.raises(GpccError, match="extent"):
+        gh.encode(dev_model_k3, np.array([[0, 0, 0], [1 << 21, 5, 5]], np.int32), 10)
+    # inside (-2^20, 2^20) the extent may still be almost 2^21
+    pts = np.array([[-(1 << 20) + 8, 0, 0], [(1 << 20) - 9, 5, 5], [3, 3, 3]], np.int32)
+    data, _ = gh.encode(dev_model_k3, pts, 10)
+    assert np.array_equal(_sorted_rows(gh.decode(dev_model_k3, data)[0]), _sorted_rows(pts))
+
+
 # ---------------------------------------------------------------- a2 calculate_morton_order
 @pytest.mark.parametrize("name", ["cube_small", "negative", "flat_x", "noncubic_int", "wide", "single"])
 def test_morton_order_golden(gh, golden_dir, name):

@@ -238,3 +238,40 @@ def test_v0_container_parses_with_the_pinned_reader(orc, request, kname):
     dec, pq = orc.decode(model, data)
     assert pq == np.float16(2)
     assert np.array_equal(dec[np.lexsort((dec[:, 0], dec[:, 1], dec[:, 2]))], pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))])
+
+
+def test_oracle_any_int32_position(orc, synth_model_k3):
+    """Clouds outside (-2^20, 2^20) (the reference keeps int32 torchsparse coordinates, pcc_utils.py:73): a translation by a
+    multiple of 2^21 >= 2^L changes the base coordinates of the container by shift >> L and nothing else; an unaligned far
+    cloud round-trips; the levels of the tree are the floor-halvings of the absolute coordinates."""
+    from gauspcc_amd.synth import synthetic_cloud
+
+    pts = synthetic_cloud(3000, seed=5, extent_log2=10)
+    T = np.array([3 << 28, -(1 << 30), (1 << 29) + (1 << 21)], np.int64)
+    far = (pts.astype(np.int64) + T).astype(np.int32)
+    a, b = orc.encode(synth_model_k3, pts, chunk_log2=0), orc.encode(synth_model_k3, far, chunk_log2=0)
+    bn = int(np.frombuffer(a[2:6], np.int32)[0])
+    L = (a[6 + 13 * bn] | a[7 + 13 * bn] << 8) // 4 + 1
+    ba = np.frombuffer(a[6:6 + 12 * bn], np.int32).reshape(-1, 3).astype(np.int64)
+    bb = np.frombuffer(b[6:6 + 12 * bn], np.int32).reshape(-1, 3).astype(np.int64)
+    assert np.array_equal(bb - ba, np.tile(T >> L, (bn, 1))) and a[6 + 12 * bn:] == b[6 + 12 * bn:]
+    assert np.array_equal(orc.decode(synth_model_k3, b)[0].astype(np.int64), orc.decode(synth_model_k3, a)[0].astype(np.int64) + T)
+    far2 = (pts.astype(np.int64) + np.array([2 ** 31 - 5000, -2 ** 31 + 17, 123456789])).astype(np.int32)
+    dec = orc.decode(synth_model_k3, orc.encode(synth_model_k3, far2, chunk_log2=10))[0]
+    srt = lambda x: x[np.lexsort((x[:, 0], x[:, 1], x[:, 2]))]
+    assert np.array_equal(srt(dec), srt(far2))
+    levels = orc.tree_build(far2)
+    cur = far2.astype(np.int64)
+    for c, o in reversed(levels):                  # kit/nn.py:38-55: parents = unique(coords >> 1), occupancy = OR of octant bits
+        par = cur >> 1
+        u, inv = np.unique(par, axis=0, return_inverse=True)
+        u = u[np.lexsort((u[:, 0], u[:, 1], u[:, 2]))]
+        assert np.array_equal(u, c.astype(np.int64))
+        key = {tuple(r): i for i, r in enumerate(u)}
+        occ = np.zeros(len(u), np.uint8)
+        for p_, ch in zip(par, cur):
+            occ[key[tuple(p_)]] |= np.uint8(1 << int((ch[0] & 1) | ((ch[1] & 1) << 1) | ((ch[2] & 1) << 2)))
+        assert np.array_equal(occ, o)
+        cur = u
+    with pytest.raises(ValueError, match="extent"):
+        orc.encode(synth_model_k3, np.array([[0, 0, 0], [2 ** 21, 5, 5]], np.int32))

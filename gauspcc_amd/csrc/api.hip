@@ -400,7 +400,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int K = kernel_size * kernel_size * kernel_size;
-    size_t want = (size_t)n * (size_t)(2 * K * 4 + K * 81 / 16 + 1300) + ((size_t)32 << 20);
+    size_t want = (size_t)n * (size_t)(4 * 125 * 2 + K * 81 / 16 + 1300) + ((size_t)32 << 20);
     for (int attempt = 0;; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         ctx->arena.reset();
@@ -414,16 +414,24 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             GP_TRY(tree_build(ctx, st, x2, n, &T));
             const Level *fin = &T.lv[T.L - 1];
             if (fin->n != n) return fail(GPCC_ERR_ARG, "internal: finest level has %lld nodes for %lld points", (long long)fin->n, (long long)n);
-            int64_t nmax = 0;
-            for (int d = 0; d < T.L; ++d) nmax = std::max(nmax, T.lv[d].n);
-            TAKE(nbA, int32_t, (int64_t)K * nmax); TAKE(nbB, int32_t, (int64_t)K * nmax);
-            int32_t *p = nbA, *c = nbB;
-            GP_TRY(nbr_base(ctx, st, &T.lv[0], kernel_size, p));
-            for (int d = 0; d + 1 < T.L; ++d) { GP_TRY(nbr_child(ctx, st, &T.lv[d], p, &T.lv[d + 1], kernel_size, c)); std::swap(p, c); }
-            TAKE(pairs, unsigned long long, 1);
-            HIP_TRY(hipMemsetAsync(pairs, 0, 8, st));
+            // tile lists of the whole tree from the production top-down path (tiles.hip); the convolution runs on the finest
+            TAKE(pairs, unsigned long long, MAXLV);
+            HIP_TRY(hipMemsetAsync(pairs, 0, 8 * MAXLV, st));
+            const int NPc = cell_map_entries(kernel_size);
+            TileLevel tl[MAXLV];
+            const int32_t *cell_prev = nullptr;
+            for (int d = 0; d < T.L; ++d) {
+                int32_t *own = nullptr;
+                if (d + 1 < T.L) { TAKE(cm, int32_t, (int64_t)NPc * T.lv[d].n); own = cm; }
+                tl[d] = TileLevel{&T.lv[d], d ? &T.lv[d - 1] : nullptr, cell_prev, own};
+                cell_prev = own;
+            }
+            const int R = conv_pick_rows(n, kernel_size);
+            TilePool pool;
+            GP_TRY(tiles_build(ctx, st, tl, T.L, kernel_size, R, conv_pick_height(n, R), &pool, pairs));
             ConvTiles tiles;
-            GP_TRY(conv_tiles_build(ctx, st, p, n, K, &tiles, pairs));
+            const int64_t zero_base[1] = {0};
+            GP_TRY(tiles_view(ctx, st, pool, T.L - 1, T.L, zero_base, &tiles));
             // weights -> B-fragment order
             std::vector<float> wf((size_t)K * 2048);
             conv_weight_fragments(w_host, K, wf.data());
@@ -440,7 +448,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
             LAUNCH_CHECK();
             unsigned long long hpairs = 0;
-            HIP_TRY(hipMemcpyAsync(&hpairs, pairs, 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&hpairs, pairs + (T.L - 1), 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             if (pairs_out) *pairs_out = (int64_t)hpairs;
             return GPCC_OK;

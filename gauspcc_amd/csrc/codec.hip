@@ -1,8 +1,8 @@
 // codec.hip -- gpcc_encode / gpcc_decode: the device pipeline behind compress_point_cloud /
 // decompress_point_cloud (HAC/utils/pcc_utils.py:24-217, 230-400).
 //
-// Encode: octree build (Morton order) -> per level: neighbour map, prior trunk (5 convs on the
-// parent level), child features, target trunk (5 convs on the child level), the four teacher-forced
+// Encode: octree build (Morton order) -> tile lists of every level (tiles.hip) -> prior trunk (5 convs on the
+// parent levels), child features, target trunk (5 convs on the coded levels), the four teacher-forced
 // stages batched into two 4-job conv launches, four head launches that emit one packed
 // (c_low, c_high) word per symbol in raster order -> ONE range-coder launch over every chunk of
 // every stream -> scan + compaction -> one D2H copy -> container assembly on the host.
@@ -45,9 +45,9 @@ int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int
 inline void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
 inline uint32_t get32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-// encode keeps the whole tree resident: ~3 nodes per point, per node two dense neighbour maps (prior / target
-// set) + tile lists (~150 B) + ~12 feature rows of 128 B; grown and retried when a cloud needs more
-size_t arena_estimate(int64_t n, int K) { return (size_t)n * 3 * (size_t)(2 * K * 4 + 200 + 12 * 128 + 64) + (size_t)n * (size_t)(2 * K * 4) + ((size_t)64 << 20); }
+// encode keeps the whole tree resident: ~3 nodes per point, per node its cell map (27 x 4 B) + tile lists (~150 B) + ~12
+// feature rows of 128 B + level arrays; grown and retried when a cloud needs more
+size_t arena_estimate(int64_t n, int K) { return (size_t)n * 3 * (size_t)(4 * 125 + 300 + 12 * 128 + 96) + (size_t)n * 64 + (size_t)K * 4096 + ((size_t)64 << 20); }
 
 // per-row metadata of the concatenated coded levels: global parent row, lohi slot of stage 0, stage stride
 __global__ __launch_bounds__(256) void k_child_meta(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ m2r, int64_t n, uint32_t parent_base,
@@ -70,7 +70,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     Tree T;
     GP_TRY(tree_build(ctx, st, xyz, n, &T));
     ht.mark("enc tree built");
-    const int L = T.L, K = m->K;
+    const int L = T.L;
     int64_t coded = 0, nmax = 0;
     for (int d = 0; d < L; ++d) { nmax = std::max(nmax, T.lv[d].n); if (d) coded += T.lv[d].n; }
     if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
@@ -83,8 +83,9 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     for (int d = 1; d < L; ++d) lohi_words += 4 * slots(T.lv[d].n);
     if (lohi_words >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many octree nodes");
     TAKE(lohi, uint32_t, std::max<int64_t>(lohi_words, 1));
-    TAKE(pairs_dev, unsigned long long, MAXLV);
-    HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
+    constexpr int NCOUNTERS = MAXLV + 16;   // pairs per level, then 16 accumulators of the ideal code length
+    TAKE(pairs_dev, unsigned long long, NCOUNTERS);
+    HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * NCOUNTERS, st));
     // Encoding is teacher-forced, so every level is independent of the others: all parent levels are
     // concatenated into one "prior set" P (levels 0..L-2) and all coded levels into one "target set" C
     // (levels 1..L-1).  Each of the 18 network layers is then ONE launch over a set instead of one per level.
@@ -95,21 +96,14 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         int64_t pb[MAXLV] = {0}, cbase[MAXLV] = {0};
         for (int d = 1; d < L; ++d) { pb[d] = pb[d - 1] + T.lv[d - 1].n; }
         for (int d = 2; d < L; ++d) { cbase[d] = cbase[d - 1] + T.lv[d - 1].n; }
-        TAKE(nbrPs, int32_t, (int64_t)K * nP);
-        TAKE(nbrCs, int32_t, (int64_t)K * nC);
         TAKE(occP, uint8_t, nP); TAKE(occC, uint8_t, nC); TAKE(rkeyC, uint64_t, nC);
         TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
-        {   // per-level neighbour maps, derived top-down and written straight into the two set maps: level d's map lives in
-            // the prior set at rows pb[d].. (d <= L-2) and in the target set at rows cbase[d].. (d >= 1)
-            GP_TRY(nbr_base(ctx, st, &T.lv[0], m->k, nbrPs, nP));
+        {   // per-row metadata of the two sets: level d lives in the prior set at rows pb[d].. (d <= L-2) and in the target
+            // set at rows cbase[d].. (d >= 1)
             HIP_TRY(hipMemcpyAsync(occP, T.lv[0].occ, (size_t)T.lv[0].n, hipMemcpyDeviceToDevice, st));
             int64_t lohi_base = 0;
             for (int d = 1; d < L; ++d) {
                 const Level *lv = &T.lv[d];
-                const NbrView in = {nbrPs + pb[d - 1], nP, (int32_t)pb[d - 1]};
-                const NbrView outC = {nbrCs + cbase[d], nC, (int32_t)cbase[d]};
-                const NbrView outP = d + 1 < L ? NbrView{nbrPs + pb[d], nP, (int32_t)pb[d]} : NbrView{nullptr, 0, 0};
-                GP_TRY(nbr_child_views(ctx, st, &T.lv[d - 1], in, lv, m->k, outC, outP));
                 if (d + 1 < L) HIP_TRY(hipMemcpyAsync(occP + pb[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
                 HIP_TRY(hipMemcpyAsync(occC + cbase[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
                 HIP_TRY(hipMemcpyAsync(rkeyC + cbase[d], lv->rkey, 8 * (size_t)lv->n, hipMemcpyDeviceToDevice, st));
@@ -120,22 +114,31 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 lohi_base += 4 * slots(lv->n);
             }
         }
-        ht.mark("enc maps queued");
-        // the target set's tile list is built on the side stream beside the prior set's trunk
-        GP_TRY(ctx->side_init());
-        hipStream_t sd = ctx->side;
-        struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } side_guard{sd};
-        HIP_TRY(hipEventRecord(ctx->ev_main, st));
+        ht.mark("enc meta queued");
+        // Tile lists of every level in one pool, built top-down from the cell maps (tiles.hip; one stream sync for the pool
+        // size).  A level's list is the same in the prior and in the target set -- tile entries are row indices inside the
+        // level -- so the two sets are two views of the pool: levels 0..L-2 and 1..L-1.
         ConvTiles tilesP, tilesC;
-        GP_TRY(conv_tiles_build(ctx, st, nbrPs, nP, K, &tilesP, pairs_dev));
+        {
+            const int NPc = cell_map_entries(m->k);
+            TileLevel tl[MAXLV];
+            const int32_t *cell_prev = nullptr;
+            for (int d = 0; d < L; ++d) {
+                int32_t *own = nullptr;
+                if (d + 1 < L) { TAKE(cm, int32_t, (int64_t)NPc * T.lv[d].n); own = cm; }
+                tl[d] = TileLevel{&T.lv[d], d ? &T.lv[d - 1] : nullptr, cell_prev, own};
+                cell_prev = own;
+            }
+            const int R = conv_pick_rows(nC, m->k), H = conv_pick_height(nC, R);
+            TilePool pool;
+            GP_TRY(tiles_build(ctx, st, tl, L, m->k, R, H, &pool, pairs_dev));
+            GP_TRY(tiles_view(ctx, st, pool, 0, L - 1, pb, &tilesP));
+            GP_TRY(tiles_view(ctx, st, pool, 1, L, cbase + 1, &tilesC));
+        }
+        ht.mark("enc tiles built");
         TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
         GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF));
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
-        HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
-        GP_TRY(conv_tiles_build(ctx, sd, nbrCs, nC, K, &tilesC, pairs_dev + 1));
-        HIP_TRY(hipEventRecord(ctx->ev_side, sd));
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
-        ht.mark("enc tiles built");
         TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
         GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX));
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)
@@ -161,7 +164,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
-            ha.bits = want_bits ? reinterpret_cast<double *>(pairs_dev + 8) : nullptr;   // slots 8..23 of the zeroed counter block
+            ha.bits = want_bits ? reinterpret_cast<double *>(pairs_dev + MAXLV) : nullptr;   // the 16 slots behind the pair counters
             GP_TRY(head_cdf(st, ha));
         }
     }
@@ -200,7 +203,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     GP_TRY(level_to_raster(ctx, st, base, T.bias, base_xyz, base_occ));
     // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ | gaps]
     const size_t off_desc = 0, off_cnt = off_desc + sizeof(RcChunk) * (size_t)std::max(nchunks, 1);
-    const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * MAXLV, off_bo = off_bx + 12 * (size_t)base->n;
+    const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * NCOUNTERS, off_bo = off_bx + 12 * (size_t)base->n;
     const size_t off_gap = (off_bo + (size_t)base->n + 63) & ~(size_t)63;
     GP_TRY(ctx->hstage.reserve(off_gap + 4 * (size_t)std::max(nchunks, 1) + 64));
     const uint32_t gap_total = gaps.empty() ? 0u : gaps.back();
@@ -228,7 +231,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload));
         payload_dev = payload;
     }
-    HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * MAXLV, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * NCOUNTERS, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + off_bx, base_xyz, 12 * (size_t)base->n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hs + off_bo, base_occ, (size_t)base->n, hipMemcpyDeviceToHost, st));
     ht.mark("enc all queued");
@@ -236,7 +239,13 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     ht.mark("enc coded (sync)");
     const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
     if (nchunks) total_payload = hcnt[nchunks];
-    if (ctx->prof.on) GP_TRY(prof_collect(ctx, reinterpret_cast<const unsigned long long *>(hs + off_pairs), 2));
+    // pairs of the two sets (the conv launches are tagged 0 = prior set, 1 = target set)
+    unsigned long long set_pairs[2] = {0, 0};
+    {
+        const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hs + off_pairs);
+        for (int d = 0; d < L; ++d) { if (d + 1 < L) set_pairs[0] += hp[d]; if (d) set_pairs[1] += hp[d]; }
+    }
+    if (ctx->prof.on) GP_TRY(prof_collect(ctx, set_pairs, 2));
     // ---- container
     size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
     GP_TRY(ctx->hbytes.reserve(fsize + 16));
@@ -288,8 +297,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         stats->num_points = n; stats->num_bytes = (int64_t)pos; stats->num_levels = L; stats->coded_nodes = coded;
         const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hs + off_pairs);
         for (int d = 0; d < L; ++d) stats->level_nodes[d] = T.lv[d].n;
-        stats->conv_pairs = (int64_t)hp[0] * 5 + (int64_t)hp[1] * 13;   // prior set: 5 convs, target set: 5 + 8
-        const double *hb = reinterpret_cast<const double *>(hp + 8);
+        stats->conv_pairs = (int64_t)set_pairs[0] * 5 + (int64_t)set_pairs[1] * 13;   // prior set: 5 convs, target set: 5 + 8
+        const double *hb = reinterpret_cast<const double *>(hp + MAXLV);
         for (int i = 0; i < 16; ++i) stats->ideal_bits += hb[i];
     }
     return GPCC_OK;
@@ -301,7 +310,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
 {
     ctx->arena.reset();
     HostTrace ht;
-    const int K = m->K;
+
     int64_t pos = 0;
     int chunk_log2 = 0, L = -1, version = 0;
     int64_t lvl_n[MAXLV] = {0};
@@ -409,22 +418,27 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     GP_TRY(level_raster_rank(ctx, st, &cur, hb));
     TAKE(dtotal, uint32_t, 4);
     uint32_t *htotal = reinterpret_cast<uint32_t *>(ctx->hstage.p);
-    // the two neighbour maps ping-pong; sizes are only known level by level in v0, so they are
-    // carved per level from the arena (a level's arrays live until the level after it is done)
-    int32_t *nbrP = nullptr;
-    {
-        TAKE(nb0, int32_t, (int64_t)K * bn);
-        nbrP = nb0;
-        GP_TRY(nbr_base(ctx, st, &cur, m->k, nbrP));
-    }
+    // a level's tile list is built from its parent's cell map (tiles.hip) and leaves its own behind for the level below;
+    // sizes are only known level by level in v0, so everything is carved per level from the arena
+    const int NPc = cell_map_entries(m->k);
+    const int64_t zero_base[1] = {0};
     TAKE(pairs_dev, unsigned long long, MAXLV);
     HIP_TRY(hipMemsetAsync(pairs_dev, 0, sizeof(unsigned long long) * MAXLV, st));
     ConvTiles tilesP;
-    GP_TRY(conv_tiles_build(ctx, st, nbrP, bn, K, &tilesP, pairs_dev));
+    int32_t *cellP = nullptr;
+    {
+        TAKE(cm, int32_t, (int64_t)NPc * bn);
+        cellP = cm;
+        const TileLevel tl = {&cur, nullptr, nullptr, cellP};
+        const int R = conv_pick_rows(bn, m->k);
+        TilePool pool;
+        GP_TRY(tiles_build(ctx, st, &tl, 1, m->k, R, conv_pick_height(bn, R), &pool, pairs_dev));
+        GP_TRY(tiles_view(ctx, st, pool, 0, 1, zero_base, &tilesP));
+    }
     int64_t coded = 0;
     // Two streams.  `st` carries the network of a level (18 convolutions, heads, range decoder).  The octree work that only
-    // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's neighbour map and
-    // tile list -- runs on the context's side stream beside the parent trunk's five convolutions and fills the idle tails
+    // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's tile list (and cell
+    // map) -- runs on the context's side stream beside the parent trunk's five convolutions and fills the idle tails
     // of their launches.  ev_main: the parent level is complete on st; ev_side: the child's structure is ready.
     GP_TRY(ctx->side_init());
     hipStream_t sd = ctx->side;
@@ -457,10 +471,16 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
         }
         GP_TRY(level_raster_rank(ctx, sd, &chi, hb + g + 1));
-        TAKE(nbrC, int32_t, (int64_t)K * nc);
-        GP_TRY(nbr_child(ctx, sd, &cur, nbrP, &chi, m->k, nbrC));
+        int32_t *cellC = nullptr;
+        if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it
         ConvTiles tilesC;
-        GP_TRY(conv_tiles_build(ctx, sd, nbrC, nc, K, &tilesC, pairs_dev + g + 1));
+        {
+            const TileLevel tl = {&chi, &cur, cellP, cellC};
+            const int R = conv_pick_rows(nc, m->k);
+            TilePool pool;
+            GP_TRY(tiles_build(ctx, sd, &tl, 1, m->k, R, conv_pick_height(nc, R), &pool, pairs_dev + g + 1));
+            GP_TRY(tiles_view(ctx, sd, pool, 0, 1, zero_base, &tilesC));
+        }
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
         // chunk descriptors of this level's four streams
@@ -517,7 +537,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
         coded += nc;
-        cur = chi; nbrP = nbrC; tilesP = tilesC;
+        cur = chi; cellP = cellC; tilesP = tilesC;
         ht.mark("dec level queued", g + 1, nc);
     }
     // ---- leaves
@@ -597,7 +617,7 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
         int64_t nodes = 0, nmax = 0;
         for (int d = 0; d < L; ++d) { const int64_t v = get32(bytes + 8 + 4 * d); nodes += v; nmax = std::max(nmax, v); }
         const int64_t npts = get32(bytes + 8 + 4 * L);
-        want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * m->K + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
+        want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
     }
     int rc = GPCC_OK;
     const int32_t *xyz = nullptr;

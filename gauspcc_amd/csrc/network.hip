@@ -28,12 +28,10 @@ namespace gpcc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CONV_WAVES = 4;
 #ifndef CONV_SC_WAVES_N
 #define CONV_SC_WAVES_N 4
 #endif
 constexpr int SC_WAVES = CONV_SC_WAVES_N;   // waves per workgroup of k_sparse_conv (every wave works alone on its own block)
-constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
 // LDS floats per wave: slot 0 = the dummy row (padding entries, tiles past the end of a list), slots 1..R = the block's rows,
 // then the tile-header ring: 32 slots + 4 mirror slots (copies of slots 0..3, so that the asm loop reaches the slots of
 // four consecutive tiles by immediate offsets): neighbour rows 36 x 16 dwords | output slots 33 x 4 dwords (16 bytes a
@@ -41,87 +39,10 @@ constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its b
 constexpr int HDR_R = 576, HDR_O = 712, HDR_DWORDS = 752;
 __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + HDR_DWORDS; }
 
-// ------------------------------------------------------------------ tile list
-template <int R, bool FILL>
-__global__ __launch_bounds__(64 * CONV_WAVES) void k_conv_tiles(const int32_t *__restrict__ nbrT, int n, int K, int nblk, int H, uint32_t *__restrict__ per_block,
-                                                                int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc,
-                                                                uint32_t *__restrict__ pairs_per_block)
+// ------------------------------------------------------------------ block policy
+int conv_pick_rows(int64_t n, int k)
 {
-    constexpr int Q = (R + 63) / 64;  // rows per lane
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int blk = blockIdx.x * CONV_WAVES + wave;
-    if (blk >= nblk) return;
-    const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    uint32_t t = FILL ? per_block[blk] : 0u, npairs = 0;
-    // the map is streamed once per pass: OB offsets' worth of loads are issued before the first ballot, so a wave pays one
-    // memory latency per OB offsets instead of one per offset
-    constexpr int OB = 4;
-    for (int o0 = 0; o0 < K; o0 += OB) {
-        int jj[OB][Q];
-#pragma unroll
-        for (int u = 0; u < OB; ++u)
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int lr = q * 64 + lane, row = blk * H + lr;
-                jj[u][q] = (o0 + u < K && lr < H && row < n) ? nbrT[(size_t)(o0 + u) * n + row] : -1;
-            }
-#pragma unroll
-        for (int u = 0; u < OB; ++u) {
-            const int o = o0 + u;
-            if (o >= K) break;
-            int j[Q];
-            uint64_t b[Q];
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                j[q] = jj[u][q];
-                b[q] = __ballot(j[q] >= 0);
-                cnt += (uint32_t)__popcll(b[q]);
-            }
-            if (cnt == 0) continue;
-            const uint32_t nt = (cnt + 15u) >> 4;
-            if (FILL) {
-                uint32_t base = 0;
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    if (j[q] >= 0) {
-                        const uint32_t p = base + (uint32_t)__popcll(b[q] & lt);
-                        tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = j[q];
-                        tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = (uint8_t)(q * 64 + lane + 1);   // LDS slot: row + 1
-                    }
-                    base += (uint32_t)__popcll(b[q]);
-                }
-                if ((uint32_t)lane < nt * 16u - cnt) {
-                    const uint32_t p = cnt + (uint32_t)lane;
-                    tj[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;
-                    tr[(size_t)(t + (p >> 4)) * 16 + (p & 15)] = 0;   // the dummy slot
-                }
-                if ((uint32_t)lane < nt) toc[t + lane] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)lane) << 16);
-            }
-            t += nt;
-            npairs += cnt;
-        }
-    }
-    if (!FILL && lane == 0) {
-        per_block[blk] = t;
-        if (pairs_per_block) pairs_per_block[blk] = npairs;   // summed by k_sum_pairs (one hot atomic per block cost 0.2 ms)
-    }
-}
-
-__global__ __launch_bounds__(256) void k_sum_pairs(const uint32_t *__restrict__ v, int n, unsigned long long *__restrict__ out)
-{
-    unsigned long long s = 0;
-    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
-    __shared__ unsigned long long red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) *out += red[0] + red[1] + red[2] + red[3];
-}
-
-int conv_pick_rows(int64_t n)
-{
+    if (k >= 7) return n >= 96 * 1024 ? 64 : n >= 24 * 1024 ? 32 : 16;   // 125 staged cells per parent: blocks of at most 64 rows (tiles.hip)
     static int forced = -1;
     if (forced < 0) {
         const char *e = getenv("GAUSPCC_CONV_R");
@@ -158,90 +79,6 @@ int conv_pick_height(int64_t n, int R)
     if (balance == 2 && (double)(k * slots * R - n) < 0.2 * (double)(k * slots * R)) return R;
     const int64_t H = cdiv(n, slots * k);
     return (int)std::min<int64_t>(R, std::max<int64_t>(H, 16));
-}
-
-__global__ __launch_bounds__(256) void k_order_keys(const uint32_t *__restrict__ first, int nblk, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= nblk) return;
-    key[b] = 0xFFFFull - (uint64_t)min(first[b + 1] - first[b], 0xFFFFu);  // ascending sort of this = descending tile count (16 bits: 2 radix passes)
-    idx[b] = (uint32_t)b;
-}
-
-// CONV_HDR_PAD zeroed tiles behind the list, whose length lives on the device
-__global__ __launch_bounds__(64) void k_pad_tiles(const uint32_t *__restrict__ total, int32_t *__restrict__ tj, uint32_t *__restrict__ tr4, uint32_t *__restrict__ toc)
-{
-    const uint32_t t = *total;
-    for (int i = threadIdx.x; i < CONV_HDR_PAD * 16; i += 64) tj[(size_t)t * 16 + i] = 0;
-    for (int i = threadIdx.x; i < CONV_HDR_PAD * 4; i += 64) tr4[(size_t)t * 4 + i] = 0;
-    for (int i = threadIdx.x; i < CONV_HDR_PAD; i += 64) toc[t + i] = 0;
-}
-
-template <int R>
-static int conv_tiles_build_r(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
-{
-    const int H = conv_pick_height(n, R);
-    const int64_t nblk = cdiv(n, H);
-    T->nblk = nblk; T->R = R; T->H = H; T->K = K;
-    TAKE(first, uint32_t, nblk + 1);
-    T->first = first;
-    const unsigned grid = (unsigned)cdiv(nblk, CONV_WAVES);
-    uint32_t *bpairs = nullptr;
-    if (pairs_dev) { TAKE(bp, uint32_t, nblk); bpairs = bp; }
-    k_conv_tiles<R, false><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, H, first, nullptr, nullptr, nullptr, bpairs);
-    LAUNCH_CHECK();
-    if (pairs_dev) { k_sum_pairs<<<1, 256, 0, st>>>(bpairs, (int)nblk, pairs_dev); LAUNCH_CHECK(); }
-    GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
-    // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the
-    // host ever learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run
-    // ahead).  Taller blocks are sized exactly: one sync.
-    const bool BOUNDED = H <= 16;
-    int64_t cap;
-    uint32_t total = 0;
-    if (BOUNDED) cap = nblk * K + CONV_HDR_PAD;
-    else {
-        HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        cap = (int64_t)total + CONV_HDR_PAD;  // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
-    }
-    TAKE(tj, int32_t, cap * 16);
-    TAKE(tr, uint8_t, cap * 16);
-    TAKE(toc, uint32_t, cap);
-    T->tj = tj; T->tr = tr; T->toc = toc;
-    k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc);
-    LAUNCH_CHECK();
-    k_conv_tiles<R, true><<<grid, 64 * CONV_WAVES, 0, st>>>(nbrT, (int)n, K, (int)nblk, H, first, tj, tr, toc, nullptr);
-    LAUNCH_CHECK();
-    // dispatch order: longest blocks first, so the tail of the launch is made of short blocks (LPT scheduling).  When all
-    // blocks are resident at once (<= 8 waves on each of 256 CUs) the order cannot matter: identity, no sort.
-    TAKE(order, uint32_t, nblk);
-    {
-        const size_t mk = ctx->arena.mark();
-        TAKE(ka, uint64_t, nblk); TAKE(kb, uint64_t, nblk); TAKE(vb, uint32_t, nblk);
-        k_order_keys<<<(unsigned)cdiv(nblk, 256), 256, 0, st>>>(first, (int)nblk, ka, order);
-        LAUNCH_CHECK();
-        if (nblk > 2048) {
-            uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = order, *v1 = vb;
-            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, nblk, 16));   // keys are 0xFFFF - min(tiles, 0xFFFF)
-            if (v0 != order) HIP_TRY(hipMemcpyAsync(order, v0, 4 * (size_t)nblk, hipMemcpyDeviceToDevice, st));
-        }
-        ctx->arena.rewind(mk);
-    }
-    T->order = order;
-    return GPCC_OK;
-}
-
-int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev)
-{
-    if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
-    switch (conv_pick_rows(n)) {
-    case 16: return conv_tiles_build_r<16>(ctx, st, nbrT, n, K, T, pairs_dev);
-    case 32: return conv_tiles_build_r<32>(ctx, st, nbrT, n, K, T, pairs_dev);
-    case 64: return conv_tiles_build_r<64>(ctx, st, nbrT, n, K, T, pairs_dev);
-    case 96: return conv_tiles_build_r<96>(ctx, st, nbrT, n, K, T, pairs_dev);
-    case 255: return conv_tiles_build_r<255>(ctx, st, nbrT, n, K, T, pairs_dev);
-    default: return conv_tiles_build_r<128>(ctx, st, nbrT, n, K, T, pairs_dev);
-    }
 }
 
 // ------------------------------------------------------------------ convolution
@@ -282,7 +119,14 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     if (job == 1) J = jobs.job[1];
     if (job == 2) J = jobs.job[2];
     if (job == 3) J = jobs.job[3];
-    const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);
+    const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);   // block id in the tile pool
+    // the level of the block (scalar search over <= 24 entries of the kernel argument): its rows in the set's feature arrays
+    int lvi = 0;
+    for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
+    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * T.H;                   // first row of the block inside its level
+    const int nrows = min(T.H, (int)T.lv_rows[lvi] - lrow0);
+    const int row0 = (int)T.lv_row0[lvi] + lrow0;                          // ... and in the set
+    J.in += (size_t)T.lv_row0[lvi] * 32;                                   // tile entries are row indices inside the level
     float *acc = lds + wave * CONV_LDS_WAVE;
     float4 *acc4 = reinterpret_cast<float4 *>(acc);
     // tile-header ring: 32 slots = two batches of 16 tiles (neighbour rows 32 x 16 dwords, output rows 32 x 4 dwords,
@@ -471,8 +315,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
     // copies, 64 rows (512 float4, 8 per lane) per batch.  Every branch is wave-uniform; only the last batch of a block
     // (and the last block of a level) is predicated.  Residual rows of a batch are all requested before the first is used.
     {
-        const int row0 = blk * T.H;
-        const int nvec = min(T.H, n - row0) * 8;   // float4 elements of this block
+        const int nvec = nrows * 8;   // float4 elements of this block
         const bool has_res = J.res != nullptr;
         const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8 + lane;
         float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8 + lane;
@@ -556,7 +399,12 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     const ConvJob J = jobs.job[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int blk = blockIdx.x;
+    const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;   // block id in the tile pool (a set's blocks are consecutive)
+    int lvi = 0;
+    for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
+    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * 16;
+    const int nrows = min(16, (int)T.lv_rows[lvi] - lrow0);
+    const int row0 = (int)T.lv_row0[lvi] + lrow0;
     const int e = lane & 15, g = lane >> 4;
     const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
@@ -566,7 +414,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     for (int i = tid; i < nt * 4; i += 64 * COOP_WAVES) hr[i] = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16)[i];
     for (int i = tid; i < nt; i += 64 * COOP_WAVES) ho[i] = T.toc[t0 + i];
     __syncthreads();
-    const float *__restrict__ in = J.in + 4 * g;
+    const float *__restrict__ in = J.in + (size_t)T.lv_row0[lvi] * 32 + 4 * g;   // tile entries are row indices inside the level
     const float *__restrict__ wf = J.w + lane * 4;
     constexpr int COOP_EPT = 512 / (64 * COOP_WAVES) > 0 ? 512 / (64 * COOP_WAVES) : 1;   // output elements per thread in phase B
     float acc[COOP_EPT];
@@ -649,8 +497,8 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #pragma unroll
     for (int u = 0; u < COOP_EPT; ++u) {
         const int el = tid + u * 64 * COOP_WAVES;
-        const int grow = blk * 16 + (el >> 5), och = el & 31;
-        if (el < 512 && grow < n) {
+        const int grow = row0 + (el >> 5), och = el & 31;
+        if (el < 512 && (el >> 5) < nrows) {
             float v = acc[u];
             if (J.res) v = v + J.res[(size_t)grow * 32 + och];
             if (relu) v = v > 0.f ? v : 0.f;

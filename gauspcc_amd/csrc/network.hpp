@@ -73,32 +73,51 @@ struct ConvJob {
 };
 struct ConvBatch { ConvJob job[4]; };
 
-// Compacted work list of one level: every wave owns H consecutive (Morton-ordered) output rows;
-// for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of
-// 16 rows (one v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per level, used by all
-// 5 / 13 convolutions that run on that level.  R is the capacity class (LDS rows per wave, selects the kernel:
-// 16 = the cooperative kernel, 255 = the wave-serial kernel at one wave per SIMD; 32 / 64 / 96 / 128 remain for the
-// variant tests), H <= R the block height picked per level (conv_pick_rows / conv_pick_height).
+// Compacted work list of a SET of levels (one level in the decoder; all parent levels / all coded levels in the encoder,
+// which batches them into one launch per layer): every wave owns a block of up to H consecutive (Morton-ordered) rows of ONE
+// level; for each kernel offset the (output row, neighbour row) pairs of the block are packed into tiles of 16 rows (one
+// v_mfma_f32_16x16x4_f32 M-tile), offsets ascending.  Built once per tree (tiles.hip: straight from the parent level's
+// structure, no dense neighbour map), used by all 5 / 13 convolutions that run on a level.  Neighbour rows are indices
+// inside the block's own level; lv_row0 places a level in the set's feature arrays.  R is the capacity class (LDS rows per
+// wave, selects the kernel: 16 = the cooperative kernel, 255 = the wave-serial kernel at one wave per SIMD; 32 / 64 / 96 /
+// 128 remain for the variant tests), H <= R the block height (conv_pick_rows / conv_pick_height).
 constexpr int CONV_R_MAX = 255;
+constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
 struct ConvTiles {
-    int32_t *tj = nullptr;     // [tiles][16] neighbour row (padding: 0, a valid row whose result is discarded)
-    uint8_t *tr = nullptr;     // [tiles][16] output row inside the block (padding: R = the dummy row)
+    int32_t *tj = nullptr;     // [tiles][16] neighbour row inside the level (padding: 0, a valid row whose result is discarded)
+    uint8_t *tr = nullptr;     // [tiles][16] LDS slot of the output row = row inside the block + 1 (padding: 0 = the dummy slot)
     uint32_t *toc = nullptr;   // [tiles]     offset | valid entries << 16
-    uint32_t *first = nullptr; // [nblk + 1]  tile range of each block
-    uint32_t *order = nullptr; // [nblk]      blocks sorted by tile count, longest first (dispatch order)
-    int64_t nblk = 0;
+    uint32_t *first = nullptr; // [pool blocks + 1]  tile range of each block, indexed by the block's id in the pool
+    uint32_t *order = nullptr; // [nblk]      the set's block ids sorted by tile count, longest first (dispatch order)
+    int64_t nblk = 0;          // blocks of the set
     int R = CONV_R_MAX;        // capacity class of the blocks (LDS rows per wave; selects the kernel)
-    int H = CONV_R_MAX;        // rows per block, <= R: chosen so that the blocks fill the chip's wave slots a whole number of times
+    int H = CONV_R_MAX;        // rows per block, <= R
     int K = 0;                 // kernel offsets
+    int nlv = 0;               // levels of the set
+    uint32_t lv_blk0[MAXLV + 1] = {0};  // pool id of each level's first block; lv_blk0[nlv] = one past the set's last block
+    uint32_t lv_row0[MAXLV] = {0};      // first row of each level in the set's feature arrays
+    uint32_t lv_rows[MAXLV] = {0};      // rows of each level
 };
-int conv_pick_rows(int64_t n);  // policy (env GAUSPCC_CONV_R overrides)
+int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides); kernel size 7 is limited to 64-row blocks
 int conv_pick_height(int64_t n, int R);  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
-static inline int64_t conv_blocks_capacity(int64_t n) { return cdiv(n, 16) + 1; }
-// Build the tile list of a level (or of several concatenated levels) from its dense neighbour map.
-// Two passes over the map (count, fill) with one stream sync in between to size the arrays exactly
-// (the worst case -- every pair alone in its tile -- would be ~6x larger).  Arrays come from the arena.
-// If pairs_dev != nullptr the number of (node, neighbour) pairs is added to it.
-int conv_tiles_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t n, int K, ConvTiles *T, unsigned long long *pairs_dev);
+
+// Tile lists of several levels in one pool (tiles.hip).  Level l is built from its parent level's cell map (par == nullptr:
+// a base level of < 64 nodes, searched directly); cell_own, when not null, receives the level's own cell map
+// [cell_map_entries(k)][n] for the level below it.
+struct Level;
+struct TileLevel { const Level *lv; const Level *par; const int32_t *cell_par; int32_t *cell_own; };
+struct TilePool {
+    int32_t *tj = nullptr; uint8_t *tr = nullptr; uint32_t *toc = nullptr; uint32_t *first = nullptr;
+    int64_t nblk = 0;
+    int R = 0, H = 0, K = 0, nlv = 0;
+    uint32_t lv_blk0[MAXLV + 1] = {0}, lv_rows[MAXLV] = {0};
+};
+int cell_map_entries(int k);
+// count pass per level -> scan -> (one stream sync unless H <= 16) -> fill pass per level.  pairs_dev (nullable): [nlv]
+// accumulators, += the (row, present neighbour) pairs of each level.  Arrays come from the arena.
+int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int k, int R, int H, TilePool *pool, unsigned long long *pairs_dev);
+// the levels [l0, l1) of a pool as the work list of one set; row_base[l - l0] = first row of level l in the set's arrays
+int tiles_view(gpcc_ctx *ctx, hipStream_t st, const TilePool &pool, int l0, int l1, const int64_t *row_base, ConvTiles *T);
 
 // out = conv(in) (+res) (relu); up to 4 independent jobs on the same tile list in one launch
 // ctx/level: when ctx->prof.on the launch is bracketed by HIP events tagged with `level` (bench.py roofline)

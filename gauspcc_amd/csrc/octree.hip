@@ -294,114 +294,6 @@ int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t
     return GPCC_OK;
 }
 
-// ------------------------------------------------------------------ neighbour maps
-__global__ __launch_bounds__(TB) void k_nbr_base(const uint64_t *__restrict__ rkey, int n, int k, int32_t *__restrict__ nbrT, int64_t stride)
-{
-    const int K = k * k * k, r = k / 2;
-    int t = blockIdx.x * TB + threadIdx.x;
-    if (t >= n * K) return;
-    const int o = t / n, i = t - o * n;
-    const int dx = o % k - r, dy = (o / k) % k - r, dz = o / (k * k) - r;
-    const uint64_t ki = rkey[i];
-    const int tx = (int)rk_x(ki) + dx, ty = (int)rk_y(ki) + dy, tz = (int)rk_z(ki) + dz;
-    int32_t res = -1;
-    if (tx >= 0 && ty >= 0 && tz >= 0) {
-        const uint64_t tgt = rkey3((uint32_t)tx, (uint32_t)ty, (uint32_t)tz);
-        for (int j = 0; j < n; ++j)
-            if (rkey[j] == tgt) res = j;
-    }
-    nbrT[(int64_t)o * stride + i] = res;
-}
-
-int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT, int64_t stride)
-{
-    if (stride <= 0) stride = lv->n;
-    if (lv->n > 4096) return fail(GPCC_ERR_ARG, "nbr_base is O(n^2): base level only");
-    const int K = k * k * k;
-    k_nbr_base<<<nblk(lv->n * K), TB, 0, st>>>(lv->rkey, (int)lv->n, k, nbrT, stride);
-    LAUNCH_CHECK();
-    return GPCC_OK;
-}
-
-// Child map from the parent's map.  The voxel at kernel offset o from child i lies in one of the (2 PR + 1)^3 parent cells
-// around i's parent (PR = (r + 1) / 2: 27 cells for k = 3 and 5, all of them in the parent's map); its octant bit in that
-// cell's occupancy says whether it exists, the cell's child start + popcount of the lower octant bits says where
-// (children are stored octant-ascending).  One wave takes 64 consecutive children -- their parents are a contiguous
-// run of at most 64 nodes -- stages the cells of those parents in LDS (one gather of map entry, occupancy and child start
-// per cell instead of one per child x offset), then every lane walks the k^3 offsets of its child: writes are one
-// coalesced row segment per offset.
-struct NbrCell { uint32_t cstart, occ; };
-__global__ __launch_bounds__(64) void k_nbr_child(const uint64_t *__restrict__ rkey_c, const uint32_t *__restrict__ parent_c, int64_t nc,
-                                                  NbrView in, const uint8_t *__restrict__ occ_p,
-                                                  const uint32_t *__restrict__ cstart_p, int k, NbrView out1, NbrView out2)
-{
-    extern __shared__ NbrCell cells[];
-    const int lane = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * 64, i = min(c0 + lane, nc - 1);
-    const int r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
-    const uint32_t my_parent = parent_c[i];
-    const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)parent_c[c0]);
-    const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)parent_c[min(c0 + 63, nc - 1)]);
-    const int ncell = (int)(p_hi - p_lo + 1u) * NP;
-    for (int idx = lane; idx < ncell; idx += 64) {
-        const uint32_t p = p_lo + (uint32_t)(idx / NP);
-        const int q = idx % NP;
-        const int px = q % PW - PR, py = (q / PW) % PW - PR, pz = q / (PW * PW) - PR;
-        const int po = (px + r) + k * (py + r) + k * k * (pz + r);
-        int32_t pn = in.p[(int64_t)po * in.stride + p];
-        NbrCell c = {0u, 0u};
-        if (pn >= 0) { pn -= in.voff; c.cstart = cstart_p[pn]; c.occ = occ_p[pn]; }
-        cells[idx] = c;
-    }
-    __syncthreads();
-    if (c0 + lane >= nc) return;
-    const uint64_t kc = rkey_c[i];
-    const int cx = (int)(rk_x(kc) & 1), cy = (int)(rk_y(kc) & 1), cz = (int)(rk_z(kc) & 1);
-    const NbrCell *mine = cells + (size_t)(my_parent - p_lo) * NP;
-    int o = 0;
-    for (int dz = -r; dz <= r; ++dz)
-        for (int dy = -r; dy <= r; ++dy)
-            for (int dx = -r; dx <= r; ++dx, ++o) {
-                const int tx = cx + dx, ty = cy + dy, tz = cz + dz;
-                const int q = ((tx >> 1) + PR) + PW * ((ty >> 1) + PR) + PW * PW * ((tz >> 1) + PR);   // floor halves: the parent cell
-                const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-                const NbrCell c = mine[q];
-                int32_t res = (c.occ >> tq) & 1u ? (int32_t)(c.cstart + (uint32_t)__popc(c.occ & ((1u << tq) - 1u))) : -1;
-                if ((int64_t)res >= nc) res = -1;   // only when a container header understates the level (reported at the decoder's final sync)
-                out1.p[(int64_t)o * out1.stride + i] = res >= 0 ? res + out1.voff : -1;
-                if (out2.p) out2.p[(int64_t)o * out2.stride + i] = res >= 0 ? res + out2.voff : -1;
-            }
-}
-
-int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in, const Level *chi, int k, NbrView out1, NbrView out2)
-{
-    const int PW = 2 * ((k / 2 + 1) / 2) + 1;   // parent cells per axis around a child's parent
-    k_nbr_child<<<(unsigned)cdiv(chi->n, 64), 64, (size_t)64 * PW * PW * PW * sizeof(NbrCell), st>>>(chi->rkey, chi->parent, chi->n, in, par->occ, par->cstart, k, out1, out2);
-    LAUNCH_CHECK();
-    return GPCC_OK;
-}
-
-int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT)
-{
-    return nbr_child_views(ctx, st, par, NbrView{const_cast<int32_t *>(nbrT_par), par->n, 0}, chi, k, NbrView{nbrT, chi->n, 0}, NbrView{nullptr, 0, 0});
-}
-
-__global__ __launch_bounds__(TB) void k_nbr_count(const int32_t *__restrict__ nbrT, int64_t total, unsigned long long *__restrict__ count)
-{
-    uint32_t c = 0;
-    for (int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TB) c += nbrT[i] >= 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
-}
-
-int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev)
-{
-    k_nbr_count<<<(unsigned)std::min<int64_t>(cdiv(total, TB), 4096), TB, 0, st>>>(nbrT, total, count_dev);
-    LAUNCH_CHECK();
-    return GPCC_OK;
-}
-
 // ------------------------------------------------------------------ outputs
 __global__ __launch_bounds__(TB) void k_popc_raster(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ cnt)
 {

@@ -80,18 +80,6 @@ int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level);
 // decode side: children of `par` (occupancy known) -> `chi` (rkey, parent; n must be known)
 int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
 
-// neighbour map, offset-major: nbrT[o*n + i], o = (dx+r) + k*(dy+r) + k*k*(dz+r), -1 = absent
-// (stride > 0: rows of the map are `stride` apart -- the level is the first of a set of concatenated levels)
-int nbr_base(gpcc_ctx *ctx, hipStream_t st, const Level *lv, int k, int32_t *nbrT, int64_t stride = 0);
-int nbr_child(gpcc_ctx *ctx, hipStream_t st, const Level *par, const int32_t *nbrT_par, const Level *chi, int k, int32_t *nbrT);
-// A level's map inside the map of a SET of concatenated levels (the encoder batches all levels into two sets):
-// element (o, i) of the level at p[o*stride + i], present entries biased by voff (= the level's first row in the set).
-struct NbrView { int32_t *p; int64_t stride; int32_t voff; };
-// child map from the parent's view, written straight into up to two set maps (out2.p may be null)
-int nbr_child_views(gpcc_ctx *ctx, hipStream_t st, const Level *par, NbrView in, const Level *chi, int k, NbrView out1, NbrView out2);
-// count present neighbours (pairs) into *count_dev (uint64 accumulate)
-int nbr_count(gpcc_ctx *ctx, hipStream_t st, const int32_t *nbrT, int64_t total, unsigned long long *count_dev);
-
 // leaves of the last level in the reference's decoder order (parents in raster order, octants ascending)
 int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, const int64_t bias[3], int32_t *xyz_out, int64_t npts);
 // copy a level to host-visible buffers in raster order: coords (n,3) int32 (un-biased), occ (n)

@@ -13,6 +13,6 @@ for v in "$@"; do
 done
 wait
 for v in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_a$v.so primitives.o octree.o ../variants/network_a$v.o rangecoder.o codec.o api.o attributes.o rasterizer.o neural_gaussians.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_a$v.so primitives.o octree.o tiles.o ../variants/network_a$v.o rangecoder.o codec.o api.o attributes.o rasterizer.o neural_gaussians.o
 done
 ls -la ../variants/*.so

@@ -42,7 +42,7 @@ __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) *
 // ------------------------------------------------------------------ block policy
 int conv_pick_rows(int64_t n, int k)
 {
-    if (k >= 7) return n >= 96 * 1024 ? 64 : n >= 24 * 1024 ? 32 : 16;   // 125 staged cells per parent: blocks of at most 64 rows (tiles.hip)
+    (void)k;
     static int forced = -1;
     if (forced < 0) {
         const char *e = getenv("GAUSPCC_CONV_R");

@@ -98,7 +98,7 @@ struct ConvTiles {
     uint32_t lv_row0[MAXLV] = {0};      // first row of each level in the set's feature arrays
     uint32_t lv_rows[MAXLV] = {0};      // rows of each level
 };
-int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides); kernel size 7 is limited to 64-row blocks
+int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides)
 int conv_pick_height(int64_t n, int R);  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
 
 // Tile lists of several levels in one pool (tiles.hip).  Level l is built from its parent level's cell map (par == nullptr:

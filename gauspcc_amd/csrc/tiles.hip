@@ -25,169 +25,222 @@ struct LevelTilesArgs {
     // its parent level: cell map [NP][np] (local indices, -1 = absent), occupancy, child starts
     const int32_t *cell_p; int64_t np; const uint8_t *occ_p; const uint32_t *cstart_p;
     int H;                      // rows per block
-    uint32_t blk0;              // global id of the level's first block
+    uint32_t blk0;              // pool id of the level's first block
     // pass 1
     int32_t *cell_c;            // [NP][nc] the level's own cell map, nullable (nobody below needs it)
-    uint32_t *per_block;        // [global blocks] tiles of each block
+    uint32_t *per_block;        // [pool blocks] tiles of each block (blocks of at most 64 rows; taller ones: k_block_sum)
     unsigned long long *pairs;  // += (row, neighbour) pairs of the level
+    uint8_t *cnt_oq;            // [pool blocks][K][4] pairs per (offset, 64-row chunk) of the blocks taller than 64 rows
     // pass 2
-    const uint32_t *first;      // [global blocks + 1] first tile of each block
+    const uint32_t *first;      // [pool blocks + 1] first tile of each block
     int32_t *tj; uint8_t *tr; uint32_t *toc;
 };
 
-// Compaction of one kernel offset: Q rows per lane (row q * 64 + lane of the wave's span), the rows with a neighbour are
-// packed in row order.  A wave covers one block of up to 64 Q rows, or -- blocks of 16 / 32 rows -- 64 / H blocks side by
-// side as lane segments (segmask selects a lane's own segment; ls = lane inside the segment).
-template <int Q, bool FILL>
-struct Packer {
-    uint64_t segmask, below;   // lanes of my segment; those of them below me
-    int ls;                    // lane index inside the segment
-    uint32_t t;                // running tile index of my block (FILL: global; else count)
-    uint32_t npairs = 0;       // pairs seen by the whole wave (uniform)
-    const LevelTilesArgs *a;
-
-    __device__ __forceinline__ void step(int o, const int (&j)[Q])
-    {
-        uint64_t b[Q];
-        uint32_t cnt = 0, all = 0;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            b[q] = __ballot(j[q] >= 0);
-            cnt += (uint32_t)__popcll(b[q] & segmask);
-            all += (uint32_t)__popcll(b[q]);
-        }
-        if (all == 0) return;           // wave-uniform
-        npairs += all;
-        const uint32_t nt = (cnt + 15u) >> 4;
-        if (FILL) {
-            uint32_t base = 0;
-#pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                if (j[q] >= 0) {
-                    const uint32_t p = base + (uint32_t)__popcll(b[q] & below);
-                    const size_t at = (size_t)(t + (p >> 4)) * 16 + (p & 15);
-                    a->tj[at] = j[q];
-                    a->tr[at] = (uint8_t)(q * 64 + ls + 1);     // LDS slot of the output row inside its block: row + 1
-                }
-                base += (uint32_t)__popcll(b[q] & segmask);
-            }
-            if ((uint32_t)ls < nt * 16u - cnt) {                // padding entries: neighbour row 0 into the dummy slot
-                const uint32_t p = cnt + (uint32_t)ls;
-                const size_t at = (size_t)(t + (p >> 4)) * 16 + (p & 15);
-                a->tj[at] = 0;
-                a->tr[at] = 0;
-            }
-            if ((uint32_t)ls < nt) a->toc[t + (uint32_t)ls] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)ls) << 16);
-        }
-        t += nt;
-    }
+// How a 64-lane wave maps to blocks.  H = 16 / 32: the wave takes 64 consecutive rows = 4 / 2 whole blocks side by side as
+// lane segments.  H <= 64 otherwise: one block.  H > 64: one 64-row CHUNK q of a block (nq = ceil(H / 64) waves per block).
+struct WaveMap {
+    bool multi; int nq, q; uint32_t blk; bool blk_live;
+    int64_t r0, rend;          // my rows [r0, rend) of the level
+    int ls; uint64_t segmask, below;
 };
-
-template <int Q, bool FILL>
-__device__ __forceinline__ void packer_init(Packer<Q, FILL> &P, const LevelTilesArgs &a, int lane, uint32_t *blk_out, bool *blk_live, int64_t w0)
+__device__ __forceinline__ WaveMap wave_map(int H, int64_t nc, uint32_t blk0, int lane)
 {
-    const int H = a.H;
-    const bool multi = Q == 1 && (H == 16 || H == 32);   // 4 or 2 blocks side by side in one wave
-    const int Hs = multi ? H : 64;                        // segment width
+    WaveMap m;
+    m.multi = H == 16 || H == 32;
+    m.nq = H > 64 ? (H + 63) >> 6 : 1;
+    const int Hs = m.multi ? H : 64;
     const int seg = lane / Hs;
-    P.ls = lane - seg * Hs;
-    P.segmask = Hs == 64 ? ~0ull : (((1ull << Hs) - 1ull) << (seg * Hs));
-    P.below = P.segmask & (lane == 0 ? 0ull : (~0ull >> (64 - lane)));
-    P.a = &a;
-    const int nseg = 64 / Hs;
-    const uint32_t blk = a.blk0 + (multi ? (uint32_t)(blockIdx.x * nseg + seg) : (uint32_t)blockIdx.x);
-    *blk_out = blk;
-    *blk_live = multi ? (w0 + (int64_t)seg * Hs < a.nc) : true;
-    P.t = (FILL && *blk_live) ? a.first[blk] : 0u;
+    m.ls = lane - seg * Hs;
+    m.segmask = Hs == 64 ? ~0ull : (((1ull << Hs) - 1ull) << (seg * Hs));
+    m.below = m.segmask & (lane == 0 ? 0ull : (~0ull >> (64 - lane)));
+    if (m.multi) {
+        m.q = 0;
+        m.r0 = (int64_t)blockIdx.x * 64; m.rend = min(nc, m.r0 + 64);
+        m.blk = blk0 + (uint32_t)(blockIdx.x * (64 / Hs) + seg);
+        m.blk_live = m.r0 + (int64_t)seg * Hs < nc;
+    } else {
+        const uint32_t b = blockIdx.x / (uint32_t)m.nq;
+        m.q = (int)(blockIdx.x - b * (uint32_t)m.nq);
+        const int64_t b0 = (int64_t)b * H, bend = min(nc, b0 + H);
+        m.r0 = min(bend, b0 + 64 * (int64_t)m.q); m.rend = min(bend, m.r0 + 64);
+        m.blk = blk0 + b;
+        m.blk_live = true;
+    }
+    return m;
 }
 
-template <int KS, int Q, bool FILL>
-__global__ __launch_bounds__(64) void k_level_tiles(LevelTilesArgs a)
+// One kernel offset of a wave whose block(s) fit the wave (multi mode or a block of at most 64 rows): the rows with a
+// neighbour are packed in row order behind the block's running tile counter.
+template <bool FILL>
+__device__ __forceinline__ void pack_local(const LevelTilesArgs &a, const WaveMap &m, int o, int j, uint32_t &t, uint32_t &npairs)
 {
-    constexpr int r = KS / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *cst = reinterpret_cast<uint32_t *>(smem);     // [Q][64 NP] child start of every staged cell
-    uint8_t *coc = smem + (size_t)Q * 64 * NP * 4;          // [Q][64 NP] occupancy (0 = the cell does not exist)
-    const int lane = threadIdx.x;
-    const int64_t span = (a.H == 16 || a.H == 32) ? 64 : a.H;    // rows of this wave: one block, or 64 rows of 16- / 32-row blocks
-    const int64_t w0 = (int64_t)blockIdx.x * span, wend = min(a.nc, w0 + span);
-    int cx[Q], cy[Q], cz[Q];
-    uint32_t mine[Q];
-    bool live[Q];
-    int64_t row[Q];
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int64_t c0 = w0 + 64 * q;
-        live[q] = false; mine[q] = 0; cx[q] = cy[q] = cz[q] = 0; row[q] = 0;
-        if (c0 >= wend) continue;                           // wave-uniform
-        const int64_t cend = min(wend, c0 + 64);
-        const int64_t i = min(c0 + lane, cend - 1);
-        const uint32_t my_parent = a.parent_c[i];
-        const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.parent_c[c0]);
-        const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.parent_c[cend - 1]);
-        const uint32_t npar = min(p_hi - p_lo, 63u) + 1u;    // a header that lies about a level cannot overrun the staging area
-        uint32_t *cs = cst + (size_t)q * 64 * NP;
-        uint8_t *co = coc + (size_t)q * 64 * NP;
-        // lane = parent: the cell map is read in coalesced rows (one per cell), the gathers of a cell's child start and
-        // occupancy hit neighbouring nodes for neighbouring parents; CB cells' loads are in flight together
-        {
-            const uint32_t p = p_lo + (uint32_t)lane;
-            const bool pl = (uint32_t)lane < npar && p < (uint32_t)a.np;
-            constexpr int CBATCH = 9;
-            for (int c0c = 0; c0c < NP; c0c += CBATCH) {
-                int32_t pn[CBATCH];
-#pragma unroll
-                for (int u = 0; u < CBATCH; ++u) pn[u] = (pl && c0c + u < NP) ? a.cell_p[(int64_t)(c0c + u) * a.np + p] : -1;
-                uint32_t sv[CBATCH], ov[CBATCH];
-#pragma unroll
-                for (int u = 0; u < CBATCH; ++u) {
-                    sv[u] = 0; ov[u] = 0;
-                    if (pn[u] >= 0) { sv[u] = a.cstart_p[pn[u]]; ov[u] = a.occ_p[pn[u]]; }
-                }
-#pragma unroll
-                for (int u = 0; u < CBATCH; ++u)
-                    if (pl && c0c + u < NP) { cs[lane * NP + c0c + u] = sv[u]; co[lane * NP + c0c + u] = (uint8_t)ov[u]; }
-            }
+    const uint64_t b = __ballot(j >= 0);
+    if (b == 0) return;                 // wave-uniform
+    npairs += (uint32_t)__popcll(b);
+    const uint32_t cnt = (uint32_t)__popcll(b & m.segmask);
+    const uint32_t nt = (cnt + 15u) >> 4;
+    if (FILL) {
+        if (j >= 0) {
+            const uint32_t p = (uint32_t)__popcll(b & m.below);
+            const size_t at = (size_t)(t + (p >> 4)) * 16 + (p & 15);
+            a.tj[at] = j;
+            a.tr[at] = (uint8_t)(m.ls + 1);                      // LDS slot of the output row inside its block: row + 1
         }
-        live[q] = c0 + lane < cend;
-        row[q] = i;
-        const uint64_t kc = a.rkey_c[i];
-        cx[q] = (int)(rk_x(kc) & 1); cy[q] = (int)(rk_y(kc) & 1); cz[q] = (int)(rk_z(kc) & 1);
-        mine[q] = min(my_parent - p_lo, 63u) * (uint32_t)NP;
+        if ((uint32_t)m.ls < nt * 16u - cnt) {                   // padding entries: neighbour row 0 into the dummy slot
+            const uint32_t p = cnt + (uint32_t)m.ls;
+            const size_t at = (size_t)(t + (p >> 4)) * 16 + (p & 15);
+            a.tj[at] = 0;
+            a.tr[at] = 0;
+        }
+        if ((uint32_t)m.ls < nt) a.toc[t + (uint32_t)m.ls] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)m.ls) << 16);
     }
+    t += nt;
+}
+
+// Tables of a block taller than 64 rows for the fill pass (from the count pass's per-chunk counts): per offset the pairs of
+// the whole block, the block-relative first tile, and the pairs of the chunks in front of mine.
+struct ChunkTables { uint16_t *tot, *obase, *cbase; };
+__device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk, int K, int q, int lane, ChunkTables T)
+{
+    uint32_t carry = 0;
+    for (int o0 = 0; o0 < K; o0 += 64) {
+        const int o = o0 + lane;
+        uint32_t c4 = 0;
+        if (o < K) c4 = *reinterpret_cast<const uint32_t *>(cnt_blk + 4 * (size_t)o);
+        const uint32_t c[4] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24};
+        const uint32_t tot = c[0] + c[1] + c[2] + c[3];
+        const uint32_t cb = (q > 0 ? c[0] : 0u) + (q > 1 ? c[1] : 0u) + (q > 2 ? c[2] : 0u);
+        const uint32_t nt = (tot + 15u) >> 4;
+        uint32_t inc = nt;                                        // inclusive wave scan
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        if (o < K) { T.tot[o] = (uint16_t)tot; T.obase[o] = (uint16_t)(carry + inc - nt); T.cbase[o] = (uint16_t)cb; }
+        carry += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+}
+
+template <int KS, bool FILL>
+__global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
+{
+    constexpr int r = KS / 2, K = KS * KS * KS, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
+    __shared__ uint32_t cst[64 * NP];     // child start of every staged cell
+    __shared__ uint8_t coc[64 * NP];      // its occupancy (0 = the cell does not exist)
+    __shared__ uint16_t tab[3 * K + 2];   // fill pass, tall blocks: tot | obase | cbase
+    __shared__ uint8_t cntl[K + 3];       // count pass, tall blocks: my chunk's pairs per offset
+    const int lane = threadIdx.x;
+    const WaveMap m = wave_map(a.H, a.nc, a.blk0, lane);
+    const bool tall = m.nq > 1;
+    if (m.r0 >= m.rend) {                 // a chunk behind the end of its (last, short) block: nothing to stage
+        if (!FILL && tall)
+            for (int o = lane; o < K; o += 64) a.cnt_oq[((size_t)m.blk * K + o) * 4 + m.q] = 0;
+        return;
+    }
+    const ChunkTables T = {tab, tab + K + 1, tab + 2 * K + 2};
+    if (FILL && tall) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T);
+    // ---- stage the cells of my rows' parents: lane = parent, the cell map is read in coalesced rows (one per cell), the
+    // gathers of a cell's child start and occupancy hit neighbouring nodes for neighbouring parents
+    const int64_t i = min(m.r0 + lane, m.rend - 1);
+    const bool live = m.r0 + lane < m.rend;
+    const uint32_t my_parent = a.parent_c[i];
+    const uint32_t p_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.parent_c[m.r0]);
+    const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.parent_c[m.rend - 1]);
+    const uint32_t npar = min(p_hi - p_lo, 63u) + 1u;     // a header that lies about a level cannot overrun the staging area
+    {
+        const uint32_t p = p_lo + (uint32_t)lane;
+        const bool pl = (uint32_t)lane < npar && p < (uint32_t)a.np;
+        constexpr int CBATCH = 9;
+        for (int c0 = 0; c0 < NP; c0 += CBATCH) {
+            int32_t pn[CBATCH];
+#pragma unroll
+            for (int u = 0; u < CBATCH; ++u) pn[u] = (pl && c0 + u < NP) ? a.cell_p[(int64_t)(c0 + u) * a.np + p] : -1;
+            uint32_t sv[CBATCH], ov[CBATCH];
+#pragma unroll
+            for (int u = 0; u < CBATCH; ++u) {
+                sv[u] = 0; ov[u] = 0;
+                if (pn[u] >= 0) { sv[u] = a.cstart_p[pn[u]]; ov[u] = a.occ_p[pn[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < CBATCH; ++u)
+                if (pl && c0 + u < NP) { cst[lane * NP + c0 + u] = sv[u]; coc[lane * NP + c0 + u] = (uint8_t)ov[u]; }
+        }
+    }
+    const uint64_t kc = a.rkey_c[i];
+    const int cx = (int)(rk_x(kc) & 1), cy = (int)(rk_y(kc) & 1), cz = (int)(rk_z(kc) & 1);
+    const uint32_t mine = min(my_parent - p_lo, 63u) * (uint32_t)NP;
     __syncthreads();
-    Packer<Q, FILL> P;
-    uint32_t blk; bool blk_live;
-    packer_init<Q, FILL>(P, a, lane, &blk, &blk_live, w0);
+    uint32_t t = (FILL && m.blk_live) ? a.first[m.blk] : 0u;   // running tile of my block (blocks that fit the wave)
+    const uint32_t t0 = t;
+    uint32_t npairs = 0;
     int o = 0;
     for (int dz = -r; dz <= r; ++dz)
-        for (int dy = -r; dy <= r; ++dy)
+        for (int dy = -r; dy <= r; ++dy) {
+            const int ty = cy + dy, tz = cz + dz;
+            const int cyz = PW * ((ty >> 1) + PR) + PW * PW * ((tz >> 1) + PR) + PR, tqyz = ((ty & 1) << 1) | ((tz & 1) << 2);
 #pragma unroll
             for (int dx = -r; dx <= r; ++dx, ++o) {
-                int j[Q];
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const int tx = cx[q] + dx, ty = cy[q] + dy, tz = cz[q] + dz;
-                    const int cq = ((tx >> 1) + PR) + PW * ((ty >> 1) + PR) + PW * PW * ((tz >> 1) + PR);   // floor halves: the parent cell
-                    const int tq = (tx & 1) | ((ty & 1) << 1) | ((tz & 1) << 2);
-                    const uint32_t oc = coc[(size_t)q * 64 * NP + mine[q] + cq];
-                    const uint32_t s = cst[(size_t)q * 64 * NP + mine[q] + cq];
-                    int32_t res = (oc >> tq) & 1u ? (int32_t)(s + (uint32_t)__popc(oc & ((1u << tq) - 1u))) : -1;
-                    if ((int64_t)res >= a.nc) res = -1;      // only when a container header understates the level (reported at the decoder's final sync)
-                    j[q] = live[q] ? res : -1;
+                const int tx = cx + dx;
+                const int cq = (tx >> 1) + cyz;                      // floor halves: the parent cell
+                const int tq = (tx & 1) | tqyz;
+                const uint32_t oc = coc[mine + cq];
+                const uint32_t s = cst[mine + cq];
+                int32_t res = (oc >> tq) & 1u ? (int32_t)(s + (uint32_t)__popc(oc & ((1u << tq) - 1u))) : -1;
+                if ((int64_t)res >= a.nc) res = -1;                  // only when a container header understates the level (reported at the decoder's final sync)
+                const int j = live ? res : -1;
+                if (!FILL && a.cell_c && live && dx >= -PR && dx <= PR && dy >= -PR && dy <= PR && dz >= -PR && dz <= PR)
+                    a.cell_c[(int64_t)((dx + PR) + PW * (dy + PR) + PW * PW * (dz + PR)) * a.nc + i] = j;
+                if (!tall) { pack_local<FILL>(a, m, o, j, t, npairs); continue; }
+                // a chunk of a tall block: its pairs go behind those of the chunks in front of it
+                const uint64_t b = __ballot(j >= 0);
+                const uint32_t cnt = (uint32_t)__popcll(b);
+                if (!FILL) {
+                    npairs += cnt;
+                    if (lane == 0) cntl[o] = (uint8_t)cnt;
+                    continue;
                 }
-                if (!FILL && a.cell_c && dx >= -PR && dx <= PR && dy >= -PR && dy <= PR && dz >= -PR && dz <= PR) {
-                    const int c = (dx + PR) + PW * (dy + PR) + PW * PW * (dz + PR);
-#pragma unroll
-                    for (int q = 0; q < Q; ++q)
-                        if (live[q]) a.cell_c[(int64_t)c * a.nc + row[q]] = j[q];
+                const uint32_t tot = T.tot[o];
+                if (tot == 0) continue;                              // wave-uniform
+                const uint32_t tb = t0 + T.obase[o], nt = (tot + 15u) >> 4;
+                if (j >= 0) {
+                    const uint32_t p = (uint32_t)T.cbase[o] + (uint32_t)__popcll(b & m.below);
+                    const size_t at = (size_t)(tb + (p >> 4)) * 16 + (p & 15);
+                    a.tj[at] = j;
+                    a.tr[at] = (uint8_t)(m.q * 64 + lane + 1);
                 }
-                P.step(o, j);
+                if (m.q == 0) {                                      // the first chunk also writes what belongs to the whole offset
+                    if ((uint32_t)lane < nt * 16u - tot) {
+                        const uint32_t p = tot + (uint32_t)lane;
+                        const size_t at = (size_t)(tb + (p >> 4)) * 16 + (p & 15);
+                        a.tj[at] = 0;
+                        a.tr[at] = 0;
+                    }
+                    if ((uint32_t)lane < nt) a.toc[tb + (uint32_t)lane] = (uint32_t)o | (min(16u, tot - 16u * (uint32_t)lane) << 16);
+                }
             }
+        }
     if (!FILL) {
-        if (P.ls == 0 && blk_live) a.per_block[blk] = P.t;
-        if (lane == 0 && a.pairs && P.npairs) atomicAdd(a.pairs, (unsigned long long)P.npairs);
+        if (tall) {
+            __syncthreads();
+            for (int oo = lane; oo < K; oo += 64) a.cnt_oq[((size_t)m.blk * K + oo) * 4 + m.q] = cntl[oo];
+        } else if (m.ls == 0 && m.blk_live) a.per_block[m.blk] = t;
+        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs, (unsigned long long)npairs);
     }
+}
+
+// tiles of the blocks taller than 64 rows from the per-chunk counts
+__global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ cnt_oq, uint32_t blk0, int nblk, int K, uint32_t *__restrict__ per_block)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nblk) return;
+    const uint32_t *c = reinterpret_cast<const uint32_t *>(cnt_oq + (size_t)(blk0 + b) * K * 4);
+    uint32_t t = 0;
+    for (int o = 0; o < K; ++o) {
+        const uint32_t c4 = c[o];
+        t += ((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24) + 15u) >> 4;
+    }
+    per_block[blk0 + b] = t;
 }
 
 // The base level (< 64 nodes, no parent): neighbours by search over the level's raster keys.
@@ -199,15 +252,11 @@ __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
     const int n = (int)a.nc, r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1;
     keys[lane] = lane < n ? a.rkey_c[lane] : ~0ull;
     __syncthreads();
-    // one wave per block, or per 64 rows of 16- / 32-row blocks (as in k_level_tiles)
-    const int span = (a.H == 16 || a.H == 32) ? 64 : a.H;
-    const int w0 = (int)blockIdx.x * span;
-    const int me = w0 + lane;                                  // my row
-    const bool live = lane < span && me < n;
+    const WaveMap m = wave_map(min(a.H, 64), a.nc, a.blk0, lane);   // n < 64: a block taller than 64 rows is the whole level
+    const int me = (int)m.r0 + lane;                                  // my row
+    const bool live = m.r0 + lane < m.rend;
     const uint64_t ki = keys[min(me, n - 1)];
-    Packer<1, FILL> P;
-    uint32_t blk; bool blk_live;
-    packer_init<1, FILL>(P, a, lane, &blk, &blk_live, w0);
+    uint32_t t = (FILL && m.blk_live) ? a.first[m.blk] : 0u, npairs = 0;
     int o = 0;
     for (int dz = -r; dz <= r; ++dz)
         for (int dy = -r; dy <= r; ++dy)
@@ -221,32 +270,28 @@ __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
                 }
                 if (!FILL && a.cell_c && live && dx >= -PR && dx <= PR && dy >= -PR && dy <= PR && dz >= -PR && dz <= PR)
                     a.cell_c[(int64_t)((dx + PR) + PW * (dy + PR) + PW * PW * (dz + PR)) * n + me] = res;
-                const int j[1] = {res};
-                P.step(o, j);
+                pack_local<FILL>(a, m, o, res, t, npairs);
             }
     if (!FILL) {
-        if (P.ls == 0 && blk_live) a.per_block[blk] = P.t;
-        if (lane == 0 && a.pairs && P.npairs) atomicAdd(a.pairs, (unsigned long long)P.npairs);
+        if (m.ls == 0 && m.blk_live) a.per_block[m.blk] = t;
+        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs, (unsigned long long)npairs);
     }
 }
 
 template <int KS, bool FILL>
 int launch_level(hipStream_t st, const LevelTilesArgs &a)
 {
-    constexpr int r = KS / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
-    const int Q = a.H <= 64 ? 1 : (a.H + 63) / 64;
-    const int64_t span = (a.H == 16 || a.H == 32) ? 64 : a.H;
-    const unsigned grid = (unsigned)cdiv(a.nc, span);
-    const size_t lds = (size_t)Q * 64 * NP * 5;
-    if (lds > 64 * 1024) return fail(GPCC_ERR_ARG, "internal: block height %d with kernel size %d", a.H, KS);
-    switch (Q) {
-    case 1: k_level_tiles<KS, 1, FILL><<<grid, 64, lds, st>>>(a); break;
-    case 2: k_level_tiles<KS, 2, FILL><<<grid, 64, lds, st>>>(a); break;
-    case 3: k_level_tiles<KS, 3, FILL><<<grid, 64, lds, st>>>(a); break;
-    case 4: k_level_tiles<KS, 4, FILL><<<grid, 64, lds, st>>>(a); break;
-    default: return fail(GPCC_ERR_ARG, "internal: block height %d", a.H);
-    }
+    const int H = a.H;
+    const bool multi = H == 16 || H == 32;
+    const int nq = H > 64 ? (H + 63) / 64 : 1;
+    const unsigned grid = multi ? (unsigned)cdiv(a.nc, 64) : (unsigned)(cdiv(a.nc, H) * nq);
+    k_chunk_tiles<KS, FILL><<<grid, 64, 0, st>>>(a);
     LAUNCH_CHECK();
+    if (!FILL && nq > 1) {
+        const int nblk = (int)cdiv(a.nc, H);
+        k_block_sum<<<(unsigned)cdiv(nblk, 256), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block);
+        LAUNCH_CHECK();
+    }
     return GPCC_OK;
 }
 
@@ -254,13 +299,14 @@ template <bool FILL>
 int run_level(hipStream_t st, const Level *par, const int32_t *cell_par, const Level *chi, int k, LevelTilesArgs a)
 {
     a.rkey_c = chi->rkey; a.parent_c = chi->parent; a.nc = chi->n;
+    if (a.H < 16 || a.H > CONV_R_MAX) return fail(GPCC_ERR_ARG, "internal: block height %d", a.H);
     if (!par) {
-        if (chi->n > 64) return fail(GPCC_ERR_ARG, "internal: base level with %lld nodes", (long long)chi->n);
-        k_base_tiles<FILL><<<(unsigned)cdiv(chi->n, (a.H == 16 || a.H == 32) ? 64 : a.H), 64, 0, st>>>(a, k);
+        if (chi->n >= 64) return fail(GPCC_ERR_ARG, "internal: base level with %lld nodes", (long long)chi->n);
+        const int Hb = std::min(a.H, 64);
+        k_base_tiles<FILL><<<(unsigned)cdiv(chi->n, (Hb == 16 || Hb == 32) ? 64 : Hb), 64, 0, st>>>(a, k);
         LAUNCH_CHECK();
         return GPCC_OK;
     }
-    if (a.H < 16 || a.H > CONV_R_MAX) return fail(GPCC_ERR_ARG, "internal: block height %d", a.H);
     a.cell_p = cell_par; a.np = par->n; a.occ_p = par->occ; a.cstart_p = par->cstart;
     switch (k) {
     case 3: return launch_level<3, FILL>(st, a);
@@ -295,7 +341,6 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
 {
     if (nlv < 1 || nlv > MAXLV) return fail(GPCC_ERR_ARG, "internal: %d levels", nlv);
     const int K = k * k * k;
-    if (k == 7 && H > 64) return fail(GPCC_ERR_ARG, "internal: kernel size 7 needs blocks of at most 64 rows (125 staged cells per parent)");
     pool->R = R; pool->H = H; pool->K = K; pool->nlv = nlv;
     int64_t nblk = 0;
     for (int l = 0; l < nlv; ++l) {
@@ -311,6 +356,11 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     pool->first = first;
     LevelTilesArgs a = {};
     a.H = H; a.per_block = first;
+    if (H > 64) {   // blocks of 2 or 3 chunks leave the other columns untouched: zero them
+        TAKE(cq, uint8_t, (size_t)nblk * K * 4);
+        a.cnt_oq = cq;
+        HIP_TRY(hipMemsetAsync(cq, 0, (size_t)nblk * K * 4, st));
+    }
     for (int l = 0; l < nlv; ++l) {
         a.blk0 = pool->lv_blk0[l]; a.cell_c = lv[l].cell_own; a.pairs = pairs_dev ? pairs_dev + l : nullptr;
         GP_TRY(run_level<false>(st, lv[l].par, lv[l].cell_par, lv[l].lv, k, a));

@@ -29,7 +29,7 @@ struct LevelTilesArgs {
     // pass 1
     int32_t *cell_c;            // [NP][nc] the level's own cell map, nullable (nobody below needs it)
     uint32_t *per_block;        // [pool blocks] tiles of each block (blocks of at most 64 rows; taller ones: k_block_sum)
-    unsigned long long *pairs;  // += (row, neighbour) pairs of the level
+    unsigned long long *pairs;  // [64] += (row, neighbour) pairs of the level, spread over 64 counters by wave index
     uint8_t *cnt_oq;            // [pool blocks][K][4] pairs per (offset, 64-row chunk) of the blocks taller than 64 rows
     // pass 2
     const uint32_t *first;      // [pool blocks + 1] first tile of each block
@@ -122,24 +122,24 @@ __device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk
     }
 }
 
-template <int KS, bool FILL>
+// TALL: the wave is one 64-row chunk of a block taller than 64 rows; else its block(s) fit the wave.
+// The k^2 neighbours of a (dy, dx) plane are computed as one batch (independent LDS reads and integer chains in flight
+// together -- a wave alone on its SIMD has nothing else to hide their latency behind), then compacted one by one.
+template <int KS, bool FILL, bool TALL>
 __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
 {
     constexpr int r = KS / 2, K = KS * KS * KS, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
     __shared__ uint32_t cst[64 * NP];     // child start of every staged cell
     __shared__ uint8_t coc[64 * NP];      // its occupancy (0 = the cell does not exist)
     __shared__ uint16_t tab[3 * K + 2];   // fill pass, tall blocks: tot | obase | cbase
-    __shared__ uint8_t cntl[K + 3];       // count pass, tall blocks: my chunk's pairs per offset
     const int lane = threadIdx.x;
+#ifdef TILES_TIMING
+    const long long tc0 = clock64();
+#endif
     const WaveMap m = wave_map(a.H, a.nc, a.blk0, lane);
-    const bool tall = m.nq > 1;
-    if (m.r0 >= m.rend) {                 // a chunk behind the end of its (last, short) block: nothing to stage
-        if (!FILL && tall)
-            for (int o = lane; o < K; o += 64) a.cnt_oq[((size_t)m.blk * K + o) * 4 + m.q] = 0;
-        return;
-    }
+    if (m.r0 >= m.rend) return;           // a chunk behind the end of its (last, short) block: its counts were zeroed by the host
     const ChunkTables T = {tab, tab + K + 1, tab + 2 * K + 2};
-    if (FILL && tall) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T);
+    if (FILL && TALL) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T);
     // ---- stage the cells of my rows' parents: lane = parent, the cell map is read in coalesced rows (one per cell), the
     // gathers of a cell's child start and occupancy hit neighbouring nodes for neighbouring parents
     const int64_t i = min(m.r0 + lane, m.rend - 1);
@@ -149,9 +149,11 @@ __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
     const uint32_t p_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.parent_c[m.rend - 1]);
     const uint32_t npar = min(p_hi - p_lo, 63u) + 1u;     // a header that lies about a level cannot overrun the staging area
     {
+        // three dependent round trips in all (parents -> cell rows -> the cells' child start / occupancy): every load of a
+        // round is in flight before the first is used.  NP > 32 (kernel size 7): in batches, registers are finite.
         const uint32_t p = p_lo + (uint32_t)lane;
         const bool pl = (uint32_t)lane < npar && p < (uint32_t)a.np;
-        constexpr int CBATCH = 9;
+        constexpr int CBATCH = NP <= 32 ? NP : 25;
         for (int c0 = 0; c0 < NP; c0 += CBATCH) {
             int32_t pn[CBATCH];
 #pragma unroll
@@ -159,88 +161,134 @@ __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
             uint32_t sv[CBATCH], ov[CBATCH];
 #pragma unroll
             for (int u = 0; u < CBATCH; ++u) {
-                sv[u] = 0; ov[u] = 0;
-                if (pn[u] >= 0) { sv[u] = a.cstart_p[pn[u]]; ov[u] = a.occ_p[pn[u]]; }
+                const int32_t q = max(pn[u], 0);             // unconditional gathers (row 0 is always there): no branch between the loads
+                sv[u] = a.cstart_p[q]; ov[u] = a.occ_p[q];
             }
 #pragma unroll
             for (int u = 0; u < CBATCH; ++u)
-                if (pl && c0 + u < NP) { cst[lane * NP + c0 + u] = sv[u]; coc[lane * NP + c0 + u] = (uint8_t)ov[u]; }
+                if (pl && c0 + u < NP) { cst[lane * NP + c0 + u] = pn[u] >= 0 ? sv[u] : 0u; coc[lane * NP + c0 + u] = pn[u] >= 0 ? (uint8_t)ov[u] : (uint8_t)0; }
         }
     }
     const uint64_t kc = a.rkey_c[i];
     const int cx = (int)(rk_x(kc) & 1), cy = (int)(rk_y(kc) & 1), cz = (int)(rk_z(kc) & 1);
     const uint32_t mine = min(my_parent - p_lo, 63u) * (uint32_t)NP;
     __syncthreads();
+#ifdef TILES_TIMING
+    const long long tc1 = clock64();
+#endif
     uint32_t t = (FILL && m.blk_live) ? a.first[m.blk] : 0u;   // running tile of my block (blocks that fit the wave)
     const uint32_t t0 = t;
     uint32_t npairs = 0;
-    int o = 0;
-    for (int dz = -r; dz <= r; ++dz)
-        for (int dy = -r; dy <= r; ++dy) {
-            const int ty = cy + dy, tz = cz + dz;
-            const int cyz = PW * ((ty >> 1) + PR) + PW * PW * ((tz >> 1) + PR) + PR, tqyz = ((ty & 1) << 1) | ((tz & 1) << 2);
+    const int nc32 = (int)min(a.nc, (int64_t)INT32_MAX);
+    for (int dz = -r; dz <= r; ++dz) {
+        const int tz = cz + dz;
+        const int cqz = PW * PW * ((tz >> 1) + PR) + PR, tqz = (tz & 1) << 2;
+        int jv[KS * KS];
+        {
+            // both LDS reads of every offset of the plane first, unconditionally (the compiler otherwise reads the child start
+            // under a branch on the occupancy bit and waits for each of the 2 k^2 reads in turn), then the integer part
+            uint32_t ocv[KS * KS], scv[KS * KS];
+            int tqv[KS * KS];
 #pragma unroll
-            for (int dx = -r; dx <= r; ++dx, ++o) {
-                const int tx = cx + dx;
-                const int cq = (tx >> 1) + cyz;                      // floor halves: the parent cell
-                const int tq = (tx & 1) | tqyz;
-                const uint32_t oc = coc[mine + cq];
-                const uint32_t s = cst[mine + cq];
-                int32_t res = (oc >> tq) & 1u ? (int32_t)(s + (uint32_t)__popc(oc & ((1u << tq) - 1u))) : -1;
-                if ((int64_t)res >= a.nc) res = -1;                  // only when a container header understates the level (reported at the decoder's final sync)
-                const int j = live ? res : -1;
-                if (!FILL && a.cell_c && live && dx >= -PR && dx <= PR && dy >= -PR && dy <= PR && dz >= -PR && dz <= PR)
-                    a.cell_c[(int64_t)((dx + PR) + PW * (dy + PR) + PW * PW * (dz + PR)) * a.nc + i] = j;
-                if (!tall) { pack_local<FILL>(a, m, o, j, t, npairs); continue; }
-                // a chunk of a tall block: its pairs go behind those of the chunks in front of it
-                const uint64_t b = __ballot(j >= 0);
-                const uint32_t cnt = (uint32_t)__popcll(b);
-                if (!FILL) {
-                    npairs += cnt;
-                    if (lane == 0) cntl[o] = (uint8_t)cnt;
-                    continue;
-                }
-                const uint32_t tot = T.tot[o];
-                if (tot == 0) continue;                              // wave-uniform
-                const uint32_t tb = t0 + T.obase[o], nt = (tot + 15u) >> 4;
-                if (j >= 0) {
-                    const uint32_t p = (uint32_t)T.cbase[o] + (uint32_t)__popcll(b & m.below);
-                    const size_t at = (size_t)(tb + (p >> 4)) * 16 + (p & 15);
-                    a.tj[at] = j;
-                    a.tr[at] = (uint8_t)(m.q * 64 + lane + 1);
-                }
-                if (m.q == 0) {                                      // the first chunk also writes what belongs to the whole offset
-                    if ((uint32_t)lane < nt * 16u - tot) {
-                        const uint32_t p = tot + (uint32_t)lane;
-                        const size_t at = (size_t)(tb + (p >> 4)) * 16 + (p & 15);
-                        a.tj[at] = 0;
-                        a.tr[at] = 0;
-                    }
-                    if ((uint32_t)lane < nt) a.toc[tb + (uint32_t)lane] = (uint32_t)o | (min(16u, tot - 16u * (uint32_t)lane) << 16);
+            for (int iy = 0; iy < KS; ++iy) {
+                const int ty = cy + iy - r;
+                const int cqy = PW * ((ty >> 1) + PR) + cqz, tqy = ((ty & 1) << 1) | tqz;
+#pragma unroll
+                for (int ix = 0; ix < KS; ++ix) {
+                    const int tx = cx + ix - r;
+                    const int cq = (tx >> 1) + cqy;                  // floor halves: the parent cell
+                    tqv[iy * KS + ix] = (tx & 1) | tqy;
+                    ocv[iy * KS + ix] = coc[mine + cq];
+                    scv[iy * KS + ix] = cst[mine + cq];
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < KS * KS; ++u) {
+                const uint32_t bit = (ocv[u] >> tqv[u]) & 1u;
+                const int32_t idx = (int32_t)(scv[u] + (uint32_t)__popc(ocv[u] & ((1u << tqv[u]) - 1u)));
+                // res >= nc: only when a container header understates the level (reported at the decoder's final sync)
+                jv[u] = (bit != 0u && idx < nc32 && live) ? idx : -1;
+            }
         }
-    if (!FILL) {
-        if (tall) {
-            __syncthreads();
-            for (int oo = lane; oo < K; oo += 64) a.cnt_oq[((size_t)m.blk * K + oo) * 4 + m.q] = cntl[oo];
-        } else if (m.ls == 0 && m.blk_live) a.per_block[m.blk] = t;
-        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs, (unsigned long long)npairs);
+        if (!FILL && a.cell_c && live && dz >= -PR && dz <= PR) {
+#pragma unroll
+            for (int iy = r - PR; iy <= r + PR; ++iy)
+#pragma unroll
+                for (int ix = r - PR; ix <= r + PR; ++ix)
+                    a.cell_c[(int64_t)((ix - r + PR) + PW * (iy - r + PR) + PW * PW * (dz + PR)) * a.nc + i] = jv[iy * KS + ix];
+        }
+        const int ob = (dz + r) * KS * KS;
+        if (!TALL) {
+#pragma unroll
+            for (int u = 0; u < KS * KS; ++u) pack_local<FILL>(a, m, ob + u, jv[u], t, npairs);
+            continue;
+        }
+        // a chunk of a tall block: its pairs go behind those of the chunks in front of it
+        if (!FILL) {
+            // the plane's counts collect in lanes 0 .. k^2 - 1 of one register (one v_writelane per offset), one store per plane
+            int acc = 0;
+#pragma unroll
+            for (int u = 0; u < KS * KS; ++u)
+            {
+                const int cnt = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(jv[u] >= 0)));
+                asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(acc) : "s"(cnt), "n"(u));
+            }
+            if (lane < KS * KS) { a.cnt_oq[((size_t)m.blk * K + ob + lane) * 4 + m.q] = (uint8_t)acc; npairs += (uint32_t)acc; }
+            continue;
+        }
+        // (pads and offset words of the tiles are written by k_tile_words from the same counts)
+        uint32_t obase[KS * KS], cbase[KS * KS];
+#pragma unroll
+        for (int u = 0; u < KS * KS; ++u) { obase[u] = T.obase[ob + u]; cbase[u] = T.cbase[ob + u]; }
+#pragma unroll
+        for (int u = 0; u < KS * KS; ++u) {
+            const int j = jv[u];
+            const uint64_t b = __ballot(j >= 0);
+            if (j >= 0) {
+                const uint32_t p = cbase[u] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                const uint32_t at = (t0 + obase[u]) * 16u + p;       // (tile, slot) = (p >> 4, p & 15) behind the offset's first tile
+                a.tj[at] = j;
+                a.tr[at] = (uint8_t)(m.q * 64 + lane + 1);
+            }
+        }
     }
+#ifdef TILES_TIMING
+    const long long tc2 = clock64();
+#endif
+    if (!FILL) {
+        if (!TALL && m.ls == 0 && m.blk_live) a.per_block[m.blk] = t;
+        // pairs: tall chunks hold partial sums in lanes 0 .. k^2 - 1; one atomic per wave on one of 64 counters (a single
+        // hot word serialises ~12 ns per wave: 180 us for the finest level of a 1 M-point cloud)
+        if (TALL) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) npairs += (uint32_t)__shfl_xor((int)npairs, d, 64);
+        }
+        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs + (blockIdx.x & 63u), (unsigned long long)npairs);
+    }
+#ifdef TILES_TIMING
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long tc3 = clock64();
+    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
+        printf("[tiles] fill %d tall %d grid %u wave %u: stage %lld loop %lld tail %lld cycles\n", (int)FILL, (int)TALL, gridDim.x, blockIdx.x, tc1 - tc0, tc2 - tc1, tc3 - tc2);
+#endif
 }
 
-// tiles of the blocks taller than 64 rows from the per-chunk counts
+// tiles of the blocks taller than 64 rows from the per-chunk counts: a wave per block, lanes over the offsets
 __global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ cnt_oq, uint32_t blk0, int nblk, int K, uint32_t *__restrict__ per_block)
 {
-    const int b = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= nblk) return;
     const uint32_t *c = reinterpret_cast<const uint32_t *>(cnt_oq + (size_t)(blk0 + b) * K * 4);
     uint32_t t = 0;
-    for (int o = 0; o < K; ++o) {
+    for (int o = lane; o < K; o += 64) {
         const uint32_t c4 = c[o];
         t += ((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24) + 15u) >> 4;
     }
-    per_block[blk0 + b] = t;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+    if (lane == 0) per_block[blk0 + b] = t;
 }
 
 // The base level (< 64 nodes, no parent): neighbours by search over the level's raster keys.
@@ -278,6 +326,34 @@ __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
     }
 }
 
+// pads and offset words of the tiles of blocks taller than 64 rows: one thread per (block, offset)
+__global__ __launch_bounds__(256) void k_tile_words(const uint8_t *__restrict__ cnt_oq, const uint32_t *__restrict__ first, uint32_t blk0, int nblk, int K,
+                                                    int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc)
+{
+    // a wave per block: lanes scan the offsets' tile counts, then every lane finishes its own offsets
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= nblk) return;
+    const uint32_t *c = reinterpret_cast<const uint32_t *>(cnt_oq + (size_t)(blk0 + b) * K * 4);
+    uint32_t carry = first[blk0 + b];
+    for (int o0 = 0; o0 < K; o0 += 64) {
+        const int o = o0 + lane;
+        const uint32_t c4 = o < K ? c[o] : 0u;
+        const uint32_t tot = (c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24);
+        const uint32_t nt = (tot + 15u) >> 4;
+        uint32_t inc = nt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        const uint32_t tb = carry + inc - nt;
+        for (uint32_t i = 0; i < nt; ++i) toc[tb + i] = (uint32_t)o | (min(16u, tot - 16u * i) << 16);
+        for (uint32_t p = tot; p < nt * 16u; ++p) { tj[(size_t)tb * 16 + p] = 0; tr[(size_t)tb * 16 + p] = 0; }
+        carry += (uint32_t)__shfl((int)inc, 63, 64);
+    }
+}
+
 template <int KS, bool FILL>
 int launch_level(hipStream_t st, const LevelTilesArgs &a)
 {
@@ -285,11 +361,13 @@ int launch_level(hipStream_t st, const LevelTilesArgs &a)
     const bool multi = H == 16 || H == 32;
     const int nq = H > 64 ? (H + 63) / 64 : 1;
     const unsigned grid = multi ? (unsigned)cdiv(a.nc, 64) : (unsigned)(cdiv(a.nc, H) * nq);
-    k_chunk_tiles<KS, FILL><<<grid, 64, 0, st>>>(a);
+    if (nq > 1) k_chunk_tiles<KS, FILL, true><<<grid, 64, 0, st>>>(a);
+    else k_chunk_tiles<KS, FILL, false><<<grid, 64, 0, st>>>(a);
     LAUNCH_CHECK();
-    if (!FILL && nq > 1) {
+    if (nq > 1) {
         const int nblk = (int)cdiv(a.nc, H);
-        k_block_sum<<<(unsigned)cdiv(nblk, 256), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block);
+        if (!FILL) k_block_sum<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block);
+        else k_tile_words<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.first, a.blk0, nblk, KS * KS * KS, a.tj, a.tr, a.toc);
         LAUNCH_CHECK();
     }
     return GPCC_OK;
@@ -313,6 +391,16 @@ int run_level(hipStream_t st, const Level *par, const int32_t *cell_par, const L
     case 5: return launch_level<5, FILL>(st, a);
     case 7: return launch_level<7, FILL>(st, a);
     default: return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+    }
+}
+
+__global__ __launch_bounds__(64) void k_fold_pairs(const unsigned long long *__restrict__ spread, int nlv, unsigned long long *__restrict__ pairs)
+{
+    for (int l = 0; l < nlv; ++l) {
+        unsigned long long v = spread[l * 64 + threadIdx.x];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (threadIdx.x == 0) pairs[l] += v;
     }
 }
 
@@ -361,10 +449,17 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         a.cnt_oq = cq;
         HIP_TRY(hipMemsetAsync(cq, 0, (size_t)nblk * K * 4, st));
     }
+    unsigned long long *spread = nullptr;
+    if (pairs_dev) {
+        TAKE(sp, unsigned long long, (size_t)nlv * 64);
+        spread = sp;
+        HIP_TRY(hipMemsetAsync(sp, 0, 8 * (size_t)nlv * 64, st));
+    }
     for (int l = 0; l < nlv; ++l) {
-        a.blk0 = pool->lv_blk0[l]; a.cell_c = lv[l].cell_own; a.pairs = pairs_dev ? pairs_dev + l : nullptr;
+        a.blk0 = pool->lv_blk0[l]; a.cell_c = lv[l].cell_own; a.pairs = spread ? spread + (size_t)l * 64 : nullptr;
         GP_TRY(run_level<false>(st, lv[l].par, lv[l].cell_par, lv[l].lv, k, a));
     }
+    if (spread) { k_fold_pairs<<<1, 64, 0, st>>>(spread, nlv, pairs_dev); LAUNCH_CHECK(); }
     GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
     // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the host ever
     // learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run ahead).
@@ -377,6 +472,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         HIP_TRY(hipStreamSynchronize(st));
         cap = (int64_t)total + CONV_HDR_PAD;   // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
     }
+    if (cap >= (int64_t)1 << 28) return fail(GPCC_ERR_ARG, "too many conv tiles (%lld): clouds beyond ~10^8 points need 64-bit tile addressing", (long long)cap);
     TAKE(tj, int32_t, cap * 16);
     TAKE(tr, uint8_t, cap * 16);
     TAKE(toc, uint32_t, cap);

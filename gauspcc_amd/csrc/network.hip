@@ -33,10 +33,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int SC_WAVES = CONV_SC_WAVES_N;   // waves per workgroup of k_sparse_conv (every wave works alone on its own block)
 // LDS floats per wave: slot 0 = the dummy row (padding entries, tiles past the end of a list), slots 1..R = the block's rows,
-// then the tile-header ring: 32 slots + 4 mirror slots (copies of slots 0..3, so that the asm loop reaches the slots of
-// four consecutive tiles by immediate offsets): neighbour rows 36 x 16 dwords | output slots 33 x 4 dwords (16 bytes a
-// tile) | kernel offsets 36 dwords
-constexpr int HDR_R = 576, HDR_O = 712, HDR_DWORDS = 752;
+// then the tile-header ring: 32 slots + 16 mirror slots (copies of slots 0..15, so that the asm loop reaches every slot
+// the eight steps of an iteration read -- up to 15 tiles ahead -- by immediate offsets): neighbour rows 48 x 16 dwords |
+// output slots 48 x 4 dwords (16 bytes a tile) | kernel offsets 48 dwords
+constexpr int HDR_R = 768, HDR_O = 960, HDR_DWORDS = 1008;
 __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + HDR_DWORDS; }
 
 // ------------------------------------------------------------------ block policy
@@ -220,15 +220,15 @@ __global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 :
         int4 *sj = reinterpret_cast<int4 *>(hdr) + lane;   // + (batch & 1) * 64
         int32_t *sr = hdr + HDR_R + lane;                  // + (batch & 1) * 64
         int32_t *so = hdr + HDR_O + (lane & 15);           // + (batch & 1) * 16
-        {   // batches 0 and 1 straight into the ring (and slots 0..3 into their mirrors behind slot 31)
+        {   // batches 0 and 1 straight into the ring (and batch 0 into its mirror behind slot 31)
             const int4 a0 = gtj[0], a1 = gtj[64];
             const uint32_t b0 = gtr[0], b1 = gtr[64], c0 = gto[0], c1 = gto[16];
             sj[0] = a0; sj[64] = a1;
             sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
             so[0] = (int32_t)(c0 & 0xFFFFu); so[16] = (int32_t)(c1 & 0xFFFFu);
-            if (lane < 16) sj[128] = a0;
-            if (lane < 4) sr[128] = (int32_t)b0;
-            if ((lane & 15) < 4) so[32] = (int32_t)(c0 & 0xFFFFu);
+            sj[128] = a0;                          // mirror of batch 0 behind slot 31
+            sr[128] = (int32_t)b0;
+            so[32] = (int32_t)(c0 & 0xFFFFu);
         }
         CT_STAMP(ct1);
         if constexpr (ASM) {

@@ -23,8 +23,11 @@ Per step: 16 MFMAs from a ZERO accumulator + 7 VALU (+3 per four steps); the res
 
 One wave owns R rows x all 32 output channels.  Per step (one tile = 16 (output row, neighbour row) pairs of one kernel
 offset):
-    gathered rows (X) and weight fragment (W) of the tile D = 3 steps ahead; vmcnt retires in order, so a step waits
-        with vmcnt(6 (D-1)): the loads of the last D-1 steps stay in flight, this tile's (issued D steps ago) have landed
+    weight fragment (W) of the tile DW = 3 steps ahead, gathered rows (X) of the tile DX steps ahead (3; CONV_ASM_DX=7 was
+        built and measured in round 2: 71.6 vs 71.9 TFLOP/s on the encoder's convolutions -- the "step-start wait" the
+        in-loop s_memtime stamps show is the stamp's own SMEM latency under lgkmcnt(0), not a late load); vmcnt retires in
+        order, so a step waits with vmcnt(6 (DW-1)): the loads of the last DW-1 steps stay in flight, this tile's W (issued
+        DW steps ago) and X (issued no later) have landed
     header words from the wave's LDS ring: neighbour rows + offset of tile u+D+1, output slot of tile u+1
     the PREVIOUS tile's products are added to its rows' running sums (read from LDS during the previous step) and
         written back; then this tile's rows are read -- LDS operations of a wave execute in program order, so
@@ -36,27 +39,37 @@ registers (gfx90a+ requirement).
 import os
 
 EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers
-D = 3                                            # issue distance of the tile loads (steps); X and W rings = D + 1 sets
+DX = int(os.environ.get("CONV_ASM_DX", "3"))     # issue distance of the gathered rows (steps); X ring = DX + 1 sets (7: measured, no gain)
+DW = 3                                           # issue distance of the weight fragments; W ring = DW + 1 sets
+assert DX in (3, 7)
+NX, NW = DX + 1, DW + 1
+_x0 = 16
+_w0 = _x0 + 8 * NX
+_c0 = _w0 + 16 * NW
+_m0 = _c0 + 32                         # first register behind X | W | C (2 x 8) | S (2 x 8)
 
 V = dict(
-    X=(16, 24, 32, 40),                # gathered rows: 4 sets x 8 regs
-    W=(48, 64, 80, 96),                # weight fragments: 4 sets x 16 regs
-    C=(112, 120),                      # products: c0 = C..C+3, c1 = C+4..C+7
-    S=(128, 136),                      # running sums of the tile's rows: 2 sets x 8 regs
-    jn=144, on=145, rb=146, ao=147, bo=148,
-    ra=(149, 150),                     # LDS address of this lane's 16 bytes in the tile row's slot
-    t0=151,
-    stj=152, str=156, sto=157,         # staged header batch
-    accb=158, hjb=159, hrb=160, hob=161, goff=162, loff=163,
-    hjp=164, hrp=165, hop=166,
-    sgr=167, sgo=168, swj=169, swr=170, swo=171, swjm=172, swrm=173, swom=174,
+    X=tuple(_x0 + 8 * i for i in range(NX)),     # gathered rows: NX sets x 8 regs
+    W=tuple(_w0 + 16 * i for i in range(NW)),    # weight fragments: NW sets x 16 regs
+    C=(_c0, _c0 + 8),                  # products: c0 = C..C+3, c1 = C+4..C+7
+    S=(_c0 + 16, _c0 + 24),            # running sums of the tile's rows: 2 sets x 8 regs
+    jn=_m0, on=_m0 + 1, rb=_m0 + 2, ao=_m0 + 3, bo=_m0 + 4,
+    ra=(_m0 + 5, _m0 + 6),             # LDS address of this lane's 16 bytes in the tile row's slot
+    t0=_m0 + 7,
+    stj=_m0 + 8, str=_m0 + 12, sto=_m0 + 13,     # staged header batch (stj: 4 registers, even-aligned)
+    accb=_m0 + 14, hjb=_m0 + 15, hrb=_m0 + 16, hob=_m0 + 17, goff=_m0 + 18, loff=_m0 + 19,
+    hjp=_m0 + 20, hrp=_m0 + 21, hop=_m0 + 22,
+    sgr=_m0 + 23, sgo=_m0 + 24, swj=_m0 + 25, swr=_m0 + 26, swo=_m0 + 27,
 )
-CLOBBER_V = list(range(16, 176))
-NSTEP = 4                              # lcm(D + 1, 2)
-WINDOW = 6 * (D - 1)                   # tile loads that may stay in flight across a step start
-# byte offsets inside the header ring (must match network.hip: HDR_R, HDR_O)
-RING_R = 2304                          # 36 slots x 64 B of neighbour rows before it
-RING_O = 2848                          # 33 slots x 16 B of output slots (padded to 544) before it
+CLOBBER_V = list(range(16, _m0 + 28))
+NSTEP = NX                             # a multiple of NX, NW and 2
+WINDOW = 6 * (DW - 1)                  # tile loads that may stay in flight across a step start
+# Header ring: 32 slots = two batches of 16 tiles, followed by a mirror of slots 0..15 so that the NSTEP steps of an
+# iteration reach every slot they read by immediate offsets from pointers that move once per iteration.
+# Byte offsets inside the ring (must match network.hip: HDR_R, HDR_O):
+RING_SLOTS = 48
+RING_R = RING_SLOTS * 64               # neighbour rows: 64 B a slot
+RING_O = RING_R + RING_SLOTS * 16      # output slots: 16 B a slot; then the kernel offsets: 4 B a slot
 
 
 def vr(base, n=1):
@@ -92,6 +105,8 @@ def sum_adds(sset, cp):
     if EXP & 1:
         return []
     S = V["S"][sset]
+    if os.environ.get("CONV_ASM_PK", "1") == "0":      # experiment: eight scalar adds instead of four packed ones
+        return [f"v_add_f32 v{S + i}, v{S + i}, v{cp + i}" for i in range(8)]
     return [f"v_pk_add_f32 {vr(S + 2 * i, 2)}, {vr(S + 2 * i, 2)}, {vr(cp + 2 * i, 2)}" for i in range(4)]
 
 
@@ -110,14 +125,15 @@ def sum_reads(sset):
 
 
 def header_reads(du):
-    # neighbour rows + offset of tile u+du+D+1 (its loads are issued in the next step), output slot of tile u+du+1
-    return [f"ds_read_b32 v{V['jn']}, v{V['hjp']} offset:{64 * (D + 1 + du)}",
-            f"ds_read_b32 v{V['on']}, v{V['hop']} offset:{4 * (D + 1 + du)}",
+    # neighbour rows of tile u+du+DX+1 and offset of tile u+du+DW+1 (their loads are issued in the next step), output slot of tile u+du+1
+    assert 24 + DX + 1 + du < RING_SLOTS
+    return [f"ds_read_b32 v{V['jn']}, v{V['hjp']} offset:{64 * (DX + 1 + du)}",
+            f"ds_read_b32 v{V['on']}, v{V['hop']} offset:{4 * (DW + 1 + du)}",
             f"ds_read_u8 v{V['rb']}, v{V['hrp']} offset:{16 * (1 + du)}"]
 
 
 def ring_pointers():
-    # ring position of tile u (u % 4 == 0): the four steps of an iteration reach slots su+1 .. su+7 <= 35 by immediate offsets
+    # ring position of tile u (u % NSTEP == 0): the steps of an iteration reach slots su+1 .. su+DX+NSTEP < 48 by immediate offsets
     return ["s_and_b32 %[t0], %[u], 31",
             f"v_lshl_add_u32 v{V['hjp']}, %[t0], 6, v{V['hjb']}",
             f"v_lshl_add_u32 v{V['hrp']}, %[t0], 4, v{V['hrb']}",
@@ -125,15 +141,13 @@ def ring_pointers():
 
 
 def staging_fetch(label):
-    # header batch (u / 16) + 1 is fetched at the first step of batch u / 16 (u > 0) ...
+    # header batch (u / 16) + 2 is fetched at the middle step of batch u / 16 ...
     return [
         "s_and_b32 %[t0], %[u], 15",
-        "s_cmp_eq_u32 %[t0], 0",
+        "s_cmp_eq_u32 %[t0], 8",
         f"s_cbranch_scc0 {label}_nofetch%=",
-        "s_cmp_eq_u32 %[u], 0",
-        f"s_cbranch_scc1 {label}_nofetch%=",
         "s_lshr_b32 %[t1], %[u], 4",
-        "s_add_u32 %[t1], %[t1], 1",
+        "s_add_u32 %[t1], %[t1], 2",
         f"v_lshl_add_u32 v{V['t0']}, %[t1], 10, v{V['loff']}",
         f"global_load_dwordx4 {vr(V['stj'], 4)}, v{V['t0']}, %[tj]",
         f"v_lshl_add_u32 v{V['t0']}, %[t1], 8, v{V['sgr']}",
@@ -145,15 +159,16 @@ def staging_fetch(label):
 
 
 def staging_store(label, younger_loads):
-    # ... and moved into the ring eight steps later -- the half of the ring it replaces was last read before step u.
-    # Slots 0..3 are mirrored behind slot 31 (the lanes that do not hold them repeat their own write).
+    # ... and moved into the ring eight steps later, at the first step of batch (u / 16): the half of the ring it replaces
+    # (batch (u / 16) - 1) was last read before this step, and the steps that read its first slots are >= 8 steps away.
+    # A batch that lands in slots 0..15 is also written to their mirror behind slot 31.
     return [
         "s_and_b32 %[t0], %[u], 15",
-        "s_cmp_eq_u32 %[t0], 8",
+        "s_cmp_eq_u32 %[t0], 0",
         f"s_cbranch_scc0 {label}_nostore%=",
-        "s_cmp_eq_u32 %[u], 8",
+        "s_cmp_eq_u32 %[u], 0",
         f"s_cbranch_scc1 {label}_nostore%=",
-        f"s_waitcnt vmcnt({younger_loads})",          # only this step's tile loads are younger
+        f"s_waitcnt vmcnt({younger_loads})",          # the staged loads are eight steps old
         "s_lshr_b32 %[t1], %[u], 4",
         "s_add_u32 %[t1], %[t1], 1",
         "s_and_b32 %[t1], %[t1], 1",
@@ -166,24 +181,22 @@ def staging_store(label, younger_loads):
         f"ds_write_b32 v{V['t0']}, v{V['sto']}",
         "s_cmp_eq_u32 %[t1], 0",
         f"s_cbranch_scc0 {label}_nostore%=",
-        f"ds_write_b128 v{V['swjm']}, {vr(V['stj'], 4)}",
-        f"ds_write_b32 v{V['swrm']}, v{V['str']}",
-        f"ds_write_b32 v{V['swom']}, v{V['sto']}",
+        f"ds_write_b128 v{V['swj']}, {vr(V['stj'], 4)} offset:2048",
+        f"ds_write_b32 v{V['swr']}, v{V['str']} offset:512",
+        f"ds_write_b32 v{V['swo']}, v{V['sto']} offset:128",
         f"{label}_nostore%=:",
     ]
 
 
 def step_wait(du, label):
-    """The loads of the last D - 1 steps may stay in flight; everything older (this tile's) must have landed.  For D
-    steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside that window as well.
-    Every LDS operation of the previous step was issued behind its first MFMA pair: long done."""
-    if not 1 <= du <= D:
+    """The loads of the last DW - 1 steps may stay in flight; everything older (this tile's W, and its X from long before)
+    must have landed.  For DW steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside
+    that window as well.  Every LDS operation of the previous step was issued behind its first MFMA pair: long done."""
+    if not 1 <= du <= DW:
         return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)"]
     return ["s_and_b32 %[t0], %[u], 15",
-            "s_cmp_eq_u32 %[t0], 0",
+            "s_cmp_eq_u32 %[t0], 8",
             f"s_cbranch_scc0 {label}_wa%=",
-            "s_cmp_eq_u32 %[u], 0",
-            f"s_cbranch_scc1 {label}_wa%=",
             f"s_waitcnt vmcnt({WINDOW + 3}) lgkmcnt(0)",
             f"s_branch {label}_wb%=",
             f"{label}_wa%=:",
@@ -216,28 +229,25 @@ def stamp_collect(par):
 
 
 def step(du):
-    rset, cur, prv = du % (D + 1), du % 2, 1 - du % 2
-    X, W, CC, CP = V["X"][rset], V["W"][rset], V["C"][cur], V["C"][prv]
+    cur, prv = du % 2, 1 - du % 2
+    X, W, CC, CP = V["X"][du % NX], V["W"][du % NW], V["C"][cur], V["C"][prv]
     label = f"s{du}"
 
     def mf(kk, first=False):
         return [mfma(CC, W + kk, X + kk, first), mfma(CC + 4, W + 8 + kk, X + kk, first)]
 
-    nset = (du + D) % (D + 1)          # the set consumed by the previous step receives tile u+du+D
-    o = [f"; ---- step: tile u+{du}: X/W set {rset}, C/S set {cur}"] + stamp("sa", cur) + step_wait(du, label) + stamp("sb", cur) + stamp_collect(cur)
+    nsx, nsw = (du + DX) % NX, (du + DW) % NW    # the sets consumed by the previous step receive tiles u+du+DX / u+du+DW
+    o = [f"; ---- step: tile u+{du}: X set {du % NX}, W set {du % NW}, C/S set {cur}"] + stamp("sa", cur) + step_wait(du, label) + stamp("sb", cur) + stamp_collect(cur)
     # slot multiplier of this tile: 128 if it exists, 0 (the dummy slot) past the end of the block's list
     o += [f"s_add_u32 %[t0], %[u], {du}", "s_cmp_lt_u32 %[t0], %[nt]", "s_cselect_b32 %[t1], 128, 0"]
     o += mf(0, True)
     # the step's only VALU burst: previous tile's products onto its rows' sums, addresses of the loads and of this tile's slot
     o += (ring_pointers() if du == 0 else [])
     o += sum_adds(prv, CP) + addr_x() + addr_w()
-    if EXP & 16:   # developer experiment: every lane on its own conflict-free slot (wrong sums, LDS timing without bank conflicts)
-        o += [f"v_mov_b32 v{V['ra'][cur]}, v{V['t0'] + 24}"]
-    else:
-        o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
+    o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
     # memory instructions issue slowly (measured: ~20 cycles an LDS, ~13 a global load instruction, during which an in-order
     # wave issues nothing else) but, unlike VALU work, they do overlap a running MFMA: one in front of each remaining MFMA
-    mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nset) + loads_w(nset)
+    mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nsx) + loads_w(nsw)
     rest = [m for kk in range(1, 8) for m in mf(kk)]
     spread = os.environ.get("CONV_ASM_SPREAD", "1") != "0"
     if not spread:
@@ -276,31 +286,16 @@ def build():
         f"v_add_u32 v{L['swr']}, %[hdr], v{L['sgr']}",
         f"v_add_u32 v{L['swr']}, {RING_R}, v{L['swr']}",
         f"v_add_u32 v{L['swo']}, v{L['hob']}, v{L['sgo']}",
-        # mirror slots 32..35 (= 0..3): lanes 0..15 hold them of the neighbour rows, lanes 0..3 slot 32 of the output slots,
-        # lanes with e < 4 of the offsets; everybody else repeats the regular write
-        f"v_add_u32 v{L['swjm']}, 2048, v{L['swj']}",
-        "v_cmp_gt_u32 vcc, 16, %[lane]",
-        f"v_cndmask_b32 v{L['swjm']}, v{L['swj']}, v{L['swjm']}, vcc",
-        f"v_add_u32 v{L['swrm']}, 512, v{L['swr']}",
-        "v_cmp_gt_u32 vcc, 4, %[lane]",
-        f"v_cndmask_b32 v{L['swrm']}, v{L['swr']}, v{L['swrm']}, vcc",
-        f"v_add_u32 v{L['swom']}, 128, v{L['swo']}",
-        f"v_cmp_gt_u32 vcc, 4, v{L['t0']}",
-        f"v_cndmask_b32 v{L['swom']}, v{L['swo']}, v{L['swom']}, vcc",
         f"v_mov_b32 v{L['ra'][1]}, v{L['accb']}",                   # "previous tile" of step 0: the dummy slot
-    ] + ([f"v_and_b32 v{L['t0']}, 15, %[lane]", f"v_lshrrev_b32 v{L['t0'] + 24}, 1, v{L['t0']}", f"v_lshrrev_b32 v{L['ao']}, 4, %[lane]",
-           f"v_xor_b32 v{L['t0'] + 24}, v{L['t0'] + 24}, v{L['ao']}", f"v_and_b32 v{L['t0'] + 24}, 7, v{L['t0'] + 24}",
-           f"v_lshlrev_b32 v{L['t0'] + 24}, 4, v{L['t0'] + 24}", f"v_lshl_add_u32 v{L['t0'] + 24}, v{L['t0']}, 7, v{L['t0'] + 24}",
-           f"v_add_u32 v{L['t0'] + 24}, %[acc], v{L['t0'] + 24}"] if EXP & 16 else []) + [
-        "; ---- pipeline prologue: X and W of tiles 0..D-1 in flight; headers j(D), o(D), slot(0) in registers",
+        "; ---- pipeline prologue: X of tiles 0..DX-1 and W of tiles 0..DW-1 in flight; headers j(DX), o(DW), slot(0) in registers",
         "s_waitcnt lgkmcnt(0)",
     ]
-    for t in range(D):
-        o += [f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * t}", f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * t}", "s_waitcnt lgkmcnt(0)"]
-        o += addr_x() + addr_w() + loads_x(t) + loads_w(t)
+    for t in range(DX):
+        o += [f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * t}"] + ([f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * t}"] if t < DW else []) + ["s_waitcnt lgkmcnt(0)"]
+        o += addr_x() + loads_x(t) + (addr_w() + loads_w(t) if t < DW else [])
     o += [
-        f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * D}",
-        f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * D}",
+        f"ds_read_b32 v{L['jn']}, v{L['hjb']} offset:{64 * DX}",
+        f"ds_read_b32 v{L['on']}, v{L['hob']} offset:{4 * DW}",
         f"ds_read_u8 v{L['rb']}, v{L['hrb']}",
         "s_mov_b32 %[u], 0",
     ] + ([f"s_mov_b32 %[w{i}], 0" for i in range(4)] + [x for n in STAMPS for x in stamp(n, 1)] if EXP & 8 else []) + [
@@ -308,8 +303,8 @@ def build():
     ]
     for du in range(NSTEP):
         o += step(du)
-        if du == 1:   # leave after an even number of steps when the list is exhausted (set 1 holds the last products either way)
-            o += ["s_add_u32 %[t0], %[u], 2", "s_cmp_ge_u32 %[t0], %[nt]", "s_cbranch_scc1 conv_drain%="]
+        if du % 2 == 1 and du != NSTEP - 1:   # leave after an even number of steps when the list is exhausted (set 1 holds the last products either way)
+            o += [f"s_add_u32 %[t0], %[u], {du + 1}", "s_cmp_ge_u32 %[t0], %[nt]", "s_cbranch_scc1 conv_drain%="]
     o += [
         f"s_add_u32 %[u], %[u], {NSTEP}",
         "s_cmp_lt_u32 %[u], %[nt]",

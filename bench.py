@@ -31,6 +31,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix peak
+HBM_PEAK_GBPS = 8000.0        # same guide: HBM3E 8.0 TB/s spec (6.3 TB/s measured with a float4 copy)
 
 
 def launcher_selftest(args, rank, world):
@@ -63,7 +64,9 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--kernel-size", type=int, default=5)
     ap.add_argument("--chunk-log2", type=int, default=10)
-    ap.add_argument("--cpu-sample", type=int, default=250_000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
+    ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
+    ap.add_argument("--skip-stages", action="store_true", help="do not run the extra pass that times the HBM-bound stages")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
     args = ap.parse_args()
 
@@ -141,10 +144,29 @@ def main():
     # size of the same cloud in the reference's container layout (one coder stream per level and stage, chunk_log2 = 0):
     # what the chunked default costs in bytes, outside the timed region
     bytes_v0 = None
-    if args.chunk_log2 and rank == 0:
+    if args.chunk_log2 and rank == 0 and not args.skip_v0:
         v0, _ = _encode_view(x, model, 0, 1)
         bytes_v0 = len(v0)
         data, st = _encode_view(x, model, args.chunk_log2, 1)   # the view above shares the context's buffer: restore `data`
+
+    # HBM-bound stages (SURVEY 8d "which roofline"): one more encode + decode with every stage bracketed by HIP events on the
+    # stream it runs on (gpcc_profile_enable(ctx, 2)) -- behind the timed region, because the brackets cost stream time
+    stages = []
+    if rank == 0 and not args.skip_stages:
+        _lib.check(L.gpcc_profile_enable(ctx, 2))
+        d2, _ = _encode_view(x, model, args.chunk_log2, 1)
+        _decode_bytes(d2, model, device)
+        torch.cuda.synchronize(device)
+        arr = (_lib.Stage * 8)()
+        ns = C.c_int()
+        _lib.check(L.gpcc_profile_stages(ctx, arr, 8, C.byref(ns)))
+        _lib.check(L.gpcc_profile_enable(ctx, 0))
+        for i in range(ns.value):
+            ms, by = arr[i].ms, arr[i].bytes
+            stages.append({"stage": arr[i].name.decode(), "bound": "hbm", "ms_per_step": round(ms, 3), "algorithmic_bytes": int(by),
+                           "achieved": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms > 0 else 0.0, "event_brackets": int(arr[i].brackets)})
+        data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
 
     # correctness of what was just timed: decoded geometry == input geometry (as sets; bit-identical)
     d = dec.cpu().numpy()
@@ -164,7 +186,7 @@ def main():
         # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_conv.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_conv.json")) as f:
                 traffic = round(json.load(f)["hbm_bytes_per_launch"])
         except Exception:
             pass
@@ -221,6 +243,9 @@ def main():
                 "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
                 "algorithmic_flops_per_step": conv_flops / args.steps,
                 "conv_time_frac_of_step": round(prof.conv_ms * 1e-3 / (enc_s + dec_s), 4),
+                # the HBM-bound stages either side of the convolutions: algorithmic bytes over the
+                # event-bracketed time of one extra untimed step; latency- / launch-bound at this size, not bandwidth-bound
+                "stages": stages,
             },
         }
         if args.cpu_sample > 0:

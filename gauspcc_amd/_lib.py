@@ -36,11 +36,15 @@ class Profile(C.Structure):
     _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_pair_jobs", C.c_int64)]
 
 
+class Stage(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("bytes", C.c_double), ("brackets", C.c_int64)]
+
+
 EXPORTS = [
     "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_raster_order", "gpcc_voxelise",
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
-    "gpcc_profile_enable", "gpcc_profile_get",
+    "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages",
     "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gshac_mlp2", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
 ]
 
@@ -77,6 +81,7 @@ def lib():
     L.gpcc_memcpy_d2d.argtypes = [vp, vp, vp, i64, vp]
     L.gpcc_profile_enable.argtypes = [vp, i32]
     L.gpcc_profile_get.argtypes = [vp, C.POINTER(Profile)]
+    L.gpcc_profile_stages.argtypes = [vp, C.POINTER(Stage), i32, C.POINTER(i32)]
     L.gsac_calculate_cdf.argtypes = [vp, vp, vp, vp, i64, i32, i32, vp, vp]
     L.gsac_encode.argtypes = [vp, vp, vp, i32, i64, i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
     L.gsac_decode.argtypes = [vp, vp, vp, i64, vp, i32, i64, i32, vp, vp]

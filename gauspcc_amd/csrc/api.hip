@@ -48,8 +48,25 @@ extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)
 {
     if (!ctx) return fail(GPCC_ERR_ARG, "null argument");
     ctx->prof.on = on != 0;
+    ctx->prof.stages = on >= 2;
     ctx->prof.conv_ms = 0.0; ctx->prof.conv_launches = 0; ctx->prof.conv_pair_jobs = 0;
-    ctx->prof.recs.clear(); ctx->prof.used = 0; ctx->prof.chain_open = false;
+    ctx->prof.recs.clear(); ctx->prof.srecs.clear(); ctx->prof.used = 0; ctx->prof.chain_open = false;
+    for (int i = 0; i < 8; ++i) { ctx->prof.stage_ms[i] = 0.0; ctx->prof.stage_bytes[i] = 0.0; ctx->prof.stage_n[i] = 0; }
+    return GPCC_OK;
+}
+
+extern "C" int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int *n_out)
+{
+    if (!ctx || !out || !n_out) return fail(GPCC_ERR_ARG, "null argument");
+    static const char *const names[ST_COUNT] = {"octree+ranks (radix sort, level build)", "tile lists (cell maps -> tiles)", "elementwise (embeddings, stage inputs)",
+                                                "heads (Linear-ReLU-Linear-softmax-CDF)", "range coder"};
+    int n = 0;
+    for (int i = 0; i < ST_COUNT && n < cap; ++i, ++n) {
+        memset(&out[n], 0, sizeof out[n]);
+        strncpy(out[n].name, names[i], sizeof out[n].name - 1);
+        out[n].ms = ctx->prof.stage_ms[i]; out[n].bytes = ctx->prof.stage_bytes[i]; out[n].brackets = ctx->prof.stage_n[i];
+    }
+    *n_out = n;
     return GPCC_OK;
 }
 

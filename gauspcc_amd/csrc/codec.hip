@@ -68,7 +68,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     HostTrace ht;
     const bool want_bits = stats && (stats->flags & GPCC_STATS_IDEAL_BITS);   // the reference's bpp estimator (a14): on request only
     Tree T;
-    GP_TRY(tree_build(ctx, st, xyz, n, &T));
+    {
+        StageTimer tm(ctx, st, ST_OCTREE, 0.0);
+        GP_TRY(tree_build(ctx, st, xyz, n, &T));
+        tm.add_bytes(tree_alg_bytes(T));
+    }
     ht.mark("enc tree built");
     const int L = T.L;
     int64_t coded = 0, nmax = 0;
@@ -100,6 +104,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
         {   // per-row metadata of the two sets: level d lives in the prior set at rows pb[d].. (d <= L-2) and in the target
             // set at rows cbase[d].. (d >= 1)
+            StageTimer tm(ctx, st, ST_ELEM, (double)nP * 2 + (double)nC * (2 + 16 + 8 + 12));
             HIP_TRY(hipMemcpyAsync(occP, T.lv[0].occ, (size_t)T.lv[0].n, hipMemcpyDeviceToDevice, st));
             int64_t lohi_base = 0;
             for (int d = 1; d < L; ++d) {
@@ -131,16 +136,18 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             }
             const int R = conv_pick_rows(nC, m->k), H = conv_pick_height(nC, R);
             TilePool pool;
+            StageTimer tm(ctx, st, ST_TILES, 0.0);
             GP_TRY(tiles_build(ctx, st, tl, L, m->k, R, H, &pool, pairs_dev));
             GP_TRY(tiles_view(ctx, st, pool, 0, L - 1, pb, &tilesP));
             GP_TRY(tiles_view(ctx, st, pool, 1, L, cbase + 1, &tilesC));
+            tm.add_bytes(pool.alg_bytes);
         }
         ht.mark("enc tiles built");
         TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
-        GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF));
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF)); }
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
         TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
-        GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX));
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX)); }
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)
         // stages: cX, cB are free now; inputs u[s], mid v[s], outputs y[s]
         TAKE(u1, float, nC * 32); TAKE(u2, float, nC * 32); TAKE(u3, float, nC * 32);
@@ -150,6 +157,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         {
             const float *const embs[3] = {m->semb[0], m->semb[1], m->semb[2]};
             float *const outs[3] = {u1, u2, u3};
+            StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 1 + 3 * 128));
             GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs));
         }
         ConvBatch cb = {};
@@ -159,6 +167,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
+        StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
@@ -221,6 +230,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(doff, uint32_t, nchunks + 1);
         TAKE(scratch, uint8_t, (size_t)nchunks * stride);
         HIP_TRY(hipMemcpyAsync(dchunks, hs + off_desc, sizeof(RcChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
+        StageTimer tm(ctx, st, ST_CODER, (double)coded * 4 * 4);   // + 3 x the payload (written, compacted), added when it is known
         GP_TRY(rc_encode_launch(st, lohi, dchunks, nchunks, scratch, stride, dcnt));
         GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
@@ -239,6 +249,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     ht.mark("enc coded (sync)");
     const uint32_t *hcnt = reinterpret_cast<const uint32_t *>(hs + off_cnt);
     if (nchunks) total_payload = hcnt[nchunks];
+    if (ctx->prof.on && ctx->prof.stages) ctx->prof.stage_bytes[ST_CODER] += 3.0 * total_payload;
     // pairs of the two sets (the conv launches are tagged 0 = prior set, 1 = target set)
     unsigned long long set_pairs[2] = {0, 0};
     {
@@ -451,7 +462,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const int64_t np = cur.n;
         // ---- st: parent trunk
         TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
-        GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF));
+        { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
         GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
         // ---- side: the child level's structure
         HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
@@ -466,11 +477,15 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         if (nc <= 0 || nc > 8 * cur.n) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", g + 1);
         GP_TRY(alloc_level(&chi, nc, L - g - 1));
-        GP_TRY(level_expand(ctx, sd, &cur, &chi, dtotal));
-        if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
-            HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
+        {
+            const int hbl = std::min(21, std::max(1, hb + g + 1));
+            StageTimer tm(ctx, sd, ST_OCTREE, (double)np * 13 + (double)nc * 12 + (double)cdiv(3 * hbl, 8) * (double)nc * 24 + (double)nc * 8);
+            GP_TRY(level_expand(ctx, sd, &cur, &chi, dtotal));
+            if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
+                HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
+            }
+            GP_TRY(level_raster_rank(ctx, sd, &chi, hb + g + 1));
         }
-        GP_TRY(level_raster_rank(ctx, sd, &chi, hb + g + 1));
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it
         ConvTiles tilesC;
@@ -478,8 +493,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             const TileLevel tl = {&chi, &cur, cellP, cellC};
             const int R = conv_pick_rows(nc, m->k);
             TilePool pool;
+            StageTimer tm(ctx, sd, ST_TILES, 0.0);
             GP_TRY(tiles_build(ctx, sd, &tl, 1, m->k, R, conv_pick_height(nc, R), &pool, pairs_dev + g + 1));
             GP_TRY(tiles_view(ctx, sd, pool, 0, 1, zero_base, &tilesC));
+            tm.add_bytes(pool.alg_bytes);
         }
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
@@ -511,14 +528,14 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         HIP_TRY(hipMemcpyAsync(dchunks, chunks, sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));   // pinned, write-once: no sync
         // ---- st: child trunk and the four stages
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
-        GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX));
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? S : nc) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc); sym[s] = sy; }
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
-            if (s) { GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
+            if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
             GP_TRY(conv_chain_begin(ctx, st));
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
@@ -530,10 +547,14 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = clog; ha.nch = (uint32_t)nch;
-            GP_TRY(head_cdf(st, ha));
-            GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
+            const int row_bytes = STAGE_M[s] == 2 ? 2 : STAGE_M[s] == 4 ? 8 : 32;     // compact CDF row
+            { StageTimer tm(ctx, st, ST_HEADS, (double)nc * (128 + 4 + row_bytes)); GP_TRY(head_cdf(st, ha)); }
+            {
+                StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
+                GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
+            }
         }
-        GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ));
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ)); }
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
         coded += nc;

@@ -118,7 +118,15 @@ struct Prof {
     std::vector<ConvRec> recs;
     double conv_ms = 0.0;
     int64_t conv_launches = 0, conv_pair_jobs = 0;
+    // gpcc_profile_enable(ctx, 2): the HBM-bound stages of the path are bracketed by events too (a handful per level: the
+    // brackets cost stream time, so bench.py measures them in a pass of their own behind the timed region)
+    bool stages = false;
+    struct StageRec { int id, e0, e1; };
+    std::vector<StageRec> srecs;
+    double stage_ms[8] = {0}, stage_bytes[8] = {0};
+    int64_t stage_n[8] = {0};
 };
+enum { ST_OCTREE = 0, ST_TILES, ST_ELEM, ST_HEADS, ST_CODER, ST_COUNT };
 }  // namespace gpcc
 
 namespace gpcc {
@@ -159,6 +167,27 @@ struct gpcc_ctx {
         return GPCC_OK;
     }
 };
+
+namespace gpcc {
+int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx);   // network.hip
+// RAII bracket of one HBM-bound stage on the stream its kernels are enqueued on; bytes = the stage's ALGORITHMIC traffic
+// (what an ideal layer-by-layer implementation reads and writes), accumulated beside the time
+struct StageTimer {
+    gpcc_ctx *c; hipStream_t st; int id, e0 = -1;
+    StageTimer(gpcc_ctx *ctx, hipStream_t stream, int stage, double bytes) : c(ctx), st(stream), id(stage)
+    {
+        if (!c || !c->prof.on || !c->prof.stages) { c = nullptr; return; }
+        if (prof_event(c, st, &e0) != GPCC_OK) { c = nullptr; return; }
+        c->prof.stage_bytes[id] += bytes;
+    }
+    void add_bytes(double b) { if (c) c->prof.stage_bytes[id] += b; }
+    ~StageTimer()
+    {
+        int e1;
+        if (c && prof_event(c, st, &e1) == GPCC_OK) c->prof.srecs.push_back(Prof::StageRec{id, e0, e1});
+    }
+};
+}  // namespace gpcc
 
 #define TAKE_TOP(var, T, count)                                                                    \
     T *var = ctx->arena.take_top<T>((size_t)(count));                                              \

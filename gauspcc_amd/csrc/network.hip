@@ -507,7 +507,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     }
 }
 
-static int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
+int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
 {
     Prof &p = ctx->prof;
     if (p.used == (int)p.pool.size()) {
@@ -637,6 +637,13 @@ int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
         if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs * r.launches;
     }
     p.recs.clear();
+    for (const Prof::StageRec &r : p.srecs) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
+        p.stage_ms[r.id] += ms;
+        p.stage_n[r.id] += 1;
+    }
+    p.srecs.clear();
     p.used = 0;
     return GPCC_OK;
 }

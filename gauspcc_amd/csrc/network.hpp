@@ -111,6 +111,10 @@ struct TilePool {
     int64_t nblk = 0;
     int R = 0, H = 0, K = 0, nlv = 0;
     uint32_t lv_blk0[MAXLV + 1] = {0}, lv_rows[MAXLV] = {0};
+    // algorithmic HBM traffic of the build (gpcc_profile stages): per node 12 B of its own structure + its cell map written
+    // (4 B a cell) + per parent its cell map row read with child start / occupancy (9 B a cell) + 84 B per tile written;
+    // both passes recompute, the figure counts ONE pass.  Tiles are counted when the pool was sized by a sync.
+    double alg_bytes = 0.0;
 };
 int cell_map_entries(int k);
 // count pass per level -> scan -> (one stream sync unless H <= 16) -> fill pass per level.  pairs_dev (nullable): [nlv]

@@ -187,6 +187,19 @@ static int level_alloc(gpcc_ctx *ctx, Level *lv, int64_t n, int lvl)
     return GPCC_OK;
 }
 
+double tree_alg_bytes(const Tree &T)
+{
+    double b = (double)T.npts * (12 + 8) + (double)cdiv(3 * T.hb, 8) * (double)T.npts * 16 + (double)T.npts * 8;
+    int64_t n_lo = T.npts;
+    for (int l = 1; l <= T.L; ++l) {
+        const int64_t n_up = T.lv[T.L - l].n;
+        const int hbl = std::max(1, T.hb - l);
+        b += (double)n_lo * (8 + 4) + (double)n_up * (25 + 16) + (double)cdiv(3 * hbl, 8) * (double)n_up * 24 + (double)n_up * 8;
+        n_lo = n_up;
+    }
+    return b;
+}
+
 int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tree *T)
 {
     if (n <= 0) return fail(GPCC_ERR_ARG, "empty point cloud");

@@ -71,6 +71,10 @@ struct Bias3 { int64_t v[3]; };
 // bias of a cloud from its bounding box (codec and oracle agree on the tree, not on the bias: any multiple of 2^L serves)
 int tree_pick_bias(const int32_t mn[3], const int32_t mx[3], int64_t bias_out[3]);
 
+// algorithmic HBM traffic of tree_build (gpcc_profile stages): input 12 B / point, the leaf key sort (ceil(3 hb / 8) passes
+// x 8 B x read + write), per level the pass over the finer keys (8 B) + its arrays (25 B / node), and the raster ranks
+// (ceil(3 hb_l / 8) passes x 12 B x 2 + 8 B / node for the inverse permutation)
+double tree_alg_bytes(const Tree &T);
 // encode side: build every level bottom-up from the raw points (one bbox sync + one counts sync)
 int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz_dev, int64_t n, Tree *T);
 

@@ -464,6 +464,13 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     // 16-row blocks hold at most one tile per kernel offset: the list is sized by that bound and built without the host ever
     // learning its length (the small levels of a decode are launch-bound; every sync removed lets the host run ahead).
     // Taller blocks are sized exactly: one sync.
+    {
+        const int NPc = cell_map_entries(k);
+        double b = 0.0;
+        for (int l = 0; l < nlv; ++l)
+            b += (double)lv[l].lv->n * (12 + (lv[l].cell_own ? 4.0 * NPc : 0.0)) + (lv[l].par ? (double)lv[l].par->n * 9.0 * NPc : 0.0);
+        pool->alg_bytes = b;
+    }
     int64_t cap;
     if (H <= 16) cap = nblk * K + CONV_HDR_PAD;
     else {
@@ -471,6 +478,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         cap = (int64_t)total + CONV_HDR_PAD;   // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
+        pool->alg_bytes += 84.0 * total;
     }
     if (cap >= (int64_t)1 << 28) return fail(GPCC_ERR_ARG, "too many conv tiles (%lld): clouds beyond ~10^8 points need 64-bit tile addressing", (long long)cap);
     TAKE(tj, int32_t, cap * 16);

@@ -126,8 +126,19 @@ typedef struct {
     int64_t conv_launches;
     int64_t conv_pair_jobs;
 } gpcc_profile;
-GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* also resets the accumulators */
+GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* 0 off, 1 the convolution, 2 also the stages below; resets the accumulators */
 GPCC_API int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out);
+
+/* The HBM-bound stages of gpcc_encode / gpcc_decode (SURVEY.md 8d "which roofline"), bracketed by HIP events on the stream
+ * their kernels run on while gpcc_profile_enable(ctx, 2) is in force: ms = bracketed time, bytes = the ALGORITHMIC traffic of
+ * the bracketed work (an ideal layer-by-layer implementation's reads + writes; formulas in DESIGN.md section 4). */
+typedef struct {
+    char name[48];
+    double ms;
+    double bytes;
+    int64_t brackets;
+} gpcc_stage;
+GPCC_API int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int *n_out);
 
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */

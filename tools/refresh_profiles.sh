@@ -1,21 +1,36 @@
 #!/bin/bash
-# Everything profiles/ holds for a round, measured in one go on the GPU box.  Usage: tools/refresh_profiles.sh OUTDIR
+# Everything profiles/ holds for a round, measured in one go on the GPU box.  Usage: tools/refresh_profiles.sh OUTDIR [ROUND]
+# (every step under its own `timeout`; PMC passes never combined with tracing)
 set -u
 OUT=$1
+R=${2:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log" 2>&1
-cp "$OUT/pmc/summary_conv.txt" "$OUT/pmc_conv_fetch_write.txt"
-python3 tools/make_pmc_json.py "$OUT/pmc_conv_fetch_write.txt" "$OUT/pmc_conv.json" > /dev/null
-cp "$OUT/pmc_conv.json" profiles/r01_pmc_conv.json     # bench.py reads the per-launch traffic from here
-python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py --cpu-sample 0 > "$OUT/bench_traced.log" 2>&1
-cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"
+QUIET="--skip-v0 --skip-stages --cpu-sample 0"
+# 1. HBM traffic of the conv kernels: FETCH_SIZE / WRITE_SIZE in separate passes
+BENCH_ARGS="$QUIET" bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log" 2>&1
+cp "$OUT/pmc/summary_conv.txt" "$OUT/${R}_pmc_conv_fetch_write.txt"
+python3 tools/make_pmc_json.py "$OUT/${R}_pmc_conv_fetch_write.txt" "$OUT/${R}_pmc_conv.json" > /dev/null
+cp "$OUT/${R}_pmc_conv.json" profiles/${R}_pmc_conv.json     # bench.py reads the per-launch traffic from here
+# 2. the bench line (default flags) and the same command under the kernel tracer
+timeout 600 python3 bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py $QUIET > "$OUT/bench_traced.log" 2>&1
+cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_kernel_stats.csv"
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
-python3 tools/timeline.py "$f" > "$OUT/timeline.txt"
-python3 tools/conv_by_level.py "$f" > "$OUT/conv_by_level.txt"
+python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
+python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
 rm -rf "$OUT/t" "$OUT/pmc"
-BENCH_ARGS="" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1
-cp "$OUT/pmc2/summary.txt" "$OUT/pmc_conv_counters.txt"; rm -rf "$OUT/pmc2"
-tail -1 "$OUT/bench.json"
+# 3. SQ / TCP / GRBM counters of the conv kernels
+BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1
+cp "$OUT/pmc2/summary.txt" "$OUT/${R}_pmc_conv_counters.txt"; rm -rf "$OUT/pmc2"
+# 4. the callers either side of the path (attribute loop, Gaussian coder, generate_neural_gaussians + rasteriser)
+timeout 600 python3 tools/bench_side_paths.py 1000000 2> "$OUT/side.err" | tail -1 > "$OUT/${R}_side_paths.json"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ts" -o tr -- python3 tools/bench_side_paths.py 1000000 > /dev/null 2>&1
+cp $(find "$OUT/ts" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_side_kernel_stats.csv"; rm -rf "$OUT/ts"
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d "$OUT/sp_$C" -o pmc -- python3 tools/bench_side_paths.py 1000000 > /dev/null 2>&1
+done
+python3 tools/pmc_summary.py "$OUT" "k_" > "$OUT/${R}_side_pmc_fetch_write.txt"
+rm -rf "$OUT"/sp_*
+tail -1 "$OUT/${R}_bench.json"

@@ -396,6 +396,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     int32_t *hj = reinterpret_cast<int32_t *>(inv + 16 * COOP_TILES);  // [tile][16] neighbour rows
     uint32_t *hr = reinterpret_cast<uint32_t *>(hj + (size_t)T.K * 16); // [tile][4]  output rows (bytes)
     uint32_t *ho = hr + (size_t)T.K * 4;                                // [tile]     offset | count << 16
+#ifdef COOP_TIMING
+    const long long q0 = clock64();
+#endif
     const ConvJob J = jobs.job[blockIdx.y];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,6 +417,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     for (int i = tid; i < nt * 4; i += 64 * COOP_WAVES) hr[i] = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16)[i];
     for (int i = tid; i < nt; i += 64 * COOP_WAVES) ho[i] = T.toc[t0 + i];
     __syncthreads();
+#ifdef COOP_TIMING
+    const long long q1 = clock64();
+#endif
     const float *__restrict__ in = J.in + (size_t)T.lv_row0[lvi] * 32 + 4 * g;   // tile entries are row indices inside the level
     const float *__restrict__ wf = J.w + lane * 4;
     constexpr int COOP_EPT = 512 / (64 * COOP_WAVES) > 0 ? 512 / (64 * COOP_WAVES) : 1;   // output elements per thread in phase B
@@ -483,8 +489,11 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #pragma unroll
                 for (int tl = 0; tl < COOP_TILES; ++tl) {
                     const uint32_t i = (wd[tl >> 2] >> (8 * (tl & 3))) & 255u;
-                    // absent (or past the end of the list): + 0.0f, which leaves the sum unchanged (the sum is never -0)
-                    pv[tl] = (tl < ntl && i != 255u) ? P[(size_t)tl * 512 + i * 32 + och] : 0.0f;
+                    // absent (or past the end of the list): + 0.0f, which leaves the sum unchanged (the sum is never -0).
+                    // The read itself is unconditional (a valid address either way) so that all 32 are in flight together;
+                    // under the condition the compiler branches around each read and waits for them one by one.
+                    const float pvv = P[(size_t)tl * 512 + (i & 15u) * 32 + och];
+                    pv[tl] = (tl < ntl && i != 255u) ? pvv : 0.0f;
                 }
 #pragma unroll
                 for (int tl = 0; tl < COOP_TILES; ++tl) acc[u] = acc[u] + pv[tl];
@@ -494,6 +503,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #pragma unroll
         for (int q = 0; q < COOP_TPW; ++q) cur[q] = nxt[q];
     }
+#ifdef COOP_TIMING
+    const long long q2 = clock64();
+#endif
 #pragma unroll
     for (int u = 0; u < COOP_EPT; ++u) {
         const int el = tid + u * 64 * COOP_WAVES;
@@ -505,6 +517,9 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
             J.out[(size_t)grow * 32 + och] = v;
         }
     }
+#ifdef COOP_TIMING
+    if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0) printf("[coop] blocks %u nt %d: headers %lld rounds %lld epilogue %lld cycles\n", gridDim.x, nt, q1 - q0, q2 - q1, clock64() - q2);
+#endif
 }
 
 int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)

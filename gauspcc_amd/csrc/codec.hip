@@ -484,7 +484,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
                 HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
             }
-            GP_TRY(level_raster_rank(ctx, sd, &chi, hb + g + 1));
+            GP_TRY(rank_level(ctx, sd, &cur, &chi, hb + g + 1));
         }
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it

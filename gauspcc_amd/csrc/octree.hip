@@ -151,6 +151,113 @@ int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level)
     return GPCC_OK;
 }
 
+// ------------------------------------------------------------------ raster ranks of a level from its parent's (no sort)
+// Raster order is (z, y, x) = (pz, dz, py, dy, px, dx) for the child (dx, dy, dz) of the parent (px, py, pz): walking the
+// parents in THEIR raster order, slab by slab (equal pz) and inside a slab row by row (equal py), the children come out in
+// raster order when every slab is walked twice (dz = 0, 1) and inside it every row twice (dy = 0, 1).  So the raster rank
+// of a child is a prefix sum over that walk of "children of parent r with this (dz, dy)" (0..2 each) -- one scan over
+// 4 n_parent small counts placed at their position in the walk -- plus 1 for the dx = 1 child behind an existing dx = 0
+// sibling.  Slab / row boundaries come from two flag scans over the parents.  ~200 B of traffic per parent against
+// ceil(3 hb / 8) = 5..6 radix passes of 24 B x 2 per child.
+__global__ __launch_bounds__(TB) void k_rr_flags(const uint64_t *__restrict__ rkey, const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ fs, uint32_t *__restrict__ fw)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    const uint64_t k = rkey[r2m[r]];
+    uint32_t s = 1, w = 1;
+    if (r > 0) {
+        const uint64_t kp = rkey[r2m[r - 1]];
+        s = rk_z(k) != rk_z(kp);
+        w = s | (uint32_t)(rk_y(k) != rk_y(kp));
+    }
+    fs[r] = s; fw[r] = w;
+}
+
+// es / ew: exclusive scans of fs / fw; segment id of r = e[r] + f[r] - 1
+__global__ __launch_bounds__(TB) void k_rr_starts(const uint32_t *__restrict__ fs, const uint32_t *__restrict__ fw, const uint32_t *__restrict__ es, const uint32_t *__restrict__ ew,
+                                                  int64_t n, uint32_t *__restrict__ sstart, uint32_t *__restrict__ wstart)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t sid = es[r] + fs[r] - 1u, wid = ew[r] + fw[r] - 1u;
+    if (fs[r]) sstart[sid] = (uint32_t)r;
+    if (fw[r]) wstart[wid] = (uint32_t)r;
+    if (r == n - 1) { sstart[sid + 1] = (uint32_t)n; wstart[wid + 1] = (uint32_t)n; }
+}
+
+__global__ __launch_bounds__(TB) void k_rr_counts(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, const uint32_t *__restrict__ fs, const uint32_t *__restrict__ fw,
+                                                  const uint32_t *__restrict__ es, const uint32_t *__restrict__ ew, const uint32_t *__restrict__ sstart,
+                                                  const uint32_t *__restrict__ wstart, int64_t n, uint32_t *__restrict__ cnt4, uint4 *__restrict__ walk)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t sid = es[r] + fs[r] - 1u, wid = ew[r] + fw[r] - 1u;
+    const uint32_t S = sstart[sid], Send = sstart[sid + 1], W = wstart[wid], Wend = wstart[wid + 1];
+    const uint32_t posbase = 4u * S + 2u * (W - S) + ((uint32_t)r - W), shalf = 2u * (Send - S), rlen = Wend - W;
+    const uint32_t m = r2m[r];
+    const uint32_t o = occ[m];
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) cnt4[posbase + dz * shalf + dy * rlen] = (uint32_t)__popc(o & (3u << (2 * dy + 4 * dz)));
+    walk[r] = make_uint4(posbase, shalf, rlen, m);
+}
+
+__global__ __launch_bounds__(TB) void k_rr_assign(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart, const uint4 *__restrict__ walk,
+                                                  const uint32_t *__restrict__ base4, int64_t n, int64_t nc, uint32_t *__restrict__ m2r_c, uint32_t *__restrict__ r2m_c)
+{
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int64_t r = t >> 3;
+    const int q = (int)(t & 7);
+    if (r >= n) return;
+    const uint4 w = walk[r];
+    const uint32_t o = occ[w.w];
+    if (!((o >> q) & 1u)) return;
+    const uint32_t ci = cstart[w.w] + (uint32_t)__popc(o & ((1u << q) - 1u));
+    const int dx = q & 1, dy = (q >> 1) & 1, dz = q >> 2;
+    const uint32_t rank = base4[w.x + dz * w.y + dy * w.z] + (uint32_t)(dx && ((o >> (q - 1)) & 1u));
+    if ((int64_t)ci >= nc || (int64_t)rank >= nc) return;   // a header that understates the level (the decoder reports it at its final sync)
+    m2r_c[ci] = rank;
+    r2m_c[rank] = ci;
+}
+
+int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi)
+{
+    const int64_t n = par->n, nc = chi->n;
+    if (4 * n >= (int64_t)1 << 32) return fail(GPCC_ERR_ARG, "level too large");
+    const size_t mk = ctx->arena.mark();
+    TAKE(fs, uint32_t, n); TAKE(fw, uint32_t, n); TAKE(es, uint32_t, n); TAKE(ew, uint32_t, n);
+    TAKE(sstart, uint32_t, n + 1); TAKE(wstart, uint32_t, n + 1);
+    TAKE(cnt4, uint32_t, 4 * n); TAKE(walk, uint4, n);
+    k_rr_flags<<<nblk(n), TB, 0, st>>>(par->rkey, par->r2m, n, fs, fw);
+    LAUNCH_CHECK();
+    GP_TRY(exclusive_scan_u32(ctx, st, fs, es, n, nullptr));
+    GP_TRY(exclusive_scan_u32(ctx, st, fw, ew, n, nullptr));
+    k_rr_starts<<<nblk(n), TB, 0, st>>>(fs, fw, es, ew, n, sstart, wstart);
+    LAUNCH_CHECK();
+    k_rr_counts<<<nblk(n), TB, 0, st>>>(par->occ, par->r2m, fs, fw, es, ew, sstart, wstart, n, cnt4, walk);
+    LAUNCH_CHECK();
+    GP_TRY(exclusive_scan_u32(ctx, st, cnt4, cnt4, 4 * n, nullptr));
+    // a lying container header may leave ranks unwritten: keep both permutations valid (identity) underneath
+    HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)nc, st));
+    HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)nc, st));
+    k_rr_assign<<<nblk(n * 8), TB, 0, st>>>(par->occ, par->cstart, walk, cnt4, n, nc, chi->m2r, chi->r2m);
+    LAUNCH_CHECK();
+    ctx->arena.rewind(mk);
+    return GPCC_OK;
+}
+
+// sort below this size (one single-workgroup launch), derive above it
+constexpr int64_t RANK_SORT_MAX = 1024;
+
+int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int hb_level)
+{
+    static int force_sort = -1;
+    if (force_sort < 0) { const char *e = getenv("GAUSPCC_RANK_SORT"); force_sort = e ? atoi(e) != 0 : 0; }   // cross-check knob
+    if (!par || chi->n <= RANK_SORT_MAX || force_sort) return level_raster_rank(ctx, st, chi, hb_level);
+    return level_ranks_from_parent(ctx, st, par, chi);
+}
+
 // ------------------------------------------------------------------ encode-side tree build
 static inline int bitlen(uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
@@ -261,8 +368,12 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tre
         ctx->arena.rewind(mk);
         k_mkey_to_rkey<<<nblk(nl[l]), TB, 0, st>>>(key_up, nl[l], up->rkey);
         LAUNCH_CHECK();
-        GP_TRY(level_raster_rank(ctx, st, up, hb - l));
         key_lo = key_up; n_lo = nl[l]; lo = up;
+    }
+    // raster ranks, top-down: small levels by a sort of their (z, y, x) keys, the others from their parent's ranks
+    for (int d = 0; d < L; ++d) {
+        Level *lv = &T->lv[d];
+        GP_TRY(rank_level(ctx, st, d ? &T->lv[d - 1] : nullptr, lv, hb - lv->lvl));
     }
     return GPCC_OK;
 }

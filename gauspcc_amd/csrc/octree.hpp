@@ -81,6 +81,11 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz_dev, int64_t n,
 // raster ranks (m2r / r2m) of one level
 int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level);
 
+// the same ranks without a sort, from the parent level's ranks, occupancy and child starts (octree.hip: one scan over a
+// raster-order walk of the parents); rank_level picks: a sort for levels of at most 1024 nodes (one launch), this otherwise
+int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi);
+int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int hb_level);
+
 // decode side: children of `par` (occupancy known) -> `chi` (rkey, parent; n must be known)
 int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
 

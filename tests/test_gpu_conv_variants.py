@@ -66,3 +66,32 @@ def test_conv_kernel_variant_bit_exact(env):
     e.update(env)
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_rank_derivation_equals_rank_sort():
+    """Raster ranks derived from the parent level (octree.hip: level_ranks_from_parent) against the radix sort of the (z, y, x)
+    keys (GAUSPCC_RANK_SORT=1 forces the sort on every level): the oracle check of SNIPPET passes either way, and the two
+    bitstreams of a 150 k-point cloud are identical."""
+    snippet = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests import gpu_helpers as gh
+from gauspcc_amd import runtime
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+dm = runtime.Model(synthetic_state_dict(32, 3), 32, 3, 0)
+pts = synthetic_cloud(150000, seed=31, negative=True)
+data, st = gh.encode(dm, pts, 10)
+dec, _, _ = gh.decode(dm, data)
+import hashlib
+print("digest", hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).hexdigest(), max(st.level_nodes[: st.num_levels]))
+""" % ROOT
+    out = []
+    for env in ({}, {"GAUSPCC_RANK_SORT": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
+    assert out[0] == out[1] and int(out[0].split()[-1]) > 100_000

@@ -200,8 +200,7 @@ def test_octree_rejects_duplicates_and_range(gh):
 
 
 # ---------------------------------------------------------------- a7 sparse conv
-@pytest.mark.parametrize("k", [3, 5])
-@pytest.mark.parametrize("n", [37, 5000])
+@pytest.mark.parametrize("k,n", [(3, 37), (3, 5000), (5, 37), (5, 5000), (7, 37), (7, 3000)])
 def test_conv3d_bit_exact(gh, orc, k, n):
     rng = np.random.RandomState(k * 100 + n % 97)
     pts = np.unique(rng.randint(-12, 12, (n * 3, 3)), axis=0)[:n].astype(np.int32)

@@ -94,9 +94,23 @@ __device__ unsigned long long g_conv_timing[16];
 
 // ASM = true: the tile loop is the hand-scheduled gfx950 instruction stream of conv_loop_gfx950.inc (row offsets are
 // 32-bit there: n < 2^25).  ASM = false: the same loop in HIP C++ (any n; also the readable statement of the schedule).
+// CONV_ONE_PER_SIMD (experiment, with CONV_SC_WAVES_N=1): one-wave workgroups whose register allocation exceeds half the
+// file, so that a SIMD can hold only one of them -- the dispatcher has to place a new workgroup on the SIMD that just
+// became free, and a wave's LDS is released when IT finishes, not when the slowest of four does.
+#ifdef CONV_ONE_PER_SIMD
+#define CONV_MIN_WAVES(R, ASM) 1
+#else
+#define CONV_MIN_WAVES(R, ASM) ((ASM) || (R) >= 128 ? 2 : (R) >= 96 ? 3 : 4)
+#endif
 template <int R, int DIST, bool ASM>
-__global__ __launch_bounds__(64 * SC_WAVES, (ASM || R >= 128 ? 2 : R >= 96 ? 3 : 4)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
+__global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
 {
+#ifdef CONV_ONE_PER_SIMD
+    asm volatile("" ::: "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23",
+                 "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47",
+                 "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71",
+                 "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+#endif
     constexpr int CONV_LDS_WAVE = conv_lds_wave_floats(R);  // R rows + 1 dummy row for padding entries + the tile-header ring
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;

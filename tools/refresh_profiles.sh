@@ -20,6 +20,7 @@ cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_kernel_stats.
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
 python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
+cp "$f" "$OUT/${R}_kernel_trace_full.csv"
 rm -rf "$OUT/t" "$OUT/pmc"
 # 3. SQ / TCP / GRBM counters of the conv kernels
 BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1

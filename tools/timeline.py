@@ -8,7 +8,8 @@ import sys
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0]))
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0]))
 rows.sort()
 starts = [i for i, r in enumerate(rows) if "k_bbox" in r[2]]
 seg = rows[starts[-1]:]

@@ -16,7 +16,7 @@ def main():
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
             for row in csv.DictReader(fh):
-                k = row["Kernel_Name"].split("(")[0]
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
                 if filt and filt not in k:
                     continue
                 acc[k][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=10)
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
     ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
+    ap.add_argument("--event-steps", type=int, default=1, help="timed steps that carry the HIP-event brackets around the conv launches (-1 = all; each bracket costs its stream ~5 us, ~0.65 ms per step)")
     ap.add_argument("--skip-stages", action="store_true", help="do not run the extra pass that times the HBM-bound stages")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
     args = ap.parse_args()
@@ -127,11 +128,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.check(L.gpcc_profile_enable(ctx, 1))
+    ev_steps = args.steps if args.event_steps < 0 else min(args.event_steps, args.steps)
+    _lib.check(L.gpcc_profile_enable(ctx, 1 if ev_steps > 0 else 0))
     barrier()
     t_start = time.perf_counter()
     enc_s = dec_s = 0.0
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == ev_steps and ev_steps > 0:
+            _lib.check(L.gpcc_profile_enable(ctx, 3))   # keep what was collected, stop recording
         data, st, dec, te, td = step()
         enc_s += te
         dec_s += td
@@ -241,8 +245,11 @@ def main():
                 "algorithmic_per_launch": conv_flops / max(prof.conv_launches, 1),
                 "launches": int(prof.conv_launches),
                 "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
-                "algorithmic_flops_per_step": conv_flops / args.steps,
-                "conv_time_frac_of_step": round(prof.conv_ms * 1e-3 / (enc_s + dec_s), 4),
+                "algorithmic_flops_per_step": conv_flops / max(ev_steps, 1),
+                "conv_time_frac_of_step": round(prof.conv_ms * 1e-3 / max(ev_steps, 1) / ((enc_s + dec_s) / args.steps), 4),
+                # every bracket is a hipEventRecord on the kernel's stream and costs it ~5 us; `event_steps` of the timed
+                # steps carry them (launches / avg_launch_us / achieved are over those steps)
+                "event_steps": ev_steps,
                 # the HBM-bound stages either side of the convolutions: algorithmic bytes over the
                 # event-bracketed time of one extra untimed step; latency- / launch-bound at this size, not bandwidth-bound
                 "stages": stages,

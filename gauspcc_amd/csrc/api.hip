@@ -37,7 +37,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); }
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
@@ -47,6 +47,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
 extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)
 {
     if (!ctx) return fail(GPCC_ERR_ARG, "null argument");
+    if (on == 3) { ctx->prof.on = false; ctx->prof.stages = false; return GPCC_OK; }   // pause: what was collected stays readable
     ctx->prof.on = on != 0;
     ctx->prof.stages = on >= 2;
     ctx->prof.conv_ms = 0.0; ctx->prof.conv_launches = 0; ctx->prof.conv_pair_jobs = 0;

@@ -219,6 +219,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     uint8_t *hs = ctx->hstage.p;
     uint32_t total_payload = 0;
     uint8_t *payload_dev = nullptr;
+    bool direct = false;
+    const size_t pos0_hdr = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2;   // where the streams start
     if (nchunks) {
         memcpy(hs + off_desc, chunks.data(), sizeof(RcChunk) * (size_t)nchunks);
         memcpy(hs + off_gap, gaps.data(), 4 * (size_t)nchunks);
@@ -237,8 +239,21 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         HIP_TRY(hipMemcpyAsync(hs + off_cnt + 4 * (size_t)nchunks, doff + nchunks, 4, hipMemcpyDeviceToHost, st));
         // worst case payload = all scratch; compact into a buffer of that size -- every chunk at its final distance from the
         // first stream's length field -- and copy back only the used part, in one piece
-        TAKE(payload, uint8_t, (size_t)nchunks * stride + gap_total);
-        GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload));
+        TAKE(payload, uint8_t, (size_t)nchunks * stride + gap_total + 32);
+        if (chunk_log2) {
+            // chunked containers: the device itself moves the compacted payload into the pinned output buffer, at its final
+            // place behind the header (known now: it depends on L and the base level only), so the one sync below ends the
+            // call.  The buffer is sized for the worst case (every chunk at its scratch stride).  The reference layout keeps
+            // the copy-after-sync: one chunk per stream would make that bound the size of the whole symbol array.
+            const size_t worst = pos0_hdr + (size_t)nchunks * stride + gap_total + 64;
+            GP_TRY(ctx->hbytes.reserve(worst));
+            const uint32_t mis = (uint32_t)(pos0_hdr & 15);   // same 16-byte phase on both sides: whole-word copies
+            GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload + mis));
+            GP_TRY(rc_to_host_launch(st, payload, doff + nchunks, gap_total + mis, ctx->hbytes.p + (pos0_hdr - mis)));
+            direct = true;
+        } else {
+            GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload));
+        }
         payload_dev = payload;
     }
     HIP_TRY(hipMemcpyAsync(hs + off_pairs, pairs_dev, 8 * NCOUNTERS, hipMemcpyDeviceToHost, st));
@@ -259,7 +274,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, set_pairs, 2));
     // ---- container
     size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
-    GP_TRY(ctx->hbytes.reserve(fsize + 16));
+    if (direct) { if (fsize + 16 > ctx->hbytes.cap) return fail(GPCC_ERR_HIP, "internal: payload beyond its bound"); }
+    else GP_TRY(ctx->hbytes.reserve(fsize + 16));
     uint8_t *out = ctx->hbytes.p;
     size_t pos = 0;
     if (chunk_log2) {
@@ -278,7 +294,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     // are then written into the gaps it left
     {
         const size_t pos0 = pos, body = (size_t)total_payload + gap_total;
-        if (body) HIP_TRY(hipMemcpyAsync(out + pos0, payload_dev, body, hipMemcpyDeviceToHost, st));
+        if (pos0 != pos0_hdr) return fail(GPCC_ERR_HIP, "internal: header size mismatch");
+        if (body && !direct) HIP_TRY(hipMemcpyAsync(out + pos0, payload_dev, body, hipMemcpyDeviceToHost, st));
         for (int si = 0; si < nstreams; ++si) {
             const int c0 = stream_first[si], c1 = stream_first[si + 1];
             size_t plen = 0;
@@ -286,7 +303,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             for (int c = c0; c < c1; ++c) if (chunk_log2 && hcnt[c] > 0xFFFF) return fail(GPCC_ERR_ARG, "chunk byte count overflows uint16");
             pos += 4 + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0) + plen;
         }
-        HIP_TRY(hipStreamSynchronize(st));
+        if (!direct) HIP_TRY(hipStreamSynchronize(st));
         size_t p = pos0;
         for (int si = 0; si < nstreams; ++si) {
             const int c0 = stream_first[si], c1 = stream_first[si + 1];
@@ -341,6 +358,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         NEED(4 * L + 4);
         for (int d = 0; d < L; ++d) { lvl_n[d] = get32(in + pos); pos += 4; }
         npts_hdr = get32(in + pos); pos += 4;
+        if (npts_hdr < 1 || npts_hdr > 8 * lvl_n[L - 1]) return fail(GPCC_ERR_FORMAT, "header: %lld points under %lld finest nodes", (long long)npts_hdr, (long long)lvl_n[L - 1]);
     } else {
         *posq_out = (uint16_t)(in[0] | in[1] << 8); pos = 2;
     }
@@ -400,8 +418,14 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         lv->rkey = rkey; lv->occ = occ; lv->cstart = cstart; lv->parent = parent; lv->m2r = m2r; lv->r2m = r2m;
         return GPCC_OK;
     };
+    // the container goes up on a stream of its own: the first reader is the range decoder of the first coded level, behind a
+    // parent trunk, the structure of that level and its own trunk (the copy was the first ~0.2 ms of every decode on st)
     TAKE(dbytes, uint8_t, nbytes + 16);
-    HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    GP_TRY(ctx->side_init());
+    hipStream_t sd = ctx->side;
+    struct SideGuard { hipStream_t s, x; ~SideGuard() { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(x); } } side_guard{sd, ctx->xfer};   // error returns leave nothing in flight
+    HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, ctx->xfer));
+    HIP_TRY(hipEventRecord(ctx->ev_bytes, ctx->xfer));
     // chunk descriptors of every level are staged in pinned memory that is written once (no reuse, so no sync before
     // a level's table may be overwritten): chunked containers know all level sizes from the header
     size_t desc_total = 0;
@@ -414,6 +438,47 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     GP_TRY(ctx->hstage.reserve(desc_off + sizeof(RcChunk) * desc_total + 64));
     RcChunk *hdesc = reinterpret_cast<RcChunk *>(ctx->hstage.p + desc_off);
     size_t desc_used = 0;
+    // the four chunk tables of coded level g + 1 (nc nodes), parsed from the container into the pinned staging area
+    auto level_chunks = [&](int g, int64_t nc, size_t *at) -> int {
+        const int clog = rc_level_chunk_log2(nc, chunk_log2, version);
+        const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
+        const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
+        if (desc_used + (size_t)4 * nch > desc_total) return fail(GPCC_ERR_FORMAT, "level %d: chunk tables exceed the header's level sizes", g + 1);
+        RcChunk *chunks = hdesc + desc_used;
+        *at = desc_used;
+        desc_used += (size_t)4 * nch;
+        for (int s = 0; s < 4; ++s) {
+            const int si = 4 * g + s;
+            const int64_t off = s_off[si], len = s_len[si];
+            if (chunk_log2) {
+                if (len < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream %d shorter than its chunk table", si);
+                int64_t p = off + 2 * (int64_t)nch;
+                for (int c = 0; c < nch; ++c) {
+                    const uint32_t cb = in[off + 2 * c] | in[off + 2 * c + 1] << 8;
+                    if (p + cb > off + len) return fail(GPCC_ERR_FORMAT, "stream %d chunk %d overruns the stream", si, c);
+                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)((int64_t)c * S), (uint32_t)p, cb};
+                    p += cb;
+                }
+                if (p != off + len) return fail(GPCC_ERR_FORMAT, "stream %d has trailing bytes", si);
+            } else {
+                chunks[(size_t)s] = RcChunk{0, 1, (uint32_t)nc, 0, (uint32_t)off, (uint32_t)len};
+            }
+        }
+        return GPCC_OK;
+    };
+    // chunked containers know every level's size from the header: all tables go up once, behind the container
+    RcChunk *dchunks_all = nullptr;
+    size_t desc_at[MAXLV] = {0};
+    if (v1 && L > 1) {
+        for (int g = 0; g + 1 < L; ++g) {
+            if (lvl_n[g + 1] <= 0 || lvl_n[g + 1] > 8 * lvl_n[g]) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", g + 1);
+            GP_TRY(level_chunks(g, lvl_n[g + 1], &desc_at[g]));
+        }
+        TAKE(dca, RcChunk, std::max<size_t>(desc_used, 1));
+        dchunks_all = dca;
+        HIP_TRY(hipMemcpyAsync(dchunks_all, hdesc, sizeof(RcChunk) * desc_used, hipMemcpyHostToDevice, ctx->xfer));
+        HIP_TRY(hipEventRecord(ctx->ev_bytes, ctx->xfer));   // replaces the record behind the container alone
+    }
     Level cur;
     GP_TRY(alloc_level(&cur, bn, L));
     {
@@ -451,9 +516,6 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's tile list (and cell
     // map) -- runs on the context's side stream beside the parent trunk's five convolutions and fills the idle tails
     // of their launches.  ev_main: the parent level is complete on st; ev_side: the child's structure is ready.
-    GP_TRY(ctx->side_init());
-    hipStream_t sd = ctx->side;
-    struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } side_guard{sd};   // error returns leave nothing in flight
     HIP_TRY(hipEventRecord(ctx->ev_main, st));
     // Arena discipline: a level's child arrays, neighbour map, tile list and chunk table come from the bottom (kept: they are
     // the next level's parent data), its feature buffers from the top (rewound at the end of the level).
@@ -500,32 +562,20 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
-        // chunk descriptors of this level's four streams
+        // chunk descriptors of this level's four streams (chunked containers: uploaded with the container, above)
         const int clog = rc_level_chunk_log2(nc, chunk_log2, version);   // this level's chunk size
         const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
         const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
-        if (desc_used + (size_t)4 * nch > desc_total) return fail(GPCC_ERR_FORMAT, "level %d: chunk tables exceed the header's level sizes", g + 1);
-        RcChunk *chunks = hdesc + desc_used;
-        desc_used += (size_t)4 * nch;
-        for (int s = 0; s < 4; ++s) {
-            const int si = 4 * g + s;
-            const int64_t off = s_off[si], len = s_len[si];
-            if (chunk_log2) {
-                if (len < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream %d shorter than its chunk table", si);
-                int64_t p = off + 2 * (int64_t)nch;
-                for (int c = 0; c < nch; ++c) {
-                    const uint32_t cb = in[off + 2 * c] | in[off + 2 * c + 1] << 8;
-                    if (p + cb > off + len) return fail(GPCC_ERR_FORMAT, "stream %d chunk %d overruns the stream", si, c);
-                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)((int64_t)c * S), (uint32_t)p, cb};
-                    p += cb;
-                }
-                if (p != off + len) return fail(GPCC_ERR_FORMAT, "stream %d has trailing bytes", si);
-            } else {
-                chunks[(size_t)s] = RcChunk{0, 1, (uint32_t)nc, 0, (uint32_t)off, (uint32_t)len};
-            }
+        const RcChunk *dchunks = nullptr;
+        if (v1) {
+            dchunks = dchunks_all + desc_at[g];
+        } else {
+            size_t at = 0;
+            GP_TRY(level_chunks(g, nc, &at));
+            TAKE(dch, RcChunk, 4 * nch);
+            HIP_TRY(hipMemcpyAsync(dch, hdesc + at, sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));   // pinned, write-once: no sync
+            dchunks = dch;
         }
-        TAKE(dchunks, RcChunk, 4 * nch);
-        HIP_TRY(hipMemcpyAsync(dchunks, chunks, sizeof(RcChunk) * 4 * (size_t)nch, hipMemcpyHostToDevice, st));   // pinned, write-once: no sync
         // ---- st: child trunk and the four stages
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
@@ -549,6 +599,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = clog; ha.nch = (uint32_t)nch;
             const int row_bytes = STAGE_M[s] == 2 ? 2 : STAGE_M[s] == 4 ? 8 : 32;     // compact CDF row
             { StageTimer tm(ctx, st, ST_HEADS, (double)nc * (128 + 4 + row_bytes)); GP_TRY(head_cdf(st, ha)); }
+            if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
                 GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
@@ -564,16 +615,15 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     // ---- leaves
     GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
     HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    ht.mark("dec levels done (sync)");
-    const int64_t npts = htotal[0];
-    // the header's level sizes against what the decoded occupancy expanded to (the copies were queued level by level;
-    // the expansion is bounded by the header, so a wrong header produced garbage, not out-of-bounds accesses)
-    if (v1)
-        for (int g = 0; g + 1 < L; ++g)
-            if (htotal[1 + g] != (uint32_t)lvl_n[g + 1])
-                return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)lvl_n[g + 1], htotal[1 + g]);
-    if (v1 && npts != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)npts, (long long)npts_hdr);
+    // chunked containers carry the point count: the leaves are queued behind the last level without a sync and every count
+    // of the header is compared with what the decoded occupancy expanded to at the one sync below (the expansions are
+    // bounded by the header's sizes, so a wrong header produced garbage, not out-of-bounds accesses)
+    int64_t npts = npts_hdr;
+    if (!v1) {
+        HIP_TRY(hipStreamSynchronize(st));
+        ht.mark("dec levels done (sync)");
+        npts = htotal[0];
+    }
     int32_t *xyz = out_user;
     if (out_user) {
         if (npts > out_cap) return fail(GPCC_ERR_ARG, "decoded %lld points, the output buffer holds %lld", (long long)npts, (long long)out_cap);
@@ -586,6 +636,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     ht.mark("dec leaves done (sync)");
+    if (v1) {
+        for (int g = 0; g + 1 < L; ++g)
+            if (htotal[1 + g] != (uint32_t)lvl_n[g + 1])
+                return fail(GPCC_ERR_FORMAT, "level %d: header says %lld nodes, occupancy expands to %u", g + 1, (long long)lvl_n[g + 1], htotal[1 + g]);
+        if ((int64_t)htotal[0] != npts_hdr) return fail(GPCC_ERR_FORMAT, "decoded %lld points, header says %lld", (long long)htotal[0], (long long)npts_hdr);
+    }
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, hpairs, L));
     ht.mark("dec prof collect");
     *xyz_out = xyz; *n_out = npts;

@@ -156,14 +156,16 @@ struct gpcc_ctx {
     gpcc::HostBuf<uint8_t> hstage;  // pinned small staging (counts, flags, descriptors)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the codec: octree / tile-list work of the next step runs beside the convolutions of this one
-    hipStream_t side = nullptr;
-    hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipStream_t side = nullptr, xfer = nullptr;   // xfer: the container's host -> device copy of a decode, beside both
+    hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_bytes = nullptr;
     int side_init()
     {
         if (side) return GPCC_OK;
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&xfer, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_bytes, hipEventDisableTiming));
         return GPCC_OK;
     }
 };

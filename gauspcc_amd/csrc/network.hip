@@ -660,7 +660,8 @@ int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
         if (log)
             for (int q = 0; q < r.launches; ++q)
-                fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3 / r.launches);
+                fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us pairs %llu\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3 / r.launches,
+                        (r.level >= 0 && r.level < nlevels) ? pairs[r.level] : 0ull);
         p.conv_ms += ms;
         p.conv_launches += r.launches;
         if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs * r.launches;

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(TB) void k_popc_raster(const uint8_t *__restrict__ 
 }
 
 __global__ __launch_bounds__(TB) void k_leaves_out(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m,
-                                                   const uint32_t *__restrict__ start_r, int64_t n, Bias3 b, int32_t *__restrict__ xyz)
+                                                   const uint32_t *__restrict__ start_r, int64_t n, Bias3 b, int32_t *__restrict__ xyz, int64_t cap)
 {
     int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
     int64_t r = t >> 3;
@@ -436,6 +436,7 @@ __global__ __launch_bounds__(TB) void k_leaves_out(const uint64_t *__restrict__ 
     const uint32_t o = occ[m];
     if (!((o >> q) & 1u)) return;
     const int64_t idx = (int64_t)start_r[r] + __popc(o & ((1u << q) - 1u));
+    if (idx >= cap) return;   // a container whose header undercounts the leaves: the caller compares the counts after its sync
     const uint64_t k = rkey[m];
     xyz[3 * idx] = (int32_t)((int64_t)(2 * rk_x(k) + (q & 1)) - b.v[0]);
     xyz[3 * idx + 1] = (int32_t)((int64_t)(2 * rk_y(k) + ((q >> 1) & 1)) - b.v[1]);
@@ -451,10 +452,9 @@ int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, con
     k_popc_raster<<<nblk(n), TB, 0, st>>>(last->occ, last->r2m, n, cnt);
     LAUNCH_CHECK();
     GP_TRY(exclusive_scan_u32(ctx, st, cnt, cnt, n, nullptr));
-    k_leaves_out<<<nblk(n * 8), TB, 0, st>>>(last->rkey, last->occ, last->r2m, cnt, n, Bias3{{bias[0], bias[1], bias[2]}}, xyz_out);
+    k_leaves_out<<<nblk(n * 8), TB, 0, st>>>(last->rkey, last->occ, last->r2m, cnt, n, Bias3{{bias[0], bias[1], bias[2]}}, xyz_out, npts);
     LAUNCH_CHECK();
     ctx->arena.rewind(mk);
-    (void)npts;
     return GPCC_OK;
 }
 

@@ -322,6 +322,19 @@ int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, c
     return GPCC_OK;
 }
 
+__global__ __launch_bounds__(256) void k_rc_to_host(const uint4 *__restrict__ src, const uint32_t *__restrict__ total, uint32_t extra, uint4 *__restrict__ dst)
+{
+    const uint32_t words = (*total + extra + 15u) >> 4;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, uint8_t *dst)
+{
+    k_rc_to_host<<<512, 256, 0, st>>>(reinterpret_cast<const uint4 *>(payload), total, extra, reinterpret_cast<uint4 *>(dst));
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
 int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym)
 {
     if (nchunks <= 0) return GPCC_OK;

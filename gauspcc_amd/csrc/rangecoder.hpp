@@ -47,6 +47,8 @@ static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_s
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);
 int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload);
+// payload[0 .. *total + extra) -> dst in 16-byte words (both 16-byte aligned; dst may be pinned host memory): the size stays on the device
+int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, uint8_t *dst);
 // cdf: compact interleaved rows (rc_row_stride uint16 per row)
 int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym);
 // full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words

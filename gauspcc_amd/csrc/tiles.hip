@@ -296,26 +296,28 @@ template <bool FILL>
 __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
 {
     __shared__ uint64_t keys[64];
+    __shared__ uint8_t nb[343 * 64];   // [offset][lane]: neighbour row + 1 of the lane's row, 0 = none
     const int lane = threadIdx.x;
-    const int n = (int)a.nc, r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1;
+    const int n = (int)a.nc, r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, K = k * k * k;
     keys[lane] = lane < n ? a.rkey_c[lane] : ~0ull;
     __syncthreads();
     const WaveMap m = wave_map(min(a.H, 64), a.nc, a.blk0, lane);   // n < 64: a block taller than 64 rows is the whole level
     const int me = (int)m.r0 + lane;                                  // my row
     const bool live = m.r0 + lane < m.rend;
     const uint64_t ki = keys[min(me, n - 1)];
+    // every node of the level against my row once (n < 64 steps) instead of a search per offset (k^3 n steps: 58 us)
+    for (int q = 0; q < K; ++q) nb[q * 64 + lane] = 0;
+    for (int jj = 0; jj < n; ++jj) {
+        const uint64_t kj = keys[jj];
+        const int dx = (int)rk_x(kj) - (int)rk_x(ki), dy = (int)rk_y(kj) - (int)rk_y(ki), dz = (int)rk_z(kj) - (int)rk_z(ki);
+        if (live && dx >= -r && dx <= r && dy >= -r && dy <= r && dz >= -r && dz <= r) nb[((dx + r) + k * (dy + r) + k * k * (dz + r)) * 64 + lane] = (uint8_t)(jj + 1);
+    }
     uint32_t t = (FILL && m.blk_live) ? a.first[m.blk] : 0u, npairs = 0;
     int o = 0;
     for (int dz = -r; dz <= r; ++dz)
         for (int dy = -r; dy <= r; ++dy)
             for (int dx = -r; dx <= r; ++dx, ++o) {
-                const int tx = (int)rk_x(ki) + dx, ty = (int)rk_y(ki) + dy, tz = (int)rk_z(ki) + dz;
-                int res = -1;
-                if (live && tx >= 0 && ty >= 0 && tz >= 0) {
-                    const uint64_t tgt = rkey3((uint32_t)tx, (uint32_t)ty, (uint32_t)tz);
-                    for (int jj = 0; jj < n; ++jj)
-                        if (keys[jj] == tgt) res = jj;
-                }
+                const int res = (int)nb[o * 64 + lane] - 1;
                 if (!FILL && a.cell_c && live && dx >= -PR && dx <= PR && dy >= -PR && dy <= PR && dz >= -PR && dz <= PR)
                     a.cell_c[(int64_t)((dx + PR) + PW * (dy + PR) + PW * PW * (dz + PR)) * n + me] = res;
                 pack_local<FILL>(a, m, o, res, t, npairs);

@@ -126,7 +126,7 @@ typedef struct {
     int64_t conv_launches;
     int64_t conv_pair_jobs;
 } gpcc_profile;
-GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* 0 off, 1 the convolution, 2 also the stages below; resets the accumulators */
+GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* 0 off, 1 the convolution, 2 also the stages below (these reset the accumulators); 3 = stop recording, keep what was collected */
 GPCC_API int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out);
 
 /* The HBM-bound stages of gpcc_encode / gpcc_decode (SURVEY.md 8d "which roofline"), bracketed by HIP events on the stream

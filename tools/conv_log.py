@@ -50,15 +50,17 @@ for line in r.stderr.splitlines():
         phase = "enc"
     if line.startswith("==decode"):
         phase = "dec"
-    m = re.match(r"\[conv\] level\s+(\d+) n\s+(\d+) R\s+(\d+) H\s+(\d+) blocks\s+(\d+) jobs (\d+)\s+([0-9.]+) us", line)
+    m = re.match(r"\[conv\] level\s+(\d+) n\s+(\d+) R\s+(\d+) H\s+(\d+) blocks\s+(\d+) jobs (\d+)\s+([0-9.]+) us pairs (\d+)", line)
     if m and phase:
         key = (phase, int(m[1]), int(m[2]), int(m[3]), int(m[4]), int(m[5]), int(m[6]))
-        a = agg.setdefault(key, [0, 0.0])
+        a = agg.setdefault(key, [0, 0.0, 0])
         a[0] += 1
         a[1] += float(m[7])
+        a[2] = int(m[8])
 tot = collections.Counter()
-for (ph, lv, nn, R, H, nb, jobs), (c, us) in agg.items():
-    print(f"{ph} level {lv:2d} n {nn:8d} R {R:3d} H {H:3d} blocks {nb:6d} jobs {jobs}  launches {c:3d}  avg {us / c:8.1f} us  sum {us / 1e3:7.3f} ms")
+for (ph, lv, nn, R, H, nb, jobs), (c, us, pairs) in agg.items():
+    tf = 2048.0 * pairs * jobs * c / (us * 1e-6) / 1e12 if us else 0.0
+    print(f"{ph} level {lv:2d} n {nn:8d} R {R:3d} H {H:3d} blocks {nb:6d} jobs {jobs}  launches {c:3d}  avg {us / c:8.1f} us  sum {us / 1e3:7.3f} ms  pairs/row {pairs / max(nn, 1):5.1f}  {tf:6.1f} TFLOP/s")
     tot[ph] += us
 print({k: round(v / 1e3, 3) for k, v in tot.items()})
 if r.returncode:

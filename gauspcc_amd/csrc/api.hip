@@ -388,6 +388,7 @@ extern "C" int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, i
         ctx->arena.reset();
         T = Tree();
         rc = tree_build(ctx, st, xyz, n, &T);
+        if (rc == GPCC_OK) rc = tree_ranks(ctx, st, &T);
         if (rc != GPCC_ERR_NOMEM) break;
         want *= 2;
     }
@@ -430,6 +431,7 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             LAUNCH_CHECK();
             Tree T;
             GP_TRY(tree_build(ctx, st, x2, n, &T));
+            GP_TRY(tree_ranks(ctx, st, &T));
             const Level *fin = &T.lv[T.L - 1];
             if (fin->n != n) return fail(GPCC_ERR_ARG, "internal: finest level has %lld nodes for %lld points", (long long)fin->n, (long long)n);
             // tile lists of the whole tree from the production top-down path (tiles.hip); the convolution runs on the finest

@@ -49,16 +49,46 @@ inline uint32_t get32(const uint8_t *p) { return p[0] | (p[1] << 8) | (p[2] << 1
 // feature rows of 128 B + level arrays; grown and retried when a cloud needs more
 size_t arena_estimate(int64_t n, int K) { return (size_t)n * 3 * (size_t)(4 * 125 + 300 + 12 * 128 + 96) + (size_t)n * 64 + (size_t)K * 4096 + ((size_t)64 << 20); }
 
-// per-row metadata of the concatenated coded levels: global parent row, lohi slot of stage 0, stage stride
-__global__ __launch_bounds__(256) void k_child_meta(const uint32_t *__restrict__ parent, const uint32_t *__restrict__ m2r, int64_t n, uint32_t parent_base,
-                                                    uint32_t lohi_base, uint32_t slots, int chunk_log2, uint32_t nch, uint32_t *__restrict__ parent_out,
-                                                    uint32_t *__restrict__ pos_out, uint32_t *__restrict__ slots_out)
+// Per-row metadata of the two concatenated sets, every level in one launch.  Level d lives in the prior set P at rows
+// pb[d].. (d <= L-2) and in the target set C at rows cbase[d].. (d >= 1).
+struct SetLevels {
+    int L;
+    uint32_t n[MAXLV], pb[MAXLV], cbase[MAXLV], lohi_base[MAXLV], slots[MAXLV], nch[MAXLV];
+    int clog[MAXLV];
+    const uint8_t *occ[MAXLV];
+    const uint64_t *rkey[MAXLV];
+    const uint32_t *parent[MAXLV], *m2r[MAXLV];
+};
+
+// occupancy of both sets, raster keys and global parent rows of C: what the network needs (no ranks)
+__global__ __launch_bounds__(256) void k_set_rows(SetLevels S, int64_t nP, int64_t nC, uint8_t *__restrict__ occP, uint8_t *__restrict__ occC, uint64_t *__restrict__ rkeyC,
+                                                  uint32_t *__restrict__ parentC)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    parent_out[i] = parent_base + parent[i];
-    pos_out[i] = lohi_base + rc_interleaved(m2r[i], chunk_log2, nch);
-    slots_out[i] = slots;
+    if (i < nP) {
+        int d = 0;
+        for (int q = 1; q + 1 < S.L; ++q) d = i >= (int64_t)S.pb[q] ? q : d;
+        occP[i] = S.occ[d][i - S.pb[d]];
+    }
+    if (i < nC) {
+        int d = 1;
+        for (int q = 2; q < S.L; ++q) d = i >= (int64_t)S.cbase[q] ? q : d;
+        const int64_t j = i - S.cbase[d];
+        occC[i] = S.occ[d][j];
+        rkeyC[i] = S.rkey[d][j];
+        parentC[i] = S.pb[d - 1] + S.parent[d][j];
+    }
+}
+
+// lohi slot of stage 0 and stage stride of every row of C: where the heads put a node's coder input (needs the raster ranks)
+__global__ __launch_bounds__(256) void k_set_pos(SetLevels S, int64_t nC, uint32_t *__restrict__ pos_out, uint32_t *__restrict__ slots_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nC) return;
+    int d = 1;
+    for (int q = 2; q < S.L; ++q) d = i >= (int64_t)S.cbase[q] ? q : d;
+    pos_out[i] = S.lohi_base[d] + rc_interleaved(S.m2r[d][i - S.cbase[d]], S.clog[d], S.nch[d]);
+    slots_out[i] = S.slots[d];
 }
 
 int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t n, int chunk_log2, uint16_t posq,
@@ -67,6 +97,9 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     ctx->arena.reset();
     HostTrace ht;
     const bool want_bits = stats && (stats->flags & GPCC_STATS_IDEAL_BITS);   // the reference's bpp estimator (a14): on request only
+    GP_TRY(ctx->side_init());
+    hipStream_t sd = ctx->side;
+    struct SideGuard { hipStream_t s; ~SideGuard() { (void)hipStreamSynchronize(s); } } side_guard{sd};   // error returns leave nothing in flight
     Tree T;
     {
         StageTimer tm(ctx, st, ST_OCTREE, 0.0);
@@ -75,6 +108,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     }
     ht.mark("enc tree built");
     const int L = T.L;
+    if (L == 1) GP_TRY(tree_ranks(ctx, st, &T));   // a cloud that is its own base level: nothing to overlap with
     int64_t coded = 0, nmax = 0;
     for (int d = 0; d < L; ++d) { nmax = std::max(nmax, T.lv[d].n); if (d) coded += T.lv[d].n; }
     if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
@@ -102,22 +136,44 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         for (int d = 2; d < L; ++d) { cbase[d] = cbase[d - 1] + T.lv[d - 1].n; }
         TAKE(occP, uint8_t, nP); TAKE(occC, uint8_t, nC); TAKE(rkeyC, uint64_t, nC);
         TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
-        {   // per-row metadata of the two sets: level d lives in the prior set at rows pb[d].. (d <= L-2) and in the target
-            // set at rows cbase[d].. (d >= 1)
-            StageTimer tm(ctx, st, ST_ELEM, (double)nP * 2 + (double)nC * (2 + 16 + 8 + 12));
-            HIP_TRY(hipMemcpyAsync(occP, T.lv[0].occ, (size_t)T.lv[0].n, hipMemcpyDeviceToDevice, st));
+        {
+            SetLevels S = {};
+            S.L = L;
             int64_t lohi_base = 0;
-            for (int d = 1; d < L; ++d) {
+            for (int d = 0; d < L; ++d) {
                 const Level *lv = &T.lv[d];
-                if (d + 1 < L) HIP_TRY(hipMemcpyAsync(occP + pb[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(occC + cbase[d], lv->occ, (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                HIP_TRY(hipMemcpyAsync(rkeyC + cbase[d], lv->rkey, 8 * (size_t)lv->n, hipMemcpyDeviceToDevice, st));
-                const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << clog(lv->n)) : 1u;
-                k_child_meta<<<(unsigned)cdiv(lv->n, 256), 256, 0, st>>>(lv->parent, lv->m2r, lv->n, (uint32_t)pb[d - 1], (uint32_t)lohi_base, (uint32_t)slots(lv->n),
-                                                                         clog(lv->n), nch, parentC + cbase[d], posC + cbase[d], slotsC + cbase[d]);
-                LAUNCH_CHECK();
-                lohi_base += 4 * slots(lv->n);
+                S.n[d] = (uint32_t)lv->n; S.pb[d] = (uint32_t)pb[d]; S.cbase[d] = (uint32_t)cbase[d];
+                S.occ[d] = lv->occ; S.rkey[d] = lv->rkey; S.parent[d] = lv->parent; S.m2r[d] = lv->m2r;
+                if (d) {
+                    S.lohi_base[d] = (uint32_t)lohi_base; S.slots[d] = (uint32_t)slots(lv->n); S.clog[d] = clog(lv->n);
+                    S.nch[d] = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << clog(lv->n)) : 1u;
+                    lohi_base += 4 * slots(lv->n);
+                }
             }
+            {
+                StageTimer tm(ctx, st, ST_ELEM, (double)nP * 2 + (double)nC * (2 + 16 + 8));
+                k_set_rows<<<(unsigned)cdiv(std::max(nP, nC), 256), 256, 0, st>>>(S, nP, nC, occP, occC, rkeyC, parentC);
+                LAUNCH_CHECK();
+            }
+            // Second stream: the raster ranks of every level and what depends on them (the coder slots of the rows of C).
+            // Their first reader is the head of stage 0, eighteen convolutions away; temporaries come from the top of the
+            // arena (Arena::flip), which nothing else in an encode uses.
+            HIP_TRY(hipEventRecord(ctx->ev_main, st));
+            HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
+            ctx->arena.flip = true;
+            int rc = GPCC_OK;
+            {
+                StageTimer tm(ctx, sd, ST_OCTREE, 0.0);
+                rc = tree_ranks(ctx, sd, &T);
+            }
+            ctx->arena.flip = false;
+            GP_TRY(rc);
+            {
+                StageTimer tm(ctx, sd, ST_ELEM, (double)nC * (4 + 8));
+                k_set_pos<<<(unsigned)cdiv(nC, 256), 256, 0, sd>>>(S, nC, posC, slotsC);
+                LAUNCH_CHECK();
+            }
+            HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         }
         ht.mark("enc meta queued");
         // Tile lists of every level in one pool, built top-down from the cell maps (tiles.hip; one stream sync for the pool
@@ -167,6 +223,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));   // ranks -> posC / slotsC
         StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};

@@ -65,9 +65,13 @@ struct Arena {
         cap = want; top = want & ~size_t(255);
         return GPCC_OK;
     }
-    void reset() { off = 0; top = cap & ~size_t(255); }
+    // flipped: take / mark / rewind serve the TOP end.  Work enqueued on a second stream takes its temporaries there, so
+    // that a rewind on one stream never hands memory to the other while kernels still use it (the encoder's rank pass).
+    bool flip = false;
+    void reset() { off = 0; top = cap & ~size_t(255); flip = false; }
     template <typename T> T *take(size_t count)
     {
+        if (flip) return take_top<T>(count);
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
         if (off + bytes > top) return nullptr;
         T *p = reinterpret_cast<T *>(base + off);
@@ -83,8 +87,8 @@ struct Arena {
     }
     size_t top_mark() const { return top; }
     void top_rewind(size_t m) { top = m; }
-    size_t mark() const { return off; }
-    void rewind(size_t m) { off = m; }
+    size_t mark() const { return flip ? top : off; }
+    void rewind(size_t m) { if (flip) top = m; else off = m; }
 };
 
 template <typename T> struct HostBuf {

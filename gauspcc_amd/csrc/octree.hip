@@ -370,10 +370,17 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tre
         LAUNCH_CHECK();
         key_lo = key_up; n_lo = nl[l]; lo = up;
     }
-    // raster ranks, top-down: small levels by a sort of their (z, y, x) keys, the others from their parent's ranks
-    for (int d = 0; d < L; ++d) {
+    return GPCC_OK;
+}
+
+// raster ranks of every level, top-down: small levels by a sort of their (z, y, x) keys, the others from their parent's
+// ranks.  Nothing of the network needs them (the convolutions run in Morton order); the encoder runs this on its second
+// stream beside the tile lists and the first convolutions.
+int tree_ranks(gpcc_ctx *ctx, hipStream_t st, Tree *T)
+{
+    for (int d = 0; d < T->L; ++d) {
         Level *lv = &T->lv[d];
-        GP_TRY(rank_level(ctx, st, d ? &T->lv[d - 1] : nullptr, lv, hb - lv->lvl));
+        GP_TRY(rank_level(ctx, st, d ? &T->lv[d - 1] : nullptr, lv, T->hb - lv->lvl));
     }
     return GPCC_OK;
 }

@@ -77,6 +77,7 @@ int tree_pick_bias(const int32_t mn[3], const int32_t mx[3], int64_t bias_out[3]
 double tree_alg_bytes(const Tree &T);
 // encode side: build every level bottom-up from the raw points (one bbox sync + one counts sync)
 int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz_dev, int64_t n, Tree *T);
+int tree_ranks(gpcc_ctx *ctx, hipStream_t st, Tree *T);   // Level::m2r / r2m of every level; tree_build leaves them unset
 
 // raster ranks (m2r / r2m) of one level
 int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level);

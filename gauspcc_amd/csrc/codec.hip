@@ -599,11 +599,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         {
             const int hbl = std::min(21, std::max(1, hb + g + 1));
             StageTimer tm(ctx, sd, ST_OCTREE, (double)np * 13 + (double)nc * 12 + (double)cdiv(3 * hbl, 8) * (double)nc * 24 + (double)nc * 8);
-            GP_TRY(level_expand(ctx, sd, &cur, &chi, dtotal));
+            GP_TRY(level_expand_rank(ctx, sd, &cur, &chi, dtotal, hb + g + 1));
             if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
                 HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
             }
-            GP_TRY(rank_level(ctx, sd, &cur, &chi, hb + g + 1));
         }
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it

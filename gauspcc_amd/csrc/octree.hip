@@ -159,39 +159,46 @@ int level_raster_rank(gpcc_ctx *ctx, hipStream_t st, Level *lv, int hb_level)
 // 4 n_parent small counts placed at their position in the walk -- plus 1 for the dx = 1 child behind an existing dx = 0
 // sibling.  Slab / row boundaries come from two flag scans over the parents.  ~200 B of traffic per parent against
 // ceil(3 hb / 8) = 5..6 radix passes of 24 B x 2 per child.
-__global__ __launch_bounds__(TB) void k_rr_flags(const uint64_t *__restrict__ rkey, const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ fs, uint32_t *__restrict__ fw)
+__device__ __forceinline__ void rr_flags_at(const uint64_t *__restrict__ rkey, const uint32_t *__restrict__ r2m, int64_t r, uint32_t &s, uint32_t &w)
 {
-    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (r >= n) return;
     const uint64_t k = rkey[r2m[r]];
-    uint32_t s = 1, w = 1;
+    s = 1; w = 1;
     if (r > 0) {
         const uint64_t kp = rkey[r2m[r - 1]];
         s = rk_z(k) != rk_z(kp);
         w = s | (uint32_t)(rk_y(k) != rk_y(kp));
     }
+}
+
+__global__ __launch_bounds__(TB) void k_rr_flags(const uint64_t *__restrict__ rkey, const uint32_t *__restrict__ r2m, int64_t n, uint32_t *__restrict__ fs, uint32_t *__restrict__ fw)
+{
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    uint32_t s, w;
+    rr_flags_at(rkey, r2m, r, s, w);
     fs[r] = s; fw[r] = w;
 }
 
 // es / ew: exclusive scans of fs / fw; segment id of r = e[r] + f[r] - 1
+__device__ __forceinline__ void rr_starts_at(uint32_t fs, uint32_t fw, uint32_t es, uint32_t ew, int64_t r, int64_t n, uint32_t *__restrict__ sstart, uint32_t *__restrict__ wstart)
+{
+    const uint32_t sid = es + fs - 1u, wid = ew + fw - 1u;
+    if (fs) sstart[sid] = (uint32_t)r;
+    if (fw) wstart[wid] = (uint32_t)r;
+    if (r == n - 1) { sstart[sid + 1] = (uint32_t)n; wstart[wid + 1] = (uint32_t)n; }
+}
+
 __global__ __launch_bounds__(TB) void k_rr_starts(const uint32_t *__restrict__ fs, const uint32_t *__restrict__ fw, const uint32_t *__restrict__ es, const uint32_t *__restrict__ ew,
                                                   int64_t n, uint32_t *__restrict__ sstart, uint32_t *__restrict__ wstart)
 {
     const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (r >= n) return;
-    const uint32_t sid = es[r] + fs[r] - 1u, wid = ew[r] + fw[r] - 1u;
-    if (fs[r]) sstart[sid] = (uint32_t)r;
-    if (fw[r]) wstart[wid] = (uint32_t)r;
-    if (r == n - 1) { sstart[sid + 1] = (uint32_t)n; wstart[wid + 1] = (uint32_t)n; }
+    rr_starts_at(fs[r], fw[r], es[r], ew[r], r, n, sstart, wstart);
 }
 
-__global__ __launch_bounds__(TB) void k_rr_counts(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, const uint32_t *__restrict__ fs, const uint32_t *__restrict__ fw,
-                                                  const uint32_t *__restrict__ es, const uint32_t *__restrict__ ew, const uint32_t *__restrict__ sstart,
-                                                  const uint32_t *__restrict__ wstart, int64_t n, uint32_t *__restrict__ cnt4, uint4 *__restrict__ walk)
+__device__ __forceinline__ void rr_counts_at(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, uint32_t sid, uint32_t wid, const uint32_t *__restrict__ sstart,
+                                             const uint32_t *__restrict__ wstart, int64_t r, uint32_t *__restrict__ cnt4, uint4 *__restrict__ walk)
 {
-    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (r >= n) return;
-    const uint32_t sid = es[r] + fs[r] - 1u, wid = ew[r] + fw[r] - 1u;
     const uint32_t S = sstart[sid], Send = sstart[sid + 1], W = wstart[wid], Wend = wstart[wid + 1];
     const uint32_t posbase = 4u * S + 2u * (W - S) + ((uint32_t)r - W), shalf = 2u * (Send - S), rlen = Wend - W;
     const uint32_t m = r2m[r];
@@ -203,13 +210,20 @@ __global__ __launch_bounds__(TB) void k_rr_counts(const uint8_t *__restrict__ oc
     walk[r] = make_uint4(posbase, shalf, rlen, m);
 }
 
-__global__ __launch_bounds__(TB) void k_rr_assign(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart, const uint4 *__restrict__ walk,
-                                                  const uint32_t *__restrict__ base4, int64_t n, int64_t nc, uint32_t *__restrict__ m2r_c, uint32_t *__restrict__ r2m_c)
+__global__ __launch_bounds__(TB) void k_rr_counts(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ r2m, const uint32_t *__restrict__ fs, const uint32_t *__restrict__ fw,
+                                                  const uint32_t *__restrict__ es, const uint32_t *__restrict__ ew, const uint32_t *__restrict__ sstart,
+                                                  const uint32_t *__restrict__ wstart, int64_t n, uint32_t *__restrict__ cnt4, uint4 *__restrict__ walk)
 {
-    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= n) return;
+    rr_counts_at(occ, r2m, es[r] + fs[r] - 1u, ew[r] + fw[r] - 1u, sstart, wstart, r, cnt4, walk);
+}
+
+__device__ __forceinline__ void rr_assign_at(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart, const uint4 *__restrict__ walk, const uint32_t *__restrict__ base4,
+                                             int64_t t, int64_t nc, uint32_t *__restrict__ m2r_c, uint32_t *__restrict__ r2m_c)
+{
     const int64_t r = t >> 3;
     const int q = (int)(t & 7);
-    if (r >= n) return;
     const uint4 w = walk[r];
     const uint32_t o = occ[w.w];
     if (!((o >> q) & 1u)) return;
@@ -220,6 +234,123 @@ __global__ __launch_bounds__(TB) void k_rr_assign(const uint8_t *__restrict__ oc
     m2r_c[ci] = rank;
     r2m_c[rank] = ci;
 }
+
+__global__ __launch_bounds__(TB) void k_rr_assign(const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart, const uint4 *__restrict__ walk,
+                                                  const uint32_t *__restrict__ base4, int64_t n, int64_t nc, uint32_t *__restrict__ m2r_c, uint32_t *__restrict__ r2m_c)
+{
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if ((t >> 3) >= n) return;
+    rr_assign_at(occ, cstart, walk, base4, t, nc, m2r_c, r2m_c);
+}
+
+__device__ __forceinline__ void expand_at(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart, int64_t t,
+                                          uint64_t *__restrict__ rkey_c, uint32_t *__restrict__ parent_c, int64_t nc_cap)
+{
+    const int64_t p = t >> 3;
+    const int q = (int)(t & 7);
+    const uint32_t o = occ[p];
+    if (!((o >> q) & 1u)) return;
+    const uint32_t idx = cstart[p] + (uint32_t)__popc(o & ((1u << q) - 1u));
+    if ((int64_t)idx >= nc_cap) return;   // a header that understates the level: the caller reports it at its next sync
+    const uint64_t k = rkey[p];
+    rkey_c[idx] = rkey3(2 * rk_x(k) + (q & 1), 2 * rk_y(k) + ((q >> 1) & 1), 2 * rk_z(k) + ((q >> 2) & 1));
+    parent_c[idx] = (uint32_t)p;
+}
+
+// ------------------------------------------------------------------ small levels: expansion + ranks in ONE single-workgroup launch
+// A decode spends ~12 launches of 4-5 us on the structure of a level (population counts, scan, expansion, the rank
+// derivation above with its three scans); for the first levels that chain, not the five parent convolutions beside it, is
+// what the level waits for.  One workgroup of 1024 threads runs the same steps with workgroup barriers between them: every
+// thread owns a contiguous run of each array, scans are (thread run -> wave shuffle -> 16 wave totals).  Measured (MI355X):
+// 6 / 8 / 15 us for 8 / 64 / 511 parents against ~55 us of launches; from ~2 k parents on the per-thread runs of dependent
+// loads make the single workgroup SLOWER than the launches (170 us at 8 k parents), hence the limits.
+constexpr int SL_T = 1024;
+constexpr int64_t SMALL_PAR_MAX = 1024, SMALL_CHI_MAX = 8192;
+
+// exclusive scan of f(0..len) into out (may alias what f reads at the same index); returns the total to every thread
+template <typename F>
+__device__ __forceinline__ uint32_t block_exscan(F f, uint32_t *__restrict__ out, int len, uint32_t *lds)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = (len + SL_T - 1) / SL_T, b = min(len, tid * C), e = min(len, b + C);
+    uint32_t s = 0;
+    for (int i = b; i < e; ++i) s += f(i);
+    uint32_t inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+        if (lane >= d) inc += v;
+    }
+    __syncthreads();   // lds free (a previous call's readers are done)
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SL_T / 64; ++w) { const uint32_t v = lds[w]; wbase += w < wave ? v : 0u; total += v; }
+    uint32_t run = wbase + inc - s;
+    for (int i = b; i < e; ++i) { const uint32_t v = f(i); out[i] = run; run += v; }
+    __syncthreads();   // out complete and visible to the workgroup
+    return total;
+}
+
+struct SmallLevelArgs {
+    const uint64_t *rkey; const uint8_t *occ; const uint32_t *r2m; uint32_t *cstart; int n;   // parent level (cstart is written when EXPAND)
+    uint64_t *rkey_c; uint32_t *parent_c, *m2r_c, *r2m_c; int nc;                              // child level (rkey_c / parent_c written when EXPAND)
+    uint32_t *total_dev;                                                                          // EXPAND: number of children the occupancy expands to
+    uint32_t *ef, *sstart, *wstart, *cnt4; uint4 *walk;                                         // scratch: n, n + 1, n + 1, 4 n, n
+};
+
+template <bool EXPAND>
+__global__ __launch_bounds__(SL_T) void k_small_level(SmallLevelArgs a)
+{
+    __shared__ uint32_t lds[SL_T / 64];
+    const int tid = threadIdx.x, n = a.n, nc = a.nc;
+    if (EXPAND) {
+        const uint32_t total = block_exscan([&](int i) { return (uint32_t)__popc((uint32_t)a.occ[i]); }, a.cstart, n, lds);
+        if (tid == 0) { a.cstart[n] = total; if (a.total_dev) *a.total_dev = total; }
+        // a lying container header may leave children unwritten: keep every index valid underneath
+        for (int i = tid; i < nc; i += SL_T) a.parent_c[i] = 0;
+    }
+    for (int i = tid; i < nc; i += SL_T) { a.m2r_c[i] = 0; a.r2m_c[i] = 0; }
+    __syncthreads();
+    if (EXPAND)
+        for (int t = tid; t < 8 * n; t += SL_T) expand_at(a.rkey, a.occ, a.cstart, t, a.rkey_c, a.parent_c, nc);
+    // slab / row flags of the parents in raster order, both scans in one (n < 2^16: a 16-bit field each)
+    auto flags = [&](int r) -> uint32_t { uint32_t s, w; rr_flags_at(a.rkey, a.r2m, r, s, w); return s | (w << 16); };
+    block_exscan(flags, a.ef, n, lds);
+    for (int r = tid; r < n; r += SL_T) {
+        const uint32_t f = flags(r), e = a.ef[r];
+        rr_starts_at(f & 0xFFFFu, f >> 16, e & 0xFFFFu, e >> 16, r, n, a.sstart, a.wstart);
+    }
+    __syncthreads();
+    for (int r = tid; r < n; r += SL_T) {
+        const uint32_t f = flags(r), e = a.ef[r];
+        rr_counts_at(a.occ, a.r2m, (e & 0xFFFFu) + (f & 0xFFFFu) - 1u, (e >> 16) + (f >> 16) - 1u, a.sstart, a.wstart, r, a.cnt4, a.walk);
+    }
+    __syncthreads();
+    block_exscan([&](int i) { return a.cnt4[i]; }, a.cnt4, 4 * n, lds);
+    for (int t = tid; t < 8 * n; t += SL_T) rr_assign_at(a.occ, a.cstart, a.walk, a.cnt4, t, nc, a.m2r_c, a.r2m_c);
+}
+
+// par (ranks known) -> chi: ranks of the children, and with `expand` also par->cstart, chi->rkey / parent and the child count
+int small_level(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, bool expand, uint32_t *total_dev)
+{
+    const int64_t n = par->n;
+    if (n > SMALL_PAR_MAX || chi->n > SMALL_CHI_MAX) return fail(GPCC_ERR_ARG, "internal: small_level on %lld -> %lld nodes", (long long)n, (long long)chi->n);
+    const size_t mk = ctx->arena.mark();
+    TAKE(ef, uint32_t, n); TAKE(sstart, uint32_t, n + 1); TAKE(wstart, uint32_t, n + 1); TAKE(cnt4, uint32_t, 4 * n); TAKE(walk, uint4, n);
+    SmallLevelArgs a;
+    a.rkey = par->rkey; a.occ = par->occ; a.r2m = par->r2m; a.cstart = par->cstart; a.n = (int)n;
+    a.rkey_c = chi->rkey; a.parent_c = chi->parent; a.m2r_c = chi->m2r; a.r2m_c = chi->r2m; a.nc = (int)chi->n;
+    a.total_dev = total_dev; a.ef = ef; a.sstart = sstart; a.wstart = wstart; a.cnt4 = cnt4; a.walk = walk;
+    if (expand) k_small_level<true><<<1, SL_T, 0, st>>>(a);
+    else k_small_level<false><<<1, SL_T, 0, st>>>(a);
+    LAUNCH_CHECK();
+    ctx->arena.rewind(mk);
+    return GPCC_OK;
+}
+
+bool small_level_fits(const Level *par, const Level *chi) { return par && par->n <= SMALL_PAR_MAX && chi->n <= SMALL_CHI_MAX; }
 
 int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi)
 {
@@ -249,12 +380,20 @@ int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Lev
 
 // sort below this size (one single-workgroup launch), derive above it
 constexpr int64_t RANK_SORT_MAX = 1024;
+static bool no_fuse()   // cross-check knob: the one-launch-per-step path for every level
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("GAUSPCC_SMALL_FUSE"); v = e ? atoi(e) == 0 : 0; }
+    return v != 0;
+}
 
 int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int hb_level)
 {
     static int force_sort = -1;
     if (force_sort < 0) { const char *e = getenv("GAUSPCC_RANK_SORT"); force_sort = e ? atoi(e) != 0 : 0; }   // cross-check knob
-    if (!par || chi->n <= RANK_SORT_MAX || force_sort) return level_raster_rank(ctx, st, chi, hb_level);
+    if (!par || force_sort) return level_raster_rank(ctx, st, chi, hb_level);
+    if (small_level_fits(par, chi) && !no_fuse()) return small_level(ctx, st, const_cast<Level *>(par), chi, false, nullptr);
+    if (chi->n <= RANK_SORT_MAX) return level_raster_rank(ctx, st, chi, hb_level);
     return level_ranks_from_parent(ctx, st, par, chi);
 }
 
@@ -395,17 +534,17 @@ __global__ __launch_bounds__(TB) void k_popc(const uint8_t *__restrict__ occ, in
 __global__ __launch_bounds__(TB) void k_expand(const uint64_t *__restrict__ rkey, const uint8_t *__restrict__ occ, const uint32_t *__restrict__ cstart,
                                                int64_t n, uint64_t *__restrict__ rkey_c, uint32_t *__restrict__ parent_c, int64_t nc_cap)
 {
-    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
-    int64_t p = t >> 3;
-    const int q = (int)(t & 7);
-    if (p >= n) return;
-    const uint32_t o = occ[p];
-    if (!((o >> q) & 1u)) return;
-    const uint32_t idx = cstart[p] + (uint32_t)__popc(o & ((1u << q) - 1u));
-    if ((int64_t)idx >= nc_cap) return;   // a header that understates the level: the caller reports it at its next sync
-    const uint64_t k = rkey[p];
-    rkey_c[idx] = rkey3(2 * rk_x(k) + (q & 1), 2 * rk_y(k) + ((q >> 1) & 1), 2 * rk_z(k) + ((q >> 2) & 1));
-    parent_c[idx] = (uint32_t)p;
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if ((t >> 3) >= n) return;
+    expand_at(rkey, occ, cstart, t, rkey_c, parent_c, nc_cap);
+}
+
+// expansion + ranks of the child level: one launch for small levels, the two chains otherwise
+int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, int hb_level)
+{
+    if (small_level_fits(par, chi) && !no_fuse()) return small_level(ctx, st, par, chi, true, total_dev);
+    GP_TRY(level_expand(ctx, st, par, chi, total_dev));
+    return rank_level(ctx, st, par, chi, hb_level);
 }
 
 int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev)

@@ -89,6 +89,8 @@ int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int 
 
 // decode side: children of `par` (occupancy known) -> `chi` (rkey, parent; n must be known)
 int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
+// level_expand + rank_level; small levels (<= 1 k parents, <= 8 k children) in ONE single-workgroup launch (GAUSPCC_SMALL_FUSE=0: never)
+int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, int hb_level);
 
 // leaves of the last level in the reference's decoder order (parents in raster order, octants ascending)
 int leaves_reference_order(gpcc_ctx *ctx, hipStream_t st, const Level *last, const int64_t bias[3], int32_t *xyz_out, int64_t npts);

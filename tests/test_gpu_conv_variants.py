@@ -70,8 +70,9 @@ def test_conv_kernel_variant_bit_exact(env):
 
 def test_rank_derivation_equals_rank_sort():
     """Raster ranks derived from the parent level (octree.hip: level_ranks_from_parent) against the radix sort of the (z, y, x)
-    keys (GAUSPCC_RANK_SORT=1 forces the sort on every level): the oracle check of SNIPPET passes either way, and the two
-    bitstreams of a 150 k-point cloud are identical."""
+    keys (GAUSPCC_RANK_SORT=1 forces the sort on every level) and against the one-launch-per-step path for the small levels
+    (GAUSPCC_SMALL_FUSE=0 switches off the single-workgroup expansion + rank kernel, octree.hip: k_small_level): the
+    bitstreams and the decoded order of a 150 k-point cloud are identical in all three."""
     snippet = r"""
 import sys
 import numpy as np
@@ -88,10 +89,10 @@ import hashlib
 print("digest", hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).hexdigest(), max(st.level_nodes[: st.num_levels]))
 """ % ROOT
     out = []
-    for env in ({}, {"GAUSPCC_RANK_SORT": "1"}):
+    for env in ({}, {"GAUSPCC_RANK_SORT": "1"}, {"GAUSPCC_SMALL_FUSE": "0"}):
         e = dict(os.environ)
         e.update(env)
         r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
-    assert out[0] == out[1] and int(out[0].split()[-1]) > 100_000
+    assert out[0] == out[1] == out[2] and int(out[0].split()[-1]) > 100_000

@@ -43,7 +43,7 @@ struct WaveMap {
     int64_t r0, rend;          // my rows [r0, rend) of the level
     int ls; uint64_t segmask, below;
 };
-__device__ __forceinline__ WaveMap wave_map(int H, int64_t nc, uint32_t blk0, int lane)
+__device__ __forceinline__ WaveMap wave_map(int H, int64_t nc, uint32_t blk0, int lane, uint32_t bid)
 {
     WaveMap m;
     m.multi = H == 16 || H == 32;
@@ -55,12 +55,12 @@ __device__ __forceinline__ WaveMap wave_map(int H, int64_t nc, uint32_t blk0, in
     m.below = m.segmask & (lane == 0 ? 0ull : (~0ull >> (64 - lane)));
     if (m.multi) {
         m.q = 0;
-        m.r0 = (int64_t)blockIdx.x * 64; m.rend = min(nc, m.r0 + 64);
-        m.blk = blk0 + (uint32_t)(blockIdx.x * (64 / Hs) + seg);
+        m.r0 = (int64_t)bid * 64; m.rend = min(nc, m.r0 + 64);
+        m.blk = blk0 + (uint32_t)(bid * (64 / Hs) + seg);
         m.blk_live = m.r0 + (int64_t)seg * Hs < nc;
     } else {
-        const uint32_t b = blockIdx.x / (uint32_t)m.nq;
-        m.q = (int)(blockIdx.x - b * (uint32_t)m.nq);
+        const uint32_t b = bid / (uint32_t)m.nq;
+        m.q = (int)(bid - b * (uint32_t)m.nq);
         const int64_t b0 = (int64_t)b * H, bend = min(nc, b0 + H);
         m.r0 = min(bend, b0 + 64 * (int64_t)m.q); m.rend = min(bend, m.r0 + 64);
         m.blk = blk0 + b;
@@ -126,7 +126,7 @@ __device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk
 // The k^2 neighbours of a (dy, dx) plane are computed as one batch (independent LDS reads and integer chains in flight
 // together -- a wave alone on its SIMD has nothing else to hide their latency behind), then compacted one by one.
 template <int KS, bool FILL, bool TALL>
-__global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
+__device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint32_t bid)
 {
     constexpr int r = KS / 2, K = KS * KS * KS, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
     __shared__ uint32_t cst[64 * NP];     // child start of every staged cell
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
 #ifdef TILES_TIMING
     const long long tc0 = clock64();
 #endif
-    const WaveMap m = wave_map(a.H, a.nc, a.blk0, lane);
+    const WaveMap m = wave_map(a.H, a.nc, a.blk0, lane, bid);
     if (m.r0 >= m.rend) return;           // a chunk behind the end of its (last, short) block: its counts were zeroed by the host
     const ChunkTables T = {tab, tab + K + 1, tab + 2 * K + 2};
     if (FILL && TALL) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T);
@@ -264,14 +264,36 @@ __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a)
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) npairs += (uint32_t)__shfl_xor((int)npairs, d, 64);
         }
-        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs + (blockIdx.x & 63u), (unsigned long long)npairs);
+        if (lane == 0 && a.pairs && npairs) atomicAdd(a.pairs + (bid & 63u), (unsigned long long)npairs);
     }
 #ifdef TILES_TIMING
     __builtin_amdgcn_s_waitcnt(0);
     const long long tc3 = clock64();
-    if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
-        printf("[tiles] fill %d tall %d grid %u wave %u: stage %lld loop %lld tail %lld cycles\n", (int)FILL, (int)TALL, gridDim.x, blockIdx.x, tc1 - tc0, tc2 - tc1, tc3 - tc2);
+    if (lane == 0 && (bid == 0 || bid == gridDim.x / 2))
+        printf("[tiles] fill %d tall %d grid %u wave %u: stage %lld loop %lld tail %lld cycles\n", (int)FILL, (int)TALL, gridDim.x, bid, tc1 - tc0, tc2 - tc1, tc3 - tc2);
 #endif
+}
+
+template <int KS, bool FILL, bool TALL>
+__global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a) { chunk_tiles<KS, FILL, TALL>(a, blockIdx.x); }
+
+// The fill pass of every level of a pool in ONE launch (an encode builds the tile lists of its whole tree; the passes of
+// different levels are independent once the counts are scanned, and ten of its fifteen levels are launch-latency-bound).
+struct SetTilesArgs {
+    int nlv;
+    uint32_t g0[MAXLV + 1];     // first workgroup of each level in the grid
+    LevelTilesArgs common;      // H, first, tj / tr / toc, cnt_oq
+    struct Lv { const uint64_t *rkey_c; const uint32_t *parent_c; const int32_t *cell_p; const uint8_t *occ_p; const uint32_t *cstart_p; int64_t nc, np; uint32_t blk0; } lv[MAXLV];
+};
+template <int KS, bool TALL>
+__global__ __launch_bounds__(64) void k_fill_tiles_set(SetTilesArgs S)
+{
+    int l = 0;
+    for (int q = 1; q < S.nlv; ++q) l = blockIdx.x >= S.g0[q] ? q : l;
+    LevelTilesArgs a = S.common;
+    a.rkey_c = S.lv[l].rkey_c; a.parent_c = S.lv[l].parent_c; a.nc = S.lv[l].nc; a.cell_p = S.lv[l].cell_p; a.np = S.lv[l].np;
+    a.occ_p = S.lv[l].occ_p; a.cstart_p = S.lv[l].cstart_p; a.blk0 = S.lv[l].blk0;
+    chunk_tiles<KS, true, TALL>(a, blockIdx.x - S.g0[l]);
 }
 
 // tiles of the blocks taller than 64 rows from the per-chunk counts: a wave per block, lanes over the offsets
@@ -301,7 +323,7 @@ __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
     const int n = (int)a.nc, r = k / 2, PR = (r + 1) / 2, PW = 2 * PR + 1, K = k * k * k;
     keys[lane] = lane < n ? a.rkey_c[lane] : ~0ull;
     __syncthreads();
-    const WaveMap m = wave_map(min(a.H, 64), a.nc, a.blk0, lane);   // n < 64: a block taller than 64 rows is the whole level
+    const WaveMap m = wave_map(min(a.H, 64), a.nc, a.blk0, lane, blockIdx.x);   // n < 64: a block taller than 64 rows is the whole level
     const int me = (int)m.r0 + lane;                                  // my row
     const bool live = m.r0 + lane < m.rend;
     const uint64_t ki = keys[min(me, n - 1)];
@@ -357,7 +379,7 @@ __global__ __launch_bounds__(256) void k_tile_words(const uint8_t *__restrict__ 
 }
 
 template <int KS, bool FILL>
-int launch_level(hipStream_t st, const LevelTilesArgs &a)
+int launch_level(hipStream_t st, const LevelTilesArgs &a, bool tail)
 {
     const int H = a.H;
     const bool multi = H == 16 || H == 32;
@@ -366,7 +388,7 @@ int launch_level(hipStream_t st, const LevelTilesArgs &a)
     if (nq > 1) k_chunk_tiles<KS, FILL, true><<<grid, 64, 0, st>>>(a);
     else k_chunk_tiles<KS, FILL, false><<<grid, 64, 0, st>>>(a);
     LAUNCH_CHECK();
-    if (nq > 1) {
+    if (nq > 1 && tail) {
         const int nblk = (int)cdiv(a.nc, H);
         if (!FILL) k_block_sum<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block);
         else k_tile_words<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.first, a.blk0, nblk, KS * KS * KS, a.tj, a.tr, a.toc);
@@ -375,8 +397,10 @@ int launch_level(hipStream_t st, const LevelTilesArgs &a)
     return GPCC_OK;
 }
 
+// tail: also the per-level pass over the blocks taller than 64 rows (k_block_sum / k_tile_words); a pool of several levels
+// runs that once over all its blocks
 template <bool FILL>
-int run_level(hipStream_t st, const Level *par, const int32_t *cell_par, const Level *chi, int k, LevelTilesArgs a)
+int run_level(hipStream_t st, const Level *par, const int32_t *cell_par, const Level *chi, int k, LevelTilesArgs a, bool tail = true)
 {
     a.rkey_c = chi->rkey; a.parent_c = chi->parent; a.nc = chi->n;
     if (a.H < 16 || a.H > CONV_R_MAX) return fail(GPCC_ERR_ARG, "internal: block height %d", a.H);
@@ -389,9 +413,9 @@ int run_level(hipStream_t st, const Level *par, const int32_t *cell_par, const L
     }
     a.cell_p = cell_par; a.np = par->n; a.occ_p = par->occ; a.cstart_p = par->cstart;
     switch (k) {
-    case 3: return launch_level<3, FILL>(st, a);
-    case 5: return launch_level<5, FILL>(st, a);
-    case 7: return launch_level<7, FILL>(st, a);
+    case 3: return launch_level<3, FILL>(st, a, tail);
+    case 5: return launch_level<5, FILL>(st, a, tail);
+    case 7: return launch_level<7, FILL>(st, a, tail);
     default: return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
     }
 }
@@ -457,9 +481,20 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         spread = sp;
         HIP_TRY(hipMemsetAsync(sp, 0, 8 * (size_t)nlv * 64, st));
     }
+    // a pool of several levels (the encoder's whole tree; only its first level may be a base level without a parent): the
+    // count passes stay one launch per level (a level reads the cell map its parent's pass wrote), everything that is
+    // independent across levels -- the sums of the tall blocks, the fill pass, the tile words -- is one launch over the pool
+    const bool batch = nlv > 1;
+    for (int l = 1; l < nlv; ++l) if (!lv[l].par) return fail(GPCC_ERR_ARG, "internal: level %d of a tile pool has no parent", l);
+    const int lp = lv[0].par ? 0 : 1;   // first level with a parent
     for (int l = 0; l < nlv; ++l) {
         a.blk0 = pool->lv_blk0[l]; a.cell_c = lv[l].cell_own; a.pairs = spread ? spread + (size_t)l * 64 : nullptr;
-        GP_TRY(run_level<false>(st, lv[l].par, lv[l].cell_par, lv[l].lv, k, a));
+        GP_TRY(run_level<false>(st, lv[l].par, lv[l].cell_par, lv[l].lv, k, a, !batch));
+    }
+    if (batch && H > 64 && lp < nlv) {
+        const uint32_t b1 = pool->lv_blk0[lp];
+        k_block_sum<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, b1, (int)(nblk - b1), K, a.per_block);
+        LAUNCH_CHECK();
     }
     if (spread) { k_fold_pairs<<<1, 64, 0, st>>>(spread, nlv, pairs_dev); LAUNCH_CHECK(); }
     GP_TRY(exclusive_scan_u32(ctx, st, first, first, nblk, first + nblk));
@@ -490,9 +525,38 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     k_pad_tiles<<<1, 64, 0, st>>>(first + nblk, tj, reinterpret_cast<uint32_t *>(tr), toc);
     LAUNCH_CHECK();
     a.first = first; a.tj = tj; a.tr = tr; a.toc = toc; a.cell_c = nullptr; a.pairs = nullptr;
-    for (int l = 0; l < nlv; ++l) {
-        a.blk0 = pool->lv_blk0[l];
-        GP_TRY(run_level<true>(st, lv[l].par, lv[l].cell_par, lv[l].lv, k, a));
+    if (!batch) {
+        a.blk0 = pool->lv_blk0[0];
+        GP_TRY(run_level<true>(st, lv[0].par, lv[0].cell_par, lv[0].lv, k, a));
+        return GPCC_OK;
+    }
+    if (lp == 1) { a.blk0 = pool->lv_blk0[0]; GP_TRY(run_level<true>(st, nullptr, nullptr, lv[0].lv, k, a)); }
+    {
+        SetTilesArgs S = {};
+        S.common = a;
+        const bool multi = H == 16 || H == 32;
+        const int nq = H > 64 ? (H + 63) / 64 : 1;
+        uint32_t g = 0;
+        for (int l = lp; l < nlv; ++l) {
+            auto &d = S.lv[l - lp];
+            d.rkey_c = lv[l].lv->rkey; d.parent_c = lv[l].lv->parent; d.nc = lv[l].lv->n; d.cell_p = lv[l].cell_par; d.np = lv[l].par->n;
+            d.occ_p = lv[l].par->occ; d.cstart_p = lv[l].par->cstart; d.blk0 = pool->lv_blk0[l];
+            S.g0[l - lp] = g;
+            g += multi ? (uint32_t)cdiv(d.nc, 64) : (uint32_t)(cdiv(d.nc, H) * nq);
+        }
+        S.nlv = nlv - lp; S.g0[S.nlv] = g;
+        switch (k) {
+        case 3: if (nq > 1) k_fill_tiles_set<3, true><<<g, 64, 0, st>>>(S); else k_fill_tiles_set<3, false><<<g, 64, 0, st>>>(S); break;
+        case 5: if (nq > 1) k_fill_tiles_set<5, true><<<g, 64, 0, st>>>(S); else k_fill_tiles_set<5, false><<<g, 64, 0, st>>>(S); break;
+        case 7: if (nq > 1) k_fill_tiles_set<7, true><<<g, 64, 0, st>>>(S); else k_fill_tiles_set<7, false><<<g, 64, 0, st>>>(S); break;
+        default: return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+        }
+        LAUNCH_CHECK();
+        if (nq > 1) {
+            const uint32_t b1 = pool->lv_blk0[lp];
+            k_tile_words<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, a.first, b1, (int)(nblk - b1), K, tj, tr, toc);
+            LAUNCH_CHECK();
+        }
     }
     return GPCC_OK;
 }

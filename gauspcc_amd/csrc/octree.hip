@@ -80,15 +80,14 @@ __global__ __launch_bounds__(TB) void k_level_flags(const uint64_t *__restrict__
     flag[i] = (i == 0 || (key[i] >> 3) != (key[i - 1] >> 3)) ? 1u : 0u;
 }
 
-__global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__ key, int64_t n, const uint32_t *__restrict__ pos,
-                                                    uint64_t *__restrict__ key_up, uint32_t *__restrict__ cstart_up,
-                                                    uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
+// one child of the level below: its parent index, and for the first child of a parent the parent's node (Morton key, raster
+// key, first child, occupancy).  pos = exclusive scan of the head flags at i.
+__device__ __forceinline__ void level_build_at(const uint64_t *__restrict__ key, int64_t n, int64_t i, uint32_t pos, uint64_t *__restrict__ key_up, uint64_t *__restrict__ rkey_up,
+                                               uint32_t *__restrict__ cstart_up, uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
 {
-    int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (i >= n) return;
     const uint64_t k = key[i], pk = k >> 3;
     const bool head = i == 0 || (key[i - 1] >> 3) != pk;
-    const uint32_t p = pos[i] - (head ? 0u : 1u);  // pos = exclusive scan of head flags
+    const uint32_t p = pos - (head ? 0u : 1u);
     if (parent_lo) parent_lo[i] = p;
     if (head) {
         uint32_t occ = 0;
@@ -98,18 +97,60 @@ __global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__
             occ |= 1u << (kj & 7);
         }
         key_up[p] = pk;
+        rkey_up[p] = rkey3(compact1by2(pk), compact1by2(pk >> 1), compact1by2(pk >> 2));
         cstart_up[p] = (uint32_t)i;
         occ_up[p] = (uint8_t)occ;
     }
     if (i == n - 1) cstart_up[p + 1] = (uint32_t)n;  // sentinel: cstart[n_up] = n_lo
 }
 
-__global__ __launch_bounds__(TB) void k_mkey_to_rkey(const uint64_t *__restrict__ mkey, int64_t n, uint64_t *__restrict__ rkey)
+__global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__ key, int64_t n, const uint32_t *__restrict__ pos,
+                                                    uint64_t *__restrict__ key_up, uint64_t *__restrict__ rkey_up, uint32_t *__restrict__ cstart_up,
+                                                    uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
 {
     int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= n) return;
-    uint64_t m = mkey[i];
-    rkey[i] = rkey3(compact1by2(m), compact1by2(m >> 1), compact1by2(m >> 2));
+    level_build_at(key, n, i, pos[i], key_up, rkey_up, cstart_up, occ_up, parent_lo);
+}
+
+// Levels of at most LEVEL_SINGLE_MAX children: head flags, their scan and the build in ONE single-workgroup launch (the upper
+// half of a tree is launch-latency-bound: four launches per level otherwise).  The workgroup walks the children in tiles of
+// 1024 with the running count in a register.
+constexpr int LS_T = 256, LS_E = 4, LS_TILE = LS_T * LS_E;
+constexpr int64_t LEVEL_SINGLE_MAX = 16 * LS_TILE;
+__global__ __launch_bounds__(LS_T) void k_level_up_single(const uint64_t *__restrict__ key, int64_t n, uint64_t *__restrict__ key_up, uint64_t *__restrict__ rkey_up,
+                                                         uint32_t *__restrict__ cstart_up, uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
+{
+    __shared__ uint32_t lds[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += LS_TILE) {
+        const int64_t base = b0 + (int64_t)threadIdx.x * LS_E;
+        uint32_t f[LS_E], s = 0;
+#pragma unroll
+        for (int e = 0; e < LS_E; ++e) {
+            const int64_t i = base + e;
+            f[e] = i < n ? (uint32_t)(i == 0 || (key[i] >> 3) != (key[i - 1] >> 3)) : 0u;
+            s += f[e];
+        }
+        uint32_t inc = s;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        __syncthreads();
+        if (lane == 63) lds[wave] = inc;
+        __syncthreads();
+        const uint32_t w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
+        uint32_t ex = carry + (wave == 0 ? 0u : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2) + inc - s;
+#pragma unroll
+        for (int e = 0; e < LS_E; ++e) {
+            if (base + e < n) level_build_at(key, n, base + e, ex, key_up, rkey_up, cstart_up, occ_up, parent_lo);
+            ex += f[e];
+        }
+        carry += w0 + w1 + w2 + w3;
+    }
 }
 
 // ------------------------------------------------------------------ raster ranks
@@ -497,16 +538,19 @@ int tree_build(gpcc_ctx *ctx, hipStream_t st, const int32_t *xyz, int64_t n, Tre
         Level *up = &T->lv[L - l];
         GP_TRY(level_alloc(ctx, up, nl[l], l));
         TAKE(key_up, uint64_t, nl[l]);
-        size_t mk = ctx->arena.mark();
-        TAKE(flag, uint32_t, n_lo);
-        k_level_flags<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag);
-        LAUNCH_CHECK();
-        GP_TRY(exclusive_scan_u32(ctx, st, flag, flag, n_lo, nullptr));
-        k_level_build<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag, key_up, up->cstart, up->occ, lo ? lo->parent : nullptr);
-        LAUNCH_CHECK();
-        ctx->arena.rewind(mk);
-        k_mkey_to_rkey<<<nblk(nl[l]), TB, 0, st>>>(key_up, nl[l], up->rkey);
-        LAUNCH_CHECK();
+        if (n_lo <= LEVEL_SINGLE_MAX) {
+            k_level_up_single<<<1, LS_T, 0, st>>>(key_lo, n_lo, key_up, up->rkey, up->cstart, up->occ, lo ? lo->parent : nullptr);
+            LAUNCH_CHECK();
+        } else {
+            size_t mk = ctx->arena.mark();
+            TAKE(flag, uint32_t, n_lo);
+            k_level_flags<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag);
+            LAUNCH_CHECK();
+            GP_TRY(exclusive_scan_u32(ctx, st, flag, flag, n_lo, nullptr));
+            k_level_build<<<nblk(n_lo), TB, 0, st>>>(key_lo, n_lo, flag, key_up, up->rkey, up->cstart, up->occ, lo ? lo->parent : nullptr);
+            LAUNCH_CHECK();
+            ctx->arena.rewind(mk);
+        }
         key_lo = key_up; n_lo = nl[l]; lo = up;
     }
     return GPCC_OK;

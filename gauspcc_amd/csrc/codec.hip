@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <chrono>
 
+#include <functional>
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
@@ -136,8 +137,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         for (int d = 2; d < L; ++d) { cbase[d] = cbase[d - 1] + T.lv[d - 1].n; }
         TAKE(occP, uint8_t, nP); TAKE(occC, uint8_t, nC); TAKE(rkeyC, uint64_t, nC);
         TAKE(parentC, uint32_t, nC); TAKE(posC, uint32_t, nC); TAKE(slotsC, uint32_t, nC);
+        SetLevels S = {};
         {
-            SetLevels S = {};
             S.L = L;
             int64_t lohi_base = 0;
             for (int d = 0; d < L; ++d) {
@@ -150,15 +151,16 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                     lohi_base += 4 * slots(lv->n);
                 }
             }
-            {
-                StageTimer tm(ctx, st, ST_ELEM, (double)nP * 2 + (double)nC * (2 + 16 + 8));
-                k_set_rows<<<(unsigned)cdiv(std::max(nP, nC), 256), 256, 0, st>>>(S, nP, nC, occP, occC, rkeyC, parentC);
-                LAUNCH_CHECK();
-            }
-            // Second stream: the raster ranks of every level and what depends on them (the coder slots of the rows of C).
-            // Their first reader is the head of stage 0, eighteen convolutions away; temporaries come from the top of the
-            // arena (Arena::flip), which nothing else in an encode uses.
-            HIP_TRY(hipEventRecord(ctx->ev_main, st));
+            StageTimer tm(ctx, st, ST_ELEM, (double)nP * 2 + (double)nC * (2 + 16 + 8));
+            k_set_rows<<<(unsigned)cdiv(std::max(nP, nC), 256), 256, 0, st>>>(S, nP, nC, occP, occC, rkeyC, parentC);
+            LAUNCH_CHECK();
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_main, st));   // the tree is complete on st
+        // Second stream: the raster ranks of every level and what depends on them (the coder slots of the rows of C).
+        // Their first reader is the head of stage 0, eighteen convolutions away; temporaries come from the top of the
+        // arena (Arena::flip), which nothing else in an encode uses.  The ~190 small launches cost the host 0.4 ms to queue:
+        // that happens behind the first trunk's launches, when the device has milliseconds of work in hand.
+        const std::function<int()> queue_ranks = [&]() -> int {
             HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
             ctx->arena.flip = true;
             int rc = GPCC_OK;
@@ -174,7 +176,8 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 LAUNCH_CHECK();
             }
             HIP_TRY(hipEventRecord(ctx->ev_side, sd));
-        }
+            return GPCC_OK;
+        };
         ht.mark("enc meta queued");
         // Tile lists of every level in one pool, built top-down from the cell maps (tiles.hip; one stream sync for the pool
         // size).  A level's list is the same in the prior and in the target set -- tile entries are row indices inside the
@@ -202,6 +205,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF)); }
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
+        GP_TRY(queue_ranks());   // the device now has milliseconds of convolutions queued: the host time of these launches is free
         TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX)); }
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)

@@ -7,7 +7,7 @@ R=${2:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-QUIET="--skip-v0 --skip-stages --cpu-sample 0"
+QUIET="--skip-v0 --skip-stages --cpu-sample 0 --scenes-in-flight 0"
 # 1. HBM traffic of the conv kernels: FETCH_SIZE / WRITE_SIZE in separate passes
 BENCH_ARGS="$QUIET" bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log" 2>&1
 cp "$OUT/pmc/summary_conv.txt" "$OUT/${R}_pmc_conv_fetch_write.txt"
@@ -20,7 +20,6 @@ cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_kernel_stats.
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
 python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
-cp "$f" "$OUT/${R}_kernel_trace_full.csv"
 rm -rf "$OUT/t" "$OUT/pmc"
 # 3. SQ / TCP / GRBM counters of the conv kernels
 BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1

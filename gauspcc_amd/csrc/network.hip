@@ -325,58 +325,74 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
 #endif
     }
     CT_STAMP(ct3);
+#ifdef CONV_TIMING
+    __builtin_amdgcn_s_waitcnt(0);   // what the tile loop left in flight (the prefetches past the last tile, the last LDS sums)
+    const long long ct3a = clock64();
+#endif
     // epilogue: the block's rows are contiguous in the output and already in the physical channel order -> straight 16-byte
-    // copies, 64 rows (512 float4, 8 per lane) per batch.  Every branch is wave-uniform; only the last batch of a block
-    // (and the last block of a level) is predicated.  Residual rows of a batch are all requested before the first is used.
+    // copies, one wave instruction per 8 rows (64 float4).  ONE code path for full and short blocks: loads run on clamped
+    // addresses (always valid memory), LDS reads are unconditional (a slot past the block's rows is LDS of this wave), only
+    // the stores are predicated per lane.  All residual rows of the block are requested before anything else: memory reads
+    // and writes complete out of order with respect to each other, so a load issued behind stores can only be waited for
+    // with vmcnt(0) -- a batch loop that loads its residuals per batch waits for the previous batch's stores every time
+    // (measured: 33 k cycles per 255-row block with a residual, 18 k without -- the short last batch went through a
+    // dword-by-dword predicated path; now ~5 k / ~3 k).
     {
         const int nvec = nrows * 8;   // float4 elements of this block
         const bool has_res = J.res != nullptr;
-        const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8 + lane;
-        float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8 + lane;
-        const float4 *src = acc4 + 8 + lane;        // slot 1 = row 0
-        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 1
-        for (int base = 0; base < nvec; base += 512) {
-            float4 v[8], r[8];
-            if (base + 512 <= nvec) {
+        const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8;
+        float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8;
+        const float4 *src = acc4 + 8;               // slot 1 = row 0
+        constexpr int NG = (R * 8 + 63) / 64;       // 8-row groups of a full-height block
+        constexpr int NB = (NG + 7) / 8;            // batches of 8 groups
+        float4 r[NG];
+        if (has_res) {
+#pragma unroll
+            for (int g8 = 0; g8 < NG; ++g8) r[g8] = res4[min(g8 * 64 + lane, nvec - 1)];
+        }
+#ifdef CONV_TIMING
+        long long te[NB + 1];
+        te[0] = clock64();
+#endif
+#pragma unroll
+        for (int bt = 0; bt < NB; ++bt) {
+            if (bt * 512 < nvec) {   // wave-uniform
+                float4 v[8];
+#pragma unroll
+                for (int b = 0; b < 8; ++b)
+                    if (bt * 8 + b < NG) v[b] = src[(bt * 8 + b) * 64 + lane];
                 if (has_res) {
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) r[b] = res4[base + 64 * b];
-                }
-#pragma unroll
-                for (int b = 0; b < 8; ++b) v[b] = src[base + 64 * b];
-                if (has_res) {
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) { v[b].x = v[b].x + r[b].x; v[b].y = v[b].y + r[b].y; v[b].z = v[b].z + r[b].z; v[b].w = v[b].w + r[b].w; }
+                    for (int b = 0; b < 8; ++b)
+                        if (bt * 8 + b < NG) { const float4 q = r[bt * 8 + b]; v[b].x = v[b].x + q.x; v[b].y = v[b].y + q.y; v[b].z = v[b].z + q.z; v[b].w = v[b].w + q.w; }
                 }
                 if (relu) {
 #pragma unroll
-                    for (int b = 0; b < 8; ++b) { v[b].x = v[b].x > 0.f ? v[b].x : 0.f; v[b].y = v[b].y > 0.f ? v[b].y : 0.f; v[b].z = v[b].z > 0.f ? v[b].z : 0.f; v[b].w = v[b].w > 0.f ? v[b].w : 0.f; }
+                    for (int b = 0; b < 8; ++b)
+                        if (bt * 8 + b < NG) { v[b].x = v[b].x > 0.f ? v[b].x : 0.f; v[b].y = v[b].y > 0.f ? v[b].y : 0.f; v[b].z = v[b].z > 0.f ? v[b].z : 0.f; v[b].w = v[b].w > 0.f ? v[b].w : 0.f; }
                 }
 #pragma unroll
-                for (int b = 0; b < 8; ++b) out4[base + 64 * b] = v[b];
-            } else {
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool ok = base + 64 * b + lane < nvec;
-                    r[b] = has_res && ok ? res4[base + 64 * b] : zero4;
-                }
-#pragma unroll
-                for (int b = 0; b < 8; ++b) {
-                    const bool ok = base + 64 * b + lane < nvec;
-                    if (ok) {
-                        float4 t = src[base + 64 * b];
-                        if (has_res) { t.x = t.x + r[b].x; t.y = t.y + r[b].y; t.z = t.z + r[b].z; t.w = t.w + r[b].w; }
-                        if (relu) { t.x = t.x > 0.f ? t.x : 0.f; t.y = t.y > 0.f ? t.y : 0.f; t.z = t.z > 0.f ? t.z : 0.f; t.w = t.w > 0.f ? t.w : 0.f; }
-                        out4[base + 64 * b] = t;
-                    }
-                }
+                for (int b = 0; b < 8; ++b)
+                    if (bt * 8 + b < NG && (bt * 8 + b) * 64 + lane < nvec) out4[(bt * 8 + b) * 64 + lane] = v[b];
             }
+#ifdef CONV_TIMING
+            te[bt + 1] = clock64();
+#endif
         }
+#ifdef CONV_TIMING
+#ifndef CONV_LOOP_STAMPS
+        if (lane == 0 && NB == 4) {
+            atomicAdd(&g_conv_timing[12], (unsigned long long)(te[1] - te[0])); atomicAdd(&g_conv_timing[13], (unsigned long long)(te[2] - te[1]));
+            atomicAdd(&g_conv_timing[14], (unsigned long long)(te[3] - te[2])); atomicAdd(&g_conv_timing[15], (unsigned long long)(te[4] - te[3]));
+        }
+#endif
+#endif
     }
 #ifdef CONV_TIMING
+    const long long ct3b = clock64();
     __builtin_amdgcn_s_waitcnt(0);
     const long long ct4 = clock64();
+    if (lane == 0) { atomicAdd(&g_conv_timing[10], (unsigned long long)(ct3a - ct3)); atomicAdd(&g_conv_timing[11], (unsigned long long)(ct3b - ct3a)); }
     const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
     if (lane == 0) {
         atomicAdd(&g_conv_timing[2], (unsigned long long)(ct4 - ct3)); atomicAdd(&g_conv_timing[4], 1ull); atomicAdd(&g_conv_timing[5], (unsigned long long)(ct4 - ct0));
@@ -619,9 +635,15 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         fprintf(stderr, "[conv] R %3d H %3d jobs %d n %8lld blocks %6.0f tiles %9.0f  %.1f us | per wave: setup %.0f loop %.0f epilogue %.0f total %.0f cyc | loop %.0f cyc/tile | clock %.0f MHz | span %.1f us, wave time / 1024 slots %.1f us, longest block %.1f us\n",
                 T.R, T.H, njobs, (long long)n, waves, tiles, ms * 1e3, h[0] / waves, h[1] / waves, h[2] / waves, h[5] / waves, h[1] / tiles, 100.0 * h[5] / (double)h[6],
                 (h[8] - h[7]) / 100.0, h[6] / 100.0 / 1024.0, h[9] / 100.0);
+        fprintf(stderr, "[conv]    epilogue: loop drain %.0f, copy-out issue %.0f, store drain %.0f cycles; residual %d relu %d\n", h[10] / waves, h[11] / waves,
+                (h[2] - h[10] - h[11]) / waves, jobs.job[0].res != nullptr, relu);
         if (h[12] + h[13] + h[14] + h[15])
+#ifdef CONV_LOOP_STAMPS
             fprintf(stderr, "[conv]    per tile: step-start wait %.0f, first pair + VALU burst + LDS issue %.0f, second pair + loads issue %.0f, remaining 12 MFMAs %.0f cycles\n",
                     h[12] / tiles, h[13] / tiles, h[14] / tiles, h[15] / tiles);
+#else
+            fprintf(stderr, "[conv]    copy-out batches of 64 rows: %.0f %.0f %.0f %.0f cycles\n", h[12] / waves, h[13] / waves, h[14] / waves, h[15] / waves);
+#endif
     }
 #endif
     return GPCC_OK;

@@ -27,9 +27,12 @@ def worker(i, x, ctx, stream, barrier, out):
         pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
         sp = C.c_void_p(stream.cuda_stream)
         _lib.check(L.gpcc_encode(ctx, model.handle, x.data_ptr(), x.shape[0], 10, runtime.f16_bits(1), C.byref(pb), C.byref(nb), C.byref(st), sp))
-        data = C.string_at(pb, nb.value)
         px, nn, pq, st2 = C.c_void_p(), C.c_int64(), C.c_uint16(), _lib.Stats()
-        _lib.check(L.gpcc_decode(ctx, model.handle, C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(px), C.byref(nn), C.byref(pq), C.byref(st2), sp))
+        if os.environ.get("PROBE_COPY"):   # through a Python bytes object (pageable memory) instead of the library's pinned buffer
+            data = C.string_at(pb, nb.value)
+            _lib.check(L.gpcc_decode(ctx, model.handle, C.cast(C.c_char_p(data), C.c_void_p), len(data), C.byref(px), C.byref(nn), C.byref(pq), C.byref(st2), sp))
+        else:
+            _lib.check(L.gpcc_decode(ctx, model.handle, pb, nb.value, C.byref(px), C.byref(nn), C.byref(pq), C.byref(st2), sp))
         assert nn.value == x.shape[0]
     step()
     barrier.wait()
@@ -39,6 +42,14 @@ def worker(i, x, ctx, stream, barrier, out):
     stream.synchronize()
     out[i] = time.perf_counter() - t0
 
+
+if os.environ.get("PROBE_MAIN_FIRST"):   # what bench.py does before its in-flight pass: a context on the default stream
+    from gauspcc_amd.pcc_utils import _decode_bytes, _encode_view
+    x0 = torch.tensor(synthetic_cloud(n, seed=1234), device=dev)
+    for _ in range(2):
+        d0, _ = _encode_view(x0, model, 10, 1)
+        _decode_bytes(d0, model, dev)
+    torch.cuda.synchronize()
 
 for S in (1, 2, 3):
     xs = [torch.tensor(synthetic_cloud(n, seed=1234 + i), device=dev) for i in range(S)]

@@ -722,6 +722,15 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
 
 }  // namespace
 
+// developer / test knob: scales the first workspace estimate of both calls, so that the grow-and-retry path (a level of the
+// tree, the tile pool, the rank pass on the second stream or a feature buffer running out of arena) can be driven on purpose
+static size_t arena_scaled(size_t want)
+{
+    static double scale = -1.0;
+    if (scale < 0.0) { const char *e = getenv("GAUSPCC_ARENA_SCALE"); scale = e ? atof(e) : 1.0; if (!(scale > 0.0)) scale = 1.0; }
+    return scale == 1.0 ? want : std::max<size_t>((size_t)((double)want * scale), (size_t)1 << 20);
+}
+
 extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz_dev, int64_t n, int chunk_log2, uint16_t posq_f16,
                            const uint8_t **bytes_out, int64_t *nbytes_out, gpcc_stats *stats, void *stream)
 {
@@ -730,9 +739,9 @@ extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xy
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const auto t0 = std::chrono::steady_clock::now();
-    size_t want = arena_estimate(n, m->K);
+    size_t want = arena_scaled(arena_estimate(n, m->K));
     int rc = GPCC_OK;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 6; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         rc = encode_body(ctx, m, xyz_dev, n, chunk_log2, posq_f16, bytes_out, nbytes_out, stats, st);
         if (rc != GPCC_ERR_NOMEM) break;
@@ -758,6 +767,7 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
         const int64_t npts = get32(bytes + 8 + 4 * L);
         want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
     }
+    want = arena_scaled(want);
     int rc = GPCC_OK;
     const int32_t *xyz = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {

@@ -96,3 +96,34 @@ print("digest", hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
     assert out[0] == out[1] == out[2] and int(out[0].split()[-1]) > 100_000
+
+
+def test_workspace_growth_retries_are_transparent():
+    """Both calls start from a workspace estimate and grow-and-retry when a cloud needs more (deep, sparse trees).  With the
+    estimate scaled down (GAUSPCC_ARENA_SCALE, developer knob) the arena runs out at different points of the two calls --
+    tree levels, the tile pool, the rank pass queued on the second stream with its temporaries at the top end, feature
+    buffers -- and every retry must leave nothing behind: same bitstream, same decoded order as an unconstrained run."""
+    snippet = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests import gpu_helpers as gh
+from gauspcc_amd import runtime
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+dm = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
+import hashlib
+for n, seed in ((120000, 3), (7000, 4), (40000, 5)):
+    pts = synthetic_cloud(n, seed=seed)
+    data, st = gh.encode(dm, pts, 10)
+    dec, _, _ = gh.decode(dm, data)
+    print("digest", n, hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).hexdigest())
+""" % ROOT
+    out = []
+    for env in ({}, {"GAUSPCC_ARENA_SCALE": "0.3"}, {"GAUSPCC_ARENA_SCALE": "0.12"}, {"GAUSPCC_ARENA_SCALE": "0.04"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])
+    assert len(out[0]) == 3 and out[0] == out[1] == out[2] == out[3]

@@ -72,3 +72,61 @@ def test_stage_brackets(env):
     # the algorithmic bytes of the streaming stages scale with the nodes: >= 128 B per coded node for the heads
     heads = [arr[i] for i in range(ns.value) if "heads" in arr[i].name.decode()][0]
     assert heads.bytes > 128.0 * 4 * 30_000
+
+
+def test_independent_contexts_run_concurrently():
+    """Two contexts on two host threads and streams (INTEGRATION.md: 'independent contexts ... run concurrently on one GPU';
+    bench.py's scenes_in_flight pass): every call gives the bytes and the decoded order of the same call made alone."""
+    import hashlib
+    import threading
+
+    import torch
+
+    from gauspcc_amd import _lib, runtime
+    from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+    from tests import gpu_helpers as gh
+
+    L = _lib.lib()
+    model = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
+    clouds = [synthetic_cloud(60_000, seed=11), synthetic_cloud(45_000, seed=12, negative=True)]
+    alone = []
+    for pts in clouds:
+        data, _ = gh.encode(model, pts, 10)
+        dec, _, _ = gh.decode(model, data)
+        alone.append((hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).hexdigest()))
+    xs = [torch.tensor(np.ascontiguousarray(p, dtype=np.int32), device=gh.dev()) for p in clouds]
+    ctxs = []
+    for _ in clouds:
+        h = C.c_void_p()
+        _lib.check(L.gpcc_ctx_create(0, C.byref(h)))
+        ctxs.append(h)
+    streams = [torch.cuda.Stream(device=gh.dev()) for _ in clouds]
+    got = [[] for _ in clouds]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(4):
+                pb, nb, s1 = C.c_void_p(), C.c_int64(), _lib.Stats()
+                sp = C.c_void_p(streams[i].cuda_stream)
+                _lib.check(L.gpcc_encode(ctxs[i], model.handle, xs[i].data_ptr(), xs[i].shape[0], 10, runtime.f16_bits(1), C.byref(pb), C.byref(nb), C.byref(s1), sp))
+                data = C.string_at(pb, nb.value)
+                px, nn, pq, s2 = C.c_void_p(), C.c_int64(), C.c_uint16(), _lib.Stats()
+                _lib.check(L.gpcc_decode(ctxs[i], model.handle, pb, nb.value, C.byref(px), C.byref(nn), C.byref(pq), C.byref(s2), sp))
+                out = torch.empty((nn.value, 3), dtype=torch.int32, device=gh.dev())
+                _lib.check(L.gpcc_memcpy_d2d(ctxs[i], out.data_ptr(), px, 12 * nn.value, sp))
+                streams[i].synchronize()
+                got[i].append((hashlib.sha256(data).hexdigest(), hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()))
+        except Exception as e:   # noqa: BLE001 - reported below, on the main thread
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(clouds))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for h in ctxs:
+        L.gpcc_ctx_destroy(h)
+    assert not errs, errs
+    for i in range(len(clouds)):
+        assert got[i] == [alone[i]] * 4

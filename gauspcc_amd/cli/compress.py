@@ -25,6 +25,7 @@ def build_parser():
     p.add_argument("--num_samples", default=-1, type=int, help="Use the first N files for quick testing. [-1 means test all data]")
     p.add_argument("--resultdir", type=str, default="./results", help="Folder to save result CSV files")
     p.add_argument("--prefix", type=str, default="ue_4stage_conv", help="Prefix for result CSV files")
+    p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context: one file's host work and idle device time overlap another's kernels)")
     p.add_argument("--chunk_log2", type=int, default=None, help="extension: 0 = reference container, 6..14 = chunked v1 container (default 10)")
     return p
 
@@ -66,10 +67,12 @@ def write_results_csv(rows, csvfile, with_avg):
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from . import io
+
+    io.export_hw_queues(args.jobs)
     import torch
 
     from .. import pcc_utils, runtime
-    from . import io
 
     os.makedirs(args.output_folder, exist_ok=True)
     os.makedirs(args.resultdir, exist_ok=True)
@@ -85,14 +88,22 @@ def main(argv=None):
 
     rows = []
     csvfile = os.path.join(args.resultdir, args.prefix + "_data" + str(len(files)) + ".csv")
-    for path, pts in zip(files, xyz_ls):
+
+    def one(item):
+        path, pts = item
         name = os.path.split(path)[-1]
         xyz = quantise(pts, args.is_data_pre_quantized, args.posQ, device)
         n_in = len(pts)
         r = pcc_utils.compress_point_cloud(xyz, args.ckpt, os.path.join(args.output_folder, name + ".bin"), channels=args.channels,
                                            kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
-        rows.append({"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in})
-        write_results_csv(rows, csvfile, with_avg=False)
+        return {"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in}
+
+    if args.jobs <= 1:
+        for item in zip(files, xyz_ls):
+            rows.append(one(item))
+            write_results_csv(rows, csvfile, with_avg=False)   # the reference rewrites the CSV after every file
+    else:
+        rows = io.run_jobs(one, zip(files, xyz_ls), args.jobs)
     write_results_csv(rows, csvfile, with_avg=True)
     print("Total: {total_n:d} | Average bitrate:{bpp:.3f} | Encoding time:{enc_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
         total_n=len(rows), bpp=np.mean([r["bpp"] for r in rows]), enc_time=np.mean([r["enc_time"] for r in rows]),

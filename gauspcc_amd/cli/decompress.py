@@ -19,11 +19,15 @@ def build_parser():
     p.add_argument("--channels", type=int, help="Neural network channel count", default=32)
     p.add_argument("--kernel_size", type=int, help="Convolution kernel size", default=3)
     p.add_argument("--ckpt", help="Checkpoint loading path ('synthetic[:seed]' = seeded random weights)", default="./model/KITTIDetection/ckpt_ue_4stage_conv.pt")
+    p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context)")
     return p
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    from . import io
+
+    io.export_hw_queues(args.jobs)
     import torch
 
     from .. import pcc_utils
@@ -32,13 +36,14 @@ def main(argv=None):
     files = sorted(glob(args.input_glob))
     if not files:
         raise SystemExit(f"no input files match {args.input_glob}")
-    dec_time_ls = []
-    for path in files:
+    def one(path):
         name = os.path.split(path)[-1]
         r = pcc_utils.decompress_point_cloud(path, args.ckpt, os.path.join(args.output_folder, name + ".ply"), channels=args.channels,
                                              kernel_size=args.kernel_size, is_data_pre_quantized=args.is_data_pre_quantized)
         print(f"Points after decompression: {r['num_points']}")
-        dec_time_ls.append(r["dec_time"])
+        return r["dec_time"]
+
+    dec_time_ls = io.run_jobs(one, files, args.jobs)
     print("Total: {total_n:d} | Decoding time:{dec_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
         total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=torch.cuda.max_memory_allocated() / 1024 / 1024))
     return 0

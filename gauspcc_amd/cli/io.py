@@ -61,3 +61,39 @@ def read_point_clouds(file_path_list, workers=8):
     print("Loading point clouds...")
     with ThreadPoolExecutor(max_workers=workers) as p:
         return list(p.map(read_points, file_path_list))
+
+
+def run_jobs(fn, items, jobs=1):
+    """fn(item) for every item, results in item order.  jobs > 1: that many host threads, each with its own torch stream (and,
+    through runtime.context, its own gpcc context): the files of a batch are independent, and two in flight fill what one
+    leaves idle on the GPU (the HIP runtime needs GPU_MAX_HW_QUEUES >= 3 x jobs for that, which main()
+    exports before the first GPU call)."""
+    items = list(items)
+    if jobs <= 1 or len(items) <= 1:
+        return [fn(it) for it in items]
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    tls = threading.local()
+
+    def call(it):
+        if not hasattr(tls, "stream"):
+            tls.stream = torch.cuda.Stream()
+        with torch.cuda.stream(tls.stream):
+            r = fn(it)
+            tls.stream.synchronize()
+        return r
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        return list(ex.map(call, items))
+
+
+def export_hw_queues(jobs):
+    """Before anything initialises HIP: the runtime maps a process's streams onto 4 hardware queues by default, a gpcc
+    context uses three streams."""
+    import os
+
+    if jobs > 1:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 4 * jobs)))

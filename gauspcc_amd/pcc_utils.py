@@ -111,10 +111,12 @@ def compress_point_cloud(
     N = xyz.shape[0]
     xyz = xyz.to(device).int().contiguous()          # reference: torch.cat(...).int()  (:73)
 
-    torch.cuda.synchronize(device)
+    # the reference brackets its span with device-wide syncs (:78, :189); the caller's stream is what this call's work is
+    # ordered on, and syncing only that lets other host threads keep their own calls in flight on the same GPU
+    torch.cuda.current_stream(device).synchronize()
     enc_time_start = time.time()
     data, st = _encode_view(xyz, model, chunk_log2, posQ)   # the context's pinned output buffer, written to the file as it is
-    torch.cuda.synchronize(device)
+    torch.cuda.current_stream(device).synchronize()
     enc_time_end = time.time()
 
     with open(output_path, 'wb') as f:
@@ -221,7 +223,7 @@ def decompress_point_cloud(
     with open(bin_file_path, 'rb') as f:
         data = f.read()
 
-    torch.cuda.synchronize(device)
+    torch.cuda.current_stream(device).synchronize()
     dec_time_start = time.time()
     with torch.no_grad():
         scan, posQ, st = _decode_bytes(data, model, device)
@@ -229,7 +231,7 @@ def decompress_point_cloud(
             scan = scan * posQ.item()                       # :378-379
         else:
             scan = (scan * posQ.item() - 131072) * 0.001    # :381
-    torch.cuda.synchronize(device)
+    torch.cuda.current_stream(device).synchronize()
     dec_time_end = time.time()
     dec_time = dec_time_end - dec_time_start
 

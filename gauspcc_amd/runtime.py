@@ -1,6 +1,7 @@
 """Per-device context and model cache above the C ABI (host-side plumbing only:
 PyTorch supplies device memory and the current HIP stream)."""
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -8,8 +9,27 @@ import torch
 from . import _lib
 from .model import load_state_dict, tensor_table
 
-_CTX = {}
 _MODELS = {}
+_MODELS_LOCK = threading.Lock()
+
+
+class _Contexts:
+    """The gpcc contexts of one host thread (device index -> handle).  A context serves one call at a time, so every
+    thread gets its own: two threads with their own torch streams run their calls concurrently on one GPU (two scenes in
+    flight fill what one leaves idle).  Destroyed with the thread."""
+
+    def __init__(self):
+        self.h = {}
+
+    def __del__(self):
+        try:
+            for h in self.h.values():
+                _lib.lib().gpcc_ctx_destroy(h)
+        except Exception:   # interpreter shutdown: the library may be gone already
+            pass
+
+
+_TLS = threading.local()
 
 
 def _device_index(device=None) -> int:
@@ -23,11 +43,14 @@ def _device_index(device=None) -> int:
 
 def context(device=None):
     idx = _device_index(device)
-    if idx not in _CTX:
+    own = getattr(_TLS, "ctx", None)
+    if own is None:
+        own = _TLS.ctx = _Contexts()
+    if idx not in own.h:
         h = C.c_void_p()
         _lib.check(_lib.lib().gpcc_ctx_create(idx, C.byref(h)))
-        _CTX[idx] = h
-    return _CTX[idx]
+        own.h[idx] = h
+    return own.h[idx]
 
 
 def stream_ptr(device=None):
@@ -72,9 +95,10 @@ def get_model(ckpt_path, channels=32, kernel_size=5, device=None, flip_offsets=N
     if flip_offsets is None:
         flip_offsets = os.environ.get("GAUSPCC_FLIP_OFFSETS", "0") not in ("", "0")
     key = (id(ckpt_path) if isinstance(ckpt_path, dict) else str(ckpt_path), channels, kernel_size, idx, bool(flip_offsets), offset_order)
-    if key not in _MODELS:
-        _MODELS[key] = Model(load_state_dict(ckpt_path, channels, kernel_size), channels, kernel_size, idx, bool(flip_offsets), offset_order)
-    return _MODELS[key]
+    with _MODELS_LOCK:   # threads share the models (weights are read-only on the device), only contexts are per thread
+        if key not in _MODELS:
+            _MODELS[key] = Model(load_state_dict(ckpt_path, channels, kernel_size), channels, kernel_size, idx, bool(flip_offsets), offset_order)
+        return _MODELS[key]
 
 
 def f16_bits(v) -> int:

@@ -22,10 +22,14 @@ class _Contexts:
         self.h = {}
 
     def __del__(self):
+        import sys
+
+        if sys.is_finalizing():   # at interpreter exit the HIP runtime may already be shutting down: the process ends anyway
+            return
         try:
             for h in self.h.values():
                 _lib.lib().gpcc_ctx_destroy(h)
-        except Exception:   # interpreter shutdown: the library may be gone already
+        except Exception:
             pass
 
 

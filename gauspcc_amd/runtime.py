@@ -1,6 +1,7 @@
 """Per-device context and model cache above the C ABI (host-side plumbing only:
 PyTorch supplies device memory and the current HIP stream)."""
 import ctypes as C
+import sys
 import threading
 
 import numpy as np
@@ -21,12 +22,10 @@ class _Contexts:
     def __init__(self):
         self.h = {}
 
-    def __del__(self):
-        import sys
-
-        if sys.is_finalizing():   # at interpreter exit the HIP runtime may already be shutting down: the process ends anyway
-            return
+    def __del__(self, _finalizing=sys.is_finalizing):
         try:
+            if _finalizing():   # at interpreter exit the HIP runtime may already be shutting down: the process ends anyway
+                return
             for h in self.h.values():
                 _lib.lib().gpcc_ctx_destroy(h)
         except Exception:

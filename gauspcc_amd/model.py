@@ -83,9 +83,18 @@ def load_state_dict(ckpt_path, channels: int = 32, kernel_size: int = 5):
 
     # upstream saves `net.state_dict()` (src/ai_pcc/GausPcgc/train.py:212-228) and loads it with
     # torch.load(ckpt_path, map_location=device) (pcc_utils.py:66, 267); tensors only, so weights_only loading suffices
+    # (a checkpoint that carries other pickled objects is refused: unpickling it would run its code.  A user who
+    # trusts such a file opts in with GAUSPCC_UNSAFE_CKPT=1, which is exactly what upstream's plain torch.load does.)
+    import os
+    import pickle
+
     try:
         sd = torch.load(p, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError as e:
+        if os.environ.get("GAUSPCC_UNSAFE_CKPT") != "1":
+            raise ValueError(
+                f"{p}: not a tensors-only checkpoint ({e}); set GAUSPCC_UNSAFE_CKPT=1 to unpickle it anyway "
+                "(this executes code stored in the file)") from e
         sd = torch.load(p, map_location="cpu", weights_only=False)
     if isinstance(sd, dict) and "state_dict" in sd and isinstance(sd["state_dict"], dict):
         sd = sd["state_dict"]

@@ -107,3 +107,22 @@ def test_compress_point_cloud_loads_a_torch_checkpoint(tmp_path, monkeypatch):
     monkeypatch.setenv("GAUSPCC_OFFSET_ORDER", "zyx")
     d = compress_point_cloud(pts, str(pz), str(tmp_path / "d.bin"), kernel_size=k)
     assert (tmp_path / "d.bin").read_bytes() == (tmp_path / "a.bin").read_bytes() and d["bpp"] == a["bpp"] and c["num_points"] == 20_000
+
+
+class _Marker:
+    """Module-level class: a checkpoint that pickles one of these is not 'tensors only'."""
+
+
+def test_checkpoint_with_pickled_objects_is_refused_unless_opted_in(tmp_path, monkeypatch):
+    """the loader must not fall back to full unpickling by itself (that executes code in the file)."""
+    sd = synthetic_state_dict(32, 3, seed=11)
+    p = tmp_path / "objs.pt"
+    t = {k: torch.tensor(v) for k, v in sd.items()}
+    t["extra"] = _Marker()
+    torch.save(t, p)
+    monkeypatch.delenv("GAUSPCC_UNSAFE_CKPT", raising=False)
+    with pytest.raises(ValueError, match="GAUSPCC_UNSAFE_CKPT"):
+        load_state_dict(str(p), 32, 3)
+    monkeypatch.setenv("GAUSPCC_UNSAFE_CKPT", "1")
+    got = load_state_dict(str(p), 32, 3)
+    assert isinstance(got["extra"], _Marker) and len(tensor_table(got, 32, 3)) == 39

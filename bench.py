@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--kernel-size", type=int, default=5)
     ap.add_argument("--chunk-log2", type=int, default=10)
+    ap.add_argument("--scenes-per-gpu", type=int, default=1, help="independent scenes each rank codes per step, one after the other (weak scaling: scene i of the "
+                    "batch -> rank i mod N, gauspcc_amd.dist.scenes_for_rank; BASELINE configs[3] is --gpus 8 with one or more scenes per GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=64, help="OpenMP threads of the CPU baseline (capped by the cores this process may use; the same at every --gpus)")
+    ap.add_argument("--measure-traffic", action="store_true", help="(informative) leave roofline.traffic null instead of quoting profiles/: run tools/pmc_traffic.sh for a fresh figure")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
     ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps that carry the HIP-event brackets around the conv launches (-1 = all; each bracket costs its stream ~5 us, ~0.65 ms per step)")
@@ -103,16 +107,20 @@ def main():
         dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     from gauspcc_amd import _lib, runtime
-    from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed
+    from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed, scenes_for_rank
     from gauspcc_amd.pcc_utils import _decode_bytes, _encode_view
     from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
 
     k = args.kernel_size
     sd = synthetic_state_dict(32, k)
     model = runtime.Model(sd, 32, k, local_rank)
-    seed = scene_seed(1234, rank)  # one independent scene per GPU
-    pts = synthetic_cloud(args.points, seed=seed)
-    x = torch.tensor(pts, device=device)  # inputs resident in HBM before the timed region
+    # the batch: scenes_per_gpu x world independent scenes, scene i on rank i mod world (scene i of rank r at K = 1 is scene r)
+    K = max(1, args.scenes_per_gpu)
+    my_scenes = scenes_for_rank(K * world, rank, world)
+    seed = scene_seed(1234, my_scenes[0])
+    clouds = [synthetic_cloud(args.points, seed=scene_seed(1234, s)) for s in my_scenes]
+    xs_batch = [torch.tensor(c, device=device) for c in clouds]  # inputs resident in HBM before the timed region
+    pts, x = clouds[0], xs_batch[0]
     ctx = runtime.context(device)
     L = _lib.lib()
 
@@ -123,14 +131,18 @@ def main():
             torch.cuda.synchronize(device)
 
     def step():
-        t0 = time.perf_counter()
-        data, st = _encode_view(x, model, args.chunk_log2, 1)   # the bitstream stays in the library's pinned host buffer
-        torch.cuda.synchronize(device)
-        t1 = time.perf_counter()
-        dec, _, _ = _decode_bytes(data, model, device)
-        torch.cuda.synchronize(device)
-        t2 = time.perf_counter()
-        return data, st, dec, t1 - t0, t2 - t1
+        te = td = 0.0
+        for xi in reversed(xs_batch):   # scene 0 last: `data` / `dec` of the step are its (checked after the timed region)
+            t0 = time.perf_counter()
+            data, st = _encode_view(xi, model, args.chunk_log2, 1)   # the bitstream stays in the library's pinned host buffer
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            dec, _, _ = _decode_bytes(data, model, device)
+            torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            te += t1 - t0
+            td += t2 - t1
+        return data, st, dec, te, td
 
     for _ in range(args.warmup):
         step()
@@ -245,13 +257,17 @@ def main():
     if rank == 0:
         # HBM traffic of the conv kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_conv.json")) as f:
-                traffic = round(json.load(f)["hbm_bytes_per_launch"])
-        except Exception:
-            pass
-        total_points = args.points * world * args.steps
+        traffic, traffic_source = None, None
+        if not args.measure_traffic:
+            for name in ("r03_pmc_conv.json", "r02_pmc_conv.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                    traffic_source = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh; not measured in this run)"
+                    break
+                except Exception:
+                    pass
+        total_points = args.points * world * K * args.steps
         value = total_points / elapsed / 1e6
         conv_flops = 2.0 * 32 * 32 * prof.conv_pair_jobs
         achieved = conv_flops / (prof.conv_ms * 1e-3) / 1e12 if prof.conv_ms > 0 else 0.0
@@ -271,14 +287,16 @@ def main():
             "config": {
                 "workload": "GausPcgc encode+decode of one synthetic anchor cloud per GPU (BASELINE configs[1])",
                 "points_per_scene": args.points,
-                "scenes_per_gpu": 1,
+                "scenes_per_gpu": K,
                 "channels": 32,
                 "kernel_size": k,
                 "container": f"v2 (per-level chunks, chunk_log2<={args.chunk_log2})" if args.chunk_log2 else "v0 (reference layout)",
                 "weights": "seeded synthetic (reference initialisers, conv gain 4)",
             },
-            "enc_ms": round(float(allstats[:, 1].mean()) * 1e3, 3),
-            "dec_ms": round(float(allstats[:, 2].mean()) * 1e3, 3),
+            "enc_ms": round(float(allstats[:, 1].mean()) * 1e3 / K, 3),     # per scene
+            "dec_ms": round(float(allstats[:, 2].mean()) * 1e3 / K, 3),
+            # aggregate encode-only rate of the batch (configs[3] is an encode batch): all scenes / the slowest rank's encode time
+            "enc_value": round(args.points * world * K / float(allstats[:, 1].max()) / 1e6, 4),
             "bpp": round(float(allstats[:, 0].mean()) * 8 / args.points, 4),
             # The chunked container pays a fixed number of bytes per chunk (u16 count + coder flush) for its parallel decode.
             # The seeded random weights code ~22 bpp; a trained model at a few bpp shrinks the payload, not this overhead, so
@@ -300,6 +318,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "algorithmic_per_launch": conv_flops / max(prof.conv_launches, 1),
                 "launches": int(prof.conv_launches),
                 "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
@@ -313,10 +332,11 @@ def main():
                 "stages": stages,
             },
         }
-        if args.cpu_sample > 0:
+        if args.cpu_sample > 0 and world == 1:   # the CPU baseline is a rank-0, N = 1 figure
             from gauspcc_amd.model import tensor_table
             from oracle import oracle as orc
 
+            threads = orc.set_threads(max(1, min(args.cpu_threads, len(os.sched_getaffinity(0)))))
             om = orc.Model(tensor_table(sd, 32, k), 32, k)
             sp = synthetic_cloud(args.cpu_sample, seed=seed)
             t0 = time.perf_counter()
@@ -328,10 +348,11 @@ def main():
             out["cpu_baseline"] = {
                 "value": round(args.cpu_sample / (t2 - t0) / 1e6, 5),
                 "unit": "Mpoints/s",
-                "cores": len(os.sched_getaffinity(0)),
+                "cores": threads,
                 "kind": "port",
                 "sample": f"oracle encode+decode of a {args.cpu_sample}-point cloud from the same generator "
-                          f"(enc {t1 - t0:.2f} s, dec {t2 - t1:.2f} s; OpenMP convs, single-thread range coder as torchac)",
+                          f"(enc {t1 - t0:.2f} s, dec {t2 - t1:.2f} s; {threads} OpenMP threads for the convolutions and heads, "
+                          f"single-thread range coder as torchac; the box has {len(os.sched_getaffinity(0))} cores)",
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

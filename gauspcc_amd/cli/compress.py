@@ -4,6 +4,12 @@ Same flags, defaults, `.bin` naming (<file name>.bin in --output_folder), CSV
 (<resultdir>/<prefix>_data<N>.csv with columns filedir,bpp,enc_time,file_size_bits,num_points and a
 final `avg` row) and summary line.  The per-file codec is gauspcc_amd.pcc_utils.compress_point_cloud
 (libgauspcc on the MI355X).  --chunk_log2 0 writes the reference's container.
+
+Batches shard over the GPUs of a node (BASELINE configs[3]): `--gpus N`, or the same command under
+`python -m torch.distributed.run --nproc-per-node N --module gauspcc_amd.cli.compress ...`.  File i of the sorted list
+goes to rank i mod N; every rank has its own device, model replica and output files, nothing is exchanged on the data
+path; one all_gather collates the per-file rows (gauspcc_amd.dist.collate_stats) and rank 0 writes the ONE CSV, in
+input order with the `avg` row, exactly as a single process would.
 """
 import argparse
 import os
@@ -26,7 +32,9 @@ def build_parser():
     p.add_argument("--resultdir", type=str, default="./results", help="Folder to save result CSV files")
     p.add_argument("--prefix", type=str, default="ue_4stage_conv", help="Prefix for result CSV files")
     p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context: one file's host work and idle device time overlap another's kernels)")
-    p.add_argument("--chunk_log2", type=int, default=None, help="extension: 0 = reference container, 6..14 = chunked v1 container (default 10)")
+    p.add_argument("--chunk_log2", type=int, default=None, help="extension: 0 = reference container, 6..14 = chunked container (default: pcc_utils.DEFAULT_CHUNK_LOG2)")
+    p.add_argument("--gpus", type=int, default=1, help="extension: shard the files over this many GPUs of the node, one process per GPU (file i -> rank i mod N)")
+    p.add_argument("--selftest-stub", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the sharding / collation path without a GPU
     return p
 
 
@@ -65,26 +73,52 @@ def write_results_csv(rows, csvfile, with_avg):
     return df
 
 
+def _stub_codec(path, pts, out_path):
+    """Deterministic stand-in for the device codec (tests of the sharding path on CPU ranks): a 'bitstream' whose size
+    depends on the file's content only."""
+    import zlib
+
+    a = np.ascontiguousarray(np.asarray(pts, dtype=np.float64))
+    blob = zlib.compress(a.tobytes(), 1)
+    with open(out_path, "wb") as f:
+        f.write(blob)
+    return {"file_size_bits": 8 * len(blob), "enc_time": 0.001 * (1 + len(a) % 7)}
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     from . import io
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # start the ranks ourselves, BEFORE anything here touches a GPU (gauspcc_amd.dist.launch_ranks); relay their exit code
+        import sys
+
+        from ..dist import launch_ranks
+
+        return launch_ranks("gauspcc_amd.cli.compress", sys.argv[1:] if argv is None else list(argv), args.gpus, module=True)
     io.export_hw_queues(args.jobs)
     import torch
 
-    from .. import pcc_utils, runtime
+    from .. import dist as gdist
 
+    rank, world, device = gdist.init_from_env(prefer_gpu=not args.selftest_stub)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     os.makedirs(args.output_folder, exist_ok=True)
     os.makedirs(args.resultdir, exist_ok=True)
     files = list_inputs(args.input_glob, args.num_samples)
     if not files:
         raise SystemExit(f"no input files match {args.input_glob}")
-    xyz_ls = io.read_point_clouds(files)
-    device = torch.device("cuda", torch.cuda.current_device())
-    runtime.get_model(args.ckpt, args.channels, args.kernel_size, device)   # load once, outside the timed span (:67-70)
-    # warm-up like :72-75: one small random cloud through the whole path
-    warm = torch.unique(torch.randint(0, 2048, (2048, 3), dtype=torch.int32), dim=0).to(device)
-    pcc_utils._encode_to_bytes(warm, runtime.get_model(args.ckpt, args.channels, args.kernel_size, device), 0, 1)
+    mine = gdist.scenes_for_rank(len(files), rank, world)          # file i -> rank i mod world
+    my_files = [files[i] for i in mine]
+    xyz_ls = io.read_point_clouds(my_files) if my_files else []
+    if not args.selftest_stub:
+        from .. import pcc_utils, runtime
+
+        runtime.get_model(args.ckpt, args.channels, args.kernel_size, device)   # load once, outside the timed span (:67-70)
+        # warm-up like :72-75: one small random cloud through the whole path
+        warm = torch.unique(torch.randint(0, 2048, (2048, 3), dtype=torch.int32), dim=0).to(device)
+        pcc_utils._encode_to_bytes(warm, runtime.get_model(args.ckpt, args.channels, args.kernel_size, device), 0, 1)
 
     rows = []
     csvfile = os.path.join(args.resultdir, args.prefix + "_data" + str(len(files)) + ".csv")
@@ -92,23 +126,49 @@ def main(argv=None):
     def one(item):
         path, pts = item
         name = os.path.split(path)[-1]
-        xyz = quantise(pts, args.is_data_pre_quantized, args.posQ, device)
         n_in = len(pts)
-        r = pcc_utils.compress_point_cloud(xyz, args.ckpt, os.path.join(args.output_folder, name + ".bin"), channels=args.channels,
-                                           kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
+        out_path = os.path.join(args.output_folder, name + ".bin")
+        if args.selftest_stub:
+            r = _stub_codec(path, pts, out_path)
+        else:
+            xyz = quantise(pts, args.is_data_pre_quantized, args.posQ, device)
+            r = pcc_utils.compress_point_cloud(xyz, args.ckpt, out_path, channels=args.channels,
+                                               kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
         return {"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in}
 
-    if args.jobs <= 1:
-        for item in zip(files, xyz_ls):
+    if args.jobs <= 1 or world > 1:
+        for item in zip(my_files, xyz_ls):
             rows.append(one(item))
-            write_results_csv(rows, csvfile, with_avg=False)   # the reference rewrites the CSV after every file
+            if world == 1:
+                write_results_csv(rows, csvfile, with_avg=False)   # the reference rewrites the CSV after every file
     else:
-        rows = io.run_jobs(one, zip(files, xyz_ls), args.jobs)
-    write_results_csv(rows, csvfile, with_avg=True)
-    print("Total: {total_n:d} | Average bitrate:{bpp:.3f} | Encoding time:{enc_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
-        total_n=len(rows), bpp=np.mean([r["bpp"] for r in rows]), enc_time=np.mean([r["enc_time"] for r in rows]),
-        memory=torch.cuda.max_memory_allocated() / 1024 / 1024))
-    print("Results saved to ", csvfile)
+        # files in flight share the GPU: a file's enc_time is its wall-clock span UNDER CONTENTION (longer than alone; the
+        # batch finishes sooner).  The CSV grows as files complete, in input order, so a failing job loses only its own row.
+        def done(results):
+            write_results_csv([r for r in results if r is not None], csvfile, with_avg=False)
+
+        rows = io.run_jobs(one, zip(my_files, xyz_ls), args.jobs, on_progress=done)
+    if world > 1:
+        # one all_gather of the per-file records; every rank learns every row, rank 0 writes them in input order
+        local = [gdist.SceneStats(num_points=r["num_points"], num_bytes=r["file_size_bits"] // 8, enc_s=r["enc_time"]) for r in rows]
+        allst = gdist.collate_stats(local, device)
+        order = gdist.scene_order(len(files), world)
+        rows = [None] * len(files)
+        for pos, s in zip(order, allst):
+            rows[pos] = {"filedir": os.path.split(files[pos])[-1], "bpp": 8.0 * s.num_bytes / s.num_points, "enc_time": s.enc_s,
+                         "file_size_bits": 8 * s.num_bytes, "num_points": s.num_points}
+    if rank == 0:
+        write_results_csv(rows, csvfile, with_avg=True)
+        mem = torch.cuda.max_memory_allocated() / 1024 / 1024 if device.type == "cuda" else 0.0
+        print("Total: {total_n:d} | Average bitrate:{bpp:.3f} | Encoding time:{enc_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
+            total_n=len(rows), bpp=np.mean([r["bpp"] for r in rows]), enc_time=np.mean([r["enc_time"] for r in rows]), memory=mem)
+            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight (times under contention)" if args.jobs > 1 and world == 1 else ""))
+        print("Results saved to ", csvfile)
+    if world > 1:
+        import torch.distributed as td
+
+        td.barrier()
+        td.destroy_process_group()
     return 0
 
 

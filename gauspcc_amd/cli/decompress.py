@@ -2,6 +2,8 @@
 
 Same flags and defaults; each <name>.bin becomes <output_folder>/<name>.bin.ply (:64) and the summary
 line reports the mean decoding time.  The per-file codec is pcc_utils.decompress_point_cloud.
+`--gpus N` (or torch.distributed.run --module gauspcc_amd.cli.decompress) shards the files like the compressor does:
+file i -> rank i mod N, one all_gather of the per-file decoding times, rank 0 prints the one summary line.
 """
 import argparse
 import os
@@ -20,6 +22,7 @@ def build_parser():
     p.add_argument("--kernel_size", type=int, help="Convolution kernel size", default=3)
     p.add_argument("--ckpt", help="Checkpoint loading path ('synthetic[:seed]' = seeded random weights)", default="./model/KITTIDetection/ckpt_ue_4stage_conv.pt")
     p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context)")
+    p.add_argument("--gpus", type=int, default=1, help="extension: shard the files over this many GPUs of the node, one process per GPU (file i -> rank i mod N)")
     return p
 
 
@@ -27,15 +30,24 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     from . import io
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import sys
+
+        from ..dist import launch_ranks
+
+        return launch_ranks("gauspcc_amd.cli.decompress", sys.argv[1:] if argv is None else list(argv), args.gpus, module=True)
     io.export_hw_queues(args.jobs)
     import torch
 
+    from .. import dist as gdist
     from .. import pcc_utils
 
+    rank, world, device = gdist.init_from_env()
     os.makedirs(args.output_folder, exist_ok=True)
-    files = sorted(glob(args.input_glob))
-    if not files:
+    all_files = sorted(glob(args.input_glob))
+    if not all_files:
         raise SystemExit(f"no input files match {args.input_glob}")
+    files = [all_files[i] for i in gdist.scenes_for_rank(len(all_files), rank, world)]
     def one(path):
         name = os.path.split(path)[-1]
         r = pcc_utils.decompress_point_cloud(path, args.ckpt, os.path.join(args.output_folder, name + ".ply"), channels=args.channels,
@@ -44,8 +56,18 @@ def main(argv=None):
         return r["dec_time"]
 
     dec_time_ls = io.run_jobs(one, files, args.jobs)
-    print("Total: {total_n:d} | Decoding time:{dec_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
-        total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=torch.cuda.max_memory_allocated() / 1024 / 1024))
+    if world > 1:
+        allst = gdist.collate_stats([gdist.SceneStats(dec_s=t) for t in dec_time_ls], device)
+        dec_time_ls = [s.dec_s for s in allst]
+    if rank == 0:
+        print("Total: {total_n:d} | Decoding time:{dec_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
+            total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=torch.cuda.max_memory_allocated() / 1024 / 1024)
+            + (f" | {world} ranks" if world > 1 else ""))
+    if world > 1:
+        import torch.distributed as td
+
+        td.barrier()
+        td.destroy_process_group()
     return 0
 
 

@@ -63,14 +63,20 @@ def read_point_clouds(file_path_list, workers=8):
         return list(p.map(read_points, file_path_list))
 
 
-def run_jobs(fn, items, jobs=1):
-    """fn(item) for every item, results in item order.  jobs > 1: that many host threads, each with its own torch stream (and,
+def run_jobs(fn, items, jobs=1, on_progress=None):
+    """fn(item) for every item, results in item order (on_progress(results) after each completed item, with None for the
+    items still running: the compress CLI rewrites its CSV there).  jobs > 1: that many host threads, each with its own torch stream (and,
     through runtime.context, its own gpcc context): the files of a batch are independent, and two in flight fill what one
     leaves idle on the GPU (the HIP runtime needs GPU_MAX_HW_QUEUES >= 3 x jobs for that, which main()
     exports before the first GPU call)."""
     items = list(items)
     if jobs <= 1 or len(items) <= 1:
-        return [fn(it) for it in items]
+        out = []
+        for it in items:
+            out.append(fn(it))
+            if on_progress:
+                on_progress(out + [None] * (len(items) - len(out)))
+        return out
     import threading
     from concurrent.futures import ThreadPoolExecutor
 
@@ -86,8 +92,26 @@ def run_jobs(fn, items, jobs=1):
             tls.stream.synchronize()
         return r
 
+    results = [None] * len(items)
+    lock = threading.Lock()
     with ThreadPoolExecutor(max_workers=jobs) as ex:
-        return list(ex.map(call, items))
+        futs = {ex.submit(call, it): i for i, it in enumerate(items)}
+        from concurrent.futures import as_completed
+
+        err = None
+        for f in as_completed(futs):
+            try:
+                r = f.result()
+            except Exception as e:   # keep the rows of the other jobs; re-raise when all are done
+                err = err or e
+                continue
+            with lock:
+                results[futs[f]] = r
+                if on_progress:
+                    on_progress(list(results))
+        if err is not None:
+            raise err
+    return results
 
 
 def export_hw_queues(jobs):

@@ -37,7 +37,13 @@ constexpr int SC_WAVES = CONV_SC_WAVES_N;   // waves per workgroup of k_sparse_c
 // the eight steps of an iteration read -- up to 15 tiles ahead -- by immediate offsets): neighbour rows 48 x 16 dwords |
 // output slots 48 x 4 dwords (16 bytes a tile) | kernel offsets 48 dwords
 constexpr int HDR_R = 768, HDR_O = 960, HDR_DWORDS = 1008;
-__host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * 32 + HDR_DWORDS; }
+// A row's 32 sums take CONV_LDS_ROW_BYTES (conv_loop_gfx950.inc) = 144 bytes of LDS, not 128: a tile's 16 rows are mostly
+// consecutive slots, and at a 128-byte pitch lane e's 16 bytes of row e fall on the same four banks for every e -- an
+// 8-way conflict on each 8-lane group of ds_write_b128 (64 LDS cycles an instruction instead of 8), 4-5-way on
+// ds_read_b128.  One 16-byte pad per row rotates consecutive rows over the bank quads.
+constexpr int ROWF = CONV_LDS_ROW_BYTES / 4;
+static_assert(ROWF >= 32 && ROWF % 4 == 0, "row pitch: whole 16-byte units");
+__host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * ROWF + HDR_DWORDS; }
 
 // ------------------------------------------------------------------ block policy
 int conv_pick_rows(int64_t n, int k)
@@ -146,10 +152,11 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     // tile-header ring: 32 slots = two batches of 16 tiles (neighbour rows 32 x 16 dwords, output rows 32 x 4 dwords,
     // offsets 32 dwords).  The tile list of a block is streamed from HBM exactly once, so its latency is the full
     // DRAM latency: a batch is fetched with three wide loads a whole batch ahead of its first use.
-    int32_t *hdr = reinterpret_cast<int32_t *>(acc + (R + 1) * 32);
+    int32_t *hdr = reinterpret_cast<int32_t *>(acc + (R + 1) * ROWF);
+    constexpr int RQ = ROWF / 4;                // 16-byte units per LDS row
 #pragma unroll
-    for (int it = 0; it < (R * 8 + 63) / 64; ++it)
-        if (it * 64 + lane < R * 8) acc4[8 + it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // slots 1..R
+    for (int it = 0; it < (R * RQ + 63) / 64; ++it)
+        if (it * 64 + lane < R * RQ) acc4[RQ + it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // slots 1..R
     const int e = lane & 15, g = lane >> 4;
     // column of this lane inside an accumulator row (physical order) for output halves 0 / 1
     const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
         int row[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            row[k] = (int)((p.r4 >> (8 * k)) & 255u) * 32;
+            row[k] = (int)((p.r4 >> (8 * k)) & 255u) * ROWF;
             s0[k] = acc[row[k] + col0];
             s1[k] = acc[row[k] + col1];
         }
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     auto accumulate = [&](const PT &p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int row = (int)((p.r4 >> (8 * k)) & 255u) * 32;
+            const int row = (int)((p.r4 >> (8 * k)) & 255u) * ROWF;
             acc[row + col0] = acc[row + col0] + p.c0[k];
             acc[row + col1] = acc[row + col1] + p.c1[k];
         }
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
         if constexpr (ASM) {
             uint32_t su, st0, st1;
             const uint32_t acc_lds = __builtin_amdgcn_groupstaticsize() + (uint32_t)(wave * CONV_LDS_WAVE * 4);
-            const uint32_t hdr_lds = acc_lds + (uint32_t)((R + 1) * 128);
+            const uint32_t hdr_lds = acc_lds + (uint32_t)((R + 1) * ROWF * 4);
 #ifdef CONV_LOOP_STAMPS
             uint32_t sw0, sw1, sw2, sw3;
             asm volatile(CONV_LOOP_ASM
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
         const bool has_res = J.res != nullptr;
         const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8;
         float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8;
-        const float4 *src = acc4 + 8;               // slot 1 = row 0
+        const float4 *src = acc4 + RQ + (lane >> 3) * RQ + (lane & 7);   // slot 1 = row 0; a wave instruction copies 8 rows
         constexpr int NG = (R * 8 + 63) / 64;       // 8-row groups of a full-height block
         constexpr int NB = (NG + 7) / 8;            // batches of 8 groups
         float4 r[NG];
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
                 float4 v[8];
 #pragma unroll
                 for (int b = 0; b < 8; ++b)
-                    if (bt * 8 + b < NG) v[b] = src[(bt * 8 + b) * 64 + lane];
+                    if (bt * 8 + b < NG) v[b] = src[(bt * 8 + b) * 8 * RQ];
                 if (has_res) {
 #pragma unroll
                     for (int b = 0; b < 8; ++b)

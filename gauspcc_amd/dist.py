@@ -85,15 +85,39 @@ def free_port() -> int:
         return s.getsockname()[1]
 
 
-def launch_ranks(script: str, argv, nproc: int, port: int = 0) -> int:
+def launch_ranks(script: str, argv, nproc: int, port: int = 0, module: bool = False) -> int:
     """Start `nproc` ranks of `script` on this node, one per GPU, the way the driver does:
-    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv`.
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv`
+    (module=True: `script` is a module name, started as `... --module script argv`).
     Called by a parent that has NOT touched the GPU (an exec / fork from a process with an initialised HIP runtime takes the
     box down); the children are ordinary subprocesses whose stdout / stderr pass straight through (rank 0 prints the JSON
     line), and the launcher's exit code is returned."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port or free_port()), script] + list(argv)
+           "--master-port", str(port or free_port())] + (["--module"] if module else []) + [script] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool: RCCL needs it
     env.setdefault("OMP_NUM_THREADS", "8")
     return subprocess.call(cmd, env=env)
+
+
+def init_from_env(prefer_gpu: bool = True):
+    """Process group of a rank started by torch.distributed.run (RANK / WORLD_SIZE / MASTER_* in the environment): RCCL
+    ("nccl") with the rank's own GPU, gloo without one.  Returns (rank, world, device); (0, 1, device) outside a launcher."""
+    import torch.distributed as dist
+
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = prefer_gpu and torch.cuda.is_available()
+    device = torch.device("cuda", local) if gpu else torch.device("cpu")
+    if gpu:
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        if gpu:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
+    return rank, world, device
+
+
+def scene_order(n_scenes: int, world: int):
+    """collate_stats returns records ordered by (rank, local index); scene_order(n, world)[p] is the scene of position p."""
+    return [s for r in range(world) for s in scenes_for_rank(n_scenes, r, world)]

@@ -31,6 +31,8 @@ def lib():
         L = C.CDLL(so)
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
         L.orc_last_error.restype = C.c_char_p
+        L.orc_set_threads.restype = i32
+        L.orc_set_threads.argtypes = [i32]
         L.orc_tree_build.restype = vp
         L.orc_tree_build.argtypes = [vp, i64]
         L.orc_tree_free.argtypes = [vp]
@@ -64,6 +66,11 @@ def lib():
         L.orc_raster_forward.argtypes = [i32, vp, i32, i32, vp, vp, vp, vp, C.c_float, vp, vp, vp, C.c_float, C.c_float, vp, vp]
         _LIB = L
     return _LIB
+
+
+def set_threads(n: int = 0) -> int:
+    """Pin the OpenMP thread count of the oracle's parallel loops (0: leave it); returns the count in force."""
+    return int(lib().orc_set_threads(int(n)))
 
 
 def _p(a):

@@ -76,3 +76,33 @@ def test_bench_relays_a_failing_rank():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--points", "1000", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode != 0
+
+
+def test_batch_cli_two_ranks_write_the_csv_of_one_rank(tmp_path):
+    """BASELINE configs[3] entry point (reference batch driver: compress_ue_4stage_conv.py:56-62,245-286): the compress CLI
+    under two gloo ranks -- file i on rank i mod 2, per-file rows through dist.collate_stats, rank 0 writes the one CSV --
+    gives the CSV (input order, avg row) and the .bin files of a single process.  Stub codec: no GPU here."""
+    import numpy as np
+    import pandas as pd
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(5)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i in range(5):
+        np.save(src / f"c{i}.npy", rng.randint(0, 512, size=(300 + 37 * i, 3)).astype(np.float64))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    out = {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2"])):
+        cmd = [sys.executable, "-m", "gauspcc_amd.cli.compress", "--input_glob", str(src), "--output_folder", str(tmp_path / tag / "bin"),
+               "--resultdir", str(tmp_path / tag / "res"), "--ckpt", "synthetic", "--selftest-stub"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stdout.count("Total: 5 |") == 1, r.stdout        # one summary line, from rank 0
+        out[tag] = pd.read_csv(tmp_path / tag / "res" / "ue_4stage_conv_data5.csv")
+    a, b = out["one"], out["two"]
+    assert a["filedir"].tolist() == [f"c{i}.npy" for i in range(5)] + ["avg"] == b["filedir"].tolist()
+    for col in ("bpp", "enc_time", "file_size_bits", "num_points"):
+        assert np.allclose(a[col].to_numpy(), b[col].to_numpy(), rtol=1e-12), col
+    for i in range(5):
+        assert (tmp_path / "one" / "bin" / f"c{i}.npy.bin").read_bytes() == (tmp_path / "two" / "bin" / f"c{i}.npy.bin").read_bytes()

@@ -41,7 +41,8 @@ import os
 EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers
 DX = int(os.environ.get("CONV_ASM_DX", "3"))     # issue distance of the gathered rows (steps); X ring = DX + 1 sets (7: measured, no gain)
 DW = 3                                           # issue distance of the weight fragments; W ring = DW + 1 sets
-assert DX in (3, 7)
+ROWB = int(os.environ.get("CONV_ASM_ROWB", "144"))   # LDS bytes per row of running sums (128 + one 16-byte pad: bank rotation, network.hip)
+assert DX in (3, 7) and ROWB % 16 == 0 and ROWB >= 128
 NX, NW = DX + 1, DW + 1
 _x0 = 16
 _w0 = _x0 + 8 * NX
@@ -238,8 +239,8 @@ def step(du):
 
     nsx, nsw = (du + DX) % NX, (du + DW) % NW    # the sets consumed by the previous step receive tiles u+du+DX / u+du+DW
     o = [f"; ---- step: tile u+{du}: X set {du % NX}, W set {du % NW}, C/S set {cur}"] + stamp("sa", cur) + step_wait(du, label) + stamp("sb", cur) + stamp_collect(cur)
-    # slot multiplier of this tile: 128 if it exists, 0 (the dummy slot) past the end of the block's list
-    o += [f"s_add_u32 %[t0], %[u], {du}", "s_cmp_lt_u32 %[t0], %[nt]", "s_cselect_b32 %[t1], 128, 0"]
+    # slot multiplier of this tile: the row pitch if it exists, 0 (the dummy slot) past the end of the block's list
+    o += [f"s_add_u32 %[t0], %[u], {du}", "s_cmp_lt_u32 %[t0], %[nt]", f"s_cselect_b32 %[t1], {ROWB}, 0"]
     o += mf(0, True)
     # the step's only VALU burst: previous tile's products onto its rows' sums, addresses of the loads and of this tile's slot
     o += (ring_pointers() if du == 0 else [])
@@ -332,6 +333,7 @@ def main():
             print(f"{name}: {len(o)} lines")
         f.write("#define CONV_LOOP_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + (", " + ", ".join(f'"s{i}"' for i in range(60, 76)) if EXP & 8 else "")
                 + ', "vcc", "scc", "memory"\n')
+        f.write(f"#define CONV_LDS_ROW_BYTES {ROWB}\n")
         if EXP & 8:
             f.write("#define CONV_LOOP_STAMPS 1\n")
     print(f"wrote {path}")

@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--points", type=int, default=1_000_000)
     ap.add_argument("--kernel-size", type=int, default=5)
-    ap.add_argument("--chunk-log2", type=int, default=10)
+    ap.add_argument("--chunk-log2", type=int, default=11)
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="independent scenes each rank codes per step, one after the other (weak scaling: scene i of the "
                     "batch -> rank i mod N, gauspcc_amd.dist.scenes_for_rank; BASELINE configs[3] is --gpus 8 with one or more scenes per GPU)")
     ap.add_argument("--cpu-threads", type=int, default=64, help="OpenMP threads of the CPU baseline (capped by the cores this process may use; the same at every --gpus)")
@@ -290,7 +290,7 @@ def main():
                 "scenes_per_gpu": K,
                 "channels": 32,
                 "kernel_size": k,
-                "container": f"v2 (per-level chunks, chunk_log2<={args.chunk_log2})" if args.chunk_log2 else "v0 (reference layout)",
+                "container": f"v3 (per-level chunks of two coder lanes, chunk_log2<={args.chunk_log2})" if args.chunk_log2 else "v0 (reference layout)",
                 "weights": "seeded synthetic (reference initialisers, conv gain 4)",
             },
             "enc_ms": round(float(allstats[:, 1].mean()) * 1e3 / K, 3),     # per scene
@@ -298,7 +298,7 @@ def main():
             # aggregate encode-only rate of the batch (configs[3] is an encode batch): all scenes / the slowest rank's encode time
             "enc_value": round(args.points * world * K / float(allstats[:, 1].max()) / 1e6, 4),
             "bpp": round(float(allstats[:, 0].mean()) * 8 / args.points, 4),
-            # The chunked container pays a fixed number of bytes per chunk (u16 count + coder flush) for its parallel decode.
+            # The chunked container pays a fixed number of bytes per chunk (LEB128 count + two coder flushes) for its parallel decode.
             # The seeded random weights code ~22 bpp; a trained model at a few bpp shrinks the payload, not this overhead, so
             # it is also quoted against a 4 bpp payload (HAC-class rates).  chunk_log2 = 0 writes bytes_v0 exactly.
             "container_bytes": len(data),

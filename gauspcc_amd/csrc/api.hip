@@ -500,6 +500,9 @@ extern "C" int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int c
     return GPCC_OK;
 }
 
+// One stream of the container as gpcc_encode writes it for a level of n nodes (rangecoder.hpp: rc_plan, version 3):
+// chunk_log2 = 0 -> one lane, the bare coder bytes; else the LEB128 chunk table, then the chunks (forward lane + reversed
+// backward lane each).
 extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *sym_dev, int64_t n, int chunk_log2,
                               const uint8_t **bytes_out, int64_t *nbytes_out, void *stream)
 {
@@ -507,30 +510,36 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
-    const int nch = (int)cdiv(n, S);
+    const RcPlan pl = rc_plan(n, chunk_log2, 3);
+    const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : n;
+    const int nch = (int)pl.nlanes;
     const uint32_t stride = rc_scratch_stride((uint32_t)std::min<int64_t>(S, n));
     GP_TRY(ctx->arena.reserve((size_t)n * 8 + (size_t)nch * S * 4 + 2 * (size_t)nch * stride + ((size_t)4 << 20)));
     ctx->arena.reset();
     std::vector<RcChunk> chunks((size_t)nch);
-    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, n - c * S), 0, 0, 0};
+    for (int c = 0; c < nch; ++c) chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)pl.lane_syms(n, (uint32_t)c), 0, 0, 0};
     TAKE(lohi, uint32_t, (int64_t)nch * S); TAKE(dch, RcChunk, nch); TAKE(dcnt, uint32_t, nch + 1); TAKE(doff, uint32_t, nch + 1);
     TAKE(scratch, uint8_t, (size_t)nch * stride); TAKE(payload, uint8_t, (size_t)nch * stride);
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    GP_TRY(rc_pack_lohi(st, cdf_dev, lp, sym_dev, n, chunk_log2, lohi));
+    GP_TRY(rc_pack_lohi(st, cdf_dev, lp, sym_dev, n, pl.llog, (uint32_t)nch, lohi));
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
-    GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nullptr, nch, payload));
+    GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nullptr, nch, payload, pl.dual ? dch : nullptr));
     std::vector<uint32_t> hcnt((size_t)nch + 1);
     HIP_TRY(hipMemcpyAsync(hcnt.data(), dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hcnt.data() + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    const size_t total = hcnt[(size_t)nch], hdr = chunk_log2 ? 2 * (size_t)nch : 0;
+    const size_t total = hcnt[(size_t)nch];
+    size_t hdr = 0;
+    if (chunk_log2)
+        for (int c = 0; c < nch; c += 2) hdr += rc_varint_size(hcnt[(size_t)c] + (c + 1 < nch ? hcnt[(size_t)c + 1] : 0u));
     GP_TRY(ctx->hbytes.reserve(total + hdr + 16));
     uint8_t *out = ctx->hbytes.p;
-    if (chunk_log2)
-        for (int c = 0; c < nch; ++c) { out[2 * c] = (uint8_t)hcnt[(size_t)c]; out[2 * c + 1] = (uint8_t)(hcnt[(size_t)c] >> 8); }
+    if (chunk_log2) {
+        size_t p = 0;
+        for (int c = 0; c < nch; c += 2) p += rc_varint_put(out + p, hcnt[(size_t)c] + (c + 1 < nch ? hcnt[(size_t)c + 1] : 0u));
+    }
     if (total) HIP_TRY(hipMemcpyAsync(out + hdr, payload, total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *bytes_out = out; *nbytes_out = (int64_t)(total + hdr);
@@ -540,31 +549,29 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
 extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *bytes, int64_t nbytes, int64_t n,
                               int chunk_log2, uint8_t *sym_dev, void *stream)
 {
-    if (!ctx || !cdf_dev || !bytes || !sym_dev || n <= 0) return fail(GPCC_ERR_ARG, "bad argument");
+    if (!ctx || !cdf_dev || !bytes || !sym_dev || n <= 0 || nbytes < 0) return fail(GPCC_ERR_ARG, "bad argument");
+    if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const int64_t S = chunk_log2 ? (int64_t)1 << chunk_log2 : n;
-    const int nch = (int)cdiv(n, S);
-    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + (size_t)nch * S * 32 + ((size_t)4 << 20)));
+    const RcPlan pl = rc_plan(n, chunk_log2, 3);
+    const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : n;
+    const int nch = (int)pl.nlanes;
+    GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + (size_t)rc_rows_capacity(nch, S) * 32 + (size_t)n + ((size_t)4 << 20)));
     ctx->arena.reset();
     std::vector<RcChunk> chunks((size_t)nch);
-    if (chunk_log2) {
-        if (nbytes < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream shorter than its chunk table");
-        int64_t p = 2 * (int64_t)nch;
-        for (int c = 0; c < nch; ++c) {
-            const uint32_t cb = bytes[2 * c] | bytes[2 * c + 1] << 8;
-            if (p + cb > nbytes) return fail(GPCC_ERR_FORMAT, "chunk %d overruns the stream", c);
-            chunks[(size_t)c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, n - c * S), (uint32_t)(c * S), (uint32_t)p, cb};
-            p += cb;
-        }
-    } else chunks[0] = RcChunk{0, 1, (uint32_t)n, 0, 0, (uint32_t)nbytes};
-    TAKE(db, uint8_t, nbytes + 16); TAKE(dch, RcChunk, nch);
+    uint32_t win = 0;
+    constexpr int64_t FRONT = 16;   // the uploaded copy starts 16 bytes into its buffer: a backwards lane's staging loads reach up to 3 bytes in front of its chunk
+    if (const char *err = rc_parse_table(bytes, FRONT, nbytes, pl, n, chunk_log2 ? 3 : 0, chunks.data(), &win)) return fail(GPCC_ERR_FORMAT, "%s", err);
+    TAKE(db, uint8_t, nbytes + FRONT + 16); TAKE(dch, RcChunk, nch);
     TAKE(rows, uint16_t, rc_rows_capacity(nch, S) * rc_row_stride(lp) + 64);
-    GP_TRY(rc_pack_rows(st, cdf_dev, lp, n, chunk_log2, rows));
-    HIP_TRY(hipMemcpyAsync(db, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
+    TAKE(symbuf, uint8_t, n + 4);   // the decoder stores groups of four
+    GP_TRY(rc_pack_rows(st, cdf_dev, lp, n, pl.llog, (uint32_t)nch, rows));
+    HIP_TRY(hipMemsetAsync(db, 0, FRONT, st));
+    HIP_TRY(hipMemcpyAsync(db + FRONT, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, sym_dev));
+    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, symbuf));
+    HIP_TRY(hipMemcpyAsync(sym_dev, symbuf, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
 }

@@ -115,9 +115,12 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     if (coded >= ((int64_t)1 << 30)) return fail(GPCC_ERR_ARG, "too many octree nodes");
     // stream-major packed symbols: stream (d, s), d = 1..L-1, occupies slots(d) words (the chunk-interleaved
     // layout pads the last chunk): offset 4 * sum_{d' < d} slots(d') + s * slots(d)
-    constexpr int CONTAINER_VERSION = 2;
-    auto clog = [&](int64_t nc) -> int { return rc_level_chunk_log2(nc, chunk_log2, CONTAINER_VERSION); };
-    auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? cdiv(nc, (int64_t)1 << clog(nc)) << clog(nc) : nc; };
+    // (container version 3: rangecoder.hpp -- a stream is cut into LANES of 2^llog symbols, one coder state each; two lanes,
+    // one coded forwards and one backwards, share a byte-counted chunk)
+    constexpr int CONTAINER_VERSION = 3;
+    auto plan = [&](int64_t nc) -> RcPlan { return rc_plan(nc, chunk_log2, CONTAINER_VERSION); };
+    auto clog = [&](int64_t nc) -> int { return plan(nc).llog; };                       // lane size log2
+    auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? (int64_t)plan(nc).nlanes << clog(nc) : nc; };
     int64_t lohi_words = 0;
     for (int d = 1; d < L; ++d) lohi_words += 4 * slots(T.lv[d].n);
     if (lohi_words >= ((int64_t)1 << 32)) return fail(GPCC_ERR_ARG, "too many octree nodes");
@@ -147,7 +150,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 S.occ[d] = lv->occ; S.rkey[d] = lv->rkey; S.parent[d] = lv->parent; S.m2r[d] = lv->m2r;
                 if (d) {
                     S.lohi_base[d] = (uint32_t)lohi_base; S.slots[d] = (uint32_t)slots(lv->n); S.clog[d] = clog(lv->n);
-                    S.nch[d] = chunk_log2 ? (uint32_t)cdiv(lv->n, (int64_t)1 << clog(lv->n)) : 1u;
+                    S.nch[d] = plan(lv->n).nlanes;
                     lohi_base += 4 * slots(lv->n);
                 }
             }
@@ -238,45 +241,48 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             GP_TRY(head_cdf(st, ha));
         }
     }
-    // ---- range coder over every chunk of every stream
+    // ---- range coder over every lane of every stream
     const int nstreams = 4 * (L - 1);
-    std::vector<RcChunk> chunks;
-    std::vector<uint32_t> gaps;          // container bytes in front of a chunk's payload that are not payload: stream lengths + chunk tables
-    std::vector<int> stream_first(nstreams + 1, 0);
+    std::vector<RcChunk> chunks;         // one descriptor per lane
+    std::vector<uint32_t> gaps;          // reference layout: container bytes in front of a lane's payload that are not payload (the stream lengths);
+                                         // chunked: the stream of every lane (the gaps depend on the byte counts: rc_layout_launch)
+    std::vector<uint32_t> stream_first(nstreams + 1, 0);
     uint32_t max_syms = 1;
+    size_t table_bound = 0;              // most bytes the chunk tables can take
     {
         int64_t pre = 0; int si = 0;
         uint32_t gap = 0;
         for (int d = 1; d < L; ++d) {
             const int64_t nc = T.lv[d].n;
-            const int64_t S = chunk_log2 ? (int64_t)1 << clog(nc) : INT64_MAX;
+            const RcPlan pl = plan(nc);
             for (int s = 0; s < 4; ++s, ++si) {
-                stream_first[si] = (int)chunks.size();
+                stream_first[si] = (uint32_t)chunks.size();
                 const int64_t base = pre + (int64_t)s * slots(nc);
-                const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(nc, S) : 1u;
-                gap += 4u + (chunk_log2 ? 2u * nch : 0u);
-                for (uint32_t c = 0; c < nch; ++c) {
-                    const int64_t cn = chunk_log2 ? std::min<int64_t>(S, nc - (int64_t)c * S) : nc;
-                    gaps.push_back(gap);
-                    chunks.push_back(RcChunk{(uint32_t)(base + c), nch, (uint32_t)cn, 0, 0, 0});
+                gap += 4u;
+                table_bound += 5 * (size_t)pl.nchunks;
+                for (uint32_t c = 0; c < pl.nlanes; ++c) {
+                    const int64_t cn = pl.lane_syms(nc, c);
+                    gaps.push_back(chunk_log2 ? (uint32_t)si : gap);
+                    chunks.push_back(RcChunk{(uint32_t)(base + c), pl.nlanes, (uint32_t)cn, 0, 0, 0});
                     max_syms = std::max<uint32_t>(max_syms, (uint32_t)cn);
                 }
             }
             pre += 4 * slots(nc);
         }
-        stream_first[nstreams] = (int)chunks.size();
+        stream_first[nstreams] = (uint32_t)chunks.size();
     }
     const int nchunks = (int)chunks.size();
     const Level *base = &T.lv[0];
     TAKE(base_xyz, int32_t, 3 * base->n);
     TAKE(base_occ, uint8_t, base->n);
     GP_TRY(level_to_raster(ctx, st, base, T.bias, base_xyz, base_occ));
-    // staging layout (pinned): [chunk descs | cnt | pairs | base xyz | base occ | gaps]
+    // staging layout (pinned): [lane descs | cnt | pairs | base xyz | base occ | gaps or lane streams | first lane of every stream]
     const size_t off_desc = 0, off_cnt = off_desc + sizeof(RcChunk) * (size_t)std::max(nchunks, 1);
     const size_t off_pairs = off_cnt + 4 * (size_t)std::max(nchunks, 1) + 8, off_bx = off_pairs + 8 * NCOUNTERS, off_bo = off_bx + 12 * (size_t)base->n;
     const size_t off_gap = (off_bo + (size_t)base->n + 63) & ~(size_t)63;
-    GP_TRY(ctx->hstage.reserve(off_gap + 4 * (size_t)std::max(nchunks, 1) + 64));
-    const uint32_t gap_total = gaps.empty() ? 0u : gaps.back();
+    const size_t off_sf = off_gap + 4 * (size_t)std::max(nchunks, 1);
+    GP_TRY(ctx->hstage.reserve(off_sf + 4 * (size_t)(nstreams + 1) + 64));
+    const uint32_t gap_bound = 4u * (uint32_t)nstreams + (chunk_log2 ? (uint32_t)table_bound : 0u);
     uint8_t *hs = ctx->hstage.p;
     uint32_t total_payload = 0;
     uint8_t *payload_dev = nullptr;
@@ -285,6 +291,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     if (nchunks) {
         memcpy(hs + off_desc, chunks.data(), sizeof(RcChunk) * (size_t)nchunks);
         memcpy(hs + off_gap, gaps.data(), 4 * (size_t)nchunks);
+        memcpy(hs + off_sf, stream_first.data(), 4 * (size_t)(nstreams + 1));
         const uint32_t stride = rc_scratch_stride(max_syms);
         TAKE(dchunks, RcChunk, nchunks);
         TAKE(dgap, uint32_t, nchunks);
@@ -298,19 +305,27 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt + 4 * (size_t)nchunks, doff + nchunks, 4, hipMemcpyDeviceToHost, st));
-        // worst case payload = all scratch; compact into a buffer of that size -- every chunk at its final distance from the
+        // worst case payload = all scratch; compact into a buffer of that size -- every lane at its final distance from the
         // first stream's length field -- and copy back only the used part, in one piece
-        TAKE(payload, uint8_t, (size_t)nchunks * stride + gap_total + 32);
+        TAKE(payload, uint8_t, (size_t)nchunks * stride + gap_bound + 32);
         if (chunk_log2) {
             // chunked containers: the device itself moves the compacted payload into the pinned output buffer, at its final
             // place behind the header (known now: it depends on L and the base level only), so the one sync below ends the
-            // call.  The buffer is sized for the worst case (every chunk at its scratch stride).  The reference layout keeps
-            // the copy-after-sync: one chunk per stream would make that bound the size of the whole symbol array.
-            const size_t worst = pos0_hdr + (size_t)nchunks * stride + gap_total + 64;
+            // call.  The buffer is sized for the worst case (every lane at its scratch stride).  The reference layout keeps
+            // the copy-after-sync: one lane per stream would make that bound the size of the whole symbol array.
+            // The varint tables make the distance between payloads depend on the byte counts: a one-workgroup kernel turns the
+            // counts into the gap in front of every lane (the host later fills the gaps with the tables it rebuilds from the counts).
+            TAKE(dsf, uint32_t, nstreams + 1);
+            TAKE(dlst, uint32_t, nchunks);
+            TAKE(dgap_total, uint32_t, 1);
+            HIP_TRY(hipMemcpyAsync(dsf, hs + off_sf, 4 * (size_t)(nstreams + 1), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dlst, hs + off_gap, 4 * (size_t)nchunks, hipMemcpyHostToDevice, st));
+            GP_TRY(rc_layout_launch(st, dcnt, dsf, nstreams, dlst, nchunks, true, dgap, dgap_total));
+            const size_t worst = pos0_hdr + (size_t)nchunks * stride + gap_bound + 64;
             GP_TRY(ctx->hbytes.reserve(worst));
             const uint32_t mis = (uint32_t)(pos0_hdr & 15);   // same 16-byte phase on both sides: whole-word copies
-            GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload + mis));
-            GP_TRY(rc_to_host_launch(st, payload, doff + nchunks, gap_total + mis, ctx->hbytes.p + (pos0_hdr - mis)));
+            GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload + mis, dchunks));
+            GP_TRY(rc_to_host_launch(st, payload, doff + nchunks, mis, dgap_total, ctx->hbytes.p + (pos0_hdr - mis)));
             direct = true;
         } else {
             GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, dgap, nchunks, payload));
@@ -334,7 +349,17 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     }
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, set_pairs, 2));
     // ---- container
-    size_t fsize = (chunk_log2 ? 8 + 4 * (size_t)L + 4 : 2) + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams + total_payload + (chunk_log2 ? 2 * (size_t)nchunks : 0);
+    // per stream: table bytes and payload bytes, from the lane byte counts
+    std::vector<size_t> s_tab((size_t)nstreams, 0), s_pay((size_t)nstreams, 0);
+    size_t tables = 0;
+    for (int si = 0; si < nstreams; ++si) {
+        const int c0 = (int)stream_first[si], c1 = (int)stream_first[si + 1];
+        for (int c = c0; c < c1; ++c) s_pay[(size_t)si] += hcnt[c];
+        if (chunk_log2)
+            for (int c = c0; c < c1; c += 2) s_tab[(size_t)si] += rc_varint_size(hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
+        tables += s_tab[(size_t)si];
+    }
+    size_t fsize = pos0_hdr + 4 * (size_t)nstreams + total_payload + tables;
     if (direct) { if (fsize + 16 > ctx->hbytes.cap) return fail(GPCC_ERR_HIP, "internal: payload beyond its bound"); }
     else GP_TRY(ctx->hbytes.reserve(fsize + 16));
     uint8_t *out = ctx->hbytes.p;
@@ -354,29 +379,18 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     // the payload comes straight from the device into its final place in one copy; the stream lengths and chunk tables
     // are then written into the gaps it left
     {
-        const size_t pos0 = pos, body = (size_t)total_payload + gap_total;
+        const size_t pos0 = pos, body = (size_t)total_payload + 4 * (size_t)nstreams + tables;
         if (pos0 != pos0_hdr) return fail(GPCC_ERR_HIP, "internal: header size mismatch");
-        if (body && !direct) HIP_TRY(hipMemcpyAsync(out + pos0, payload_dev, body, hipMemcpyDeviceToHost, st));
-        for (int si = 0; si < nstreams; ++si) {
-            const int c0 = stream_first[si], c1 = stream_first[si + 1];
-            size_t plen = 0;
-            for (int c = c0; c < c1; ++c) plen += hcnt[c];
-            for (int c = c0; c < c1; ++c) if (chunk_log2 && hcnt[c] > 0xFFFF) return fail(GPCC_ERR_ARG, "chunk byte count overflows uint16");
-            pos += 4 + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0) + plen;
-        }
-        if (!direct) HIP_TRY(hipStreamSynchronize(st));
+        if (body && !direct) { HIP_TRY(hipMemcpyAsync(out + pos0, payload_dev, body, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
         size_t p = pos0;
         for (int si = 0; si < nstreams; ++si) {
-            const int c0 = stream_first[si], c1 = stream_first[si + 1];
-            size_t plen = 0;
-            for (int c = c0; c < c1; ++c) plen += hcnt[c];
-            const size_t slen = plen + (chunk_log2 ? 2 * (size_t)(c1 - c0) : 0);
-            put32(out + p, (uint32_t)slen); p += 4;
+            const int c0 = (int)stream_first[si], c1 = (int)stream_first[si + 1];
+            put32(out + p, (uint32_t)(s_tab[(size_t)si] + s_pay[(size_t)si])); p += 4;
             if (chunk_log2)
-                for (int c = c0; c < c1; ++c) { out[p] = (uint8_t)hcnt[c]; out[p + 1] = (uint8_t)(hcnt[c] >> 8); p += 2; }
-            p += plen;
+                for (int c = c0; c < c1; c += 2) p += rc_varint_put(out + p, hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
+            p += s_pay[(size_t)si];
         }
-        if (p != pos) return fail(GPCC_ERR_HIP, "internal: container layout mismatch");
+        pos = p;
     }
     ht.mark("enc payload d2h");
     if (pos != fsize) return fail(GPCC_ERR_HIP, "internal: container size mismatch (%zu vs %zu)", pos, fsize);
@@ -410,7 +424,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     if (v1) {
         NEED(8);
         version = in[2];
-        if (version != 1 && version != 2) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
+        if (version < 1 || version > 3) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
         chunk_log2 = in[3];
         if (chunk_log2 < 6 || chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "bad chunk_log2 %d", chunk_log2);
         *posq_out = (uint16_t)(in[4] | in[5] << 8);
@@ -487,43 +501,26 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     struct SideGuard { hipStream_t s, x; ~SideGuard() { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(x); } } side_guard{sd, ctx->xfer};   // error returns leave nothing in flight
     HIP_TRY(hipMemcpyAsync(dbytes, in, (size_t)nbytes, hipMemcpyHostToDevice, ctx->xfer));
     HIP_TRY(hipEventRecord(ctx->ev_bytes, ctx->xfer));
-    // chunk descriptors of every level are staged in pinned memory that is written once (no reuse, so no sync before
+    // lane descriptors of every level are staged in pinned memory that is written once (no reuse, so no sync before
     // a level's table may be overwritten): chunked containers know all level sizes from the header
     size_t desc_total = 0;
-    for (int g = 0; g + 1 < L; ++g) {
-        const int64_t ncg = v1 ? lvl_n[g + 1] : 0;
-        const int clog = rc_level_chunk_log2(ncg, chunk_log2, version);
-        desc_total += 4 * (size_t)(chunk_log2 ? cdiv(std::max<int64_t>(ncg, 1), (int64_t)1 << clog) : 1);
-    }
+    for (int g = 0; g + 1 < L; ++g) desc_total += 4 * (size_t)rc_plan(v1 ? lvl_n[g + 1] : 0, chunk_log2, version).nlanes;
     const size_t desc_off = (4096 + 16 * (size_t)bn + 63) & ~(size_t)63;
     GP_TRY(ctx->hstage.reserve(desc_off + sizeof(RcChunk) * desc_total + 64));
     RcChunk *hdesc = reinterpret_cast<RcChunk *>(ctx->hstage.p + desc_off);
     size_t desc_used = 0;
-    // the four chunk tables of coded level g + 1 (nc nodes), parsed from the container into the pinned staging area
+    uint32_t win_bytes[MAXLV][4] = {};   // longest byte window of a lane, per (level, stage): decides how the decoder reads it
+    // the four lane tables of coded level g + 1 (nc nodes), parsed from the container into the pinned staging area
     auto level_chunks = [&](int g, int64_t nc, size_t *at) -> int {
-        const int clog = rc_level_chunk_log2(nc, chunk_log2, version);
-        const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
-        const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
-        if (desc_used + (size_t)4 * nch > desc_total) return fail(GPCC_ERR_FORMAT, "level %d: chunk tables exceed the header's level sizes", g + 1);
-        RcChunk *chunks = hdesc + desc_used;
+        const RcPlan pl = rc_plan(nc, chunk_log2, version);
+        if (desc_used + (size_t)4 * pl.nlanes > desc_total) return fail(GPCC_ERR_FORMAT, "level %d: chunk tables exceed the header's level sizes", g + 1);
+        RcChunk *lanes = hdesc + desc_used;
         *at = desc_used;
-        desc_used += (size_t)4 * nch;
+        desc_used += (size_t)4 * pl.nlanes;
         for (int s = 0; s < 4; ++s) {
             const int si = 4 * g + s;
-            const int64_t off = s_off[si], len = s_len[si];
-            if (chunk_log2) {
-                if (len < 2 * (int64_t)nch) return fail(GPCC_ERR_FORMAT, "stream %d shorter than its chunk table", si);
-                int64_t p = off + 2 * (int64_t)nch;
-                for (int c = 0; c < nch; ++c) {
-                    const uint32_t cb = in[off + 2 * c] | in[off + 2 * c + 1] << 8;
-                    if (p + cb > off + len) return fail(GPCC_ERR_FORMAT, "stream %d chunk %d overruns the stream", si, c);
-                    chunks[(size_t)s * nch + c] = RcChunk{(uint32_t)c, (uint32_t)nch, (uint32_t)std::min<int64_t>(S, nc - (int64_t)c * S), (uint32_t)((int64_t)c * S), (uint32_t)p, cb};
-                    p += cb;
-                }
-                if (p != off + len) return fail(GPCC_ERR_FORMAT, "stream %d has trailing bytes", si);
-            } else {
-                chunks[(size_t)s] = RcChunk{0, 1, (uint32_t)nc, 0, (uint32_t)off, (uint32_t)len};
-            }
+            const char *err = rc_parse_table(in + s_off[si], s_off[si], s_len[si], pl, nc, version, lanes + (size_t)s * pl.nlanes, &win_bytes[g][s]);
+            if (err) return fail(GPCC_ERR_FORMAT, "stream %d: %s", si, err);
         }
         return GPCC_OK;
     };
@@ -623,10 +620,11 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
-        // chunk descriptors of this level's four streams (chunked containers: uploaded with the container, above)
-        const int clog = rc_level_chunk_log2(nc, chunk_log2, version);   // this level's chunk size
-        const int64_t S = chunk_log2 ? (int64_t)1 << clog : INT64_MAX;
-        const int nch = chunk_log2 ? (int)cdiv(nc, S) : 1;
+        // lane descriptors of this level's four streams (chunked containers: uploaded with the container, above)
+        const RcPlan pl = rc_plan(nc, chunk_log2, version);
+        const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : nc;   // symbols of a lane
+        const int nch = (int)pl.nlanes;
+        const int clog = pl.llog;
         const RcChunk *dchunks = nullptr;
         if (v1) {
             if (g == 0) GP_TRY(upload_tables());
@@ -642,9 +640,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, chunk_log2 ? S : nc) * 16);  // interleaved rows + the decoder's look-ahead
+        TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
-        for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc); sym[s] = sy; }
+        for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc + 4); sym[s] = sy; }   // + the last group of four of the last lane
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
             if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
@@ -664,7 +662,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
-                GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, sym[s]));
+                GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], sym[s]));
             }
         }
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ)); }
@@ -762,9 +760,18 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
     size_t want = arena_estimate(std::max<int64_t>(nbytes, 1 << 16), m->K);
     if (nbytes >= 8 && bytes[0] == 0xFF && bytes[1] == 0xFF && bytes[6] >= 1 && bytes[6] <= 21 && nbytes >= 12 + 4 * (int64_t)bytes[6]) {
         const int L = bytes[6];
-        int64_t nodes = 0, nmax = 0;
-        for (int d = 0; d < L; ++d) { const int64_t v = get32(bytes + 8 + 4 * d); nodes += v; nmax = std::max(nmax, v); }
+        int64_t nodes = 0, nmax = 0, prev = 0;
+        for (int d = 0; d < L; ++d) {
+            const int64_t v = get32(bytes + 8 + 4 * d);
+            // the cheap consistency checks BEFORE the header sizes the workspace: a base level below 64 nodes, at most 8
+            // children per node, and no more symbols than the file can carry (a lane of up to 2^14 symbols costs a table
+            // byte and a payload byte at least) -- a corrupt header of a few hundred bytes must not reserve gigabytes
+            if (v <= 0 || (d == 0 ? v >= 64 : v > 8 * prev)) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", d);
+            nodes += v; nmax = std::max(nmax, v); prev = v;
+        }
         const int64_t npts = get32(bytes + 8 + 4 * L);
+        if (npts < 1 || npts > 8 * prev) return fail(GPCC_ERR_FORMAT, "header: %lld points under %lld finest nodes", (long long)npts, (long long)prev);
+        if (nodes > (nbytes << 13)) return fail(GPCC_ERR_FORMAT, "header: %lld nodes cannot come from %lld bytes", (long long)nodes, (long long)nbytes);
         want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
     }
     want = arena_scaled(want);

@@ -13,10 +13,44 @@
 //   * bits move through a 64-bit reservoir, memory is touched 4 bytes at a time.
 // Integer / byte work; latency-bound per lane, not bandwidth-bound.
 #include "rangecoder.hpp"
+#include <type_traits>
 
 namespace gpcc {
 
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
+
+// ------------------------------------------------------------------ LDS-DMA ring (decoder: CDF rows; encoder: symbol words)
+// CDF rows run DEPTH symbols ahead of the coder through a ring -- in LDS, filled by LDS-DMA loads (global_load_lds_*: no
+// VGPR destination, so nothing the register allocator could copy, spill or reuse before the data lands; a sub-dword LDS-DMA load writes a zero-extended DWORD per lane -- tools/ubench/lds_dma_probe.hip).  A register ring
+// left to the compiler costs a full memory round trip per trip of the unrolled loop: it clusters the loads, renames the
+// ring across the back edge and waits with vmcnt(0) for loads it has just issued (measured: ~0.15 us per symbol whatever
+// the instruction count); the same ring as inline-asm loads into "=v" registers is not safe (hipcc copied a destination
+// register in front of the hand-written wait).  Slot s of the ring is 64 lanes x 4 bytes at ring + 256 s: lane l's
+// datum of row i sits at slot (i % DEPTH), offset 4 l.  Loads return in order, so with (DEPTH - 1) x LPR younger ring
+// loads in flight `vmcnt((DEPTH - 1) * LPR)` means "row i has landed" (the symbol stores count too and may retire early,
+// which only makes the wait conservative).  M0 carries the LDS destination and is compiler-reserved: saved and restored
+// inside the statement.  Single-wave workgroups and every lane reads what its own lane's DMA wrote: no barrier.
+__device__ __forceinline__ void ring_dma_u16(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// an 8-byte row as two dwords into two slots (there is no 8-byte LDS-DMA).  The instruction offset of an LDS-DMA load
+// moves the LDS destination as well as the source: the caller passes the second slot's address minus 4.
+__device__ __forceinline__ void ring_dma_2xb32(const void *gsrc, uint32_t lds_dst0, uint32_t lds_dst1_minus4)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst0), "s"(lds_dst1_minus4) : "memory");
+}
+template <int N> __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+constexpr int RC_RING_DEPTH = 16;
+
+__device__ __forceinline__ void ring_dma_b32(const void *gsrc, uint32_t lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 
 // ------------------------------------------------------------------ encode
 struct BitOut {
@@ -45,37 +79,63 @@ struct BitOut {
 __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ lohi, const RcChunk *__restrict__ chunks, int nchunks,
                                                   uint8_t *__restrict__ scratch, uint32_t sstride, uint32_t *__restrict__ cnt)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= nchunks) return;
-    const RcChunk ch = chunks[c];
-    BitOut w = {scratch + (size_t)c * sstride, 0, 0, 0};
+    // the packed (c_low | (c_high - 1) << 16) words of the lanes come through the LDS-DMA ring, RC_RING_DEPTH symbols ahead:
+    // one load per symbol fetched one symbol ahead was a memory round trip per symbol (0.42 us: the whole encode coder
+    // took as long as its longest lane times that)
+    constexpr int DEPTH = RC_RING_DEPTH;
+    extern __shared__ uint32_t ring[];        // DEPTH slots of 64 dwords (dynamic: its LDS address is the static size)
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * 64 + lane;
+    RcChunk ch = {0, 0, 0, 0, 0, 0};
+    if (c < nchunks) ch = chunks[c];
+    uint32_t nmax = ch.n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    BitOut w = {scratch + (size_t)min(c, nchunks - 1) * sstride, 0, 0, 0};
     uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
-    uint32_t lh = ch.n ? lohi[ch.first] : 0;
-    for (uint32_t i = 0; i < ch.n; ++i) {
-        const uint32_t cur = lh;
-        if (i + 1 < ch.n) lh = lohi[ch.first + (size_t)(i + 1) * ch.stride];  // next symbol's word: independent of the coder state
-        const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
-        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
-        low = low + (uint32_t)((span * c_low) >> 16);
-        const int n1 = clz32(low ^ high);  // leading bits on which low and high agree (< 32: low < high)
-        if (n1) {
-            const uint32_t bits = low >> (32 - n1);
-            const uint32_t b = bits >> (n1 - 1);
-            w.put(b, 1);
-            if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
-            if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), (uint32_t)n1 - 1u);
-            low <<= n1;
-            high = (high << n1) | ((1u << n1) - 1u);
-        }
-        // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times
-        const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-        if (n2) {
-            pending += (uint32_t)n2;
-            low = (low << n2) & 0x7FFFFFFFu;
-            high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+    // loads run past a lane's last word: clamp the element index to the lane's own words (a finished lane re-reads its last one)
+    const uint32_t last = ch.n ? ch.n - 1u : 0u;
+    auto src = [&](uint32_t t) -> const uint32_t * { return lohi + ch.first + (size_t)min(t, last) * ch.stride; };
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_groupstaticsize());
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ring_dma_b32(src((uint32_t)d), ring_lds + (uint32_t)d * 256u);
+    ring_wait<DEPTH - 1>();
+    uint32_t next = ring[lane];
+    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const uint32_t i = i0 + (uint32_t)d;
+            const uint32_t cur = next;
+            ring_wait<DEPTH - 2>();
+            next = ring[((d + 1) % DEPTH) * 64 + lane];
+            ring_dma_b32(src(i + (uint32_t)DEPTH), ring_lds + (uint32_t)d * 256u);
+            if (i < ch.n) {
+                const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
+                const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+                high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+                low = low + (uint32_t)((span * c_low) >> 16);
+                const int n1 = clz32(low ^ high);  // leading bits on which low and high agree (< 32: low < high)
+                if (n1) {
+                    const uint32_t bits = low >> (32 - n1);
+                    const uint32_t b = bits >> (n1 - 1);
+                    w.put(b, 1);
+                    if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
+                    if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), (uint32_t)n1 - 1u);
+                    low <<= n1;
+                    high = (high << n1) | ((1u << n1) - 1u);
+                }
+                // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times
+                const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
+                if (n2) {
+                    pending += (uint32_t)n2;
+                    low = (low << n2) & 0x7FFFFFFFu;
+                    high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+                }
+            }
         }
     }
+    if (c >= nchunks) return;
     pending += 1;
     const uint32_t b = low < 0x40000000u ? 0u : 1u;
     w.put(b, 1);
@@ -89,14 +149,49 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
 // gather the per-chunk scratch rows into one contiguous payload; one block per chunk
 // (gap, optional: bytes the container puts in front of chunk c on top of the chunk bytes before it -- stream headers and
 // chunk tables -- so that the payload lands in its final place and leaves the device in one copy)
+// (lanes != null, container version 3: lane 2c + 1 of a stream is the backwards half of chunk c -- its bytes go out last byte first, so that
+// they read forwards from the chunk's end)
 __global__ __launch_bounds__(256) void k_rc_compact(const uint8_t *__restrict__ scratch, uint32_t stride, const uint32_t *__restrict__ cnt,
-                                                    const uint32_t *__restrict__ off, const uint32_t *__restrict__ gap, uint8_t *__restrict__ payload)
+                                                    const uint32_t *__restrict__ off, const uint32_t *__restrict__ gap, uint8_t *__restrict__ payload,
+                                                    const RcChunk *__restrict__ lanes)
 {
     const int c = blockIdx.x;
     const uint32_t n = cnt[c];
     const uint8_t *src = scratch + (size_t)c * stride;
     uint8_t *dst = payload + off[c] + (gap ? gap[c] : 0u);
-    for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    // the lane's index inside its stream has the parity of its first element (streams start on even slots)
+    if (lanes && (lanes[c].first & 1u)) { for (uint32_t i = threadIdx.x; i < n; i += 256) dst[n - 1u - i] = src[i]; }
+    else { for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i]; }
+}
+
+// Version-3 containers: bytes in front of lane l's payload that are not payload = sum over the streams up to and including
+// its own of (4-byte stream length + the stream's varint table).  One workgroup; a wave per stream sums the varint sizes.
+__global__ __launch_bounds__(256) void k_rc_layout(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ stream_first, int nstreams,
+                                                   const uint32_t *__restrict__ lane_stream, int nlanes, int dual, uint32_t *__restrict__ gap, uint32_t *__restrict__ gap_total)
+{
+    __shared__ uint32_t pre[4 * MAXLV + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < nstreams; s += 4) {
+        const uint32_t l0 = stream_first[s], l1 = stream_first[s + 1];
+        uint32_t t = 0;
+        if (dual) {
+            for (uint32_t l = l0 + 2u * (uint32_t)lane; l < l1; l += 128u) {
+                const uint32_t b = cnt[l] + (l + 1u < l1 ? cnt[l + 1u] : 0u);
+                t += b < (1u << 7) ? 1u : b < (1u << 14) ? 2u : b < (1u << 21) ? 3u : b < (1u << 28) ? 4u : 5u;
+            }
+        } else t = lane == 0 ? 2u * (l1 - l0) : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+        if (lane == 0) pre[s] = 4u + t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (int s = 0; s < nstreams; ++s) { a += pre[s]; pre[s] = a; }
+        *gap_total = a;
+    }
+    __syncthreads();
+    for (int l = threadIdx.x; l < nlanes; l += 256) gap[l] = pre[lane_stream[l]];
 }
 
 // ------------------------------------------------------------------ decode
@@ -306,38 +401,283 @@ __global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__
     }
 }
 
+// ------------------------------------------------------------------ decode from an LDS image of the lanes' bytes
+// The kernels above read a lane's bytes through a window in global memory, one 8-byte load per symbol: every lane of the
+// wave crosses into a new cache line of ITS chunk at its own time, and each crossing is a miss the whole wave waits for.
+// The lanes of a chunked container are short (a few hundred bytes), so the wave first copies the byte windows of all its
+// lanes into LDS in one sweep -- big-endian dwords in each lane's READING order, which is where the backwards lanes of
+// version-3 chunks stop being special -- and the serial part of a symbol touches memory only through two LDS dwords
+// (no miss, no clamp: LDS reads past the allocation return zero) and the CDF-row ring.
+// State per lane: low, d = high - low, x = value - low, q = bits consumed - 1.  high and value themselves are never needed:
+//   d' = (d1 << k) | ones(k),  x' = (x1 << k) | next k bits   (the E3 flip adds 2^31 to low, high and value alike;
+//   d rather than the span itself because a span of 2^32 does occur: a symbol of probability 2^-16 renormalises to it),
+// k = n1 + n2 as in the kernels above.  ~40 instructions per binary symbol instead of ~75 (profiles/r03_rc_decode_isa.txt).
+constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
+
+__device__ __forceinline__ uint32_t ones_below(uint32_t k) { return (1u << (k & 31u)) - 1u; }
+
+struct LaneWin {
+    const uint32_t *w;      // the lane's window in LDS
+    uint32_t q;             // bits consumed - 1 (starts at 31: the first dword is the initial value)
+    uint32_t w0, w1;        // dwords q / 32 and q / 32 + 1
+    __device__ __forceinline__ void init(const uint32_t *p) { w = p; q = 31u; w0 = p[0]; w1 = p[1]; }
+    // the next 32 unread bits: bits [s, s + 32) of w0:w1 with s = q % 32 + 1 in [1, 32]
+    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w0, w1, ~q); }
+    __device__ __forceinline__ void advance(uint32_t k) { q += k; const uint32_t i = q >> 5; w0 = w[i]; w1 = w[i + 1u]; }
+};
+
+// stage the byte windows of the workgroup's lanes (thread j * owner_stride holds the descriptor of lane j): win[j * rdw + d] = logical bytes 4d .. 4d + 3 of lane j, first byte in the
+// most significant position; zero past the lane's byte count (what the reference's reader supplies past the end of a stream)
+__device__ __forceinline__ void stage_windows(uint32_t *win, const uint8_t *__restrict__ bytes, const RcChunk &ch, int nl, uint32_t rdw, int nthreads, int owner_stride)
+{
+    const uint32_t total = (uint32_t)nl * rdw;
+    const uint32_t nbf = ch.nbytes;
+    for (uint32_t f0 = 0; f0 < total; f0 += 4u * (uint32_t)nthreads) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t f = f0 + (uint32_t)u * (uint32_t)nthreads + threadIdx.x;
+            const uint32_t j = min(f / rdw, (uint32_t)nl - 1u), dq = f - (f / rdw) * rdw;
+            const uint32_t off = (uint32_t)__shfl((int)ch.byte_off, (int)j * owner_stride, 64);
+            const uint32_t nb = (uint32_t)__shfl((int)nbf, (int)j * owner_stride, 64);
+            const bool back = (nb & RC_BACKWARDS) != 0u;
+            const uint32_t n = nb & ~RC_BACKWARDS;
+            uint32_t raw = 0;
+            if (f < total && 4u * dq < n) {
+                const uint8_t *src = back ? bytes + (size_t)off - 4u * (size_t)dq - 3u : bytes + (size_t)off + 4u * (size_t)dq;
+                __builtin_memcpy(&raw, src, 4);
+                if (!back) raw = __builtin_bswap32(raw);
+                const uint32_t left = n - 4u * dq;                       // valid bytes of this dword: the top `left` of them
+                if (left < 4u) raw &= 0xFFFFFFFFu << (8u * (4u - left));
+            }
+            v[u] = raw;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t f = f0 + (uint32_t)u * (uint32_t)nthreads + threadIdx.x;
+            if (f < total) win[f] = v[u];
+        }
+    }
+}
+
+// one symbol of a lane: interval update + renormalisation on (low, d = span - 1, x); `t` = the next 32 unread bits.
+// lo / d1 = scaled lower bound and width - 1 of the decoded symbol's slice of [0, span).
+__device__ __forceinline__ uint32_t ffbh(uint32_t v) { uint32_t r; asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }   // v != 0: no zero check
+__device__ __forceinline__ void rc_renorm(uint32_t &low, uint32_t &d, uint32_t &x, uint32_t lo, uint32_t d1, uint32_t t, uint32_t &k_out)
+{
+    const uint32_t x1 = x - lo, low1 = low + lo, high1 = low1 + d1;
+    const uint32_t n1 = ffbh(low1 ^ high1);                                          // low1 < high1 for every valid row: 0..31
+    const uint32_t l1 = low1 << n1, h1 = (high1 << n1) | ~(0xFFFFFFFFu << n1);
+    const uint32_t n2 = ffbh((((~l1) | h1) << 1) | 1u);                              // run of (low bit 1, high bit 0) behind the top bit
+    const uint32_t k = n1 + n2;                                                      // <= 19 for a valid row (shifts use the low 5 / 6 bits)
+    low = (l1 << n2) & 0x7FFFFFFFu;
+    d = (d1 << k) | ~(0xFFFFFFFFu << k);                                             // span - 1: a span of 2^32 (a certain symbol's bounds renormalised) fits
+    x = (uint32_t)(((((uint64_t)x1) << 32 | (uint64_t)t) << k) >> 32);
+    k_out = k;
+}
+
+// Lanes of 3- and 5-entry rows.  Symbols leave four at a time; a lane's first symbol sits on a multiple of 4 (lanes are
+// 2^llog >= 32 symbols) and `sym` has 3 bytes of slack behind the stream for the last group of its last lane.
+template <int LP>
+__global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
+                                                      int nchunks, int lpw, uint32_t rdw, uint8_t *__restrict__ sym)
+{
+    static_assert(LP == 3 || LP == 5, "17-entry rows are decoded by k_rc_decode17_lds");
+    constexpr int RS = LP == 3 ? 1 : 4;
+    constexpr int DEPTH = RC_RING_DEPTH;
+    constexpr int LPR = LP == 3 ? 1 : 2;                       // ring loads per row
+    constexpr uint32_t SLOT = 256u;                            // bytes of a ring slot: a dword per lane
+    static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
+    extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows, then the row ring
+    const int lane = threadIdx.x;
+    const int c = blockIdx.x * lpw + lane;
+    RcChunk ch = {0, 0, 0, 0, 0, 0};
+    if (lane < lpw && c < nchunks) ch = chunks[c];
+    uint32_t nmax = ch.n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    if (nmax == 0) return;
+    stage_windows(win, bytes, ch, lpw, rdw, 64, 1);   // lane j's descriptor lives in thread j
+    __syncthreads();
+    LaneWin in;
+    in.init(win + (size_t)min(lane, lpw - 1) * rdw);
+    const char *rowp = reinterpret_cast<const char *>(cdf) + (size_t)ch.first * (2 * RS);   // this lane's row of the next ring load
+    const size_t rstep = (size_t)ch.stride * (2 * RS);
+    uint32_t *ring = win + (size_t)lpw * rdw;
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + (uint32_t)lpw * rdw * 4u));
+    auto ring_load = [&](int slot) {
+        if (LP == 3) ring_dma_u16(rowp, ring_lds + (uint32_t)slot * SLOT);
+        else ring_dma_2xb32(rowp, ring_lds + (uint32_t)slot * SLOT, ring_lds + (uint32_t)(DEPTH + slot) * SLOT - 4u);
+        rowp += rstep;
+    };
+    uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
+    uint32_t pack = 0;
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
+    uint8_t *out = sym + ch.out;
+    // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain)
+    auto ring_read = [&](int slot, uint32_t &a, uint32_t &b) {
+        a = ring[slot * 64 + lane];
+        if (LP != 3) b = ring[(DEPTH + slot) * 64 + lane];
+    };
+    uint32_t n0 = 0, n1r = 0;
+    ring_wait<(DEPTH - 1) * LPR>();
+    ring_read(0, n0, n1r);
+    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const uint32_t i = i0 + (uint32_t)dd;
+            const uint32_t r0 = n0, r1 = n1r;
+            ring_wait<(DEPTH - 2) * LPR>();                    // row i + 1 has landed: DEPTH - 2 younger rows in flight
+            ring_read((dd + 1) % DEPTH, n0, n1r);
+            ring_load(dd);          // slot dd (row i, read one symbol ago) takes row i + DEPTH
+            const uint32_t t = in.peek();
+            uint32_t s, lo, d1;
+            if (LP == 3) {
+                const uint32_t t1 = scale_d(d, r0);
+                const bool ge = t1 <= x;
+                s = ge; lo = ge ? t1 : 0u;
+                d1 = ge ? d - t1 : t1 - 1u;
+            } else {
+                const uint32_t t1 = scale_d(d, r0 & 0xFFFFu), t2 = scale_d(d, r0 >> 16), t3 = scale_d(d, r1 & 0xFFFFu);
+                // the scaled bounds are monotone: (t3 <= x) implies (t2 <= x) implies (t1 <= x).  Selects, no branches.
+                const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
+                lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
+                const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));              // scaled upper bound (mod 2^32: a span of 2^32 wraps to 0)
+                s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
+                d1 = hi + ~lo;                                                           // hi - lo - 1
+            }
+            if ((dd & 3) == 0) pack = s; else pack |= s << (8 * (dd & 3));
+            if ((dd & 3) == 3 && i - 3u < ch.n) *reinterpret_cast<uint32_t *>(out + (i - 3u)) = pack;
+            rc_renorm(low, d, x, lo, d1, t, k);
+            in.advance(k);
+        }
+    }
+}
+
+// 17-entry rows: a 16-lane group per coder lane as in k_rc_decode17, the byte windows staged in LDS.
+__global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
+                                                        int nchunks, uint32_t rdw, uint8_t *__restrict__ sym)
+{
+    constexpr int DEPTH = RC_RING_DEPTH;
+    static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
+    extern __shared__ uint32_t win[];
+    const int lane = threadIdx.x, grp = lane >> 4, kk = lane & 15;
+    const int c = blockIdx.x * 4 + grp;
+    RcChunk ch = {0, 0, 0, 0, 0, 0};
+    if (c < nchunks) ch = chunks[c];
+    uint32_t nmax = ch.n;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    if (nmax == 0) return;
+    stage_windows(win, bytes, ch, 4, rdw, 64, 16);   // coder lane j's descriptor lives in thread 16 j
+    __syncthreads();
+    LaneWin in;
+    in.init(win + (size_t)grp * rdw);
+    // compact row: v[1..15] at [0..14]; lane 0 stands for v[0] = 0 and reads the unused slot 15
+    const char *rowp = reinterpret_cast<const char *>(cdf) + ((size_t)ch.first * 16 + (size_t)(kk ? kk - 1 : 15)) * 2;
+    const size_t rstep = (size_t)ch.stride * 32;
+    const uint32_t *ring = win + (size_t)4 * rdw;
+    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + 4u * rdw * 4u));
+    auto ring_load = [&](int slot) { ring_dma_u16(rowp, ring_lds + (uint32_t)slot * 256u); rowp += rstep; };
+    const int g16 = grp << 4;
+    uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
+    uint32_t pack = 0;
+#pragma unroll
+    for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
+    uint8_t *out = sym + ch.out;
+    ring_wait<DEPTH - 1>();
+    uint32_t vnext = ring[lane];
+    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
+#pragma unroll
+        for (int dd = 0; dd < DEPTH; ++dd) {
+            const uint32_t i = i0 + (uint32_t)dd;
+            const uint32_t v = vnext;
+            ring_wait<DEPTH - 2>();                            // row i + 1 has landed
+            vnext = ring[((dd + 1) % DEPTH) * 64 + lane];
+            ring_load(dd);
+            const uint32_t tw = in.peek();
+            const uint32_t t = kk ? scale_d(d, v) : 0u;
+            const uint64_t bal = __ballot(t <= x);
+            const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+            const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
+            const uint32_t s = ((uint32_t)__popc(bits) - 1u) & 15u;
+            const uint32_t lo = (uint32_t)__shfl((int)t, g16 + (int)s);
+            const uint32_t nx = (uint32_t)__shfl((int)t, g16 + (int)min(s + 1u, 15u));
+            const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
+            if ((dd & 3) == 0) pack = s; else pack |= s << (8 * (dd & 3));
+            if ((dd & 3) == 3 && kk == 0 && i - 3u < ch.n) *reinterpret_cast<uint32_t *>(out + (i - 3u)) = pack;
+            rc_renorm(low, d, x, lo, d1, tw, k);
+            in.advance(k);
+        }
+    }
+}
+
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt)
 {
     if (nchunks <= 0) return GPCC_OK;
-    k_rc_encode<<<(unsigned)cdiv(nchunks, 64), 64, 0, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
+    k_rc_encode<<<(unsigned)cdiv(nchunks, 64), 64, RC_RING_DEPTH * 256, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
-int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload)
+int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload, const RcChunk *dual_lanes)
 {
     if (nchunks <= 0) return GPCC_OK;
-    k_rc_compact<<<(unsigned)nchunks, 256, 0, st>>>(scratch, stride, cnt, off, gap, payload);
+    k_rc_compact<<<(unsigned)nchunks, 256, 0, st>>>(scratch, stride, cnt, off, gap, payload, dual_lanes);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
-__global__ __launch_bounds__(256) void k_rc_to_host(const uint4 *__restrict__ src, const uint32_t *__restrict__ total, uint32_t extra, uint4 *__restrict__ dst)
+int rc_layout_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream_first, int nstreams, const uint32_t *lane_stream, int nlanes, bool dual, uint32_t *gap, uint32_t *gap_total)
 {
-    const uint32_t words = (*total + extra + 15u) >> 4;
+    if (nstreams > 4 * MAXLV) return fail(GPCC_ERR_ARG, "internal: %d streams", nstreams);
+    k_rc_layout<<<1, 256, 0, st>>>(cnt, stream_first, nstreams, lane_stream, nlanes, dual ? 1 : 0, gap, gap_total);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+__global__ __launch_bounds__(256) void k_rc_to_host(const uint4 *__restrict__ src, const uint32_t *__restrict__ total, uint32_t extra, const uint32_t *__restrict__ extra_dev,
+                                                    uint4 *__restrict__ dst)
+{
+    const uint32_t words = (*total + extra + (extra_dev ? *extra_dev : 0u) + 15u) >> 4;
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) dst[i] = src[i];
 }
 
-int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, uint8_t *dst)
+int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, const uint32_t *extra_dev, uint8_t *dst)
 {
-    k_rc_to_host<<<512, 256, 0, st>>>(reinterpret_cast<const uint4 *>(payload), total, extra, reinterpret_cast<uint4 *>(dst));
+    k_rc_to_host<<<512, 256, 0, st>>>(reinterpret_cast<const uint4 *>(payload), total, extra, extra_dev, reinterpret_cast<uint4 *>(dst));
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym)
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, uint8_t *sym)
 {
     if (nchunks <= 0) return GPCC_OK;
+    // staged path: every lane's window (+ the two dwords the reader runs ahead) in LDS; as many lanes per wave as fit
+    const uint64_t rdw = ((uint64_t)max_bytes + 3u) / 4u + 3u;
+    const uint32_t ring_bytes = (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u);       // the row ring behind the windows
+    const uint32_t cap = RC_LDS_CAP - ring_bytes;
+    static const bool staged_off = [] { const char *e = getenv("GAUSPCC_RC_STAGED"); return e && atoi(e) == 0; }();
+    if (!staged_off && rdw * 4u * (lp == 17 ? 4u : 1u) <= cap) {
+        if (lp == 17) {
+            k_rc_decode17_lds<<<(unsigned)cdiv(nchunks, 4), 64, (size_t)(4u * rdw * 4u) + ring_bytes, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
+        } else {
+            int lpw = 64;
+            while ((uint64_t)lpw * rdw * 4u > cap) lpw >>= 1;
+            const unsigned g = (unsigned)cdiv(nchunks, lpw);
+            const size_t lds = (size_t)lpw * rdw * 4u + ring_bytes;
+            if (lp == 3) k_rc_decode_lds<3><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            else if (lp == 5) k_rc_decode_lds<5><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            else return fail(GPCC_ERR_ARG, "rc_decode: Lp must be 3, 5 or 17");
+        }
+        LAUNCH_CHECK();
+        return GPCC_OK;
+    }
+    // lanes too long for LDS (the reference layout: one lane per stream) read their bytes through a window in memory;
+    // forwards only (backwards lanes exist in version-3 chunks, which are short by construction)
     const unsigned g = (unsigned)cdiv(nchunks, 64);
     switch (lp) {
     case 3: k_rc_decode<3><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;
@@ -369,17 +709,15 @@ __global__ __launch_bounds__(256) void k_rc_pack_lohi(const uint16_t *__restrict
     lohi[rc_interleaved((uint32_t)r, chunk_log2, nch)] = lo | ((hi - 1u) << 16);
 }
 
-int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int chunk_log2, uint16_t *rows)
+int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int chunk_log2, uint32_t nch, uint16_t *rows)
 {
-    const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(n, (int64_t)1 << chunk_log2) : 1u;
     k_rc_pack_rows<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(cdf_full, lp, n, chunk_log2, nch, rc_row_stride(lp), rows);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
-int rc_pack_lohi(hipStream_t st, const uint16_t *cdf_full, int lp, const uint8_t *sym, int64_t n, int chunk_log2, uint32_t *lohi)
+int rc_pack_lohi(hipStream_t st, const uint16_t *cdf_full, int lp, const uint8_t *sym, int64_t n, int chunk_log2, uint32_t nch, uint32_t *lohi)
 {
-    const uint32_t nch = chunk_log2 ? (uint32_t)cdiv(n, (int64_t)1 << chunk_log2) : 1u;
     k_rc_pack_lohi<<<(unsigned)cdiv(n, 256), 256, 0, st>>>(cdf_full, lp, sym, n, chunk_log2, nch, lohi);
     LAUNCH_CHECK();
     return GPCC_OK;

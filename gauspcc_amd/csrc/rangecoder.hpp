@@ -1,6 +1,8 @@
 // rangecoder.hpp -- device range coder launchers (see rangecoder.hip).
 #pragma once
 #include "common.hpp"
+#include <algorithm>
+#include <vector>
 
 namespace gpcc {
 
@@ -12,9 +14,10 @@ struct RcChunk {
     uint32_t stride;    // elements between consecutive symbols of this chunk (= chunks in the stream)
     uint32_t n;         // symbols in the chunk
     uint32_t out;       // decode: index of the chunk's first symbol in the (raster-ordered) output
-    uint32_t byte_off;  // decode: offset of the chunk's bytes in the uploaded file
-    uint32_t nbytes;    // decode: byte count
+    uint32_t byte_off;  // decode: offset of the lane's FIRST byte in the uploaded file (a backwards lane: its chunk's last byte)
+    uint32_t nbytes;    // decode: bytes the lane may read (its chunk's byte count) | RC_BACKWARDS
 };
+constexpr uint32_t RC_BACKWARDS = 0x80000000u;   // RcChunk::nbytes flag: the lane's bytes run towards lower addresses
 
 // compact CDF row: only the interior values v[1..Lp-2] are stored (v[0] = 0, v[Lp-1] is never read)
 static inline int rc_row_stride(int lp) { return lp == 3 ? 1 : lp == 5 ? 4 : 16; }  // uint16 units
@@ -26,33 +29,124 @@ __host__ __device__ __forceinline__ uint32_t rc_interleaved(uint32_t r, int chun
 
 // The decoder fetches compact rows RC_ROW_LOOKAHEAD symbols ahead without clamping: the row buffer of a stream of
 // nch chunks of (at most) S symbols must hold rc_rows_capacity(nch, S) rows (what lies past the last row is never used).
-constexpr int RC_ROW_LOOKAHEAD = 8;
+constexpr int RC_ROW_LOOKAHEAD = 40;   // staged kernels: a ring of 16 rows + a last round that runs up to 15 symbols past a lane of any length
 static inline int64_t rc_rows_capacity(int64_t nch, int64_t S) { return (S + RC_ROW_LOOKAHEAD) * nch; }
 
-// Container version 2: the chunk size of a level's four streams follows the level's size, so that a small level still
-// spreads over many lanes (the decoder's latency per stream is chunk length x ~0.14 us, whatever the level's size):
-// 2^clog symbols with clog = clamp(ceil_log2(ceil(n / 256)), 7, chunk_log2) -- about 256 chunks per stream until the
-// header's chunk_log2 (the maximum) is reached at n >= 2^(chunk_log2 + 8) nodes.  Version 1 used chunk_log2 everywhere.
+// How a stream of n symbols is cut (by container version).  A LANE is what one coder state covers: 2^llog consecutive
+// symbols (raster order), coded independently of every other lane.  A CHUNK is what the container counts bytes for.
+//   version 1      chunk = lane = 2^chunk_log2 symbols, u16 byte count per chunk.
+//   version 2      as 1 with the chunk size following the level's size: 2^clog, clog = clamp(ceil_log2(ceil(n / 256)), 7,
+//                  chunk_log2) -- about 256 lanes per stream until the header's chunk_log2 is reached (the decoder's
+//                  latency per stream is lane length x time per symbol, whatever the level's size).
+//   version 3      a chunk is TWO lanes sharing one byte count: the first half of the chunk's symbols is coded forwards from
+//                  the chunk's first byte, the second half backwards from its last byte (the bytes of that lane are stored
+//                  in reverse order).  A coder's flush leaves its last symbols decodable whatever bits follow, so each
+//                  lane simply reads on into the other's bytes.  One count per two lanes, and the count is a LEB128 varint
+//                  (1 byte below 128 bytes): ~1.1 bytes of table per 2 lanes instead of 2 per lane.  Chunk size 2^clog with
+//                  clog = clamp(ceil_log2(ceil(n / 128)), 7, chunk_log2): the same ~256 lanes per stream as version 2.
+//   chunk_log2 = 0 the reference layout: one lane per stream, no table.
+struct RcPlan {
+    int llog;           // lane size log2 (0 with nlanes == 1: the whole stream)
+    uint32_t nlanes;    // coder states of the stream
+    uint32_t nchunks;   // byte-counted units of the stream's table
+    bool dual;          // version 3: lanes 2c (forwards) and 2c + 1 (backwards) share chunk c
+    int64_t lane_syms(int64_t n, uint32_t l) const { const int64_t S = llog || nlanes > 1 ? (int64_t)1 << llog : n, r = n - (int64_t)l * S; return r < 0 ? 0 : (r < S ? r : S); }
+};
+static inline int rc_ceil_log2(int64_t v) { int c = 0; while (((int64_t)1 << c) < v) ++c; return c; }
 static inline int rc_level_chunk_log2(int64_t n, int chunk_log2, int version)
 {
     if (chunk_log2 == 0 || version < 2) return chunk_log2;
-    const int64_t want = (n + 255) / 256;
-    int c = 0;
-    while (((int64_t)1 << c) < want) ++c;
+    const int c = rc_ceil_log2((n + (version >= 3 ? 127 : 255)) / (version >= 3 ? 128 : 256));
     const int lo = chunk_log2 < 7 ? chunk_log2 : 7;
     return c < lo ? lo : (c > chunk_log2 ? chunk_log2 : c);
+}
+static inline RcPlan rc_plan(int64_t n, int chunk_log2, int version)
+{
+    RcPlan p = {0, 1u, 1u, false};
+    if (chunk_log2 == 0) return p;
+    const int clog = rc_level_chunk_log2(n, chunk_log2, version);
+    p.dual = version >= 3;
+    p.llog = p.dual ? clog - 1 : clog;
+    const int64_t nl = (std::max<int64_t>(n, 1) + ((int64_t)1 << p.llog) - 1) >> p.llog;
+    p.nlanes = (uint32_t)nl;
+    p.nchunks = p.dual ? (uint32_t)((nl + 1) / 2) : (uint32_t)nl;
+    return p;
+}
+// chunk tables: u16 per chunk (versions 1, 2), LEB128 (version 3)
+static inline size_t rc_varint_size(uint32_t v) { return v < (1u << 7) ? 1 : v < (1u << 14) ? 2 : v < (1u << 21) ? 3 : v < (1u << 28) ? 4 : 5; }
+static inline size_t rc_varint_put(uint8_t *o, uint32_t v) { size_t k = 0; while (v >= 128u) { o[k++] = (uint8_t)(v | 128u); v >>= 7; } o[k++] = (uint8_t)v; return k; }
+// returns bytes read, 0 on a malformed / truncated varint
+static inline size_t rc_varint_get(const uint8_t *p, size_t avail, uint32_t *v)
+{
+    uint32_t r = 0;
+    for (size_t k = 0; k < 5 && k < avail; ++k) {
+        r |= (uint32_t)(p[k] & 127u) << (7 * k);
+        if (!(p[k] & 128u)) { if (k == 4 && p[k] > 15u) return 0; *v = r; return k + 1; }
+    }
+    return 0;
+}
+// Lane descriptors of one stream from its table.  `tab` points at the stream body (table, then the chunk payloads) of `len`
+// bytes which starts at byte `off` of the uploaded file; lanes[0 .. plan.nlanes) are filled, *max_bytes = the longest lane's
+// byte window (a dual chunk's lanes both see the whole chunk).  Returns 0, or a message.
+static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_t len, const RcPlan &plan, int64_t n, int version, RcChunk *lanes, uint32_t *max_bytes)
+{
+    uint32_t mb = 0;
+    if (plan.nlanes == 1 && plan.llog == 0 && !plan.dual && version == 0) {
+        lanes[0] = RcChunk{0, 1, (uint32_t)n, 0, (uint32_t)off, (uint32_t)len};
+        *max_bytes = (uint32_t)len;
+        return nullptr;
+    }
+    int64_t t = 0;                                   // table cursor
+    std::vector<uint32_t> cb(plan.nchunks);
+    for (uint32_t c = 0; c < plan.nchunks; ++c) {
+        if (version >= 3) {
+            const size_t k = rc_varint_get(tab + t, (size_t)(len - t), &cb[c]);
+            if (!k) return "chunk table: bad varint";
+            t += (int64_t)k;
+        } else {
+            if (t + 2 > len) return "stream shorter than its chunk table";
+            cb[c] = tab[t] | tab[t + 1] << 8;
+            t += 2;
+        }
+    }
+    int64_t p = off + t;
+    const int64_t end = off + len;
+    for (uint32_t c = 0; c < plan.nchunks; ++c) {
+        if (p + (int64_t)cb[c] > end) return "chunk overruns its stream";
+        if (plan.dual) {
+            const uint32_t l0 = 2 * c, l1 = 2 * c + 1;
+            lanes[l0] = RcChunk{l0, plan.nlanes, (uint32_t)plan.lane_syms(n, l0), (uint32_t)((int64_t)l0 << plan.llog), (uint32_t)p, cb[c]};
+            if (l1 < plan.nlanes)   // backwards from the chunk's last byte
+                lanes[l1] = RcChunk{l1, plan.nlanes, (uint32_t)plan.lane_syms(n, l1), (uint32_t)((int64_t)l1 << plan.llog), (uint32_t)(p + cb[c]) - 1u, cb[c] | RC_BACKWARDS};
+        } else {
+            lanes[c] = RcChunk{c, plan.nlanes, (uint32_t)plan.lane_syms(n, c), (uint32_t)((int64_t)c << plan.llog), (uint32_t)p, cb[c]};
+        }
+        mb = cb[c] > mb ? cb[c] : mb;
+        p += cb[c];
+    }
+    if (p != end) return "stream has trailing bytes";
+    *max_bytes = mb;
+    return nullptr;
 }
 
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);
-int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload);
-// payload[0 .. *total + extra) -> dst in 16-byte words (both 16-byte aligned; dst may be pinned host memory): the size stays on the device
-int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, uint8_t *dst);
+// dual_lanes (the device lane descriptors, version 3): the bytes of a stream's odd lanes are written in reverse order (the backwards half of a chunk)
+int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload, const RcChunk *dual_lanes = nullptr);
+// payload[0 .. *total + extra (+ *extra_dev)) -> dst in 16-byte words (both 16-byte aligned; dst may be pinned host memory): the size stays on the device
+int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *total, uint32_t extra, const uint32_t *extra_dev, uint8_t *dst);
 // cdf: compact interleaved rows (rc_row_stride uint16 per row)
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint8_t *sym);
-// full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words
-int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int chunk_log2, uint16_t *rows);
-int rc_pack_lohi(hipStream_t st, const uint16_t *cdf_full, int lp, const uint8_t *sym, int64_t n, int chunk_log2, uint32_t *lohi);
+// max_bytes: the longest byte window of the lanes (rc_parse_table); lanes whose windows fit the LDS are decoded from a staged
+// copy, one lane of any size (the reference layout) straight from memory
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, uint8_t *sym);
+// version-3 streams: the bytes in front of every lane's payload (stream lengths + varint tables) depend on the byte counts
+// and are worked out on the device: lane_stream[l] = stream of lane l, stream_first[s] = first lane of stream s (nstreams + 1
+// entries), dual: lanes pair up into chunks.  gap[l] and *gap_total come out.
+int rc_layout_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream_first, int nstreams, const uint32_t *lane_stream, int nlanes, bool dual, uint32_t *gap, uint32_t *gap_total);
+// full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words (lanes of 2^lane_log2
+// symbols, nlanes of them; lane_log2 = 0: one lane)
+int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int lane_log2, uint32_t nlanes, uint16_t *rows);
+int rc_pack_lohi(hipStream_t st, const uint16_t *cdf_full, int lp, const uint8_t *sym, int64_t n, int lane_log2, uint32_t nlanes, uint32_t *lohi);
 
 }  // namespace gpcc

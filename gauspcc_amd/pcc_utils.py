@@ -10,8 +10,9 @@ Deliberate differences, all on the error side:
   * a bare file name as output_path works (reference: os.makedirs('') raises, :47);
   * decompress_point_cloud(output_path=...) really writes the ASCII PLY (reference: NameError,
     `io` is never imported, :392).
-The container written by default is the chunked one (version 2: per-level chunk sizes, parallel decode, DESIGN.md);
-chunk_log2=0 writes the reference's exact layout.  Both are read back transparently.
+The container written by default is the chunked one (version 3: per-level chunk sizes, two coder lanes per byte-counted
+chunk, parallel decode); chunk_log2=0 writes the reference's exact layout.  Every layout this library
+ever wrote (versions 1-3) and the reference's are read back transparently.
 """
 import ctypes as C
 import os
@@ -22,7 +23,7 @@ import torch
 
 from . import _lib, runtime
 
-DEFAULT_CHUNK_LOG2 = int(os.environ.get("GAUSPCC_CHUNK_LOG2", "10"))
+DEFAULT_CHUNK_LOG2 = int(os.environ.get("GAUSPCC_CHUNK_LOG2", "11"))
 
 _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
 
@@ -87,7 +88,7 @@ def compress_point_cloud(
     kernel_size=5,            # Convolution kernel size
     posQ=1,                   # Quantization scale
     *,
-    chunk_log2=None,          # extension: 0 = reference container, 6..14 = largest chunk size of the chunked container (default 10)
+    chunk_log2=None,          # extension: 0 = reference container, 6..14 = largest chunk size of the chunked container (default 11)
 ):
     """Compress point cloud into a bin file (reference: pcc_utils.py:24-217).
 

@@ -48,6 +48,10 @@ def lib():
         L.orc_rc_encode.restype = i64
         L.orc_rc_encode.argtypes = [vp, i32, vp, i64, vp, i64]
         L.orc_rc_decode.argtypes = [vp, i32, vp, i64, i64, vp]
+        L.orc_stream_encode.restype = i64
+        L.orc_stream_encode.argtypes = [vp, i32, vp, i64, i32, i32, vp, i64]
+        L.orc_stream_decode.argtypes = [vp, i32, vp, i64, i64, i32, i32, vp]
+        L.orc_set_container_version.argtypes = [i32]
         L.orc_encode.restype = i64
         L.orc_encode.argtypes = [vp, i32, i32, vp, i64, i32, C.c_uint16, vp, i64]
         L.orc_decode.restype = i64
@@ -203,6 +207,32 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes) -> np.ndarray:
     return out
 
 
+def stream_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version: int = 3) -> bytes:
+    """One (level, stage) stream of the container as the codec writes it for a level of len(sym) nodes: the chunk table and
+    the chunks (version 3: LEB128 counts, forward + reversed backward lane per chunk); chunk_log2 = 0: the bare coder bytes."""
+    cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
+    sym = np.ascontiguousarray(sym, dtype=np.uint8)
+    cap = sym.size * 4 + 64 + 8 * (sym.size // 32 + 1)
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().orc_stream_encode(_p(cdf), cdf.shape[1], _p(sym), sym.size, chunk_log2, version, _p(out), cap)
+    assert 0 <= n <= cap
+    return out[:n].tobytes()
+
+
+def stream_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int, version: int = 3) -> np.ndarray:
+    cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(cdf.shape[0], dtype=np.uint8)
+    if lib().orc_stream_decode(_p(cdf), cdf.shape[1], _p(buf), buf.size, cdf.shape[0], chunk_log2, version, _p(out)):
+        raise ValueError("malformed stream")
+    return out
+
+
+def set_container_version(v: int = 3) -> int:
+    """Version orc.encode writes for chunk_log2 != 0 (default 3); returns the version in force."""
+    return int(lib().orc_set_container_version(int(v)))
+
+
 class Model:
     """Holds the 39-tensor table alive and exposes it as float**."""
 
@@ -217,7 +247,7 @@ def f16_bits(v) -> int:
     return int(np.array(v, dtype=np.float16).view(np.uint16))
 
 
-def encode(model: Model, xyz: np.ndarray, chunk_log2: int = 10, posq=1, trace: bool = False) -> bytes:
+def encode(model: Model, xyz: np.ndarray, chunk_log2: int = 11, posq=1, trace: bool = False) -> bytes:
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)
     n = xyz.shape[0]
     cap = 64 * 1024 + n * 16

@@ -20,7 +20,13 @@ pts = synthetic_cloud(700, seed=2024)
 out = {"points": pts}
 for k in (5, 3):
     m = orc.Model(tensor_table(synthetic_state_dict(32, k), 32, k), 32, k)
+    # k*_chunk*: the reference layout (0) and container version 2, which readers must keep reading (round 2's writer);
+    # k*_chunk*_v3: version 3, what the encoder writes now (two lanes per byte-counted chunk, LEB128 counts)
+    orc.set_container_version(2)
     for cl in (0, 6, 10):
         out[f"k{k}_chunk{cl}"] = np.frombuffer(orc.encode(m, pts, chunk_log2=cl), dtype=np.uint8)
+    orc.set_container_version(3)
+    for cl in (6, 11):
+        out[f"k{k}_chunk{cl}_v3"] = np.frombuffer(orc.encode(m, pts, chunk_log2=cl), dtype=np.uint8)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "containers.npz"), **out)
 print({k: v.shape for k, v in out.items()})

@@ -77,7 +77,7 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int) -> np.ndarray:
     return out.cpu().numpy()
 
 
-def encode(model, xyz: np.ndarray, chunk_log2=10, posq=1, ideal_bits=False):
+def encode(model, xyz: np.ndarray, chunk_log2=11, posq=1, ideal_bits=False):
     from gauspcc_amd.pcc_utils import _encode_to_bytes
 
     x = torch.tensor(np.ascontiguousarray(xyz, dtype=np.int32), device=dev())

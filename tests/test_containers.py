@@ -1,13 +1,15 @@
 """Format and numerics regression: the stored bitstreams of tests/golden/containers.npz (written by this implementation's
 oracle, tests/golden/make_containers.py) must be reproduced byte for byte -- by the oracle on the CPU and by the HIP path
-on the GPU -- and must decode to the stored cloud.  Covers the three layouts (reference layout, chunked with 64- and
-up-to-1024-symbol chunks) and both kernel sizes."""
+on the GPU -- and must decode to the stored cloud.  Covers the reference layout, container version 3 (what the encoder
+writes: two lanes per byte-counted chunk, LEB128 counts) and version 2 (round 2's writer: still read, and still reproduced
+by the oracle on request), both kernel sizes."""
 import os
 
 import numpy as np
 import pytest
 
-CASES = [(k, cl) for k in (5, 3) for cl in (0, 6, 10)]
+CASES = [(k, cl) for k in (5, 3) for cl in (0, 6, 10)]          # stored with the version-2 writer (0: reference layout)
+CASES_V3 = [(k, cl) for k in (5, 3) for cl in (6, 11)]
 
 
 def _rows(a):
@@ -23,6 +25,20 @@ def fixture(golden_dir):
 def test_oracle_reproduces_stored_stream(orc, fixture, synth_model_k5, synth_model_k3, k, cl):
     model = synth_model_k5 if k == 5 else synth_model_k3
     stored = fixture[f"k{k}_chunk{cl}"].tobytes()
+    orc.set_container_version(2)
+    try:
+        assert orc.encode(model, fixture["points"], chunk_log2=cl) == stored
+    finally:
+        orc.set_container_version(3)
+    dec, posq = orc.decode(model, stored)
+    assert float(posq) == 1.0
+    assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+
+
+@pytest.mark.parametrize("k,cl", CASES_V3)
+def test_oracle_reproduces_stored_stream_v3(orc, fixture, synth_model_k5, synth_model_k3, k, cl):
+    model = synth_model_k5 if k == 5 else synth_model_k3
+    stored = fixture[f"k{k}_chunk{cl}_v3"].tobytes()
     assert orc.encode(model, fixture["points"], chunk_log2=cl) == stored
     dec, posq = orc.decode(model, stored)
     assert float(posq) == 1.0
@@ -35,6 +51,47 @@ def test_stored_headers(fixture):
     assert fixture["k5_chunk0"][:2].tolist() == [0x00, 0x3C]
     for cl in (6, 10):
         assert fixture[f"k5_chunk{cl}"][:4].tolist() == [0xFF, 0xFF, 2, cl]
+    for cl in (6, 11):
+        assert fixture[f"k5_chunk{cl}_v3"][:4].tolist() == [0xFF, 0xFF, 3, cl]
+    # version 3 is never larger than version 2 at the same lane length (chunk_log2 one higher: two lanes per chunk)
+    assert len(fixture["k5_chunk11_v3"]) < len(fixture["k5_chunk10"]) and len(fixture["k3_chunk11_v3"]) < len(fixture["k3_chunk10"])
+
+
+def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5):
+    """Version 3 by hand: a stream is LEB128 byte counts, then per chunk the forward lane's coder bytes followed by the
+    backward lane's coder bytes reversed -- checked against the plain coder (orc.rc_encode) on the traced CDFs / symbols."""
+    pts = fixture["points"]
+    data = orc.encode(synth_model_k5, pts, chunk_log2=6, trace=True)
+    levels = orc.trace()
+    L = data[6]
+    pos = 8 + 4 * L + 4
+    bn = int.from_bytes(data[pos:pos + 4], "little")
+    pos += 4 + 13 * bn
+    assert int.from_bytes(data[pos:pos + 2], "little") == 4 * (L - 1)
+    pos += 2
+    checked = 0
+    for lv in levels:
+        n = len(lv["sym"][0])
+        S = 32                                                        # chunk_log2 6: lanes of 32 symbols
+        nl = -(-n // S)
+        for s in range(4):
+            ln = int.from_bytes(data[pos:pos + 4], "little")
+            body = data[pos + 4:pos + 4 + ln]
+            pos += 4 + ln
+            lanes = [orc.rc_encode(lv["cdf"][s][l * S:(l + 1) * S], lv["sym"][s][l * S:(l + 1) * S]) for l in range(nl)]
+            want_tab, want_pay = b"", b""
+            for c in range(0, nl, 2):
+                b = len(lanes[c]) + (len(lanes[c + 1]) if c + 1 < nl else 0)
+                v = b
+                while v >= 128:
+                    want_tab += bytes([(v & 127) | 128])
+                    v >>= 7
+                want_tab += bytes([v])
+                want_pay += lanes[c] + (lanes[c + 1][::-1] if c + 1 < nl else b"")
+            assert body == want_tab + want_pay
+            checked += 1
+    assert pos == len(data) and checked == 4 * (L - 1)
+
 
 
 def _as_version1(stream: bytes) -> bytes:
@@ -61,16 +118,18 @@ def test_device_reads_version1(fixture):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,cl", CASES)
-def test_device_reproduces_stored_stream(fixture, k, cl):
+@pytest.mark.parametrize("k,cl,tag", [(k, cl, "") for k, cl in CASES] + [(k, cl, "_v3") for k, cl in CASES_V3])
+def test_device_reproduces_stored_stream(fixture, k, cl, tag):
+    """The device writes the reference layout and version 3 byte for byte; it READS every stored layout (version 2 too)."""
     from gauspcc_amd import runtime
     from gauspcc_amd.synth import synthetic_state_dict
     from tests import gpu_helpers as gh
 
     model = runtime.Model(synthetic_state_dict(32, k), 32, k, 0)
-    stored = fixture[f"k{k}_chunk{cl}"].tobytes()
-    data, _ = gh.encode(model, fixture["points"], cl)
-    assert data == stored
+    stored = fixture[f"k{k}_chunk{cl}{tag}"].tobytes()
+    if tag == "_v3" or cl == 0:
+        data, _ = gh.encode(model, fixture["points"], cl)
+        assert data == stored
     dec, posq, _ = gh.decode(model, stored)
     assert float(posq) == 1.0
     assert np.array_equal(_rows(dec), _rows(fixture["points"]))

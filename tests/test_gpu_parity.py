@@ -249,8 +249,11 @@ def test_head_cdf_bit_exact(gh, orc, m):
 
 # ---------------------------------------------------------------- a10 range coder
 @pytest.mark.parametrize("lp", [3, 5, 17])
-@pytest.mark.parametrize("chunk_log2", [0, 6, 10])
+@pytest.mark.parametrize("chunk_log2", [0, 6, 10, 11])
 def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2):
+    """gpcc_rc_encode writes ONE stream as the container holds it (chunk_log2 = 0: the bare torchac-compatible coder bytes;
+    else version 3: LEB128 chunk table, forward + reversed backward lane per chunk): bytes == the oracle's stream encoder,
+    either side decodes the other's stream.  n = 7001 at chunk_log2 = 11 is one short last chunk with an odd lane count."""
     rng = np.random.RandomState(lp * 31 + chunk_log2)
     n = 7001
     logits = rng.randn(n, lp - 1).astype(np.float32) * 2.5
@@ -263,8 +266,27 @@ def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2):
     if chunk_log2 == 0:
         assert data == orc.rc_encode(cdf_i, sym)
         assert np.array_equal(orc.rc_decode(cdf_i, data), sym)
+    ref = orc.stream_encode(cdf_i, sym, chunk_log2)
+    assert data == ref, f"first differing byte at {next((i for i, (a, b) in enumerate(zip(data, ref)) if a != b), min(len(data), len(ref)))} of {len(data)} / {len(ref)}"
+    assert np.array_equal(orc.stream_decode(cdf_i, data, chunk_log2), sym)
     dec = gh.rc_decode(cdf_i, data, chunk_log2)
     assert np.array_equal(dec, sym)
+
+
+@pytest.mark.parametrize("lp", [3, 5, 17])
+def test_range_coder_long_lanes_and_high_rates(gh, orc, lp):
+    """Lanes whose byte windows do not fit 64 lanes per wave (8192-symbol lanes at a high rate: the staged decoder runs
+    fewer lanes per wave) and near-uniform rows (most bits per symbol)."""
+    rng = np.random.RandomState(lp)
+    n = 40_000
+    p = rng.dirichlet(np.ones(lp - 1) * 20.0, size=n).astype(np.float32)
+    cdf = np.concatenate([np.zeros((n, 1), np.float32), np.cumsum(p, 1)], 1).clip(0, 1).astype(np.float32)
+    cdf_i = orc.cdf_to_int16(cdf).view(np.uint16)
+    sym = rng.randint(0, lp - 1, size=n).astype(np.uint8)          # symbols against the model: ~log2(Lp - 1) + bits each
+    for chunk_log2 in (14, 8):
+        data = gh.rc_encode(cdf_i, sym, chunk_log2)
+        assert data == orc.stream_encode(cdf_i, sym, chunk_log2)
+        assert np.array_equal(gh.rc_decode(cdf_i, data, chunk_log2), sym)
 
 
 def test_range_coder_extreme_rows(gh, orc):
@@ -309,8 +331,8 @@ def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_m
     several blocks per wave slot in the encoder's batched sets, tile lists sized through a stream sync, the second
     stream busy beside the trunks -- still the oracle's bytes, and the oracle's points back."""
     pts = _cloud(150_000, seed=11)
-    data, st = gh.encode(dev_model_k5, pts, 10)
-    ref = orc.encode(synth_model_k5, pts, chunk_log2=10)
+    data, st = gh.encode(dev_model_k5, pts, 11)
+    ref = orc.encode(synth_model_k5, pts, chunk_log2=11)
     assert data == ref
     assert max(st.level_nodes[: st.num_levels]) > 100_000
     dec, _, _ = gh.decode(dev_model_k5, data)
@@ -318,12 +340,12 @@ def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_m
 
 
 def test_codec_bitstream_identical_to_oracle_1m(gh, orc, dev_model_k5, synth_model_k5):
-    """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v2.  The device
+    """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v3 with chunk_log2 = 11 (bench.py's default).  The device
     writes the oracle's bytes and decodes to the oracle's points in the oracle's order (the oracle needs ~15 s of the box's
     host cores for each direction)."""
     pts = _cloud(1_000_000, seed=1234)
-    data, st = gh.encode(dev_model_k5, pts, 10)
-    ref = orc.encode(synth_model_k5, pts, chunk_log2=10)
+    data, st = gh.encode(dev_model_k5, pts, 11)
+    ref = orc.encode(synth_model_k5, pts, chunk_log2=11)
     assert len(data) == len(ref)
     assert data == ref
     assert st.num_points == 1_000_000 and st.coded_nodes > 2_500_000
@@ -384,7 +406,7 @@ def test_codec_rejects_bad_input(gh, dev_model_k5):
             gh.decode(dev_model_k5, data[:cut])
     # a header whose level sizes do not match the coded occupancy (the device expands into arrays sized from the header
     # and verifies at its final sync): an error, never an out-of-bounds access
-    assert data[:2] == b"\xff\xff" and data[2] == 2
+    assert data[:2] == b"\xff\xff" and data[2] == 3
     L = data[6]
     for lvl, delta in ((L - 1, +3), (L - 1, -3), (L - 2, +1), (2, -1)):
         bad = bytearray(data)

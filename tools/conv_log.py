@@ -23,13 +23,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     x = torch.tensor(synthetic_cloud(n, seed=1234), device=dev)
     ctx = runtime.context(dev)
     for _ in range(2):
-        data, _ = _encode_to_bytes(x, model, 10, 1)
+        data, _ = _encode_to_bytes(x, model, 11, 1)
         _decode_bytes(data, model, dev)
     _lib.check(_lib.lib().gpcc_profile_enable(ctx, 1))
     torch.cuda.synchronize()
     sys.stderr.write("==encode\n")
     t0 = time.perf_counter()
-    data, _ = _encode_to_bytes(x, model, 10, 1)
+    data, _ = _encode_to_bytes(x, model, 11, 1)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     sys.stderr.write("==decode\n")

@@ -20,12 +20,12 @@ model = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
 x = torch.tensor(synthetic_cloud(n, seed=1234), device=dev)
 ctx = runtime.context(dev)
 L = _lib.lib()
-_encode_to_bytes(x, model, 10, 1)
+_encode_to_bytes(x, model, 11, 1)
 _lib.check(L.gpcc_profile_enable(ctx, 1))
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
-    data, st = _encode_to_bytes(x, model, 10, 1)
+    data, st = _encode_to_bytes(x, model, 11, 1)
 torch.cuda.synchronize()
 t1 = time.perf_counter()
 prof = _lib.Profile()

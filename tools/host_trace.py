@@ -21,7 +21,7 @@ x = torch.tensor(synthetic_cloud(n, seed=1234), device=dev)
 ctx = runtime.context(dev)
 os.environ["GAUSPCC_HOST_TRACE"] = "0"
 for _ in range(2):
-    data, _ = _encode_to_bytes(x, model, 10, 1)
+    data, _ = _encode_to_bytes(x, model, 11, 1)
     _decode_bytes(data, model, dev)
 _lib.check(_lib.lib().gpcc_profile_enable(ctx, prof))
 os.environ["GAUSPCC_HOST_TRACE"] = "1"
@@ -29,7 +29,7 @@ torch.cuda.synchronize()
 for rep in range(2):
     sys.stderr.write(f"---- step {rep}\n")
     t0 = time.perf_counter()
-    data, st = _encode_to_bytes(x, model, 10, 1)
+    data, st = _encode_to_bytes(x, model, 11, 1)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     dec, _, st2 = _decode_bytes(data, model, dev)

@@ -47,7 +47,7 @@ if os.environ.get("PROBE_MAIN_FIRST"):   # what bench.py does before its in-flig
     from gauspcc_amd.pcc_utils import _decode_bytes, _encode_view
     x0 = torch.tensor(synthetic_cloud(n, seed=1234), device=dev)
     for _ in range(2):
-        d0, _ = _encode_view(x0, model, 10, 1)
+        d0, _ = _encode_view(x0, model, 11, 1)
         _decode_bytes(d0, model, dev)
     torch.cuda.synchronize()
 

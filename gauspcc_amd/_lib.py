@@ -58,6 +58,10 @@ def lib():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(make -C gauspcc_amd/csrc). gauspcc_amd has no CPU fallback."
         )
+    # torch first: the library and torch must share ONE HIP runtime (torch ships its own libamdhip64; a process that loads
+    # /opt/rocm's copy through this library before torch's ends up with two, and the second finds no device)
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     vp, i64, i32, u16 = C.c_void_p, C.c_int64, C.c_int, C.c_uint16
     L.gpcc_last_error.restype = C.c_char_p

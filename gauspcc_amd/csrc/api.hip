@@ -39,6 +39,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); }
     if (c->arena.base) (void)hipFree(c->arena.base);
+    if (c->conv_products) (void)hipFree(c->conv_products);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
     delete c;
@@ -570,7 +571,7 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     HIP_TRY(hipMemcpyAsync(db + FRONT, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, symbuf));
+    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, pl.dual, symbuf));
     HIP_TRY(hipMemcpyAsync(sym_dev, symbuf, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;

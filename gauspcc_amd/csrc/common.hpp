@@ -162,6 +162,11 @@ struct gpcc_ctx {
     // second stream of the codec: octree / tile-list work of the next step runs beside the convolutions of this one
     hipStream_t side = nullptr, xfer = nullptr;   // xfer: the container's host -> device copy of a decode, beside both
     hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_bytes = nullptr;
+    // partial products of the two-launch convolution of the small levels (network.hip: k_conv_products / k_conv_sum): one
+    // buffer per context, grown on demand, used by one convolution at a time (the launches of a context's convolutions are
+    // ordered on one stream)
+    float *conv_products = nullptr;
+    size_t conv_products_cap = 0;   // floats
     int side_init()
     {
         if (side) return GPCC_OK;

@@ -464,9 +464,10 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #pragma unroll
     for (int u = 0; u < COOP_EPT; ++u) acc[u] = 0.0f;
     struct AB { float4 a0, a1, b00, b01, b10, b11; };
-    auto fetch = [&](int t) -> AB {   // gathered rows + weight fragment of tile t of this block (t < nt)
-        const float *p = in + (size_t)(uint32_t)hj[t * 16 + e] * 32;
-        const float *w = wf + (size_t)(ho[t] & 0xFFFFu) * 1024;
+    const uint32_t nlv_rows = max(T.lv_rows[lvi], 1u);
+    auto fetch = [&](int t) -> AB {   // gathered rows + weight fragment of tile t of this block (t < nt); clamped: see k_conv_products
+        const float *p = in + (size_t)min((uint32_t)hj[t * 16 + e], nlv_rows - 1u) * 32;
+        const float *w = wf + (size_t)min(ho[t] & 0xFFFFu, (uint32_t)T.K - 1u) * 1024;
         AB r;
         r.a0 = ld4(p); r.a1 = ld4(p + 16);
         r.b00 = ld4(w); r.b01 = ld4(w + 256); r.b10 = ld4(w + 512); r.b11 = ld4(w + 768);
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
         if (lane < 16) inv[lane * COOP_TILES + tl] = 255;
         const uint32_t cnt = ho[t] >> 16;
         const uint32_t r = (hr[t * 4 + (e >> 2)] >> (8 * (e & 3))) & 255u;
-        if (lane < 16 && (uint32_t)lane < cnt) inv[(r - 1u) * COOP_TILES + tl] = (uint8_t)lane;   // tr holds row + 1; same wave: ordered behind the 255s
+        if (lane < 16 && (uint32_t)lane < cnt && r >= 1u && r <= 16u) inv[(r - 1u) * COOP_TILES + tl] = (uint8_t)lane;   // tr holds row + 1; same wave: ordered behind the 255s
     };
     // this wave's two tiles of a round: base + 2 wave + {0, 1}; the next round's operands are requested before this
     // round's products are summed, so a round costs MFMAs + two barriers, not a memory latency
@@ -559,6 +560,125 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #endif
 }
 
+// Small levels, spread over the whole chip: TWO launches per convolution instead of a chain inside one CU.
+// The cooperative kernel above gives a 16-row block to one workgroup; a dense small level (40 .. 77 neighbours per node)
+// has ~100 tiles per block, so a block is ~10^4 matrix cycles on ONE CU while a level of 500 nodes leaves 220 CUs idle
+// (17 .. 39 us per convolution, 131 of them per decode).  Here
+//   k_conv_products   a wave per tile, the tiles of a block spread over up to 32 workgroups: the 16 x 32 products of the
+//                     tile's pairs -- MFMAs from a zero accumulator, the transposed product of the asm loop, so a lane holds
+//                     four physically consecutive channels of one tile row -- go to P[tile][entry][32] in global memory
+//                     (valid entries only);
+//   k_conv_sum        a workgroup per block, a thread per output element: the products of the tiles that contain its row,
+//                     added in tile (= offset) order.  The same sums in the same order as every other conv kernel.
+// P lives in the context (gpcc_ctx::conv_products), 2 KiB per tile of the list's bound; traffic is 128 B per pair each way.
+constexpr int PROD_WAVES = 4;
+__global__ __launch_bounds__(64 * PROD_WAVES) void k_conv_products(ConvJob J, ConvTiles T, float *__restrict__ P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;
+    int lvi = 0;
+    for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
+    const int e = lane & 15, g = lane >> 4;
+    const float *__restrict__ in = J.in + (size_t)T.lv_row0[lvi] * 32 + 4 * g;   // tile entries are row indices inside the level
+    const float *__restrict__ wt = J.w + (size_t)T.K * 1024 + lane * 4;          // the transposed fragments (conv_weight_fragments_t)
+    const uint32_t nlv_rows = max(T.lv_rows[lvi], 1u);
+    P -= (size_t)T.first[T.lv_blk0[0]] * 512;                                    // P[0] = the set's first tile (the set's blocks are consecutive in the pool)
+    const uint32_t tend = t0 + min(t1 - t0, (uint32_t)T.K);   // a 16-row block has at most one tile per offset (a decoder fed a lying header builds lists from garbage: stay inside them)
+    for (uint32_t t = t0 + blockIdx.y * PROD_WAVES + (uint32_t)wave; t < tend; t += gridDim.y * PROD_WAVES) {
+        // (row and offset clamped: the lists of a level whose container header lies are built from stale rows, and round 3
+        // found unwritten tiles in the last block of such a level -- garbage in, garbage out, but inside the arrays)
+        const uint32_t oc = T.toc[t];
+        const uint32_t cnt = oc >> 16;
+        const float *p = in + (size_t)min((uint32_t)T.tj[(size_t)t * 16 + e], nlv_rows - 1u) * 32;
+        const float *w = wt + (size_t)min(oc & 0xFFFFu, (uint32_t)T.K - 1u) * 1024;
+        const float4 x0 = ld4(p), x1 = ld4(p + 16);
+        const float4 w0 = ld4(w), w1 = ld4(w + 256), w2 = ld4(w + 512), w3 = ld4(w + 768);
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+        MF(c0, w0.x, x0.x); MF(c1, w2.x, x0.x);
+        MF(c0, w0.y, x0.y); MF(c1, w2.y, x0.y);
+        MF(c0, w0.z, x0.z); MF(c1, w2.z, x0.z);
+        MF(c0, w0.w, x0.w); MF(c1, w2.w, x0.w);
+        MF(c0, w1.x, x1.x); MF(c1, w3.x, x1.x);
+        MF(c0, w1.y, x1.y); MF(c1, w3.y, x1.y);
+        MF(c0, w1.z, x1.z); MF(c1, w3.z, x1.z);
+        MF(c0, w1.w, x1.w); MF(c1, w3.w, x1.w);
+#undef MF
+        if ((uint32_t)e < cnt) {
+            float *dst = P + ((size_t)t * 16 + e) * 32 + 4 * g;
+            *reinterpret_cast<float4 *>(dst) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+            *reinterpret_cast<float4 *>(dst + 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        }
+    }
+}
+
+// developer check (GAUSPCC_DEBUG_LAUNCH): every tile of the set inside its bounds?
+__global__ void k_check_tiles(ConvTiles T, int64_t n, unsigned long long total_cap, int *bad)
+{
+    const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;
+    const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
+    if (threadIdx.x == 0 && (t1 < t0 || t1 - t0 > (uint32_t)T.K || t1 > total_cap)) { printf("[check] block %d: tiles %u .. %u (K %d, cap %llu)\n", blk, t0, t1, T.K, total_cap); atomicAdd(bad, 1); }
+    const uint32_t tend = t0 + min(t1 - t0, (uint32_t)T.K);
+    for (uint32_t t = t0 + threadIdx.x / 16; t < tend && t < total_cap; t += blockDim.x / 16) {
+        const int e = threadIdx.x & 15;
+        const int32_t j = T.tj[(size_t)t * 16 + e];
+        const uint32_t oc = T.toc[t];
+        if (j < 0 || j >= n || (oc & 0xFFFFu) >= (uint32_t)T.K || (oc >> 16) > 16u) { printf("[check] block %d tile %u entry %d: j %d (n %lld) toc %08x\n", blk, t, e, j, (long long)n, oc); atomicAdd(bad, 1); }
+    }
+}
+
+constexpr int SUM_BATCH = 32;   // products a thread has in flight
+__global__ __launch_bounds__(512) void k_conv_sum(ConvJob J, ConvTiles T, const float *__restrict__ P, int relu)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t inv[];   // [16][ntp]: entry of row r in tile t of the block, 255 = absent
+    const int tid = threadIdx.x;
+    const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;
+    int lvi = 0;
+    for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
+    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * 16;
+    const int nrows = min(16, (int)T.lv_rows[lvi] - lrow0);
+    const int row0 = (int)T.lv_row0[lvi] + lrow0;
+    const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
+    const int nt = (int)min(t1 - t0, (uint32_t)T.K);          // a 16-row block has at most one tile per kernel offset
+    const int ntp = (T.K + SUM_BATCH - 1) / SUM_BATCH * SUM_BATCH;   // row pitch of inv: whole batches, read unconditionally
+    for (int i = tid; i < 16 * ntp; i += 512) inv[i] = 255;
+    __syncthreads();
+    for (int i = tid; i < nt * 16; i += 512) {
+        const int t = i >> 4, en = i & 15;
+        const uint32_t cnt = T.toc[t0 + t] >> 16;
+        const uint32_t r = T.tr[(size_t)(t0 + t) * 16 + en];      // LDS slot = row + 1, 0 = padding
+        if ((uint32_t)en < cnt && r >= 1u && r <= 16u) inv[(r - 1u) * ntp + t] = (uint8_t)en;
+    }
+    __syncthreads();
+    const int r = tid >> 5, ch = tid & 31;
+    const float *__restrict__ Pb = P + (size_t)(t0 - T.first[T.lv_blk0[0]]) * 512 + ch;
+    const uint8_t *iv = inv + r * ntp;
+    float acc = 0.0f;
+    for (int tb = 0; tb < nt; tb += SUM_BATCH) {
+        float pv[SUM_BATCH];
+#pragma unroll
+        for (int u = 0; u < SUM_BATCH; ++u) {
+            // every load is issued whether the row is in the tile or not (a valid address either way: tiles past the block's
+            // last read the first tile again): SUM_BATCH loads in flight instead of one branch and one wait per tile
+            const int t = tb + u;
+            const uint32_t en = iv[t];
+            const float v = Pb[(size_t)(t < nt ? t : 0) * 512 + (en & 15u) * 32];
+            pv[u] = (t < nt && en != 255u) ? v : 0.0f;             // absent: + 0.0f leaves the sum unchanged (it is never -0)
+        }
+#pragma unroll
+        for (int u = 0; u < SUM_BATCH; ++u) acc = acc + pv[u];
+    }
+    if (r < nrows) {
+        const size_t at = (size_t)(row0 + r) * 32 + ch;
+        float v = acc;
+        if (J.res) v = v + J.res[at];
+        if (relu) v = v > 0.f ? v : 0.f;
+        J.out[at] = v;
+    }
+}
+
 int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx)
 {
     Prof &p = ctx->prof;
@@ -595,8 +715,53 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         lds_attr_set = true;
     }
-    static int use_coop = -1;
+    static int use_coop = -1, use_split = -1;
     if (use_coop < 0) { const char *e = getenv("GAUSPCC_CONV_COOP"); use_coop = e ? atoi(e) != 0 : 1; }
+    if (use_split < 0) { const char *e = getenv("GAUSPCC_CONV_SPLIT"); use_split = e ? atoi(e) != 0 : 1; }
+    // 16-row blocks.  Up to 64 blocks (a level of at most 1 k nodes): products over the whole chip + ordered sums, two
+    // launches -- measured 11.7 / 15.2 us against 18.8 / 26.2 for the one-workgroup-per-block kernel at 4 / 32 blocks.
+    // Beyond that the two launches cost what they save (26.9 vs 25.8 us at 160 blocks): the cooperative kernel.
+    // (A second cooperative kernel -- 8 waves, two workgroups per CU, transposed products parked with 16-byte swizzled
+    // stores, operands one tile ahead -- was built and measured in round 3: 25.1 / 34.3 / 24.7 us at 160 / 263 / 315 blocks
+    // against 25.8 / 36.5 / 22.5: a block's ~100 tiles move ~750 KB through one CU's L1 whatever the schedule.  Dropped.)
+    static int split_max = -1;
+    if (split_max < 0) { const char *e = getenv("GAUSPCC_CONV_SPLIT_MAX"); split_max = e ? atoi(e) : 64; }
+    const size_t prod_floats = ((size_t)T.nblk * (size_t)T.K + CONV_HDR_PAD) * 512;
+    if (T.R == 16 && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
+        if (ctx->conv_products_cap < prod_floats) {
+            HIP_TRY(hipStreamSynchronize(st));   // an earlier convolution of this context may still read the old buffer
+            if (ctx->conv_products) HIP_TRY(hipFree(ctx->conv_products));
+            ctx->conv_products = nullptr; ctx->conv_products_cap = 0;
+            const size_t want = std::max(prod_floats, (size_t)16 << 20);
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->conv_products), want * 4));
+            ctx->conv_products_cap = want;
+        }
+        // tiles of a block over `split` workgroups of 4 waves: about 2 k workgroups in all, at most one tile per wave
+        const unsigned split = (unsigned)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, (int64_t)cdiv(T.K, PROD_WAVES), (int64_t)cdiv(2048, T.nblk)}));
+        const int ntp = (T.K + SUM_BATCH - 1) / SUM_BATCH * SUM_BATCH;
+        static const bool dbg = getenv("GAUSPCC_DEBUG_LAUNCH") != nullptr;
+        for (int j = 0; j < njobs; ++j) {
+            if (dbg) {
+                int *bad = nullptr, hb = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bad), 4));
+                HIP_TRY(hipMemsetAsync(bad, 0, 4, st));
+                k_check_tiles<<<(unsigned)T.nblk, 256, 0, st>>>(T, n, (unsigned long long)((size_t)T.nblk * T.K + CONV_HDR_PAD), bad);
+                HIP_TRY(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                (void)hipFree(bad);
+                fprintf(stderr, "[dbg] tile check: %d bad\n", hb);
+            }
+            if (dbg) { fprintf(stderr, "[dbg] products level %d n %lld nblk %lld split %u K %d cap %zu need %zu\n", level, (long long)n, (long long)T.nblk, split, T.K, ctx->conv_products_cap, prod_floats); fflush(stderr); }
+            k_conv_products<<<dim3((unsigned)T.nblk, split), 64 * PROD_WAVES, 0, st>>>(jobs.job[j], T, ctx->conv_products);
+            LAUNCH_CHECK();
+            if (dbg) { HIP_TRY(hipStreamSynchronize(st)); fprintf(stderr, "[dbg] sum\n"); fflush(stderr); }
+            k_conv_sum<<<(unsigned)T.nblk, 512, (size_t)16 * ntp, st>>>(jobs.job[j], T, ctx->conv_products, relu);
+            LAUNCH_CHECK();
+            if (dbg) { HIP_TRY(hipStreamSynchronize(st)); fprintf(stderr, "[dbg] done\n"); fflush(stderr); }
+        }
+        if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+        return GPCC_OK;
+    }
     if (T.R == 16 && use_coop) {
         static bool coop_attr_set = false;
         if (!coop_attr_set) {

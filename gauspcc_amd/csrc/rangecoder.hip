@@ -407,7 +407,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__
 // The lanes of a chunked container are short (a few hundred bytes), so the wave first copies the byte windows of all its
 // lanes into LDS in one sweep -- big-endian dwords in each lane's READING order, which is where the backwards lanes of
 // version-3 chunks stop being special -- and the serial part of a symbol touches memory only through two LDS dwords
-// (no miss, no clamp: LDS reads past the allocation return zero) and the CDF-row ring.
+// (no miss; the dword index is clamped to the lane's window) and the CDF-row ring.
 // State per lane: low, d = high - low, x = value - low, q = bits consumed - 1.  high and value themselves are never needed:
 //   d' = (d1 << k) | ones(k),  x' = (x1 << k) | next k bits   (the E3 flip adds 2^31 to low, high and value alike;
 //   d rather than the span itself because a span of 2^32 does occur: a symbol of probability 2^-16 renormalises to it),
@@ -420,10 +420,13 @@ struct LaneWin {
     const uint32_t *w;      // the lane's window in LDS
     uint32_t q;             // bits consumed - 1 (starts at 31: the first dword is the initial value)
     uint32_t w0, w1;        // dwords q / 32 and q / 32 + 1
-    __device__ __forceinline__ void init(const uint32_t *p) { w = p; q = 31u; w0 = p[0]; w1 = p[1]; }
+    uint32_t last;          // the last dword pair a reader may touch: a lane past its symbols, or fed a corrupt stream, runs
+                            // on garbage and its position may run anywhere -- an LDS access outside the workgroup's
+                            // allocation raises a memory violation that the runtime turns into abort()
+    __device__ __forceinline__ void init(const uint32_t *p, uint32_t rdw) { w = p; q = 31u; w0 = p[0]; w1 = p[1]; last = rdw - 2u; }
     // the next 32 unread bits: bits [s, s + 32) of w0:w1 with s = q % 32 + 1 in [1, 32]
     __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w0, w1, ~q); }
-    __device__ __forceinline__ void advance(uint32_t k) { q += k; const uint32_t i = q >> 5; w0 = w[i]; w1 = w[i + 1u]; }
+    __device__ __forceinline__ void advance(uint32_t k) { q += k; const uint32_t i = min(q >> 5, last); w0 = w[i]; w1 = w[i + 1u]; }
 };
 
 // stage the byte windows of the workgroup's lanes (thread j * owner_stride holds the descriptor of lane j): win[j * rdw + d] = logical bytes 4d .. 4d + 3 of lane j, first byte in the
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     stage_windows(win, bytes, ch, lpw, rdw, 64, 1);   // lane j's descriptor lives in thread j
     __syncthreads();
     LaneWin in;
-    in.init(win + (size_t)min(lane, lpw - 1) * rdw);
+    in.init(win + (size_t)min(lane, lpw - 1) * rdw, rdw);
     const char *rowp = reinterpret_cast<const char *>(cdf) + (size_t)ch.first * (2 * RS);   // this lane's row of the next ring load
     const size_t rstep = (size_t)ch.stride * (2 * RS);
     uint32_t *ring = win + (size_t)lpw * rdw;
@@ -575,7 +578,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     stage_windows(win, bytes, ch, 4, rdw, 64, 16);   // coder lane j's descriptor lives in thread 16 j
     __syncthreads();
     LaneWin in;
-    in.init(win + (size_t)grp * rdw);
+    in.init(win + (size_t)grp * rdw, rdw);
     // compact row: v[1..15] at [0..14]; lane 0 stands for v[0] = 0 and reads the unused slot 15
     const char *rowp = reinterpret_cast<const char *>(cdf) + ((size_t)ch.first * 16 + (size_t)(kk ? kk - 1 : 15)) * 2;
     const size_t rstep = (size_t)ch.stride * 32;
@@ -653,15 +656,14 @@ int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *to
     return GPCC_OK;
 }
 
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, uint8_t *sym)
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym)
 {
     if (nchunks <= 0) return GPCC_OK;
     // staged path: every lane's window (+ the two dwords the reader runs ahead) in LDS; as many lanes per wave as fit
     const uint64_t rdw = ((uint64_t)max_bytes + 3u) / 4u + 3u;
     const uint32_t ring_bytes = (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u);       // the row ring behind the windows
     const uint32_t cap = RC_LDS_CAP - ring_bytes;
-    static const bool staged_off = [] { const char *e = getenv("GAUSPCC_RC_STAGED"); return e && atoi(e) == 0; }();
-    if (!staged_off && rdw * 4u * (lp == 17 ? 4u : 1u) <= cap) {
+    if (rdw * 4u * (lp == 17 ? 4u : 1u) <= cap) {
         if (lp == 17) {
             k_rc_decode17_lds<<<(unsigned)cdiv(nchunks, 4), 64, (size_t)(4u * rdw * 4u) + ring_bytes, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
         } else {
@@ -678,6 +680,7 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
     }
     // lanes too long for LDS (the reference layout: one lane per stream) read their bytes through a window in memory;
     // forwards only (backwards lanes exist in version-3 chunks, which are short by construction)
+    if (dual) return fail(GPCC_ERR_FORMAT, "a chunk of %u bytes is beyond the decoder's LDS window", max_bytes);
     const unsigned g = (unsigned)cdiv(nchunks, 64);
     switch (lp) {
     case 3: k_rc_decode<3><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;

@@ -139,7 +139,8 @@ int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *to
 // cdf: compact interleaved rows (rc_row_stride uint16 per row)
 // max_bytes: the longest byte window of the lanes (rc_parse_table); lanes whose windows fit the LDS are decoded from a staged
 // copy, one lane of any size (the reference layout) straight from memory
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, uint8_t *sym);
+// dual: the lanes are version-3 chunk halves (some run backwards: staged path only)
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym);
 // version-3 streams: the bytes in front of every lane's payload (stream lengths + varint tables) depend on the byte counts
 // and are worked out on the device: lane_stream[l] = stream of lane l, stream_first[s] = first lane of stream s (nstreams + 1
 // entries), dual: lanes pair up into chunks.  gap[l] and *gap_total come out.

@@ -13,6 +13,8 @@ materialise the (n, max-min+2) float table):
     encode_gaussian(x, mean, scale, Q, chunk_size)                    -> (min, max, Tensor uint8, Tensor int32[chunks])
     decode_gaussian(mean, scale, Q, min, max, bytes, cnt, chunk_size) -> Tensor float32 (n)
     encode_gaussian_slices / decode_gaussian_slices: the same for every slice of an attribute in one call
+    encode_gaussian_mixed / decode_gaussian_mixed / calculate_cdf_mixed: HAC++'s K-component mixture
+        (HAC-plus/utils/encodings_cuda.py:205-247, 285-317): lower = clamp(sum_c calculate_cdf(mean_c, scale_c, Q) * prob_c, 0, 1)
 """
 import ctypes as C
 
@@ -139,4 +141,62 @@ def decode_gaussian_slices(mean, scale, Q, slice_start, mins, maxs, data, cnt, c
     _lib.check(_lib.lib().gsac_decode_gaussian_slices(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(),
                                                       ss.ctypes.data, ss.size - 1, mins.ctypes.data, maxs.ctypes.data, data.ctypes.data, data.size,
                                                       cnt.ctypes.data, int(chunk_size), out.data_ptr(), runtime.stream_ptr(mean.device)))
+    return out
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _mix_args(mean_list, scale_list, prob_list, Q):
+    k = len(mean_list)
+    if not (1 <= k <= 4) or len(scale_list) != k or len(prob_list) != k:
+        raise RuntimeError("a mixture has 1..4 components with one mean, scale and prob tensor each")
+    for i, (m, s, p) in enumerate(zip(mean_list, scale_list, prob_list)):
+        for t, nm in ((m, f"mean[{i}]"), (s, f"scale[{i}]"), (p, f"prob[{i}]")):
+            _chk(t, nm)
+    _chk(Q, "Q")
+    keep = _f32(*mean_list, *scale_list, *prob_list, Q)      # alive until the library call has returned
+    return k, keep, _ptr_array(keep[:k]), _ptr_array(keep[k:2 * k]), _ptr_array(keep[2 * k:3 * k]), keep[3 * k]
+
+
+def calculate_cdf_mixed(mean_list, scale_list, prob_list, Q, min_value, max_value):
+    """The mixture's (n, max-min+2) table: sum of calculate_cdf(mean_c, scale_c, Q) * prob_c over the components, clamped."""
+    k, keep, pm, ps, pp, q32 = _mix_args(mean_list, scale_list, prob_list, Q)
+    mn, mx = int(min_value), int(max_value)
+    n = int(q32.shape[0])
+    lower = torch.zeros((n, mx - mn + 2), dtype=torch.float32, device=q32.device)
+    if n:
+        _lib.check(_lib.lib().gsac_calculate_cdf_mixed(runtime.context(q32.device), pm, ps, pp, k, q32.data_ptr(), n, mn, mx, lower.data_ptr(),
+                                                        runtime.stream_ptr(q32.device)))
+    return lower
+
+
+def encode_gaussian_mixed(x, mean_list, scale_list, prob_list, Q, chunk_size):
+    """round(x / Q) -> symbols -> chunked range coder, the mixture's CDF entries evaluated on the fly.
+    Byte-identical to calculate_cdf_mixed + arithmetic_encode."""
+    _chk(x, "x")
+    k, keep, pm, ps, pp, q32 = _mix_args(mean_list, scale_list, prob_list, Q)
+    (x32,) = _f32(x)
+    n = int(x32.shape[0])
+    mn, mx = C.c_float(), C.c_float()
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode_gaussian_mixed(runtime.context(x.device), x32.data_ptr(), pm, ps, pp, k, q32.data_ptr(), n, int(chunk_size),
+                                                     C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc),
+                                                     runtime.stream_ptr(x.device)))
+    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
+    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    return mn.value, mx.value, torch.from_numpy(out).to(x.device), torch.from_numpy(cnt).to(x.device)
+
+
+def decode_gaussian_mixed(mean_list, scale_list, prob_list, Q, min_value, max_value, in_cache_all, in_cnt_all, chunk_size):
+    """Inverse of encode_gaussian_mixed: (sym + min) * Q, float32 on the parameters' device."""
+    k, keep, pm, ps, pp, q32 = _mix_args(mean_list, scale_list, prob_list, Q)
+    data = np.ascontiguousarray(in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False))
+    cnt = np.ascontiguousarray(in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False))
+    n = int(q32.shape[0])
+    out = torch.empty(n, dtype=torch.float32, device=q32.device)
+    _lib.check(_lib.lib().gsac_decode_gaussian_mixed(runtime.context(q32.device), pm, ps, pp, k, q32.data_ptr(), n, float(min_value), float(max_value),
+                                                     data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size), out.data_ptr(),
+                                                     runtime.stream_ptr(q32.device)))
     return out

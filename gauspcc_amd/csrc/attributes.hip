@@ -46,11 +46,43 @@ __global__ __launch_bounds__(TB) void k_gaussian_cdf(const float *__restrict__ m
 // decoding wave compares, are evaluated in registers).
 struct GaussTable { const float *mean, *scale, *q; int min_value; };
 struct GaussRow { float mean, scale, q; int min_value; };
+// HAC++'s mixture (HAC-plus/utils/encodings_cuda.py:205-225, 285-299): lower = clamp(sum_i calculate_cdf(mean_i, scale_i, Q) *
+// prob_i, 0, 1), the components added in list order in fp32 (a product, then a sum: no fused multiply-add)
+constexpr int MIX_MAX = 4;
+struct MixTable { const float *mean[MIX_MAX], *scale[MIX_MAX], *prob[MIX_MAX]; const float *q; int k, min_value; };
+struct MixRow { float mean[MIX_MAX], scale[MIX_MAX], prob[MIX_MAX]; float q; int k, min_value; };
 template <typename CT> struct RowOf { typedef const CT *type; };
 template <> struct RowOf<GaussTable> { typedef GaussRow type; };
+template <> struct RowOf<MixTable> { typedef MixRow type; };
 __device__ __forceinline__ const float *row_of(const float *t, int64_t idx, int lp) { return t + idx * lp; }
 __device__ __forceinline__ const uint16_t *row_of(const uint16_t *t, int64_t idx, int lp) { return t + idx * lp; }
 __device__ __forceinline__ GaussRow row_of(const GaussTable &t, int64_t idx, int) { return GaussRow{t.mean[idx], t.scale[idx], t.q[idx], t.min_value}; }
+__device__ __forceinline__ MixRow row_of(const MixTable &t, int64_t idx, int)
+{
+    MixRow r;
+    r.q = t.q[idx]; r.k = t.k; r.min_value = t.min_value;
+#pragma unroll
+    for (int i = 0; i < MIX_MAX; ++i)
+        if (i < t.k) { r.mean[i] = t.mean[i][idx]; r.scale[i] = t.scale[i][idx]; r.prob[i] = t.prob[i][idx]; }
+    return r;
+}
+__device__ __forceinline__ float mix_cdf_entry(const MixRow &row, int m)
+{
+    float acc = gaussian_cdf_entry(row.mean[0], row.scale[0], row.q, row.min_value, m) * row.prob[0];
+#pragma unroll
+    for (int i = 1; i < MIX_MAX; ++i)
+        if (i < row.k) acc = acc + gaussian_cdf_entry(row.mean[i], row.scale[i], row.q, row.min_value, m) * row.prob[i];
+    return fminf(fmaxf(acc, 0.0f), 1.0f);
+}
+
+// the mixture's table (tests, and callers that want the reference's two-step form)
+__global__ __launch_bounds__(TB) void k_mixture_cdf(MixTable t, int64_t n, int lp, float *__restrict__ lower)
+{
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= n * lp) return;
+    const int64_t idx = q / lp;
+    lower[q] = mix_cdf_entry(row_of(t, idx, lp), (int)(q - idx * lp));
+}
 
 // ------------------------------------------------------------------ encode pre-pass
 // CDF entry -> integer: float rows are integerised on the fly (arithmetic_kernel.cu:124-125 == kit/op.py:67-79),
@@ -61,6 +93,7 @@ __device__ __forceinline__ uint32_t cdf_int(const GaussRow &row, int m, float sc
 {
     return (uint32_t)((int)__builtin_rintf(gaussian_cdf_entry(row.mean, row.scale, row.q, row.min_value, m) * scale) + m);
 }
+__device__ __forceinline__ uint32_t cdf_int(const MixRow &row, int m, float scale) { return (uint32_t)((int)__builtin_rintf(mix_cdf_entry(row, m) * scale) + m); }
 
 template <typename CT>
 __global__ __launch_bounds__(TB) void k_hac_pack(const CT cdf, const int16_t *__restrict__ sym, int64_t n, int lp, int chunk, uint32_t nch,
@@ -529,6 +562,95 @@ extern "C" int gsac_encode_gaussian(gpcc_ctx *ctx, const float *x, const float *
     LAUNCH_CHECK();
     *min_out = (float)hmm[0]; *max_out = (float)hmm[1];
     return gsac_encode_impl<GaussTable>(ctx, sym, GaussTable{mean, scale, Q, hmm[0]}, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream, true);
+}
+
+static int mix_table(const float *const *mean, const float *const *scale, const float *const *prob, int k, const float *Q, int min_value, MixTable *t)
+{
+    if (!mean || !scale || !prob || !Q) return fail(GPCC_ERR_ARG, "null argument");
+    if (k < 1 || k > MIX_MAX) return fail(GPCC_ERR_ARG, "a mixture has 1..%d components", MIX_MAX);
+    *t = MixTable{};
+    for (int i = 0; i < k; ++i) {
+        if (!mean[i] || !scale[i] || !prob[i]) return fail(GPCC_ERR_ARG, "null argument");
+        t->mean[i] = mean[i]; t->scale[i] = scale[i]; t->prob[i] = prob[i];
+    }
+    t->q = Q; t->k = k; t->min_value = min_value;
+    return GPCC_OK;
+}
+
+// HAC++'s encoder_gaussian_mixed without the (n, max - min + 2) table (HAC-plus/utils/encodings_cuda.py:205-247)
+extern "C" int gsac_encode_gaussian_mixed(gpcc_ctx *ctx, const float *x, const float *const *mean, const float *const *scale, const float *const *prob, int k,
+                                          const float *Q, int64_t n, int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out,
+                                          int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    if (!ctx || !x || !min_out || !max_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    MixTable t;
+    GP_TRY(mix_table(mean, scale, prob, k, Q, 0, &t));
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    const uint32_t sstride = rc_scratch_stride((uint32_t)std::min<int64_t>(chunk_size, n));
+    GP_TRY(ctx->arena.reserve((size_t)n * 8 + (size_t)nch * chunk_size * 4 + 2 * (size_t)nch * sstride + (size_t)nch * 64 + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(xi, int32_t, n); TAKE(sym, int16_t, n); TAKE(mm, int32_t, 2);
+    const int32_t init[2] = {INT32_MAX, INT32_MIN};
+    HIP_TRY(hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, st));
+    k_quantise_minmax<<<(unsigned)std::min<int64_t>(cdiv(n, TB), 512), TB, 0, st>>>(x, Q, n, xi, mm);
+    LAUNCH_CHECK();
+    int32_t hmm[2];
+    HIP_TRY(hipMemcpyAsync(hmm, mm, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int lp = hmm[1] - hmm[0] + 2;
+    // (the reference clamps the symbol to 32767, :227-228, and would then need a table of more than 32767 columns per element)
+    if (lp > 32767) return fail(GPCC_ERR_RANGE, "quantised values span %d levels (int16 symbols)", lp - 1);
+    k_to_symbols<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(xi, n, hmm[0], sym);
+    LAUNCH_CHECK();
+    *min_out = (float)hmm[0]; *max_out = (float)hmm[1];
+    t.min_value = hmm[0];
+    return gsac_encode_impl<MixTable>(ctx, sym, t, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream, true);
+}
+
+// ... and decoder_gaussian_mixed (:271-317)
+extern "C" int gsac_decode_gaussian_mixed(gpcc_ctx *ctx, const float *const *mean, const float *const *scale, const float *const *prob, int k, const float *Q,
+                                          int64_t n, float min_value, float max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
+                                          float *x_out, void *stream)
+{
+    if (!ctx || !x_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (n <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
+    if (!(min_value >= -1.0e9f && min_value <= 1.0e9f) || !(max_value >= -1.0e9f && max_value <= 1.0e9f))
+        return fail(GPCC_ERR_FORMAT, "bad symbol range [%g, %g]", (double)min_value, (double)max_value);
+    const int mn = (int)min_value, mx = (int)max_value;
+    const int64_t lp64 = (int64_t)mx - mn + 2;
+    if (lp64 < 2 || lp64 > 32767) return fail(GPCC_ERR_FORMAT, "bad symbol range [%d, %d]", mn, mx);
+    MixTable t;
+    GP_TRY(mix_table(mean, scale, prob, k, Q, mn, &t));
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nch = (int)cdiv(n, chunk_size);
+    GP_TRY(ctx->arena.reserve((size_t)n * 2 + (size_t)nbytes + 8 * (size_t)nch + ((size_t)4 << 20)));
+    ctx->arena.reset();
+    TAKE(sym, int16_t, n);
+    GP_TRY(gsac_decode_impl<MixTable>(ctx, t, bytes, nbytes, cnt, chunk_size, n, (int)lp64, sym, stream, true));
+    k_from_symbols<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(sym, Q, n, min_value, x_out);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+}
+
+// the mixture's CDF table itself: lower (n, max - min + 2), as HAC++ builds it before arithmetic_encode (:210-225)
+extern "C" int gsac_calculate_cdf_mixed(gpcc_ctx *ctx, const float *const *mean, const float *const *scale, const float *const *prob, int k, const float *Q,
+                                        int64_t n, int min_value, int max_value, float *lower, void *stream)
+{
+    if (!ctx || !lower) return fail(GPCC_ERR_ARG, "null argument");
+    const int64_t lp = (int64_t)max_value - min_value + 2;
+    if (n <= 0 || lp < 2 || lp > 32767) return fail(GPCC_ERR_ARG, "bad size");
+    MixTable t;
+    GP_TRY(mix_table(mean, scale, prob, k, Q, min_value, &t));
+    HIP_TRY(hipSetDevice(ctx->device));
+    k_mixture_cdf<<<(unsigned)cdiv(n * lp, TB), TB, 0, (hipStream_t)stream>>>(t, n, (int)lp, lower);
+    LAUNCH_CHECK();
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return GPCC_OK;
 }
 
 extern "C" int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, int64_t n, float min_value, float max_value,

@@ -4,6 +4,9 @@ gauspcc_amd.arithmetic instead of the CUDA `arithmetic` extension.
 
     encoder_gaussian(_chunk) / decoder_gaussian(_chunk)   :317-433
     encoder / decoder (Bernoulli, one global p)            :435-492
+    encoder_factorized(_chunk) / decoder_factorized(_chunk) :38-175   (a learned per-channel density, `lower_func`)
+    encoder_gaussian_mixed(_chunk) / decoder_gaussian_mixed(_chunk)   HAC-plus/utils/encodings_cuda.py:177-317 (HAC++'s
+                                                           K-component mixture; callers HAC-plus/scene/gaussian_model.py:1315, 1499)
 
 encoder_gaussian / decoder_gaussian go through the fused gsac_encode_gaussian / gsac_decode_gaussian: the reference
 writes and re-reads an (n, max-min+2) float table per slice (36 MB for a 3000-anchor feature slice, 334 slices per
@@ -36,53 +39,29 @@ def _write_files(jobs):
 
 
 def encoder_gaussian_chunk(x, mean, scale, Q, file_name='tmp.b', chunk_size=1000_0000):
+    """Pieces of at most chunk_size elements, one `<name>_<c>.b` file each (:317-337)."""
     assert file_name.endswith('.b')
     assert len(x.shape) == 1
-    x_view, mean_view, scale_view = x.view(-1), mean.view(-1), scale.view(-1)
-    N = x_view.shape[0]
-    chunks = int(np.ceil(N / chunk_size))
-    is_q_tensor = isinstance(Q, torch.Tensor)
-    if is_q_tensor:
-        Q_view = Q.view(-1)
-    bit_len_list = []
-    for c in range(chunks):
-        sl = slice(c * chunk_size, c * chunk_size + chunk_size)
-        bit_len_list.append(encoder_gaussian(x=x_view[sl], mean=mean_view[sl], scale=scale_view[sl],
-                                             Q=Q_view[sl] if is_q_tensor else Q, file_name=file_name.replace('.b', f'_{str(c)}.b')))
-    return sum(bit_len_list)
+    xv, mv, sv = x.view(-1), mean.view(-1), scale.view(-1)
+    qv = Q.view(-1) if isinstance(Q, torch.Tensor) else None
+    return sum(encoder_gaussian(xv[sl], mv[sl], sv[sl], qv[sl] if qv is not None else Q, file_name.replace('.b', f'_{str(c)}.b'))
+               for c, sl in enumerate(_chunk_slices(xv.shape[0], chunk_size)))
 
 
 def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
     assert file_name.endswith('.b')
     assert len(x.shape) == 1
-    if not isinstance(Q, torch.Tensor):
-        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
-    min_value, max_value, byte_stream_torch, cnt_torch = arithmetic.encode_gaussian(x.contiguous(), mean.contiguous(), scale.contiguous(),
-                                                                                     Q.contiguous(), chunk_size_cuda)
-    cnt_bytes = cnt_torch.cpu().numpy().tobytes()
-    byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
-    with open(file_name, 'wb') as fout:
-        fout.write(np.float32(min_value).tobytes())
-        fout.write(np.float32(max_value).tobytes())
-        fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
-        fout.write(cnt_bytes)
-        fout.write(byte_stream_bytes)
-    return (len(byte_stream_bytes) + len(cnt_bytes)) * 8 + 32 * 3
+    Q = _as_q(Q, mean)
+    min_value, max_value, data, cnt = arithmetic.encode_gaussian(x.contiguous(), mean.contiguous(), scale.contiguous(), Q.contiguous(), chunk_size_cuda)
+    return _write_b(file_name, min_value, max_value, data, cnt)
 
 
 def decoder_gaussian_chunk(mean, scale, Q, file_name='tmp.b', chunk_size=1000_0000):
     assert file_name.endswith('.b')
-    mean_view, scale_view = mean.view(-1), scale.view(-1)
-    N = mean_view.shape[0]
-    chunks = int(np.ceil(N / chunk_size))
-    is_q_tensor = isinstance(Q, torch.Tensor)
-    if is_q_tensor:
-        Q_view = Q.view(-1)
-    out = []
-    for c in range(chunks):
-        sl = slice(c * chunk_size, c * chunk_size + chunk_size)
-        out.append(decoder_gaussian(mean=mean_view[sl], scale=scale_view[sl], Q=Q_view[sl] if is_q_tensor else Q,
-                                    file_name=file_name.replace('.b', f'_{str(c)}.b')))
+    mv, sv = mean.view(-1), scale.view(-1)
+    qv = Q.view(-1) if isinstance(Q, torch.Tensor) else None
+    out = [decoder_gaussian(mv[sl], sv[sl], qv[sl] if qv is not None else Q, file_name.replace('.b', f'_{str(c)}.b'))
+           for c, sl in enumerate(_chunk_slices(mv.shape[0], chunk_size))]
     return torch.cat(out, dim=0).type_as(mean)
 
 
@@ -90,16 +69,9 @@ def decoder_gaussian(mean, scale, Q, file_name='tmp.b'):
     assert file_name.endswith('.b')
     assert len(mean.shape) == 1
     assert mean.shape == scale.shape
-    if not isinstance(Q, torch.Tensor):
-        Q = torch.tensor([Q], dtype=mean.dtype, device=mean.device).repeat(mean.shape[0])
-    with open(file_name, 'rb') as fin:
-        min_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
-        max_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
-        len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
-        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy())
-        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy())
-    return arithmetic.decode_gaussian(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value, byte_stream_torch, cnt_torch,
-                                      chunk_size_cuda)
+    Q = _as_q(Q, mean)
+    min_value, max_value, data, cnt = _read_b(file_name)
+    return arithmetic.decode_gaussian(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value, data, cnt, chunk_size_cuda)
 
 
 def _bernoulli_cdf(p1: torch.Tensor, n: int, device):
@@ -192,3 +164,133 @@ def decoder_gaussian_slices(mean, scale, Q, slice_start, file_names):
     cs = np.concatenate([[0], np.cumsum(lens[keep])])
     return arithmetic.decode_gaussian_slices(pick(mean), pick(scale), pick(Q), cs, np.array(mins), np.array(maxs), np.concatenate(datas),
                                              np.concatenate(cnts), chunk_size_cuda)
+
+
+# ---------------------------------------------------------------- `.b` container shared by the Gaussian-family coders
+def _write_b(file_name, min_value, max_value, byte_stream_torch, cnt_torch):
+    """f32 min | f32 max | i32 len(cnt bytes) | cnt | payload  (HAC/utils/encodings_cuda.py:366-376); returns the bit count"""
+    cnt_bytes = cnt_torch.cpu().numpy().tobytes()
+    byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
+    with open(file_name, 'wb') as fout:
+        fout.write(np.float32(min_value).tobytes())
+        fout.write(np.float32(max_value).tobytes())
+        fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
+        fout.write(cnt_bytes)
+        fout.write(byte_stream_bytes)
+    return (len(byte_stream_bytes) + len(cnt_bytes)) * 8 + 32 * 3
+
+
+def _read_b(file_name):
+    with open(file_name, 'rb') as fin:
+        min_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+        max_value = float(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+        len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+        cnt = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy())
+        data = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy())
+    return min_value, max_value, data, cnt
+
+
+def _chunk_slices(n, chunk_size):
+    return [slice(c * chunk_size, c * chunk_size + chunk_size) for c in range(int(np.ceil(n / chunk_size)))]
+
+
+def _as_q(Q, like):
+    return Q if isinstance(Q, torch.Tensor) else torch.tensor([Q], dtype=like.dtype, device=like.device).repeat(like.shape[0])
+
+
+# ---------------------------------------------------------------- HAC++: Gaussian mixture
+def encoder_gaussian_mixed_chunk(x, mean_list, scale_list, prob_list, Q, file_name='tmp.b', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 1
+    x_view = x.view(-1)
+    means, scales, probs = ([t.view(-1) for t in lst] for lst in (mean_list, scale_list, prob_list))
+    assert x_view.shape[0] == means[0].shape[0] == scales[0].shape[0] == probs[0].shape[0]
+    q_view = Q.view(-1) if isinstance(Q, torch.Tensor) else None
+    bits = 0
+    for c, sl in enumerate(_chunk_slices(x_view.shape[0], chunk_size)):
+        bits += encoder_gaussian_mixed(x_view[sl], [m[sl] for m in means], [s[sl] for s in scales], [p[sl] for p in probs],
+                                       q_view[sl] if q_view is not None else Q, file_name=file_name.replace('.b', f'_{str(c)}.b'))
+    return bits
+
+
+def encoder_gaussian_mixed(x, mean_list, scale_list, prob_list, Q, file_name='tmp.b'):
+    """One device call: quantise, min / max, the mixture's CDF entries inside the coder (no (n, max-min+2) table per
+    component as in :210-225).  Same `.b` bytes as the table path (tests/test_gpu_attributes.py)."""
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 1
+    Q = _as_q(Q, x)
+    assert x.shape == mean_list[0].shape == scale_list[0].shape == prob_list[0].shape == Q.shape
+    cont = lambda lst: [t.contiguous() for t in lst]
+    min_value, max_value, data, cnt = arithmetic.encode_gaussian_mixed(x.contiguous(), cont(mean_list), cont(scale_list), cont(prob_list),
+                                                                       Q.contiguous(), chunk_size_cuda)
+    return _write_b(file_name, min_value, max_value, data, cnt)
+
+
+def decoder_gaussian_mixed_chunk(mean_list, scale_list, prob_list, Q, file_name='tmp.b', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    means, scales, probs = ([t.view(-1) for t in lst] for lst in (mean_list, scale_list, prob_list))
+    q_view = Q.view(-1) if isinstance(Q, torch.Tensor) else None
+    out = []
+    for c, sl in enumerate(_chunk_slices(means[0].shape[0], chunk_size)):
+        out.append(decoder_gaussian_mixed([m[sl] for m in means], [s[sl] for s in scales], [p[sl] for p in probs],
+                                          q_view[sl] if q_view is not None else Q, file_name=file_name.replace('.b', f'_{str(c)}.b')))
+    return torch.cat(out, dim=0).type_as(mean_list[0])
+
+
+def decoder_gaussian_mixed(mean_list, scale_list, prob_list, Q, file_name='tmp.b'):
+    assert file_name.endswith('.b')
+    Q = _as_q(Q, mean_list[0])
+    assert mean_list[0].shape == scale_list[0].shape == prob_list[0].shape == Q.shape
+    min_value, max_value, data, cnt = _read_b(file_name)
+    cont = lambda lst: [t.contiguous() for t in lst]
+    return arithmetic.decode_gaussian_mixed(cont(mean_list), cont(scale_list), cont(prob_list), Q.contiguous(), min_value, max_value, data, cnt,
+                                            chunk_size_cuda)
+
+
+# ---------------------------------------------------------------- factorized density (a per-channel learned CDF)
+def _factorized_table(lower_func, Q, min_value, max_value, dim, rows, device):
+    """(rows * dim, max - min + 2) CDF table of :91-105 / :156-165: per channel the pmf |sigmoid(s u) - sigmoid(s l)| between the
+    half-integer bounds of every level, accumulated, a leading zero, clamped; the same row for every element of a channel."""
+    levels = torch.arange(int(min_value), int(max_value) + 1, dtype=torch.float, device=device)
+    samples = levels.view(1, 1, -1).repeat(dim, 1, 1)                       # [C, 1, L]
+    lower = lower_func((samples - 0.5) * Q, stop_gradient=False)
+    upper = lower_func((samples + 0.5) * Q, stop_gradient=False)
+    sign = -torch.sign(torch.add(lower, upper)).detach()
+    pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+    cdf = torch.cumsum(pmf, dim=-1)
+    table = torch.cat([torch.zeros_like(cdf[..., 0:1]), cdf], dim=-1)       # [C, 1, L + 1]
+    table = table.permute(1, 0, 2).contiguous().repeat(rows, 1, 1).view(rows * dim, -1)
+    return torch.clamp(table, min=0.0, max=1.0)
+
+
+def encoder_factorized_chunk(x, lower_func, Q: float = 1, file_name='tmp.b', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 2
+    return sum(encoder_factorized(x[sl], lower_func, Q, file_name.replace('.b', f'_{str(c)}.b')) for c, sl in enumerate(_chunk_slices(x.shape[0], chunk_size)))
+
+
+def encoder_factorized(x, lower_func, Q: float = 1, file_name='tmp.b'):
+    """x (N, C); lower_func = the entropy model's `_logits_cumulative` (callable on a [C, 1, L] tensor)."""
+    assert file_name.endswith('.b')
+    assert len(x.shape) == 2
+    x_int_round = torch.round(x / Q)
+    max_value, min_value = x_int_round.max(), x_int_round.min()
+    table = _factorized_table(lower_func, Q, min_value.item(), max_value.item(), x.shape[-1], x.shape[0], x.device)
+    sym = (x_int_round - min_value).to(torch.int16).view(-1)
+    data, cnt = arithmetic.arithmetic_encode(sym.contiguous(), table.contiguous(), chunk_size_cuda, int(table.shape[0]), int(table.shape[1]))
+    return _write_b(file_name, min_value.item(), max_value.item(), data, cnt)
+
+
+def decoder_factorized_chunk(lower_func, Q, N_len, dim, file_name='tmp.b', device='cuda', chunk_size=1000_0000):
+    assert file_name.endswith('.b')
+    out = [decoder_factorized(lower_func, Q, min(chunk_size, N_len - c * chunk_size), dim, file_name.replace('.b', f'_{str(c)}.b'), device)
+           for c in range(int(np.ceil(N_len / chunk_size)))]
+    return torch.cat(out, dim=0)
+
+
+def decoder_factorized(lower_func, Q, N_len, dim, file_name='tmp.b', device='cuda'):
+    assert file_name.endswith('.b')
+    min_value, max_value, data, cnt = _read_b(file_name)
+    table = _factorized_table(lower_func, Q, min_value, max_value, dim, N_len, device)
+    sym = arithmetic.arithmetic_decode(table.contiguous(), data, cnt, chunk_size_cuda, int(table.shape[0]), int(table.shape[1])).to(device).to(torch.float32)
+    return ((sym + min_value) * Q).reshape(N_len, dim)

@@ -221,6 +221,23 @@ GPCC_API int gsac_decode_gaussian(gpcc_ctx *ctx, const float *mean_dev, const fl
                                   float max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out_dev,
                                   void *stream);
 
+/* HAC++'s Gaussian-MIXTURE coder (src/gs_compress/HAC-plus/utils/encodings_cuda.py:177-317; callers
+ * HAC-plus/scene/gaussian_model.py:1315, 1499): the CDF row of element i is
+ *     lower[i][t] = clamp( sum_c calculate_cdf(mean_c[i], scale_c[i], Q[i])[t] * prob_c[i], 0, 1 ),   c = 0 .. k-1 in list order, fp32
+ * with the same integerisation, chunking, symbol range and `.b` layout as the single Gaussian.  As above the table is never
+ * materialised: gsac_encode_gaussian_mixed == calculate_cdf x k, multiply, add, clamp, arithmetic_encode of :205-247 in one
+ * call, gsac_decode_gaussian_mixed == :285-317.  mean / scale / prob: host arrays of k (1..4) device pointers, (n) each.
+ * gsac_calculate_cdf_mixed writes the table itself, (n, max - min + 2) fp32 on the device (tests; two-step callers). */
+GPCC_API int gsac_encode_gaussian_mixed(gpcc_ctx *ctx, const float *x_dev, const float *const *mean_dev, const float *const *scale_dev,
+                                        const float *const *prob_dev, int k, const float *q_dev, int64_t n, int chunk_size, float *min_out,
+                                        float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out,
+                                        int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_gaussian_mixed(gpcc_ctx *ctx, const float *const *mean_dev, const float *const *scale_dev, const float *const *prob_dev, int k,
+                                        const float *q_dev, int64_t n, float min_value, float max_value, const uint8_t *bytes, int64_t nbytes,
+                                        const int32_t *cnt, int chunk_size, float *x_out_dev, void *stream);
+GPCC_API int gsac_calculate_cdf_mixed(gpcc_ctx *ctx, const float *const *mean_dev, const float *const *scale_dev, const float *const *prob_dev, int k,
+                                      const float *q_dev, int64_t n, int min_value, int max_value, float *lower_dev, void *stream);
+
 /* The same for every slice of an attribute in ONE call: conduct_encoding / conduct_decoding code each 3000-anchor
  * slice into its own `.b` file (own min / max, hence own alphabet; HAC/scene/gaussian_model.py:1123-1206, 1262-1311) --
  * 334 slices x 3 attributes per million anchors, each a serial chain of 10000-symbol chunks.  Here all chunks of all

@@ -61,6 +61,7 @@ def lib():
         L.orc_trace_get.argtypes = [i32, i32, vp, vp, vp, vp]
         L.orc_ideal_bits.restype = C.c_double
         L.orc_gaussian_cdf.argtypes = [vp, vp, vp, i64, i32, i32, vp]
+        L.orc_gaussian_mixed_cdf.argtypes = [vp, vp, vp, i32, vp, i64, i32, i32, vp]
         L.orc_hac_encode.restype = i64
         L.orc_hac_encode.argtypes = [vp, i32, vp, i64, i32, vp, i64, vp]
         L.orc_hac_decode.argtypes = [vp, i32, vp, vp, i64, i32, vp]
@@ -298,6 +299,17 @@ def gaussian_cdf(mean, scale, q, min_value: int, max_value: int) -> np.ndarray:
     mean, scale, q = (np.ascontiguousarray(a, dtype=np.float32) for a in (mean, scale, q))
     out = np.empty((mean.size, max_value - min_value + 2), dtype=np.float32)
     lib().orc_gaussian_cdf(_p(mean), _p(scale), _p(q), mean.size, min_value, max_value, _p(out))
+    return out
+
+
+def gaussian_mixed_cdf(means, scales, probs, q, min_value: int, max_value: int) -> np.ndarray:
+    """HAC++'s mixture table: clamp(sum_c gaussian_cdf(mean_c, scale_c, q) * prob_c, 0, 1), components in list order."""
+    k = len(means)
+    arrs = [[np.ascontiguousarray(a, dtype=np.float32) for a in lst] for lst in (means, scales, probs)]
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    ptrs = [(C.c_void_p * k)(*[a.ctypes.data for a in lst]) for lst in arrs]
+    out = np.empty((q.size, max_value - min_value + 2), dtype=np.float32)
+    lib().orc_gaussian_mixed_cdf(ptrs[0], ptrs[1], ptrs[2], k, _p(q), q.size, min_value, max_value, _p(out))
     return out
 
 

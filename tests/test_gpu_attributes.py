@@ -234,3 +234,80 @@ def test_psnr_matches_reference_golden(torch_cuda, golden_dir):
     got = psnr(torch.tensor(z["a"]).cuda(), torch.tensor(z["b"]).cuda())
     assert got.shape == tuple(z["psnr"].shape) and got.is_cuda
     np.testing.assert_allclose(got.cpu().numpy(), z["psnr"], rtol=1e-5)
+
+
+def test_mixture_coder_matches_table_path_and_oracle_files(torch_cuda, orc, tmp_path):
+    """HAC++ (HAC-plus/utils/encodings_cuda.py:177-317; callers HAC-plus/scene/gaussian_model.py:1315, 1499): the two-component
+    Gaussian-mixture coder.  (1) the device's mixture table == sum of its single-Gaussian tables times the weights, clamped
+    (the reference's torch expression, op for op) and within 2e-7 of the oracle's (two erfc implementations); (2) the fused
+    coder writes the `.b` file the ORACLE coder assembles from that table; (3) round trip through the wrappers, scalar and
+    tensor Q, chunked file names; (4) a one-component mixture with weight 1 is the plain Gaussian coder, byte for byte."""
+    torch = torch_cuda
+    from gauspcc_amd import arithmetic
+    from gauspcc_amd import encodings_cuda as ec
+
+    g = torch.Generator(device="cpu").manual_seed(33)
+    n = 23_457
+    mean = [(torch.randn(n, generator=g) * 2).cuda(), (torch.randn(n, generator=g) * 2).cuda()]
+    scale = [(torch.rand(n, generator=g) * 3 + 0.05).cuda(), (torch.rand(n, generator=g) * 0.5 + 1e-3).cuda()]
+    w = torch.softmax(torch.randn(n, 2, generator=g), dim=-1).cuda()
+    prob = [w[:, 0].contiguous(), w[:, 1].contiguous()]
+    q = (torch.rand(n, generator=g) * 0.5 + 0.75).cuda()
+    pick = (torch.rand(n, generator=g) < w[:, 0].cpu()).cuda()
+    x = torch.where(pick, mean[0] + torch.randn(n, generator=g).cuda() * scale[0], mean[1] + torch.randn(n, generator=g).cuda() * scale[1])
+    xq = torch.round(x / q) * q
+    xi = torch.round(xq / q)
+    mn, mx = float(xi.min()), float(xi.max())
+    # (1) the table
+    table = arithmetic.calculate_cdf_mixed(mean, scale, prob, q, mn, mx)
+    ref = arithmetic.calculate_cdf(mean[0], scale[0], q, mn, mx) * prob[0].unsqueeze(-1)
+    ref += arithmetic.calculate_cdf(mean[1], scale[1], q, mn, mx) * prob[1].unsqueeze(-1)
+    assert torch.equal(table, torch.clamp(ref, min=0.0, max=1.0))
+    otab = orc.gaussian_mixed_cdf([t.cpu().numpy() for t in mean], [t.cpu().numpy() for t in scale], [t.cpu().numpy() for t in prob], q.cpu().numpy(), int(mn), int(mx))
+    assert np.abs(table.cpu().numpy() - otab).max() < 2e-7
+    # (2) whole file == oracle-assembled file
+    bits = ec.encoder_gaussian_mixed(xq, mean, scale, prob, q, file_name=str(tmp_path / "feat.b"))
+    payload, cnt = orc.hac_encode((xi - mn).to(torch.int16).cpu().numpy(), table.cpu().numpy(), 10000)
+    want = np.float32(mn).tobytes() + np.float32(mx).tobytes() + np.array([4 * len(cnt)], np.int32).tobytes() + cnt.astype(np.int32).tobytes() + payload.tobytes()
+    assert (tmp_path / "feat.b").read_bytes() == want
+    assert bits == (len(payload) + 4 * len(cnt)) * 8 + 96
+    # fused == table path on the device as well
+    tb, tc = arithmetic.arithmetic_encode((xi - mn).to(torch.int16), table, 10000, n, table.shape[1])
+    assert tb.cpu().numpy().tobytes() == payload.tobytes() and np.array_equal(tc.cpu().numpy(), cnt)
+    # (3) round trips
+    assert torch.equal(ec.decoder_gaussian_mixed(mean, scale, prob, q, file_name=str(tmp_path / "feat.b")), xq)
+    xs = torch.round(x)                                               # scalar Q = 1, pieces of 10 000 elements -> feat2_0.b .. feat2_2.b
+    b2 = ec.encoder_gaussian_mixed_chunk(xs, mean, scale, prob, 1, file_name=str(tmp_path / "feat2.b"), chunk_size=10_000)
+    assert sorted(p.name for p in tmp_path.glob("feat2_*.b")) == ["feat2_0.b", "feat2_1.b", "feat2_2.b"] and b2 > 0
+    assert torch.equal(ec.decoder_gaussian_mixed_chunk(mean, scale, prob, 1, file_name=str(tmp_path / "feat2.b"), chunk_size=10_000), xs)
+    # (4) K = 1, weight 1: the single-Gaussian coder
+    one = torch.ones(n, device="cuda")
+    ec.encoder_gaussian_mixed(xq, mean[:1], scale[:1], [one], q, file_name=str(tmp_path / "k1.b"))
+    ec.encoder_gaussian(xq, mean[0], scale[0], q, file_name=str(tmp_path / "g.b"))
+    assert (tmp_path / "k1.b").read_bytes() == (tmp_path / "g.b").read_bytes()
+
+
+def test_factorized_coder_roundtrip_and_table(torch_cuda, orc, tmp_path):
+    """encoder_factorized / decoder_factorized (HAC/utils/encodings_cuda.py:38-175): a per-channel learned density given as
+    `lower_func` (the entropy bottleneck's cumulative logits).  The payload equals the oracle coder's on the same table, the
+    file layout is the Gaussian one, and the round trip is exact for every chunking."""
+    torch = torch_cuda
+    from gauspcc_amd import encodings_cuda as ec
+
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, Cdim, Q = 1234, 6, 0.5
+    a = (torch.rand(Cdim, 1, 1, generator=g) * 1.5 + 0.3).cuda(); b = (torch.randn(Cdim, 1, 1, generator=g) * 0.7).cuda()
+    lower_func = lambda v, stop_gradient=False: a * v + b               # monotone per channel, like _logits_cumulative
+    x = torch.round((torch.randn(N, Cdim, generator=g).cuda() * 2 - b.view(1, -1)) / Q) * Q
+    bits = ec.encoder_factorized(x, lower_func, Q, file_name=str(tmp_path / "f.b"))
+    assert torch.equal(ec.decoder_factorized(lower_func, Q, N, Cdim, file_name=str(tmp_path / "f.b")), x)
+    xi = torch.round(x / Q)
+    mn, mx = float(xi.min()), float(xi.max())
+    table = ec._factorized_table(lower_func, Q, mn, mx, Cdim, N, x.device)
+    assert table.shape == (N * Cdim, int(mx - mn) + 2) and float(table.min()) >= 0 and float(table.max()) <= 1
+    payload, cnt = orc.hac_encode((xi - mn).to(torch.int16).view(-1).cpu().numpy(), table.cpu().numpy(), 10000)
+    want = np.float32(mn).tobytes() + np.float32(mx).tobytes() + np.array([4 * len(cnt)], np.int32).tobytes() + cnt.astype(np.int32).tobytes() + payload.tobytes()
+    assert (tmp_path / "f.b").read_bytes() == want and bits == (len(payload) + 4 * len(cnt)) * 8 + 96
+    ec.encoder_factorized_chunk(x, lower_func, Q, file_name=str(tmp_path / "fc.b"), chunk_size=500)
+    assert len(list(tmp_path.glob("fc_*.b"))) == 3
+    assert torch.equal(ec.decoder_factorized_chunk(lower_func, Q, N, Cdim, file_name=str(tmp_path / "fc.b"), chunk_size=500), x)

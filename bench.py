@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps that carry the HIP-event brackets around the conv launches (-1 = all; each bracket costs its stream ~5 us, ~0.65 ms per step)")
     ap.add_argument("--scenes-in-flight", type=int, default=2, help="also report the throughput with this many independent scenes in flight on the GPU "
                     "(own context, stream and host thread each; untimed extra pass on rank 0 at N = 1; 0 = skip)")
+    ap.add_argument("--side-anchors", type=int, default=200_000, help="anchors of the synthetic HAC-style scene behind the `side_paths` object (SURVEY 8f: attribute "
+                    "loop, Gaussian coder, mlp_grid, generate_neural_gaussians + rasteriser, torchac shim; untimed pass on rank 0 at N = 1; 0 = skip)")
     ap.add_argument("--skip-stages", action="store_true", help="do not run the extra pass that times the HBM-bound stages")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
     args = ap.parse_args()
@@ -332,6 +334,24 @@ def main():
                 "stages": stages,
             },
         }
+        if args.side_anchors > 0 and world == 1:
+            # the callers either side of the path, measured behind the timed region on a synthetic
+            # scene: seconds / ms / symbol rates as observed in THIS run (tools/bench_side_paths.py holds the harness)
+            import importlib.util
+
+            spec = importlib.util.spec_from_file_location("bench_side_paths", os.path.join(ROOT, "tools", "bench_side_paths.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            sp = mod.measure(args.side_anchors)
+            out["side_paths"] = {
+                "scene": f"synthetic HAC-style scene, {sp['n_anchors']} anchors x 50 features x 10 offsets, {sp['image'][0]}x{sp['image'][1]} frame",
+                "attribute_loop": {k: sp["attribute_loop"][k] for k in ("anchors_coded", "files_bytes", "conduct_encoding_s", "conduct_decoding_s")},
+                "gaussian_coder": {k: sp["gaussian_coder"][k] for k in ("symbols", "encode_fused_ms", "decode_fused_ms", "Msymbols_per_s_encode", "Msymbols_per_s_decode",
+                                                                        "fused_bytes_equal_table_bytes")},
+                "mlp_grid": sp["mlp_grid"],
+                "rd_loop": {k: sp["rd_loop"][k] for k in ("gaussians", "generate_neural_gaussians_ms", "generate_plus_rasterise_ms", "psnr_decoded_vs_encoder_side_dB")},
+                "torchac_shim": sp["torchac_shim"],
+            }
         if args.cpu_sample > 0 and world == 1:   # the CPU baseline is a rank-0, N = 1 figure
             from gauspcc_amd.model import tensor_table
             from oracle import oracle as orc

@@ -490,6 +490,90 @@ __global__ __launch_bounds__(TB) void k_mlp2(const float *__restrict__ x, const 
 }
 }  // namespace
 
+namespace {
+// The same two layers on the matrix pipe (round 3; k_mlp2 above stays for layer sizes this kernel does not take and as the
+// readable statement of the arithmetic).  v_mfma_f32_16x16x4_f32 with the bias as the initial accumulator is the specified
+// chain -- acc = b; for k ascending: acc = fmaf(x[k], W[c][k], acc) -- exactly (the heads of the geometry network rely on the
+// same fact): MFMA number kk covers k = 4 kk .. 4 kk + 3, lane group g supplying k = 4 kk + g.  16 rows x 16 outputs per
+// accumulator tile: 16 anchors are 7 x 24 + 11 x 25 = 443 MFMAs for HAC's 96-100-175 mlp_grid instead of ~55 k scalar
+// fmas per row at one lane each (9.5 ms per million anchors at 5.8 TFLOP/s; the matrix pipes need 0.4 ms).
+// One persistent workgroup per CU: both weight matrices in LDS ([c][k] at a pitch of K + 2 floats: the 32 lanes of an LDS
+// read group hit 32 different banks), every wave takes whole 16-row tiles: the rows staged in LDS, the hidden layer written
+// back over them, no block barrier after the weights have landed.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+constexpr int MLPM_WAVES = 4;
+template <int DIN, int DH, int DOUT>
+__global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+                                                              const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, float *__restrict__ y)
+{
+    static_assert(DIN % 4 == 0 && DH % 4 == 0, "whole MFMA k-steps");
+    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2, PX = (DIN > DH ? DIN : DH) + 2;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *W1s = sm, *W2s = W1s + NT1 * 16 * P1, *B1s = W2s + NT2 * 16 * P2, *B2s = B1s + NT1 * 16, *XS = B2s + NT2 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e = lane & 15, g = lane >> 4;
+    for (int i = tid; i < NT1 * 16 * DIN; i += 64 * MLPM_WAVES) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = c < DH ? w1[(size_t)c * DIN + k] : 0.0f; }
+    for (int i = tid; i < NT2 * 16 * DH; i += 64 * MLPM_WAVES) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = c < DOUT ? w2[(size_t)c * DH + k] : 0.0f; }
+    for (int i = tid; i < NT1 * 16; i += 64 * MLPM_WAVES) B1s[i] = i < DH ? b1[i] : 0.0f;
+    for (int i = tid; i < NT2 * 16; i += 64 * MLPM_WAVES) B2s[i] = i < DOUT ? b2[i] : 0.0f;
+    __syncthreads();
+    float *xs = XS + wave * 16 * PX;
+    const int64_t ntiles = (n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * MLPM_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * MLPM_WAVES) {
+        const int64_t row0 = tile * 16;
+        // the tile's rows: coalesced float2 loads (rows past n: the last row again), the wave's own LDS slice
+        for (int i = lane; i < 16 * DIN / 2; i += 64) {
+            const int r = i / (DIN / 2), c2 = i - r * (DIN / 2);
+            const float2 v = *reinterpret_cast<const float2 *>(x + (size_t)min(row0 + r, n - 1) * DIN + 2 * c2);
+            *reinterpret_cast<float2 *>(xs + r * PX + 2 * c2) = v;
+        }
+        float a[DIN / 4 > DH / 4 ? DIN / 4 : DH / 4];
+#pragma unroll
+        for (int kk = 0; kk < DIN / 4; ++kk) a[kk] = xs[e * PX + 4 * kk + g];        // A operand: row e, k = 4 kk + g
+        f32x4m hid[NT1];
+#pragma unroll
+        for (int t = 0; t < NT1; ++t) {
+            const float bias = B1s[16 * t + e];
+            f32x4m acc = {bias, bias, bias, bias};
+            const float *wr = W1s + (16 * t + e) * P1 + g;                         // B operand: output 16 t + e, k = 4 kk + g
+#pragma unroll
+            for (int kk = 0; kk < DIN / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wr[4 * kk], acc, 0, 0, 0);
+            hid[t] = acc;
+        }
+        // hidden = relu(...) over the rows' slots: lane (g, e) holds rows 4 g .. 4 g + 3 of output 16 t + e (LDS operations of a
+        // wave execute in program order: the A reads above are done)
+#pragma unroll
+        for (int t = 0; t < NT1; ++t)
+            if (16 * t + e < DH) {                 // the padding outputs of the last tile have no slot (and no reader)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + 16 * t + e] = hid[t][i] > 0.0f ? hid[t][i] : 0.0f;
+            }
+#pragma unroll
+        for (int kk = 0; kk < DH / 4; ++kk) a[kk] = xs[e * PX + 4 * kk + g];
+#pragma unroll
+        for (int t = 0; t < NT2; ++t) {
+            const float bias = B2s[16 * t + e];
+            f32x4m acc = {bias, bias, bias, bias};
+            const float *wr = W2s + (16 * t + e) * P2 + g;
+#pragma unroll
+            for (int kk = 0; kk < DH / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wr[4 * kk], acc, 0, 0, 0);
+            const int c = 16 * t + e;
+            if (c < DOUT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (row0 + 4 * g + i < n) y[(size_t)(row0 + 4 * g + i) * DOUT + c] = acc[i];
+            }
+        }
+    }
+}
+template <int DIN, int DH, int DOUT>
+static size_t mlpm_lds_bytes()
+{
+    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2, PX = (DIN > DH ? DIN : DH) + 2;
+    return sizeof(float) * ((size_t)NT1 * 16 * P1 + (size_t)NT2 * 16 * P2 + NT1 * 16 + NT2 * 16 + (size_t)MLPM_WAVES * 16 * PX);
+}
+}  // namespace
+
 extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh,
                           int dout, float *y, void *stream)
 {
@@ -497,6 +581,19 @@ extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const 
     if (n <= 0) return GPCC_OK;
     if (din <= 0 || dh <= 0 || dout <= 0 || (size_t)MLP_ROWS * (size_t)(din + dh) * 4 > 64 * 1024) return fail(GPCC_ERR_ARG, "mlp2: unsupported layer sizes");
     HIP_TRY(hipSetDevice(ctx->device));
+    static const bool use_mfma = [] { const char *e = getenv("GAUSPCC_MLP2_MFMA"); return !e || atoi(e) != 0; }();
+    if (use_mfma && din == 96 && dh == 100 && dout == 175) {   // HAC's mlp_grid (HAC/scene/gaussian_model.py:258-262)
+        static bool attr_set = false;
+        const size_t lds = mlpm_lds_bytes<96, 100, 175>();
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<96, 100, 175>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), MLPM_WAVES));
+        k_mlp2_mfma<96, 100, 175><<<grid, 64 * MLPM_WAVES, lds, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, y);
+        LAUNCH_CHECK();
+        return GPCC_OK;
+    }
     k_mlp2<<<(unsigned)cdiv(n, MLP_ROWS), TB, (size_t)MLP_ROWS * (size_t)(din + dh) * 4, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, din, dh, dout, y);
     LAUNCH_CHECK();
     return GPCC_OK;

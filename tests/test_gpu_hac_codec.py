@@ -18,7 +18,7 @@ def torch_cuda():
     return torch
 
 
-@pytest.mark.parametrize("n,din,dh,dout", [(3000, 96, 100, 175), (17, 8, 5, 3), (4099, 48, 64, 97)])
+@pytest.mark.parametrize("n,din,dh,dout", [(3000, 96, 100, 175), (17, 8, 5, 3), (4099, 48, 64, 97), (70_003, 96, 100, 175), (5, 96, 100, 175)])
 def test_mlp2_matches_oracle_bit_for_bit(torch_cuda, orc, n, din, dh, dout):
     torch = torch_cuda
     from gauspcc_amd import hac_codec

@@ -19,93 +19,118 @@ from gauspcc_amd.neural_gaussians import generate_neural_gaussians
 from gauspcc_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer, psnr
 from gauspcc_amd.synth import SyntheticGaussianModel
 
-n_anchors = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
-W = int(sys.argv[2]) if len(sys.argv) > 2 else 1600
-H = int(sys.argv[3]) if len(sys.argv) > 3 else 1060
-dev = torch.device("cuda", 0)
-out = {"n_anchors_requested": n_anchors, "image": [W, H]}
+def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None):
+    """The side paths of SURVEY.md section 8(f) on a synthetic HAC-style scene of n_anchors anchors; returns the dict
+    bench.py embeds as `side_paths` (tools/bench_side_paths.py prints it for 1 M anchors: profiles/r03_side_paths.json)."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    out = {'n_anchors_requested': n_anchors, 'image': [W, H]}
 
 
-def timed(fn, reps=3):
-    fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        r = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps, r
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
 
 
-# ---- the Gaussian coder on one attribute of the whole scene: table path vs fused path
-g = torch.Generator(device="cpu").manual_seed(1)
-n = n_anchors * 50
-mean = (torch.randn(n, generator=g) * 2).to(dev); scale = (torch.rand(n, generator=g) * 3 + 0.05).to(dev)
-q = (torch.rand(n, generator=g) * 0.5 + 0.75).to(dev); x = (mean + torch.randn(n, generator=g).to(dev) * scale).contiguous()
+    # ---- the Gaussian coder on one attribute of the whole scene: table path vs fused path
+    g = torch.Generator(device="cpu").manual_seed(1)
+    n = n_anchors * 50
+    mean = (torch.randn(n, generator=g) * 2).to(dev); scale = (torch.rand(n, generator=g) * 3 + 0.05).to(dev)
+    q = (torch.rand(n, generator=g) * 0.5 + 0.75).to(dev); x = (mean + torch.randn(n, generator=g).to(dev) * scale).contiguous()
 
 
-def table_path():
-    xi = torch.round(x / q)
-    lower = arithmetic.calculate_cdf(mean, scale, q, xi.min(), xi.max())
-    return arithmetic.arithmetic_encode((xi - xi.min()).to(torch.int16).contiguous(), lower, 10000, n, int(lower.shape[1])), lower.shape[1]
+    def table_path():
+        xi = torch.round(x / q)
+        lower = arithmetic.calculate_cdf(mean, scale, q, xi.min(), xi.max())
+        return arithmetic.arithmetic_encode((xi - xi.min()).to(torch.int16).contiguous(), lower, 10000, n, int(lower.shape[1])), lower.shape[1]
 
 
-t_tab, ((b_tab, c_tab), lp) = timed(table_path, 2)
-t_fus, (mn, mx, b_fus, c_fus) = timed(lambda: arithmetic.encode_gaussian(x, mean, scale, q, 10000), 2)
-t_dec, xd = timed(lambda: arithmetic.decode_gaussian(mean, scale, q, mn, mx, b_fus, c_fus, 10000), 2)
-out["gaussian_coder"] = {"symbols": n, "alphabet": int(lp) - 1, "table_bytes": n * int(lp) * 4, "encode_table_path_ms": round(t_tab * 1e3, 2),
-                         "encode_fused_ms": round(t_fus * 1e3, 2), "decode_fused_ms": round(t_dec * 1e3, 2),
-                         "fused_bytes_equal_table_bytes": bool(torch.equal(b_tab.cpu(), b_fus.cpu())),
-                         "Msymbols_per_s_encode": round(n / t_fus / 1e6, 1), "Msymbols_per_s_decode": round(n / t_dec / 1e6, 1)}
-del mean, scale, q, x, xd
+    t_tab, ((b_tab, c_tab), lp) = timed(table_path, 2)
+    t_fus, (mn, mx, b_fus, c_fus) = timed(lambda: arithmetic.encode_gaussian(x, mean, scale, q, 10000), 2)
+    t_dec, xd = timed(lambda: arithmetic.decode_gaussian(mean, scale, q, mn, mx, b_fus, c_fus, 10000), 2)
+    out["gaussian_coder"] = {"symbols": n, "alphabet": int(lp) - 1, "table_bytes": n * int(lp) * 4, "encode_table_path_ms": round(t_tab * 1e3, 2),
+                             "encode_fused_ms": round(t_fus * 1e3, 2), "decode_fused_ms": round(t_dec * 1e3, 2),
+                             "fused_bytes_equal_table_bytes": bool(torch.equal(b_tab.cpu(), b_fus.cpu())),
+                             "Msymbols_per_s_encode": round(n / t_fus / 1e6, 1), "Msymbols_per_s_decode": round(n / t_dec / 1e6, 1)}
+    del mean, scale, q, x, xd
 
-# ---- the attribute loop and the RD loop
-enc = SyntheticGaussianModel(n_anchors, seed=3)
-out["n_anchors"] = int(enc._anchor.shape[0])
-with tempfile.TemporaryDirectory() as d:      # warm-up: model upload, workspace growth, first-touch of the pinned buffers
-    hac_codec.conduct_encoding(enc, d, ckpt_path="synthetic")
-with tempfile.TemporaryDirectory() as d:
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    patched, log = hac_codec.conduct_encoding(enc, d, ckpt_path="synthetic")
-    torch.cuda.synchronize(); t1 = time.perf_counter()
-    dec = SyntheticGaussianModel(64, seed=9)
-    for k in ("encoding_xyz", "mlp_grid", "mlp_opacity", "mlp_cov", "mlp_color", "x_bound_min", "x_bound_max", "voxel_size"):
-        setattr(dec, k, getattr(enc, k))
-    dec._anchor_feat = torch.zeros(1, enc.feat_dim, device=dev)
-    t2 = time.perf_counter()
-    hac_codec.conduct_decoding(dec, d, patched, ckpt_path="synthetic")
-    torch.cuda.synchronize(); t3 = time.perf_counter()
-    size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
-out["attribute_loop"] = {"anchors_coded": patched[1], "files_bytes": size, "conduct_encoding_s": round(t1 - t0, 3), "conduct_decoding_s": round(t3 - t2, 3),
-                         "log": log.strip()}
+    # ---- the attribute loop and the RD loop
+    enc = SyntheticGaussianModel(n_anchors, seed=3)
+    out["n_anchors"] = int(enc._anchor.shape[0])
+    with tempfile.TemporaryDirectory() as d:      # warm-up: model upload, workspace growth, first-touch of the pinned buffers
+        hac_codec.conduct_encoding(enc, d, ckpt_path="synthetic")
+    with tempfile.TemporaryDirectory() as d:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        patched, log = hac_codec.conduct_encoding(enc, d, ckpt_path="synthetic")
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        dec = SyntheticGaussianModel(64, seed=9)
+        for k in ("encoding_xyz", "mlp_grid", "mlp_opacity", "mlp_cov", "mlp_color", "x_bound_min", "x_bound_max", "voxel_size"):
+            setattr(dec, k, getattr(enc, k))
+        dec._anchor_feat = torch.zeros(1, enc.feat_dim, device=dev)
+        t2 = time.perf_counter()
+        hac_codec.conduct_decoding(dec, d, patched, ckpt_path="synthetic")
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        size = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+    out["attribute_loop"] = {"anchors_coded": patched[1], "files_bytes": size, "conduct_encoding_s": round(t1 - t0, 3), "conduct_decoding_s": round(t3 - t2, 3),
+                             "log": log.strip()}
 
-# camera on an orbit around the scene, looking at its centre (HAC/scene/cameras.py conventions: transposed matrices)
-ctr = enc._anchor.mean(dim=0); ext = float((enc._anchor.max(dim=0).values - enc._anchor.min(dim=0).values).max())
-eye = ctr + torch.tensor([0.0, 0.0, -1.4 * ext], device=dev)
-Rt = torch.eye(4, device=dev); Rt[:3, 3] = -eye       # world -> view: translate (camera looks down +z)
-fovx = math.radians(60); fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
-zn, zf = 0.01, 100.0
-P = torch.zeros(4, 4, device=dev)
-P[0, 0] = 1 / math.tan(fovx / 2); P[1, 1] = 1 / math.tan(fovy / 2); P[3, 2] = 1.0; P[2, 2] = zf / (zf - zn); P[2, 3] = -(zf * zn) / (zf - zn)
-view = Rt.T.contiguous(); full = (view @ P.T).contiguous()
-cam = types.SimpleNamespace(camera_center=eye)
-settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2),
-                                         bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=view, projmatrix=full, sh_degree=1,
-                                         campos=eye, prefiltered=False, debug=False)
-rast = GaussianRasterizer(settings)
-
-
-def frame(pc):
-    xyz, color, opacity, scaling, rot, _ = generate_neural_gaussians(cam, pc, None)
-    img, radii = rast(means3D=xyz, means2D=torch.zeros_like(xyz), shs=None, colors_precomp=color, opacities=opacity, scales=scaling, rotations=rot,
-                      cov3D_precomp=None)
-    return img, xyz.shape[0], int((radii > 0).sum())
+    # camera on an orbit around the scene, looking at its centre (HAC/scene/cameras.py conventions: transposed matrices)
+    ctr = enc._anchor.mean(dim=0); ext = float((enc._anchor.max(dim=0).values - enc._anchor.min(dim=0).values).max())
+    eye = ctr + torch.tensor([0.0, 0.0, -1.4 * ext], device=dev)
+    Rt = torch.eye(4, device=dev); Rt[:3, 3] = -eye       # world -> view: translate (camera looks down +z)
+    fovx = math.radians(60); fovy = 2 * math.atan(math.tan(fovx / 2) * H / W)
+    zn, zf = 0.01, 100.0
+    P = torch.zeros(4, 4, device=dev)
+    P[0, 0] = 1 / math.tan(fovx / 2); P[1, 1] = 1 / math.tan(fovy / 2); P[3, 2] = 1.0; P[2, 2] = zf / (zf - zn); P[2, 3] = -(zf * zn) / (zf - zn)
+    view = Rt.T.contiguous(); full = (view @ P.T).contiguous()
+    cam = types.SimpleNamespace(camera_center=eye)
+    settings = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=math.tan(fovx / 2), tanfovy=math.tan(fovy / 2),
+                                             bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=view, projmatrix=full, sh_degree=1,
+                                             campos=eye, prefiltered=False, debug=False)
+    rast = GaussianRasterizer(settings)
 
 
-t_gen, g_out = timed(lambda: generate_neural_gaussians(cam, dec, None), 3)
-t_frame, (img_dec, n_gauss, n_vis) = timed(lambda: frame(dec), 3)
-img_enc, _, _ = frame(enc)      # the un-decoded model quantises its attributes on the fly: the same picture
-out["rd_loop"] = {"gaussians": n_gauss, "visible": n_vis, "generate_neural_gaussians_ms": round(t_gen * 1e3, 2),
-                  "generate_plus_rasterise_ms": round(t_frame * 1e3, 2), "rendered_tiles_instances": int(rast.num_rendered),
-                  "psnr_decoded_vs_encoder_side_dB": round(float(psnr(img_dec.clamp(0, 1), img_enc.clamp(0, 1)).mean()), 2),
-                  "max_abs_pixel_diff": float((img_dec - img_enc).abs().max())}
-print(json.dumps(out))
+    def frame(pc):
+        xyz, color, opacity, scaling, rot, _ = generate_neural_gaussians(cam, pc, None)
+        img, radii = rast(means3D=xyz, means2D=torch.zeros_like(xyz), shs=None, colors_precomp=color, opacities=opacity, scales=scaling, rotations=rot,
+                          cov3D_precomp=None)
+        return img, xyz.shape[0], int((radii > 0).sum())
+
+
+    t_gen, g_out = timed(lambda: generate_neural_gaussians(cam, dec, None), 3)
+    t_frame, (img_dec, n_gauss, n_vis) = timed(lambda: frame(dec), 3)
+    img_enc, _, _ = frame(enc)      # the un-decoded model quantises its attributes on the fly: the same picture
+    out["rd_loop"] = {"gaussians": n_gauss, "visible": n_vis, "generate_neural_gaussians_ms": round(t_gen * 1e3, 2),
+                      "generate_plus_rasterise_ms": round(t_frame * 1e3, 2), "rendered_tiles_instances": int(rast.num_rendered),
+                      "psnr_decoded_vs_encoder_side_dB": round(float(psnr(img_dec.clamp(0, 1), img_enc.clamp(0, 1)).mean()), 2),
+                      "max_abs_pixel_diff": float((img_dec - img_enc).abs().max())}
+    # ---- mlp_grid (HAC's context MLP, 96-100-175) on its own: the matrix-pipe kernel
+    rows = mlp_rows or out["n_anchors"]
+    gm = torch.Generator(device="cpu").manual_seed(2)
+    xm = torch.randn(rows, 96, generator=gm).to(dev)
+    w1 = (torch.randn(100, 96, generator=gm) / 10).to(dev); b1 = torch.zeros(100, device=dev)
+    w2 = (torch.randn(175, 100, generator=gm) / 10).to(dev); b2 = torch.zeros(175, device=dev)
+    t_mlp, _ = timed(lambda: hac_codec.mlp2(xm, w1, b1, w2, b2), 5)
+    out["mlp_grid"] = {"rows": rows, "ms": round(t_mlp * 1e3, 3), "TFLOP_per_s": round(rows * 2.0 * (96 * 100 + 100 * 175) / t_mlp / 1e12, 2)}
+    del xm
+    # ---- the torchac-compatible shim (one stream = one lane: the reference's CPU coder format): float-CDF encode / decode
+    from gauspcc_amd import torchac as tac
+    nt, lp_t = 200_000, 17
+    pt = torch.softmax(torch.randn(nt, lp_t - 1, generator=gm), dim=-1)
+    cdf_t = torch.cat([torch.zeros(nt, 1), torch.cumsum(pt, dim=-1)], dim=-1).clamp(0, 1).to(dev)
+    sym_t = torch.multinomial(pt, 1).view(-1).to(torch.int16).to(dev)
+    t_te, blob = timed(lambda: tac.encode_float_cdf(cdf_t, sym_t), 2)
+    t_td, sd = timed(lambda: tac.decode_float_cdf(cdf_t, blob), 2)
+    out["torchac_shim"] = {"symbols": nt, "encode_Msym_per_s": round(nt / t_te / 1e6, 2), "decode_Msym_per_s": round(nt / t_td / 1e6, 2),
+                           "roundtrip": bool(torch.equal(sd.to(dev), sym_t))}
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps(measure(int(sys.argv[1]) if len(sys.argv) > 1 else 200_000, int(sys.argv[2]) if len(sys.argv) > 2 else 1600,
+                             int(sys.argv[3]) if len(sys.argv) > 3 else 1060)))

@@ -8,7 +8,7 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 bench.py --steps 1 --warmup 0 ${BENCH_ARGS:---cpu-sample 0} > "$OUT/p$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 bench.py --steps 1 --warmup 0 ${BENCH_ARGS:---cpu-sample 0 --side-anchors 0} > "$OUT/p$i.log" 2>&1
   echo "pass $i exit $?"
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU

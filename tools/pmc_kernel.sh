@@ -9,7 +9,7 @@ i=0
 while read -r grp; do
   [ -z "$grp" ] && continue
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 > "$OUT/p$i.log" 2>&1
+  timeout 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/p$i" -o pmc -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --side-anchors 0 > "$OUT/p$i.log" 2>&1
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU
 SQ_INSTS_SMEM SQ_WAVES SQ_BUSY_CU_CYCLES SQ_INST_LEVEL_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

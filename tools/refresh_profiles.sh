@@ -7,7 +7,7 @@ R=${2:-r02}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-QUIET="--skip-v0 --skip-stages --cpu-sample 0 --scenes-in-flight 0"
+QUIET="--skip-v0 --skip-stages --cpu-sample 0 --scenes-in-flight 0 --side-anchors 0"
 # 1. HBM traffic of the conv kernels: FETCH_SIZE / WRITE_SIZE in separate passes
 BENCH_ARGS="$QUIET" bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log" 2>&1
 cp "$OUT/pmc/summary_conv.txt" "$OUT/${R}_pmc_conv_fetch_write.txt"

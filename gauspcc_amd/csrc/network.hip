@@ -23,6 +23,8 @@
 #define CONV_LOOP_INC "conv_loop_gfx950.inc"   // generated: tools/gen_conv_loop.py (tools/build_variants.sh substitutes ablations)
 #endif
 #include CONV_LOOP_INC
+#include "conv_loop2_gfx950.inc"               // generated: tools/gen_conv_loop2.py (the pair-step loop of paired tile lists)
+static_assert(CONV_LOOP2_ROW_BYTES == CONV_LDS_ROW_BYTES, "both asm loops address the running sums at one LDS row pitch");
 
 namespace gpcc {
 
@@ -108,7 +110,10 @@ __device__ unsigned long long g_conv_timing[16];
 #else
 #define CONV_MIN_WAVES(R, ASM) ((ASM) || (R) >= 128 ? 2 : (R) >= 96 ? 3 : 4)
 #endif
-template <int R, int DIST, bool ASM>
+// PAIR (with ASM): the pool holds paired lists (tiles.hip: every run an even number of tiles) for the blocks whose runs are long
+// enough (T.pflag); those run the pair-step loop of conv_loop2_gfx950.inc -- two tiles of one kernel offset per step, one
+// weight fragment for both -- the others the one-tile loop.
+template <int R, int DIST, bool ASM, bool PAIR = false>
 __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
 {
 #ifdef CONV_ONE_PER_SIMD
@@ -268,11 +273,18 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
                 atomicAdd(&g_conv_timing[14], (unsigned long long)sw2); atomicAdd(&g_conv_timing[15], (unsigned long long)sw3);
             }
 #else
-            asm volatile(CONV_LOOP_ASM
-                         : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
-                         : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
-                           [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
-                         : CONV_LOOP_CLOBBERS);
+            if (PAIR && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
+                asm volatile(CONV_LOOP2_ASM
+                             : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
+                             : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                               [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                             : CONV_LOOP2_CLOBBERS);
+            else
+                asm volatile(CONV_LOOP_ASM
+                             : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
+                             : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                               [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                             : CONV_LOOP_CLOBBERS);
 #endif
         } else {
         int4 st_j = make_int4(0, 0, 0, 0);
@@ -709,6 +721,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         const int bytes = SC_WAVES * conv_lds_wave_floats(128) * 4;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -783,7 +796,11 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 32: if (asm_ok) CONV_LAUNCH(32, 1, true); else CONV_LAUNCH(32, 1, false); break;
     case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
     case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
-    case 255: if (asm_ok) CONV_LAUNCH(255, 1, true); else CONV_LAUNCH(255, 1, false); break;
+    case 255:
+        if (asm_ok && T.paired) k_sparse_conv<255, 1, true, true><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
+        else if (asm_ok) CONV_LAUNCH(255, 1, true);
+        else CONV_LAUNCH(255, 1, false);
+        break;
     default:
         if (asm_ok) CONV_LAUNCH(128, 1, true);
         else if (dist == 3) CONV_LAUNCH(128, 3, false);

@@ -93,6 +93,9 @@ struct ConvTiles {
     int R = CONV_R_MAX;        // capacity class of the blocks (LDS rows per wave; selects the kernel)
     int H = CONV_R_MAX;        // rows per block, <= R
     int K = 0;                 // kernel offsets
+    int paired = 0;            // blocks may hold PAIRED lists: every (block, offset) run an even number of tiles (odd runs end in an empty
+                               // tile) for the pair-step loop; pflag[block id in the pool] says which do
+    const uint8_t *pflag = nullptr;
     int nlv = 0;               // levels of the set
     uint32_t lv_blk0[MAXLV + 1] = {0};  // pool id of each level's first block; lv_blk0[nlv] = one past the set's last block
     uint32_t lv_row0[MAXLV] = {0};      // first row of each level in the set's feature arrays
@@ -109,7 +112,8 @@ struct TileLevel { const Level *lv; const Level *par; const int32_t *cell_par; i
 struct TilePool {
     int32_t *tj = nullptr; uint8_t *tr = nullptr; uint32_t *toc = nullptr; uint32_t *first = nullptr;
     int64_t nblk = 0;
-    int R = 0, H = 0, K = 0, nlv = 0;
+    int R = 0, H = 0, K = 0, nlv = 0, paired = 0;
+    uint8_t *pflag = nullptr;
     uint32_t lv_blk0[MAXLV + 1] = {0}, lv_rows[MAXLV] = {0};
     // algorithmic HBM traffic of the build (gpcc_profile stages): per node 12 B of its own structure + its cell map written
     // (4 B a cell) + per parent its cell map row read with child start / occupancy (9 B a cell) + 84 B per tile written;

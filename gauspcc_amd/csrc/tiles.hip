@@ -25,6 +25,9 @@ struct LevelTilesArgs {
     // its parent level: cell map [NP][np] (local indices, -1 = absent), occupancy, child starts
     const int32_t *cell_p; int64_t np; const uint8_t *occ_p; const uint32_t *cstart_p;
     int H;                      // rows per block
+    int paired;                 // blocks taller than 64 rows MAY be paired: every (block, offset) run padded to an EVEN number of tiles (the
+                                // pair-step conv loop) -- decided block by block from the run lengths (k_block_sum -> pflag)
+    uint8_t *pflag;             // [pool blocks] 1 = this block's list is paired
     uint32_t blk0;              // pool id of the level's first block
     // pass 1
     int32_t *cell_c;            // [NP][nc] the level's own cell map, nullable (nobody below needs it)
@@ -69,6 +72,9 @@ __device__ __forceinline__ WaveMap wave_map(int H, int64_t nc, uint32_t blk0, in
     return m;
 }
 
+// tiles of a run of `tot` pairs: ceil(tot / 16), rounded up to an even number in a paired pool (the padding tile is empty)
+__host__ __device__ __forceinline__ uint32_t run_tiles(uint32_t tot, int paired) { return paired ? ((tot + 31u) >> 5) << 1 : (tot + 15u) >> 4; }
+
 // One kernel offset of a wave whose block(s) fit the wave (multi mode or a block of at most 64 rows): the rows with a
 // neighbour are packed in row order behind the block's running tile counter.
 template <bool FILL>
@@ -78,7 +84,7 @@ __device__ __forceinline__ void pack_local(const LevelTilesArgs &a, const WaveMa
     if (b == 0) return;                 // wave-uniform
     npairs += (uint32_t)__popcll(b);
     const uint32_t cnt = (uint32_t)__popcll(b & m.segmask);
-    const uint32_t nt = (cnt + 15u) >> 4;
+    const uint32_t nt = (cnt + 15u) >> 4;           // (blocks that fit a wave are never paired)
     if (FILL) {
         if (j >= 0) {
             const uint32_t p = (uint32_t)__popcll(b & m.below);
@@ -92,7 +98,7 @@ __device__ __forceinline__ void pack_local(const LevelTilesArgs &a, const WaveMa
             a.tj[at] = 0;
             a.tr[at] = 0;
         }
-        if ((uint32_t)m.ls < nt) a.toc[t + (uint32_t)m.ls] = (uint32_t)o | (min(16u, cnt - 16u * (uint32_t)m.ls) << 16);
+        if ((uint32_t)m.ls < nt) a.toc[t + (uint32_t)m.ls] = (uint32_t)o | ((cnt > 16u * (uint32_t)m.ls ? min(16u, cnt - 16u * (uint32_t)m.ls) : 0u) << 16);
     }
     t += nt;
 }
@@ -100,7 +106,7 @@ __device__ __forceinline__ void pack_local(const LevelTilesArgs &a, const WaveMa
 // Tables of a block taller than 64 rows for the fill pass (from the count pass's per-chunk counts): per offset the pairs of
 // the whole block, the block-relative first tile, and the pairs of the chunks in front of mine.
 struct ChunkTables { uint16_t *tot, *obase, *cbase; };
-__device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk, int K, int q, int lane, ChunkTables T)
+__device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk, int K, int q, int lane, ChunkTables T, int paired)
 {
     uint32_t carry = 0;
     for (int o0 = 0; o0 < K; o0 += 64) {
@@ -110,7 +116,7 @@ __device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk
         const uint32_t c[4] = {c4 & 255u, (c4 >> 8) & 255u, (c4 >> 16) & 255u, c4 >> 24};
         const uint32_t tot = c[0] + c[1] + c[2] + c[3];
         const uint32_t cb = (q > 0 ? c[0] : 0u) + (q > 1 ? c[1] : 0u) + (q > 2 ? c[2] : 0u);
-        const uint32_t nt = (tot + 15u) >> 4;
+        const uint32_t nt = run_tiles(tot, paired);
         uint32_t inc = nt;                                        // inclusive wave scan
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -139,7 +145,7 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
     const WaveMap m = wave_map(a.H, a.nc, a.blk0, lane, bid);
     if (m.r0 >= m.rend) return;           // a chunk behind the end of its (last, short) block: its counts were zeroed by the host
     const ChunkTables T = {tab, tab + K + 1, tab + 2 * K + 2};
-    if (FILL && TALL) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T);
+    if (FILL && TALL) chunk_tables(a.cnt_oq + (size_t)m.blk * K * 4, K, m.q, lane, T, a.pflag ? (int)a.pflag[m.blk] : 0);
     // ---- stage the cells of my rows' parents: lane = parent, the cell map is read in coalesced rows (one per cell), the
     // gathers of a cell's child start and occupancy hit neighbouring nodes for neighbouring parents
     const int64_t i = min(m.r0 + lane, m.rend - 1);
@@ -297,20 +303,27 @@ __global__ __launch_bounds__(64) void k_fill_tiles_set(SetTilesArgs S)
 }
 
 // tiles of the blocks taller than 64 rows from the per-chunk counts: a wave per block, lanes over the offsets
-__global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ cnt_oq, uint32_t blk0, int nblk, int K, uint32_t *__restrict__ per_block)
+// Pairing pays when runs are long: a pair step of two full tiles costs ~1350 cycles against 2 x 750, the half step that ends
+// an odd run ~800 against 750, and the empty tile it reads is header traffic.  Measured per level (1 M-point cloud, TFLOP/s
+// paired / unpaired): 25 pairs per row 78.3 / 71.9, 22.6: 76.9 / 75.0, 13.5: 64.6 / 66.5, 6.8: 50.6 / 55.4.  So the choice is
+// made per block: paired when its runs average at least 1.5 tiles.
+__global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ cnt_oq, uint32_t blk0, int nblk, int K, uint32_t *__restrict__ per_block, int paired,
+                                                   uint8_t *__restrict__ pflag)
 {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= nblk) return;
     const uint32_t *c = reinterpret_cast<const uint32_t *>(cnt_oq + (size_t)(blk0 + b) * K * 4);
-    uint32_t t = 0;
+    uint32_t tu = 0, tp = 0, runs = 0;
     for (int o = lane; o < K; o += 64) {
         const uint32_t c4 = c[o];
-        t += ((c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24) + 15u) >> 4;
+        const uint32_t tot = (c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24);
+        tu += run_tiles(tot, 0); tp += run_tiles(tot, 1); runs += tot ? 1u : 0u;
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
-    if (lane == 0) per_block[blk0 + b] = t;
+    for (int d = 32; d >= 1; d >>= 1) { tu += (uint32_t)__shfl_xor((int)tu, d, 64); tp += (uint32_t)__shfl_xor((int)tp, d, 64); runs += (uint32_t)__shfl_xor((int)runs, d, 64); }
+    const bool pair = paired && 2u * tu >= 3u * runs;
+    if (lane == 0) { per_block[blk0 + b] = pair ? tp : tu; if (pflag) pflag[blk0 + b] = pair ? 1 : 0; }
 }
 
 // The base level (< 64 nodes, no parent): neighbours by search over the level's raster keys.
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64) void k_base_tiles(LevelTilesArgs a, int k)
 
 // pads and offset words of the tiles of blocks taller than 64 rows: one thread per (block, offset)
 __global__ __launch_bounds__(256) void k_tile_words(const uint8_t *__restrict__ cnt_oq, const uint32_t *__restrict__ first, uint32_t blk0, int nblk, int K,
-                                                    int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc)
+                                                    int32_t *__restrict__ tj, uint8_t *__restrict__ tr, uint32_t *__restrict__ toc, const uint8_t *__restrict__ pflag)
 {
     // a wave per block: lanes scan the offsets' tile counts, then every lane finishes its own offsets
     const int lane = threadIdx.x & 63;
@@ -360,11 +373,12 @@ __global__ __launch_bounds__(256) void k_tile_words(const uint8_t *__restrict__ 
     if (b >= nblk) return;
     const uint32_t *c = reinterpret_cast<const uint32_t *>(cnt_oq + (size_t)(blk0 + b) * K * 4);
     uint32_t carry = first[blk0 + b];
+    const int paired = pflag ? (int)pflag[blk0 + b] : 0;
     for (int o0 = 0; o0 < K; o0 += 64) {
         const int o = o0 + lane;
         const uint32_t c4 = o < K ? c[o] : 0u;
         const uint32_t tot = (c4 & 255u) + ((c4 >> 8) & 255u) + ((c4 >> 16) & 255u) + (c4 >> 24);
-        const uint32_t nt = (tot + 15u) >> 4;
+        const uint32_t nt = run_tiles(tot, paired);
         uint32_t inc = nt;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -372,7 +386,7 @@ __global__ __launch_bounds__(256) void k_tile_words(const uint8_t *__restrict__ 
             if (lane >= d) inc += v;
         }
         const uint32_t tb = carry + inc - nt;
-        for (uint32_t i = 0; i < nt; ++i) toc[tb + i] = (uint32_t)o | (min(16u, tot - 16u * i) << 16);
+        for (uint32_t i = 0; i < nt; ++i) toc[tb + i] = (uint32_t)o | ((tot > 16u * i ? min(16u, tot - 16u * i) : 0u) << 16);   // a paired run's padding tile: 0 entries
         for (uint32_t p = tot; p < nt * 16u; ++p) { tj[(size_t)tb * 16 + p] = 0; tr[(size_t)tb * 16 + p] = 0; }
         carry += (uint32_t)__shfl((int)inc, 63, 64);
     }
@@ -390,8 +404,8 @@ int launch_level(hipStream_t st, const LevelTilesArgs &a, bool tail)
     LAUNCH_CHECK();
     if (nq > 1 && tail) {
         const int nblk = (int)cdiv(a.nc, H);
-        if (!FILL) k_block_sum<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block);
-        else k_tile_words<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.first, a.blk0, nblk, KS * KS * KS, a.tj, a.tr, a.toc);
+        if (!FILL) k_block_sum<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.blk0, nblk, KS * KS * KS, a.per_block, a.paired, a.pflag);
+        else k_tile_words<<<(unsigned)cdiv(nblk, 4), 256, 0, st>>>(a.cnt_oq, a.first, a.blk0, nblk, KS * KS * KS, a.tj, a.tr, a.toc, a.pflag);
         LAUNCH_CHECK();
     }
     return GPCC_OK;
@@ -469,7 +483,15 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     TAKE(first, uint32_t, nblk + 1);
     pool->first = first;
     LevelTilesArgs a = {};
-    a.H = H; a.per_block = first;
+    static const bool pair_on = [] { const char *e = getenv("GAUSPCC_CONV_PAIR"); return !e || atoi(e) != 0; }();
+    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on) ? 1 : 0;   // tall blocks of the wave-serial class may be paired (block by block)
+    pool->pflag = nullptr;
+    if (pool->paired) {
+        TAKE(pf, uint8_t, nblk);
+        HIP_TRY(hipMemsetAsync(pf, 0, (size_t)nblk, st));   // the base level's block (built by k_base_tiles) is never paired
+        pool->pflag = pf;
+    }
+    a.H = H; a.paired = pool->paired; a.pflag = pool->pflag; a.per_block = first;
     if (H > 64) {   // blocks of 2 or 3 chunks leave the other columns untouched: zero them
         TAKE(cq, uint8_t, (size_t)nblk * K * 4);
         a.cnt_oq = cq;
@@ -493,7 +515,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     }
     if (batch && H > 64 && lp < nlv) {
         const uint32_t b1 = pool->lv_blk0[lp];
-        k_block_sum<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, b1, (int)(nblk - b1), K, a.per_block);
+        k_block_sum<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, b1, (int)(nblk - b1), K, a.per_block, a.paired, a.pflag);
         LAUNCH_CHECK();
     }
     if (spread) { k_fold_pairs<<<1, 64, 0, st>>>(spread, nlv, pairs_dev); LAUNCH_CHECK(); }
@@ -554,7 +576,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         LAUNCH_CHECK();
         if (nq > 1) {
             const uint32_t b1 = pool->lv_blk0[lp];
-            k_tile_words<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, a.first, b1, (int)(nblk - b1), K, tj, tr, toc);
+            k_tile_words<<<(unsigned)cdiv(nblk - b1, 4), 256, 0, st>>>(a.cnt_oq, a.first, b1, (int)(nblk - b1), K, tj, tr, toc, a.pflag);
             LAUNCH_CHECK();
         }
     }
@@ -565,7 +587,7 @@ int tiles_view(gpcc_ctx *ctx, hipStream_t st, const TilePool &pool, int l0, int 
 {
     if (l0 < 0 || l1 > pool.nlv || l0 >= l1) return fail(GPCC_ERR_ARG, "internal: level range [%d, %d)", l0, l1);
     T->tj = pool.tj; T->tr = pool.tr; T->toc = pool.toc; T->first = pool.first;
-    T->R = pool.R; T->H = pool.H; T->K = pool.K;
+    T->R = pool.R; T->H = pool.H; T->K = pool.K; T->paired = pool.paired; T->pflag = pool.pflag;
     T->nlv = l1 - l0;
     for (int l = l0; l <= l1; ++l) T->lv_blk0[l - l0] = pool.lv_blk0[l];
     for (int l = l0; l < l1; ++l) { T->lv_rows[l - l0] = pool.lv_rows[l]; T->lv_row0[l - l0] = (uint32_t)row_base[l - l0]; }

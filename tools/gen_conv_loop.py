@@ -38,7 +38,9 @@ registers (gfx90a+ requirement).
 """
 import os
 
-EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers
+EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no sums in LDS, 2 no weight loads, 4 no gathers,
+                                                 # 16 every odd tile multiplies with the previous tile's weights and loads none (timing of "two tiles share a fragment", WRONG results)
+                                                 # 32 as 16, but the odd tiles still issue four loads -- of one 16-byte address for all lanes, into scratch registers (issue slots kept, L1 traffic gone)
 DX = int(os.environ.get("CONV_ASM_DX", "3"))     # issue distance of the gathered rows (steps); X ring = DX + 1 sets (7: measured, no gain)
 DW = 3                                           # issue distance of the weight fragments; W ring = DW + 1 sets
 ROWB = int(os.environ.get("CONV_ASM_ROWB", "144"))   # LDS bytes per row of running sums (128 + one 16-byte pad: bank rotation, network.hip)
@@ -61,8 +63,9 @@ V = dict(
     accb=_m0 + 14, hjb=_m0 + 15, hrb=_m0 + 16, hob=_m0 + 17, goff=_m0 + 18, loff=_m0 + 19,
     hjp=_m0 + 20, hrp=_m0 + 21, hop=_m0 + 22,
     sgr=_m0 + 23, sgo=_m0 + 24, swj=_m0 + 25, swr=_m0 + 26, swo=_m0 + 27,
+    zero=_m0 + 28, dummy=_m0 + 30,     # EXP 32: a zero offset and 16 scratch registers (even-aligned)
 )
-CLOBBER_V = list(range(16, _m0 + 28))
+CLOBBER_V = list(range(16, _m0 + 28 + (20 if EXP & 32 else 0)))
 NSTEP = NX                             # a multiple of NX, NW and 2
 WINDOW = 6 * (DW - 1)                  # tile loads that may stay in flight across a step start
 # Header ring: 32 slots = two batches of 16 tiles, followed by a mirror of slots 0..15 so that the NSTEP steps of an
@@ -92,6 +95,11 @@ def loads_w(wset):
     W = V["W"][wset]
     o = [f"global_load_dwordx4 {vr(W + 4 * i, 4)}, v{V['bo']}, %[w]" + (f" offset:{1024 * i}" if i else "") for i in range(4)]
     return ["s_nop 0"] * 4 if EXP & 2 else o
+
+
+def loads_w_dummy():
+    D = V["dummy"]
+    return [f"global_load_dwordx4 {vr(D + 4 * i, 4)}, v{V['zero']}, %[w]" for i in range(4)]
 
 
 def addr_x():
@@ -193,6 +201,13 @@ def step_wait(du, label):
     """The loads of the last DW - 1 steps may stay in flight; everything older (this tile's W, and its X from long before)
     must have landed.  For DW steps after a header fetch (issued behind the tile loads of step 0) its 3 loads are inside
     that window as well.  Every LDS operation of the previous step was issued behind its first MFMA pair: long done."""
+    if EXP & 16 and not EXP & 32:
+        # loads of the last DW - 1 = 2 steps: one step with W (6) and one without (2)
+        win = 8
+        if not 1 <= du <= DW:
+            return [f"s_waitcnt vmcnt({win}) lgkmcnt(0)"]
+        return ["s_and_b32 %[t0], %[u], 15", "s_cmp_eq_u32 %[t0], 8", f"s_cbranch_scc0 {label}_wa%=", f"s_waitcnt vmcnt({win + 3}) lgkmcnt(0)", f"s_branch {label}_wb%=",
+                f"{label}_wa%=:", f"s_waitcnt vmcnt({win}) lgkmcnt(0)", f"{label}_wb%=:"]
     if not 1 <= du <= DW:
         return [f"s_waitcnt vmcnt({WINDOW}) lgkmcnt(0)"]
     return ["s_and_b32 %[t0], %[u], 15",
@@ -231,7 +246,7 @@ def stamp_collect(par):
 
 def step(du):
     cur, prv = du % 2, 1 - du % 2
-    X, W, CC, CP = V["X"][du % NX], V["W"][du % NW], V["C"][cur], V["C"][prv]
+    X, W, CC, CP = V["X"][du % NX], V["W"][(du - (du & 1 if EXP & 48 else 0)) % NW], V["C"][cur], V["C"][prv]
     label = f"s{du}"
 
     def mf(kk, first=False):
@@ -248,7 +263,7 @@ def step(du):
     o += [f"v_mad_u32_u24 v{V['ra'][cur]}, v{V['rb']}, %[t1], v{V['accb']}"]
     # memory instructions issue slowly (measured: ~20 cycles an LDS, ~13 a global load instruction, during which an in-order
     # wave issues nothing else) but, unlike VALU work, they do overlap a running MFMA: one in front of each remaining MFMA
-    mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nsx) + loads_w(nsw)
+    mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nsx) + ((loads_w_dummy() if EXP & 32 else []) if (EXP & 48) and (du + DW) % 2 == 1 else loads_w(nsw))
     rest = [m for kk in range(1, 8) for m in mf(kk)]
     spread = os.environ.get("CONV_ASM_SPREAD", "1") != "0"
     if not spread:
@@ -259,7 +274,7 @@ def step(du):
         if i < len(mem):
             o.append(mem[i])
         if i == len(mem):
-            o += (staging_fetch(label) + staging_store(label, WINDOW + 6) if du == 0 else [])
+            o += (staging_fetch(label) + staging_store(label, (8 if EXP & 16 and not EXP & 32 else WINDOW) + (2 if EXP & 16 and not EXP & 32 else 6)) if du == 0 else [])
         if i == 7:
             o += stamp("sc", cur)
         o.append(m)
@@ -288,6 +303,7 @@ def build():
         f"v_add_u32 v{L['swr']}, {RING_R}, v{L['swr']}",
         f"v_add_u32 v{L['swo']}, v{L['hob']}, v{L['sgo']}",
         f"v_mov_b32 v{L['ra'][1]}, v{L['accb']}",                   # "previous tile" of step 0: the dummy slot
+    ] + ([f"v_mov_b32 v{L['zero']}, 0"] if EXP & 32 else []) + [
         "; ---- pipeline prologue: X of tiles 0..DX-1 and W of tiles 0..DW-1 in flight; headers j(DX), o(DW), slot(0) in registers",
         "s_waitcnt lgkmcnt(0)",
     ]

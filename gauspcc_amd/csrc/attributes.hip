@@ -583,12 +583,12 @@ extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const 
     HIP_TRY(hipSetDevice(ctx->device));
     static const bool use_mfma = [] { const char *e = getenv("GAUSPCC_MLP2_MFMA"); return !e || atoi(e) != 0; }();
     if (use_mfma && din == 96 && dh == 100 && dout == 175) {   // HAC's mlp_grid (HAC/scene/gaussian_model.py:258-262)
-        static bool attr_set = false;
+        static PerDeviceOnce attr;
         const size_t lds = mlpm_lds_bytes<96, 100, 175>();
-        if (!attr_set) {
+        GP_TRY(attr.run(ctx->device, [&]() -> int {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<96, 100, 175>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+            return GPCC_OK;
+        }));
         const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), MLPM_WAVES));
         k_mlp2_mfma<96, 100, 175><<<grid, 64 * MLPM_WAVES, lds, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, y);
         LAUNCH_CHECK();

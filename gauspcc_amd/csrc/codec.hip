@@ -231,6 +231,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));   // ranks -> posC / slotsC
+        ctx->arena.release_top_low();                       // what is enqueued on st from here on runs behind the rank pass: its temporaries are free
         StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
             HeadArgs ha = {};
@@ -724,8 +725,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
 // tree, the tile pool, the rank pass on the second stream or a feature buffer running out of arena) can be driven on purpose
 static size_t arena_scaled(size_t want)
 {
-    static double scale = -1.0;
-    if (scale < 0.0) { const char *e = getenv("GAUSPCC_ARENA_SCALE"); scale = e ? atof(e) : 1.0; if (!(scale > 0.0)) scale = 1.0; }
+    static const double scale = [] { const char *e = getenv("GAUSPCC_ARENA_SCALE"); const double v = e ? atof(e) : 1.0; return v > 0.0 ? v : 1.0; }();
     return scale == 1.0 ? want : std::max<size_t>((size_t)((double)want * scale), (size_t)1 << 20);
 }
 

@@ -9,6 +9,7 @@
 
 #include <chrono>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/gauspcc.h"
@@ -67,13 +68,19 @@ struct Arena {
     }
     // flipped: take / mark / rewind serve the TOP end.  Work enqueued on a second stream takes its temporaries there, so
     // that a rewind on one stream never hands memory to the other while kernels still use it (the encoder's rank pass).
+    // The host rewinds `top` as soon as the second stream's launches are ENQUEUED, while its kernels may still be running:
+    // top_low remembers the lowest top a flipped section reached, and bottom takes stay below it until the caller has made
+    // the first stream wait for the second one (release_top_low) -- otherwise a nearly full arena could hand the rank
+    // pass's live temporaries to the first stream's next buffers.
     bool flip = false;
-    void reset() { off = 0; top = cap & ~size_t(255); flip = false; }
+    size_t top_low = ~size_t(0);
+    void release_top_low() { top_low = ~size_t(0); }
+    void reset() { off = 0; top = cap & ~size_t(255); flip = false; top_low = ~size_t(0); }
     template <typename T> T *take(size_t count)
     {
         if (flip) return take_top<T>(count);
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
-        if (off + bytes > top) return nullptr;
+        if (off + bytes > (top < top_low ? top : top_low)) return nullptr;
         T *p = reinterpret_cast<T *>(base + off);
         off += bytes;
         return p;
@@ -83,12 +90,32 @@ struct Arena {
         size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
         if (off + bytes > top) return nullptr;
         top -= bytes;
+        if (flip && top < top_low) top_low = top;
         return reinterpret_cast<T *>(base + top);
     }
     size_t top_mark() const { return top; }
     void top_rewind(size_t m) { top = m; }
     size_t mark() const { return flip ? top : off; }
     void rewind(size_t m) { if (flip) top = m; else off = m; }
+};
+
+// Environment knobs and per-device one-time set-up, safe when several host threads (one context each) enter for the first
+// time together: function-local statics initialised from a lambda are initialised once (C++11), and what has to happen once
+// PER DEVICE (hipFuncSetAttribute is a per-device setting) runs under a mutex with a bit per device.
+inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+inline long long env_ll(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+struct PerDeviceOnce {
+    std::mutex m;
+    uint64_t done = 0;
+    template <typename F> int run(int device, F f)
+    {
+        std::lock_guard<std::mutex> g(m);
+        const uint64_t bit = 1ull << (device & 63);
+        if (done & bit) return GPCC_OK;
+        const int rc = f();
+        if (rc == GPCC_OK) done |= bit;
+        return rc;
+    }
 };
 
 template <typename T> struct HostBuf {

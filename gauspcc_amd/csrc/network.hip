@@ -51,19 +51,16 @@ __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) *
 int conv_pick_rows(int64_t n, int k)
 {
     (void)k;
-    static int forced = -1;
-    if (forced < 0) {
-        const char *e = getenv("GAUSPCC_CONV_R");
-        forced = e ? atoi(e) : 0;
-        if (forced != 0 && forced != 16 && forced != 32 && forced != 64 && forced != 96 && forced != 128 && forced != 255) forced = 0;
-    }
+    static const int forced = [] {
+        const int f = env_int("GAUSPCC_CONV_R", 0);
+        return (f != 0 && f != 16 && f != 32 && f != 64 && f != 96 && f != 128 && f != 255) ? 0 : f;
+    }();
     if (forced) return forced;
     // every level the cooperative kernel does not take (it wins below ~12 k nodes): the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
     // with the block height set by conv_pick_height -- up to 1024 blocks run as ONE round of equal blocks, one per SIMD
     // (measured against 2-3 waves per SIMD on 32..128-row blocks: 34 k nodes 40 vs 56 us, 92 k 75 vs 88, 251 k 185 vs 199,
     // 540 k 322 vs 377).  The asm loop addresses rows with 32-bit offsets: n < 2^25.
-    static int64_t tall_min = -1;
-    if (tall_min < 0) { const char *e = getenv("GAUSPCC_CONV_TALL_MIN"); tall_min = e ? atoll(e) : 12 * 1024; }
+    static const int64_t tall_min = env_ll("GAUSPCC_CONV_TALL_MIN", 12 * 1024);
     if (n >= tall_min && n < ((int64_t)1 << 25)) return 255;
     if (n >= 192 * 1024) return 128;
     if (n >= 96 * 1024) return 64;
@@ -77,8 +74,7 @@ int conv_pick_rows(int64_t n, int k)
 // number of rounds the class allows -- slightly lower blocks, every round full.
 int conv_pick_height(int64_t n, int R)
 {
-    static int balance = -1;
-    if (balance < 0) { const char *e = getenv("GAUSPCC_CONV_BALANCE"); balance = e ? atoi(e) : 2; }
+    static const int balance = env_int("GAUSPCC_CONV_BALANCE", 2);
     if (!balance || R <= 16) return R;
     const int64_t slots = 1024 * (int64_t)(R >= 255 ? 1 : 2);
     const int64_t k = cdiv(n, slots * R);
@@ -713,11 +709,12 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk, 1};
     if (chained) { ConvRec &c = ctx->prof.chain; c.level = level; c.njobs = njobs; c.R = T.R; c.H = T.H; c.n = (long long)n; c.nblk = (long long)T.nblk; c.launches += 1; }
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
-    static int dist = -1, use_asm = -1;
-    if (dist < 0) { const char *e = getenv("GAUSPCC_CONV_DIST"); dist = e ? atoi(e) : 1; if (dist < 1 || dist > 3) dist = 1; }
-    if (use_asm < 0) { const char *e = getenv("GAUSPCC_CONV_ASM"); use_asm = e ? atoi(e) != 0 : 1; }
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {  // 128-row blocks need more LDS per workgroup than the 64 KiB default cap
+    static const int dist = [] { const int d = env_int("GAUSPCC_CONV_DIST", 1); return d < 1 || d > 3 ? 1 : d; }();
+    static const int use_asm = env_int("GAUSPCC_CONV_ASM", 1) != 0;
+    static PerDeviceOnce lds_attr;
+    int cur_dev = 0;
+    HIP_TRY(hipGetDevice(&cur_dev));
+    GP_TRY(lds_attr.run(cur_dev, [&]() -> int {  // 128-row blocks need more LDS per workgroup than the 64 KiB default cap
         const int bytes = SC_WAVES * conv_lds_wave_floats(128) * 4;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
@@ -726,19 +723,17 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        lds_attr_set = true;
-    }
-    static int use_coop = -1, use_split = -1;
-    if (use_coop < 0) { const char *e = getenv("GAUSPCC_CONV_COOP"); use_coop = e ? atoi(e) != 0 : 1; }
-    if (use_split < 0) { const char *e = getenv("GAUSPCC_CONV_SPLIT"); use_split = e ? atoi(e) != 0 : 1; }
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343)));
+        return GPCC_OK;
+    }));
+    static const int use_coop = env_int("GAUSPCC_CONV_COOP", 1) != 0, use_split = env_int("GAUSPCC_CONV_SPLIT", 1) != 0;
     // 16-row blocks.  Up to 64 blocks (a level of at most 1 k nodes): products over the whole chip + ordered sums, two
     // launches -- measured 11.7 / 15.2 us against 18.8 / 26.2 for the one-workgroup-per-block kernel at 4 / 32 blocks.
     // Beyond that the two launches cost what they save (26.9 vs 25.8 us at 160 blocks): the cooperative kernel.
     // (A second cooperative kernel -- 8 waves, two workgroups per CU, transposed products parked with 16-byte swizzled
     // stores, operands one tile ahead -- was built and measured in round 3: 25.1 / 34.3 / 24.7 us at 160 / 263 / 315 blocks
     // against 25.8 / 36.5 / 22.5: a block's ~100 tiles move ~750 KB through one CU's L1 whatever the schedule.  Dropped.)
-    static int split_max = -1;
-    if (split_max < 0) { const char *e = getenv("GAUSPCC_CONV_SPLIT_MAX"); split_max = e ? atoi(e) : 64; }
+    static const int split_max = env_int("GAUSPCC_CONV_SPLIT_MAX", 64);
     const size_t prod_floats = ((size_t)T.nblk * (size_t)T.K + CONV_HDR_PAD) * 512;
     if (T.R == 16 && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
         if (ctx->conv_products_cap < prod_floats) {
@@ -750,6 +745,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
             ctx->conv_products_cap = want;
         }
         // tiles of a block over `split` workgroups of 4 waves: about 2 k workgroups in all, at most one tile per wave
+        // (requesting the headers, then the operands of four tiles per wave together and 128 products per thread in the sum
+        // was built and measured: slower at every size -- 30 / 45 / 41 us at 160 / 263 / 315 blocks)
         const unsigned split = (unsigned)std::max<int64_t>(1, std::min<int64_t>({(int64_t)32, (int64_t)cdiv(T.K, PROD_WAVES), (int64_t)cdiv(2048, T.nblk)}));
         const int ntp = (T.K + SUM_BATCH - 1) / SUM_BATCH * SUM_BATCH;
         static const bool dbg = getenv("GAUSPCC_DEBUG_LAUNCH") != nullptr;
@@ -776,11 +773,6 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         return GPCC_OK;
     }
     if (T.R == 16 && use_coop) {
-        static bool coop_attr_set = false;
-        if (!coop_attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343)));
-            coop_attr_set = true;
-        }
         if (T.K > 343) return fail(GPCC_ERR_ARG, "kernel size > 7 is not supported");
         k_sparse_conv_coop<<<dim3((unsigned)T.nblk, (unsigned)njobs), 64 * COOP_WAVES, coop_lds_bytes(T.K), st>>>(jobs, T, (int)n, relu);
         LAUNCH_CHECK();
@@ -864,8 +856,7 @@ int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
 {
     Prof &p = ctx->prof;
     p.chain_open = false;
-    static int log = -1;
-    if (log < 0) { const char *e = getenv("GAUSPCC_CONV_LOG"); log = e ? atoi(e) : 0; }
+    static const int log = env_int("GAUSPCC_CONV_LOG", 0);
     for (const ConvRec &r : p.recs) {
         float ms = 0.f;
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));

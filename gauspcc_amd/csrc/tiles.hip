@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64) void k_fill_tiles_set(SetTilesArgs S)
 // paired / unpaired): 25 pairs per row 78.3 / 71.9, 22.6: 76.9 / 75.0, 13.5: 64.6 / 66.5, 6.8: 50.6 / 55.4.  So the choice is
 // made per block: paired when its runs average at least 1.5 tiles.
 __global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ cnt_oq, uint32_t blk0, int nblk, int K, uint32_t *__restrict__ per_block, int paired,
-                                                   uint8_t *__restrict__ pflag)
+                                                   uint8_t *__restrict__ pflag)   // paired: 0, or 100 x the least average run length (tiles) of a paired block
 {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_block_sum(const uint8_t *__restrict__ c
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { tu += (uint32_t)__shfl_xor((int)tu, d, 64); tp += (uint32_t)__shfl_xor((int)tp, d, 64); runs += (uint32_t)__shfl_xor((int)runs, d, 64); }
-    const bool pair = paired && 2u * tu >= 3u * runs;
+    const bool pair = paired && 100u * tu >= (uint32_t)paired * runs;
     if (lane == 0) { per_block[blk0 + b] = pair ? tp : tu; if (pflag) pflag[blk0 + b] = pair ? 1 : 0; }
 }
 
@@ -484,7 +484,8 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     pool->first = first;
     LevelTilesArgs a = {};
     static const bool pair_on = [] { const char *e = getenv("GAUSPCC_CONV_PAIR"); return !e || atoi(e) != 0; }();
-    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on) ? 1 : 0;   // tall blocks of the wave-serial class may be paired (block by block)
+    static const int pair_min = env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
+    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block)
     pool->pflag = nullptr;
     if (pool->paired) {
         TAKE(pf, uint8_t, nblk);

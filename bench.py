@@ -300,7 +300,7 @@ def main():
             # aggregate encode-only rate of the batch (configs[3] is an encode batch): all scenes / the slowest rank's encode time
             "enc_value": round(args.points * world * K / float(allstats[:, 1].max()) / 1e6, 4),
             "bpp": round(float(allstats[:, 0].mean()) * 8 / args.points, 4),
-            # The chunked container pays a fixed number of bytes per chunk (LEB128 count + two coder flushes) for its parallel decode.
+            # The chunked container pays a fixed number of bytes per chunk (~5 bits of chunk table + two coder flushes) for its parallel decode.
             # The seeded random weights code ~22 bpp; a trained model at a few bpp shrinks the payload, not this overhead, so
             # it is also quoted against a 4 bpp payload (HAC-class rates).  chunk_log2 = 0 writes bytes_v0 exactly.
             "container_bytes": len(data),

@@ -502,7 +502,7 @@ extern "C" int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int c
 }
 
 // One stream of the container as gpcc_encode writes it for a level of n nodes (rangecoder.hpp: rc_plan, version 3):
-// chunk_log2 = 0 -> one lane, the bare coder bytes; else the LEB128 chunk table, then the chunks (forward lane + reversed
+// chunk_log2 = 0 -> one lane, the bare coder bytes; else the chunk table (rangecoder.hpp: rc_table_*), then the chunks (forward lane + reversed
 // backward lane each).
 extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *sym_dev, int64_t n, int chunk_log2,
                               const uint8_t **bytes_out, int64_t *nbytes_out, void *stream)
@@ -533,14 +533,11 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     HIP_TRY(hipStreamSynchronize(st));
     const size_t total = hcnt[(size_t)nch];
     size_t hdr = 0;
-    if (chunk_log2)
-        for (int c = 0; c < nch; c += 2) hdr += rc_varint_size(hcnt[(size_t)c] + (c + 1 < nch ? hcnt[(size_t)c + 1] : 0u));
+    auto chunk_bytes = [&](uint32_t c) { const size_t l = 2 * (size_t)c; return hcnt[l] + (l + 1 < (size_t)nch ? hcnt[l + 1] : 0u); };
+    if (chunk_log2) hdr = rc_table_size(chunk_bytes, (uint32_t)((nch + 1) / 2));
     GP_TRY(ctx->hbytes.reserve(total + hdr + 16));
     uint8_t *out = ctx->hbytes.p;
-    if (chunk_log2) {
-        size_t p = 0;
-        for (int c = 0; c < nch; c += 2) p += rc_varint_put(out + p, hcnt[(size_t)c] + (c + 1 < nch ? hcnt[(size_t)c + 1] : 0u));
-    }
+    if (chunk_log2 && rc_table_put(out, chunk_bytes, (uint32_t)((nch + 1) / 2)) != hdr) return fail(GPCC_ERR_HIP, "internal: chunk table size mismatch");
     if (total) HIP_TRY(hipMemcpyAsync(out + hdr, payload, total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *bytes_out = out; *nbytes_out = (int64_t)(total + hdr);

@@ -260,7 +260,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 stream_first[si] = (uint32_t)chunks.size();
                 const int64_t base = pre + (int64_t)s * slots(nc);
                 gap += 4u;
-                table_bound += 5 * (size_t)pl.nchunks;
+                table_bound += 6 * (size_t)pl.nchunks + 8;   // escape code: 48 bits a chunk; first count + k
                 for (uint32_t c = 0; c < pl.nlanes; ++c) {
                     const int64_t cn = pl.lane_syms(nc, c);
                     gaps.push_back(chunk_log2 ? (uint32_t)si : gap);
@@ -357,7 +357,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         const int c0 = (int)stream_first[si], c1 = (int)stream_first[si + 1];
         for (int c = c0; c < c1; ++c) s_pay[(size_t)si] += hcnt[c];
         if (chunk_log2)
-            for (int c = c0; c < c1; c += 2) s_tab[(size_t)si] += rc_varint_size(hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
+            s_tab[(size_t)si] = rc_table_size([&](uint32_t c) { const int l = c0 + 2 * (int)c; return hcnt[l] + (l + 1 < c1 ? hcnt[l + 1] : 0u); }, (uint32_t)((c1 - c0 + 1) / 2));
         tables += s_tab[(size_t)si];
     }
     size_t fsize = pos0_hdr + 4 * (size_t)nstreams + total_payload + tables;
@@ -388,7 +388,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             const int c0 = (int)stream_first[si], c1 = (int)stream_first[si + 1];
             put32(out + p, (uint32_t)(s_tab[(size_t)si] + s_pay[(size_t)si])); p += 4;
             if (chunk_log2)
-                for (int c = c0; c < c1; c += 2) p += rc_varint_put(out + p, hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
+                p += rc_table_put(out + p, [&](uint32_t c) { const int l = c0 + 2 * (int)c; return hcnt[l] + (l + 1 < c1 ? hcnt[l + 1] : 0u); }, (uint32_t)((c1 - c0 + 1) / 2));
             p += s_pay[(size_t)si];
         }
         pos = p;

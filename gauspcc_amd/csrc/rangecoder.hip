@@ -174,14 +174,26 @@ __global__ __launch_bounds__(256) void k_rc_layout(const uint32_t *__restrict__ 
     for (int s = wave; s < nstreams; s += 4) {
         const uint32_t l0 = stream_first[s], l1 = stream_first[s + 1];
         uint32_t t = 0;
-        if (dual) {
-            for (uint32_t l = l0 + 2u * (uint32_t)lane; l < l1; l += 128u) {
-                const uint32_t b = cnt[l] + (l + 1u < l1 ? cnt[l + 1u] : 0u);
-                t += b < (1u << 7) ? 1u : b < (1u << 14) ? 2u : b < (1u << 21) ? 3u : b < (1u << 28) ? 4u : 5u;
-            }
-        } else t = lane == 0 ? 2u * (l1 - l0) : 0u;
+        if (dual) {   // the version-3 table (rangecoder.hpp: rc_table_size): bits of the Rice-coded differences for every k, the best k wins
+            uint32_t bits[RC_TAB_KMAX + 1];
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) t += (uint32_t)__shfl_xor((int)t, d, 64);
+            for (int k = 0; k <= RC_TAB_KMAX; ++k) bits[k] = 0u;
+            auto chunk_bytes = [&](uint32_t l) { return cnt[l] + (l + 1u < l1 ? cnt[l + 1u] : 0u); };
+            for (uint32_t l = l0 + 2u + 2u * (uint32_t)lane; l < l1; l += 128u) {
+                const uint32_t z = rc_zigzag(chunk_bytes(l), chunk_bytes(l - 2u));
+#pragma unroll
+                for (int k = 0; k <= RC_TAB_KMAX; ++k) bits[k] += rc_tab_cost(z, k);
+            }
+            uint64_t tot[RC_TAB_KMAX + 1];
+#pragma unroll
+            for (int k = 0; k <= RC_TAB_KMAX; ++k) {
+                uint32_t v = bits[k];          // at most 48 bits x 2^25 chunks a stream: no overflow
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+                tot[k] = v;
+            }
+            t = l1 > l0 ? rc_tab_bytes(chunk_bytes(l0), (l1 - l0 + 1u) / 2u, tot, nullptr) : 0u;
+        } else t = 2u * (l1 - l0);
         if (lane == 0) pre[s] = 4u + t;
     }
     __syncthreads();

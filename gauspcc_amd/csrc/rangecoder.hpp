@@ -41,9 +41,13 @@ static inline int64_t rc_rows_capacity(int64_t nch, int64_t S) { return (S + RC_
 //   version 3      a chunk is TWO lanes sharing one byte count: the first half of the chunk's symbols is coded forwards from
 //                  the chunk's first byte, the second half backwards from its last byte (the bytes of that lane are stored
 //                  in reverse order).  A coder's flush leaves its last symbols decodable whatever bits follow, so each
-//                  lane simply reads on into the other's bytes.  One count per two lanes, and the count is a LEB128 varint
-//                  (1 byte below 128 bytes): ~1.1 bytes of table per 2 lanes instead of 2 per lane.  Chunk size 2^clog with
-//                  clog = clamp(ceil_log2(ceil(n / 128)), 7, chunk_log2): the same ~256 lanes per stream as version 2.
+//                  lane simply reads on into the other's bytes.  One count per two lanes; the table is the first count as
+//                  a LEB128 varint, then (more than one chunk) a byte k in 0..7 and the zigzag differences to the previous
+//                  count as Rice codes -- bits MSB first, zero-padded to a byte: q = z >> k < 16: q ones, a zero, the low
+//                  k bits of z; otherwise sixteen ones and z in 32 bits; k = the value giving the fewest bits, the smallest
+//                  on a tie.  The chunks of a stream differ by a few bytes: ~5 bits of table per 2 lanes instead of 16 per
+//                  lane.  Chunk size 2^clog with clog = clamp(ceil_log2(ceil(n / 128)), 7, chunk_log2): the same ~256
+//                  lanes per stream as version 2.
 //   chunk_log2 = 0 the reference layout: one lane per stream, no table.
 struct RcPlan {
     int llog;           // lane size log2 (0 with nlanes == 1: the whole stream)
@@ -72,7 +76,7 @@ static inline RcPlan rc_plan(int64_t n, int chunk_log2, int version)
     p.nchunks = p.dual ? (uint32_t)((nl + 1) / 2) : (uint32_t)nl;
     return p;
 }
-// chunk tables: u16 per chunk (versions 1, 2), LEB128 (version 3)
+// chunk tables: u16 per chunk (versions 1, 2); version 3: LEB128 first count + Rice-coded differences (rc_table_*)
 static inline size_t rc_varint_size(uint32_t v) { return v < (1u << 7) ? 1 : v < (1u << 14) ? 2 : v < (1u << 21) ? 3 : v < (1u << 28) ? 4 : 5; }
 static inline size_t rc_varint_put(uint8_t *o, uint32_t v) { size_t k = 0; while (v >= 128u) { o[k++] = (uint8_t)(v | 128u); v >>= 7; } o[k++] = (uint8_t)v; return k; }
 // returns bytes read, 0 on a malformed / truncated varint
@@ -84,6 +88,68 @@ static inline size_t rc_varint_get(const uint8_t *p, size_t avail, uint32_t *v)
         if (!(p[k] & 128u)) { if (k == 4 && p[k] > 15u) return 0; *v = r; return k + 1; }
     }
     return 0;
+}
+// Version-3 chunk table.  b(c) = byte count of chunk c (both lanes), c < nch.
+constexpr int RC_TAB_KMAX = 7;
+constexpr uint32_t RC_TAB_ESC = 16u, RC_TAB_ESC_BITS = 48u;
+__host__ __device__ __forceinline__ uint32_t rc_zigzag(uint32_t cur, uint32_t prev) { const int32_t d = (int32_t)(cur - prev); return ((uint32_t)d << 1) ^ (uint32_t)(d >> 31); }
+__host__ __device__ __forceinline__ uint32_t rc_tab_cost(uint32_t z, int k) { const uint32_t q = z >> k; return q < RC_TAB_ESC ? q + 1u + (uint32_t)k : RC_TAB_ESC_BITS; }
+__host__ __device__ __forceinline__ uint32_t rc_tab_bytes(uint32_t first, uint32_t nch, const uint64_t bits[RC_TAB_KMAX + 1], int *kbest)
+{
+    const uint32_t v = first < (1u << 7) ? 1u : first < (1u << 14) ? 2u : first < (1u << 21) ? 3u : first < (1u << 28) ? 4u : 5u;
+    int k = 0;
+    for (int j = 1; j <= RC_TAB_KMAX; ++j) k = bits[j] < bits[k] ? j : k;
+    if (kbest) *kbest = k;
+    return nch < 2u ? v : v + 1u + (uint32_t)((bits[k] + 7u) >> 3);
+}
+template <class F> static inline size_t rc_table_size(F b, uint32_t nch, int *kbest = nullptr)
+{
+    uint64_t bits[RC_TAB_KMAX + 1] = {0};
+    if (!nch) return 0;
+    for (uint32_t c = 1; c < nch; ++c) {
+        const uint32_t z = rc_zigzag(b(c), b(c - 1));
+        for (int k = 0; k <= RC_TAB_KMAX; ++k) bits[k] += rc_tab_cost(z, k);
+    }
+    return rc_tab_bytes(b(0), nch, bits, kbest);
+}
+template <class F> static inline size_t rc_table_put(uint8_t *o, F b, uint32_t nch)
+{
+    int k = 0;
+    if (!nch) return 0;
+    (void)rc_table_size(b, nch, &k);
+    size_t pos = rc_varint_put(o, b(0));
+    if (nch < 2u) return pos;
+    o[pos++] = (uint8_t)k;
+    uint64_t acc = 0; int na = 0;   // MSB first
+    auto put = [&](uint32_t v, int n) { acc = (acc << n) | v; na += n; while (na >= 8) { o[pos++] = (uint8_t)(acc >> (na - 8)); na -= 8; } };
+    for (uint32_t c = 1; c < nch; ++c) {
+        const uint32_t z = rc_zigzag(b(c), b(c - 1)), q = z >> k;
+        if (q < RC_TAB_ESC) { put((1u << (q + 1u)) - 2u, (int)q + 1); if (k) put(z & ((1u << k) - 1u), k); }
+        else { put(0xFFFFu, 16); put(z >> 16, 16); put(z & 0xFFFFu, 16); }
+    }
+    if (na) put(0u, 8 - na);
+    return pos;
+}
+// reads the table of nch chunks into cb; returns its bytes, 0 when malformed / truncated
+static inline size_t rc_table_get(const uint8_t *p, size_t avail, uint32_t *cb, uint32_t nch)
+{
+    size_t pos = rc_varint_get(p, avail, &cb[0]);
+    if (!pos || nch < 2u) return pos;
+    if (pos >= avail || p[pos] > (uint8_t)RC_TAB_KMAX) return 0;
+    const int k = p[pos++];
+    uint64_t bit = (uint64_t)pos * 8u;
+    const uint64_t end = (uint64_t)avail * 8u;
+    auto get = [&](uint32_t &dst) -> bool { if (bit >= end) return false; dst = (p[bit >> 3] >> (7u - (bit & 7u))) & 1u; ++bit; return true; };
+    for (uint32_t c = 1; c < nch; ++c) {
+        uint32_t q = 0, one = 1, z = 0;
+        while (q < RC_TAB_ESC) { if (!get(one)) return 0; if (!one) break; ++q; }
+        if (q < RC_TAB_ESC) { for (int i = 0; i < k; ++i) { if (!get(one)) return 0; z = z << 1 | one; } z |= q << k; }
+        else for (int i = 0; i < 32; ++i) { if (!get(one)) return 0; z = z << 1 | one; }
+        const int64_t v = (int64_t)cb[c - 1] + ((int64_t)(z >> 1) ^ -(int64_t)(z & 1u));
+        if (v < 0 || v > 0x7FFFFFFF) return 0;
+        cb[c] = (uint32_t)v;
+    }
+    return (size_t)((bit + 7u) >> 3);
 }
 // Lane descriptors of one stream from its table.  `tab` points at the stream body (table, then the chunk payloads) of `len`
 // bytes which starts at byte `off` of the uploaded file; lanes[0 .. plan.nlanes) are filled, *max_bytes = the longest lane's
@@ -98,12 +164,11 @@ static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_
     }
     int64_t t = 0;                                   // table cursor
     std::vector<uint32_t> cb(plan.nchunks);
-    for (uint32_t c = 0; c < plan.nchunks; ++c) {
-        if (version >= 3) {
-            const size_t k = rc_varint_get(tab + t, (size_t)(len - t), &cb[c]);
-            if (!k) return "chunk table: bad varint";
-            t += (int64_t)k;
-        } else {
+    if (version >= 3) {
+        t = (int64_t)rc_table_get(tab, (size_t)std::max<int64_t>(len, 0), cb.data(), plan.nchunks);
+        if (!t) return "chunk table: malformed";
+    } else {
+        for (uint32_t c = 0; c < plan.nchunks; ++c) {
             if (t + 2 > len) return "stream shorter than its chunk table";
             cb[c] = tab[t] | tab[t + 1] << 8;
             t += 2;

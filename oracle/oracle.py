@@ -51,6 +51,10 @@ def lib():
         L.orc_stream_encode.restype = i64
         L.orc_stream_encode.argtypes = [vp, i32, vp, i64, i32, i32, vp, i64]
         L.orc_stream_decode.argtypes = [vp, i32, vp, i64, i64, i32, i32, vp]
+        L.orc_chunk_table_put.restype = i64
+        L.orc_chunk_table_put.argtypes = [vp, i64, vp]
+        L.orc_chunk_table_get.restype = i64
+        L.orc_chunk_table_get.argtypes = [vp, i64, i64, vp]
         L.orc_set_container_version.argtypes = [i32]
         L.orc_encode.restype = i64
         L.orc_encode.argtypes = [vp, i32, i32, vp, i64, i32, C.c_uint16, vp, i64]
@@ -210,7 +214,7 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes) -> np.ndarray:
 
 def stream_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version: int = 3) -> bytes:
     """One (level, stage) stream of the container as the codec writes it for a level of len(sym) nodes: the chunk table and
-    the chunks (version 3: LEB128 counts, forward + reversed backward lane per chunk); chunk_log2 = 0: the bare coder bytes."""
+    the chunks (version 3: Rice-coded counts, forward + reversed backward lane per chunk); chunk_log2 = 0: the bare coder bytes."""
     cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
     sym = np.ascontiguousarray(sym, dtype=np.uint8)
     cap = sym.size * 4 + 64 + 8 * (sym.size // 32 + 1)
@@ -227,6 +231,23 @@ def stream_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int, version: in
     if lib().orc_stream_decode(_p(cdf), cdf.shape[1], _p(buf), buf.size, cdf.shape[0], chunk_log2, version, _p(out)):
         raise ValueError("malformed stream")
     return out
+
+
+def chunk_table(counts) -> bytes:
+    """The version-3 chunk table of a stream whose chunks take `counts` bytes."""
+    c = np.ascontiguousarray(counts, dtype=np.int64)
+    out = np.empty(16 + 6 * c.size, dtype=np.uint8)
+    return out[:lib().orc_chunk_table_put(_p(c), c.size, _p(out))].tobytes()
+
+
+def chunk_table_parse(data: bytes, nch: int):
+    """(counts, bytes read) of a version-3 chunk table; ValueError when malformed."""
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.zeros(nch, dtype=np.uint32)
+    k = lib().orc_chunk_table_get(_p(buf), buf.size, nch, _p(out))
+    if not k:
+        raise ValueError("malformed chunk table")
+    return out, int(k)
 
 
 def set_container_version(v: int = 3) -> int:

@@ -1,7 +1,7 @@
 """Format and numerics regression: the stored bitstreams of tests/golden/containers.npz (written by this implementation's
 oracle, tests/golden/make_containers.py) must be reproduced byte for byte -- by the oracle on the CPU and by the HIP path
 on the GPU -- and must decode to the stored cloud.  Covers the reference layout, container version 3 (what the encoder
-writes: two lanes per byte-counted chunk, LEB128 counts) and version 2 (round 2's writer: still read, and still reproduced
+writes: two lanes per byte-counted chunk, Rice-coded count differences) and version 2 (round 2's writer: still read, and still reproduced
 by the oracle on request), both kernel sizes."""
 import os
 
@@ -57,8 +57,60 @@ def test_stored_headers(fixture):
     assert len(fixture["k5_chunk11_v3"]) < len(fixture["k5_chunk10"]) and len(fixture["k3_chunk11_v3"]) < len(fixture["k3_chunk10"])
 
 
+def _v3_table(counts):
+    """The version-3 chunk table, restated: LEB128 first count; with more chunks a byte k and the zigzag differences as Rice
+    codes (q = z >> k ones, a zero, k low bits; q >= 16: sixteen ones + z in 32 bits), MSB first, zero padded; k = fewest
+    bits, smallest on a tie."""
+    out = bytearray()
+    v = counts[0]
+    while v >= 128:
+        out.append((v & 127) | 128)
+        v >>= 7
+    out.append(v)
+    if len(counts) < 2:
+        return bytes(out)
+    zz = [(d << 1) if d >= 0 else ((-d) << 1) - 1 for d in (counts[i] - counts[i - 1] for i in range(1, len(counts)))]
+    cost = [sum((z >> k) + 1 + k if (z >> k) < 16 else 48 for z in zz) for k in range(8)]
+    k = cost.index(min(cost))
+    out.append(k)
+    bits = ""
+    for z in zz:
+        q = z >> k
+        bits += "1" * q + "0" + (format(z & ((1 << k) - 1), f"0{k}b") if k else "") if q < 16 else "1" * 16 + format(z, "032b")
+    bits += "0" * (-len(bits) % 8)
+    out += int(bits, 2).to_bytes(len(bits) // 8, "big") if bits else b""
+    return bytes(out)
+
+
+def test_v3_table_escape_and_ties():
+    # a difference of 0 costs k + 1 bits: k = 0 wins the tie; 3000 -> 12 needs the escape at every k <= 7 (5976 >> 7 = 46)
+    assert _v3_table([200, 200, 200]) == bytes([0xC8, 0x01, 0, 0b00000000])
+    t = _v3_table([3000, 12])
+    assert t[:3] == bytes([0xB8, 0x17, 0]) and t[3:] == bytes([0xFF, 0xFF]) + (5975).to_bytes(4, "big")
+
+
+def test_v3_table_oracle_matches_the_restatement(orc):
+    rng = np.random.RandomState(5)
+    cases = [[7], [0, 0], [200, 200, 200], [3000, 12], [5, 2 ** 31 - 1, 0, 77],
+             list(rng.randint(200, 240, size=500)) + [17],                       # a stream's chunks and its short last one
+             list(rng.randint(0, 5, size=64) * 3000), list(rng.randint(0, 2 ** 20, size=33))]
+    for counts in cases:
+        counts = [int(c) for c in counts]
+        tab = orc.chunk_table(counts)
+        assert tab == _v3_table(counts)
+        got, used = orc.chunk_table_parse(tab + b"\xAA\xBB", len(counts))
+        assert used == len(tab) and got.tolist() == counts
+        if len(counts) > 1:
+            with pytest.raises(ValueError):
+                orc.chunk_table_parse(tab[:-1], len(counts))                     # truncated
+            bad = bytearray(tab)
+            bad[len(_v3_table(counts[:1]))] = 8                                  # the byte behind the first count
+            with pytest.raises(ValueError):
+                orc.chunk_table_parse(bytes(bad), len(counts))                   # k > 7
+
+
 def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5):
-    """Version 3 by hand: a stream is LEB128 byte counts, then per chunk the forward lane's coder bytes followed by the
+    """Version 3 by hand: a stream is its chunk table, then per chunk the forward lane's coder bytes followed by the
     backward lane's coder bytes reversed -- checked against the plain coder (orc.rc_encode) on the traced CDFs / symbols."""
     pts = fixture["points"]
     data = orc.encode(synth_model_k5, pts, chunk_log2=6, trace=True)
@@ -79,19 +131,13 @@ def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5):
             body = data[pos + 4:pos + 4 + ln]
             pos += 4 + ln
             lanes = [orc.rc_encode(lv["cdf"][s][l * S:(l + 1) * S], lv["sym"][s][l * S:(l + 1) * S]) for l in range(nl)]
-            want_tab, want_pay = b"", b""
+            counts, want_pay = [], b""
             for c in range(0, nl, 2):
-                b = len(lanes[c]) + (len(lanes[c + 1]) if c + 1 < nl else 0)
-                v = b
-                while v >= 128:
-                    want_tab += bytes([(v & 127) | 128])
-                    v >>= 7
-                want_tab += bytes([v])
+                counts.append(len(lanes[c]) + (len(lanes[c + 1]) if c + 1 < nl else 0))
                 want_pay += lanes[c] + (lanes[c + 1][::-1] if c + 1 < nl else b"")
-            assert body == want_tab + want_pay
+            assert body == _v3_table(counts) + want_pay
             checked += 1
     assert pos == len(data) and checked == 4 * (L - 1)
-
 
 
 def _as_version1(stream: bytes) -> bytes:

@@ -252,7 +252,7 @@ def test_head_cdf_bit_exact(gh, orc, m):
 @pytest.mark.parametrize("chunk_log2", [0, 6, 10, 11])
 def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2):
     """gpcc_rc_encode writes ONE stream as the container holds it (chunk_log2 = 0: the bare torchac-compatible coder bytes;
-    else version 3: LEB128 chunk table, forward + reversed backward lane per chunk): bytes == the oracle's stream encoder,
+    else version 3: chunk table, forward + reversed backward lane per chunk): bytes == the oracle's stream encoder,
     either side decodes the other's stream.  n = 7001 at chunk_log2 = 11 is one short last chunk with an odd lane count."""
     rng = np.random.RandomState(lp * 31 + chunk_log2)
     n = 7001
@@ -287,6 +287,28 @@ def test_range_coder_long_lanes_and_high_rates(gh, orc, lp):
         data = gh.rc_encode(cdf_i, sym, chunk_log2)
         assert data == orc.stream_encode(cdf_i, sym, chunk_log2)
         assert np.array_equal(gh.rc_decode(cdf_i, data, chunk_log2), sym)
+
+
+def test_range_coder_chunk_table_escape(gh, orc):
+    """A stream whose chunks jump from a few bytes to 2 KiB: the difference does not fit the Rice code's unary part at any k
+    and takes the escape (sixteen ones + 32 bits).  4096-symbol chunks need a level of 2^19 symbols."""
+    lp, n = 17, 1 << 19
+    cdf = np.zeros((n, lp), np.float32)
+    cdf[:, 1:] = np.linspace(1 / 16, 1, 16, dtype=np.float32)[None, :]
+    half = n // 2
+    cdf[:half, 1:] = 1.0
+    cdf[:half, 1] = 1 - 1e-4                                       # first half: symbol 0 almost surely
+    cdf_i = orc.cdf_to_int16(cdf).view(np.uint16)
+    rng = np.random.RandomState(11)
+    sym = np.zeros(n, np.uint8)
+    sym[half:] = rng.randint(0, 16, size=half)
+    data = gh.rc_encode(cdf_i, sym, 12)
+    ref = orc.stream_encode(cdf_i, sym, 12)
+    counts, used = orc.chunk_table_parse(ref, n >> 12)
+    # 127 differences: 126 zeros (one bit each at k = 0) and one of 2048 bytes (48 bits: the escape), behind the first count and k
+    assert int(np.abs(np.diff(counts.astype(np.int64))).max()) == 2048 and used == 2 + (126 + 48 + 7) // 8
+    assert data == ref
+    assert np.array_equal(gh.rc_decode(cdf_i, data, 12), sym)
 
 
 def test_range_coder_extreme_rows(gh, orc):

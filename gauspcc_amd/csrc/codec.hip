@@ -356,6 +356,13 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     for (int si = 0; si < nstreams; ++si) {
         const int c0 = (int)stream_first[si], c1 = (int)stream_first[si + 1];
         for (int c = c0; c < c1; ++c) s_pay[(size_t)si] += hcnt[c];
+        if (chunk_log2) {   // never write a chunk the staged decoder could not hold (rangecoder.hpp: rc_window_fits)
+            const int stage_lp[4] = {STAGE_M[0] + 1, STAGE_M[1] + 1, STAGE_M[2] + 1, STAGE_M[3] + 1};
+            uint32_t mb = 0;
+            for (int c = c0; c < c1; c += 2) mb = std::max(mb, hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
+            if (!rc_window_fits(stage_lp[si & 3], mb))
+                return fail(GPCC_ERR_ARG, "a chunk of stream %d takes %u bytes, more than the decoder's window holds at chunk_log2 = %d: use a smaller chunk_log2", si, mb, chunk_log2);
+        }
         if (chunk_log2)
             s_tab[(size_t)si] = rc_table_size([&](uint32_t c) { const int l = c0 + 2 * (int)c; return hcnt[l] + (l + 1 < c1 ? hcnt[l + 1] : 0u); }, (uint32_t)((c1 - c0 + 1) / 2));
         tables += s_tab[(size_t)si];

@@ -48,24 +48,51 @@ static_assert(ROWF >= 32 && ROWF % 4 == 0, "row pitch: whole 16-byte units");
 __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) * ROWF + HDR_DWORDS; }
 
 // ------------------------------------------------------------------ block policy
-int conv_pick_rows(int64_t n, int k)
+static int conv_rows_forced()
 {
-    (void)k;
     static const int forced = [] {
         const int f = env_int("GAUSPCC_CONV_R", 0);
         return (f != 0 && f != 16 && f != 32 && f != 64 && f != 96 && f != 128 && f != 255) ? 0 : f;
     }();
-    if (forced) return forced;
-    // every level the cooperative kernel does not take (it wins below ~12 k nodes): the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
+    return forced;
+}
+static int64_t conv_tall_min()
+{
+    static const int64_t tall_min = env_ll("GAUSPCC_CONV_TALL_MIN", 64 * 256 + 1);   // 245 64-row workgroups: 22.2 us against 23.1 for 977 16-row waves at 15.6 k nodes
+    return tall_min;
+}
+
+// Levels the cooperative kernel takes (up to 16 k nodes; one workgroup per block, one workgroup per CU): the block height
+// is the smallest of 16 / 32 / 64 rows that runs the level as ONE round of at most 256 workgroups -- 263 16-row blocks
+// take two rounds (38 us per convolution on the 4 k-node level of the 1 M-point cloud), 132 32-row blocks one.  Taller blocks have
+// better-filled tiles (a 16-row block of a k = 5 level has ~100 tiles of 2-3 pairs) but more of them per block, so the
+// height only grows when the rounds of workgroups shrink.  (k = 7: the headers of a 64-row block do not fit the LDS; 16.)
+int conv_coop_rows(int64_t n, int k)
+{
+    static const int tall = env_int("GAUSPCC_COOP_TALL", 1);
+    if (!tall || k > 5) return 16;
+    return n <= 16 * 256 ? 16 : n <= 32 * 256 ? 32 : 64;
+}
+bool conv_is_coop(int64_t n, int R)
+{
+    static const int use_coop = env_int("GAUSPCC_CONV_COOP", 1) != 0;
+    if (!use_coop) return false;
+    if (R == 16) return true;
+    return (R == 32 || R == 64) && !conv_rows_forced() && n < conv_tall_min() && n <= 64 * 256;
+}
+
+int conv_pick_rows(int64_t n, int k)
+{
+    if (conv_rows_forced()) return conv_rows_forced();
+    // every level the cooperative kernel does not take (it wins up to ~16 k nodes): the 255-row class at one wave per SIMD (4 x 35 KiB of LDS per CU),
     // with the block height set by conv_pick_height -- up to 1024 blocks run as ONE round of equal blocks, one per SIMD
     // (measured against 2-3 waves per SIMD on 32..128-row blocks: 34 k nodes 40 vs 56 us, 92 k 75 vs 88, 251 k 185 vs 199,
     // 540 k 322 vs 377).  The asm loop addresses rows with 32-bit offsets: n < 2^25.
-    static const int64_t tall_min = env_ll("GAUSPCC_CONV_TALL_MIN", 12 * 1024);
-    if (n >= tall_min && n < ((int64_t)1 << 25)) return 255;
+    if (n >= conv_tall_min() && n < ((int64_t)1 << 25)) return 255;
     if (n >= 192 * 1024) return 128;
     if (n >= 96 * 1024) return 64;
     if (n >= 24 * 1024) return 32;
-    return 16;
+    return conv_coop_rows(n, k);
 }
 
 // A launch runs nblk single-wave blocks on a fixed number of wave slots (LDS and registers allow 1 wave per SIMD for the
@@ -75,7 +102,7 @@ int conv_pick_rows(int64_t n, int k)
 int conv_pick_height(int64_t n, int R)
 {
     static const int balance = env_int("GAUSPCC_CONV_BALANCE", 2);
-    if (!balance || R <= 16) return R;
+    if (!balance || R <= 16 || conv_is_coop(n, R)) return R;
     const int64_t slots = 1024 * (int64_t)(R >= 255 ? 1 : 2);
     const int64_t k = cdiv(n, slots * R);
     // measured (MI355X, 1 M-point cloud): with the longest-first order a last round that is mostly full costs nothing
@@ -430,17 +457,20 @@ constexpr int COOP_TILES = 32;
 #endif
 constexpr int COOP_WAVES = COOP_WAVES_N;
 constexpr int COOP_TPW = COOP_TILES / COOP_WAVES;   // tiles per wave and round
-// LDS: products [32][16][32] f32, row->entry map [16][32] u8, then the block's tile headers (K tiles: 16 + 4 + 1 dwords each)
-static inline size_t coop_lds_bytes(int K) { return (size_t)COOP_TILES * 16 * 32 * 4 + 16 * COOP_TILES + (size_t)K * 84; }
+// LDS: products [32][16][32] f32, row->entry map [ROWS][32] u8, then the block's tile headers (at most K x ROWS / 16 tiles: 16 + 4 + 1 dwords each)
+// ROWS = 16 / 32 / 64 rows per block (conv_coop_rows); a block of ROWS rows has at most ROWS / 16 tiles per kernel offset.
+static inline size_t coop_lds_bytes(int K, int rows) { return (size_t)COOP_TILES * 16 * 32 * 4 + (size_t)rows * COOP_TILES + (size_t)K * (rows / 16) * 84; }
 
+template <int ROWS>
 __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch jobs, ConvTiles T, int n, int relu)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int NTMAX = T.K * (ROWS / 16);                              // the most tiles a block can have
     float *P = lds;                                                   // [tile][entry][channel (physical)]
     uint8_t *inv = reinterpret_cast<uint8_t *>(lds + COOP_TILES * 16 * 32);   // [row][tile] -> entry of that row in the tile, 255 = absent
-    int32_t *hj = reinterpret_cast<int32_t *>(inv + 16 * COOP_TILES);  // [tile][16] neighbour rows
-    uint32_t *hr = reinterpret_cast<uint32_t *>(hj + (size_t)T.K * 16); // [tile][4]  output rows (bytes)
-    uint32_t *ho = hr + (size_t)T.K * 4;                                // [tile]     offset | count << 16
+    int32_t *hj = reinterpret_cast<int32_t *>(inv + ROWS * COOP_TILES);  // [tile][16] neighbour rows
+    uint32_t *hr = reinterpret_cast<uint32_t *>(hj + (size_t)NTMAX * 16); // [tile][4]  output rows (bytes)
+    uint32_t *ho = hr + (size_t)NTMAX * 4;                                // [tile]     offset | count << 16
 #ifdef COOP_TIMING
     const long long q0 = clock64();
 #endif
@@ -450,13 +480,13 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;   // block id in the tile pool (a set's blocks are consecutive)
     int lvi = 0;
     for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
-    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * 16;
-    const int nrows = min(16, (int)T.lv_rows[lvi] - lrow0);
+    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * ROWS;
+    const int nrows = min(ROWS, (int)T.lv_rows[lvi] - lrow0);
     const int row0 = (int)T.lv_row0[lvi] + lrow0;
     const int e = lane & 15, g = lane >> 4;
     const int col0 = 4 * (e & 3) + (e >> 2), col1 = col0 + 16;
     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
-    const int nt = (int)min(t1 - t0, (uint32_t)T.K);   // a 16-row block has at most one tile per kernel offset
+    const int nt = (int)min(t1 - t0, (uint32_t)NTMAX);   // a block has at most ROWS / 16 tiles per kernel offset
     // the whole header list of the block in one sweep (three latencies instead of one per round)
     for (int i = tid; i < nt * 16; i += 64 * COOP_WAVES) hj[i] = T.tj[(size_t)t0 * 16 + i];
     for (int i = tid; i < nt * 4; i += 64 * COOP_WAVES) hr[i] = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16)[i];
@@ -467,7 +497,8 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #endif
     const float *__restrict__ in = J.in + (size_t)T.lv_row0[lvi] * 32 + 4 * g;   // tile entries are row indices inside the level
     const float *__restrict__ wf = J.w + lane * 4;
-    constexpr int COOP_EPT = 512 / (64 * COOP_WAVES) > 0 ? 512 / (64 * COOP_WAVES) : 1;   // output elements per thread in phase B
+    constexpr int NEL = ROWS * 32;                                                        // output elements of the block
+    constexpr int COOP_EPT = NEL / (64 * COOP_WAVES) > 0 ? NEL / (64 * COOP_WAVES) : 1;   // output elements per thread in phase B
     float acc[COOP_EPT];
 #pragma unroll
     for (int u = 0; u < COOP_EPT; ++u) acc[u] = 0.0f;
@@ -500,10 +531,10 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
             dst[(4 * g + k) * 32 + col0] = c0[k];
             dst[(4 * g + k) * 32 + col1] = c1[k];
         }
-        if (lane < 16) inv[lane * COOP_TILES + tl] = 255;
+        if (lane < ROWS) inv[lane * COOP_TILES + tl] = 255;
         const uint32_t cnt = ho[t] >> 16;
         const uint32_t r = (hr[t * 4 + (e >> 2)] >> (8 * (e & 3))) & 255u;
-        if (lane < 16 && (uint32_t)lane < cnt && r >= 1u && r <= 16u) inv[(r - 1u) * COOP_TILES + tl] = (uint8_t)lane;   // tr holds row + 1; same wave: ordered behind the 255s
+        if (lane < 16 && (uint32_t)lane < cnt && r >= 1u && r <= (uint32_t)ROWS) inv[(r - 1u) * COOP_TILES + tl] = (uint8_t)lane;   // tr holds row + 1; same wave: ordered behind the 255s
     };
     // this wave's two tiles of a round: base + 2 wave + {0, 1}; the next round's operands are requested before this
     // round's products are summed, so a round costs MFMAs + two barriers, not a memory latency
@@ -526,7 +557,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
 #pragma unroll
         for (int u = 0; u < COOP_EPT; ++u) {   // ordered sum over the tiles of this round, one output element at a time
             const int el = tid + u * 64 * COOP_WAVES;
-            if (el < 512) {
+            if (el < NEL) {
                 const int orow = el >> 5, och = el & 31;
                 const int ntl = min(COOP_TILES, nt - base);
                 const uint4 w0 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES), w1 = *reinterpret_cast<const uint4 *>(inv + orow * COOP_TILES + 16);
@@ -556,7 +587,7 @@ __global__ __launch_bounds__(64 * COOP_WAVES) void k_sparse_conv_coop(ConvBatch 
     for (int u = 0; u < COOP_EPT; ++u) {
         const int el = tid + u * 64 * COOP_WAVES;
         const int grow = row0 + (el >> 5), och = el & 31;
-        if (el < 512 && (el >> 5) < nrows) {
+        if (el < NEL && (el >> 5) < nrows) {
             float v = acc[u];
             if (J.res) v = v + J.res[(size_t)grow * 32 + och];
             if (relu) v = v > 0.f ? v : 0.f;
@@ -723,10 +754,13 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343, 16)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(125, 32)));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(125, 64)));
         return GPCC_OK;
     }));
-    static const int use_coop = env_int("GAUSPCC_CONV_COOP", 1) != 0, use_split = env_int("GAUSPCC_CONV_SPLIT", 1) != 0;
+    static const int use_split = env_int("GAUSPCC_CONV_SPLIT", 1) != 0;
+    const bool use_coop = conv_is_coop(n, T.R) && T.H == T.R;
     // 16-row blocks.  Up to 64 blocks (a level of at most 1 k nodes): products over the whole chip + ordered sums, two
     // launches -- measured 11.7 / 15.2 us against 18.8 / 26.2 for the one-workgroup-per-block kernel at 4 / 32 blocks.
     // Beyond that the two launches cost what they save (26.9 vs 25.8 us at 160 blocks): the cooperative kernel.
@@ -735,7 +769,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     // against 25.8 / 36.5 / 22.5: a block's ~100 tiles move ~750 KB through one CU's L1 whatever the schedule.  Dropped.)
     static const int split_max = env_int("GAUSPCC_CONV_SPLIT_MAX", 64);
     const size_t prod_floats = ((size_t)T.nblk * (size_t)T.K + CONV_HDR_PAD) * 512;
-    if (T.R == 16 && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
+    if (T.R == 16 && use_coop && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
         if (ctx->conv_products_cap < prod_floats) {
             HIP_TRY(hipStreamSynchronize(st));   // an earlier convolution of this context may still read the old buffer
             if (ctx->conv_products) HIP_TRY(hipFree(ctx->conv_products));
@@ -772,9 +806,13 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
         return GPCC_OK;
     }
-    if (T.R == 16 && use_coop) {
-        if (T.K > 343) return fail(GPCC_ERR_ARG, "kernel size > 7 is not supported");
-        k_sparse_conv_coop<<<dim3((unsigned)T.nblk, (unsigned)njobs), 64 * COOP_WAVES, coop_lds_bytes(T.K), st>>>(jobs, T, (int)n, relu);
+    if (use_coop) {
+        if (T.K > 343 || (T.R > 16 && T.K > 125)) return fail(GPCC_ERR_ARG, "kernel size > 7 is not supported");
+        const dim3 cg((unsigned)T.nblk, (unsigned)njobs);
+        const size_t cl = coop_lds_bytes(T.K, T.R);
+        if (T.R == 16) k_sparse_conv_coop<16><<<cg, 64 * COOP_WAVES, cl, st>>>(jobs, T, (int)n, relu);
+        else if (T.R == 32) k_sparse_conv_coop<32><<<cg, 64 * COOP_WAVES, cl, st>>>(jobs, T, (int)n, relu);
+        else k_sparse_conv_coop<64><<<cg, 64 * COOP_WAVES, cl, st>>>(jobs, T, (int)n, relu);
         LAUNCH_CHECK();
         if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
         return GPCC_OK;

@@ -102,6 +102,7 @@ struct ConvTiles {
     uint32_t lv_rows[MAXLV] = {0};      // rows of each level
 };
 int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides)
+bool conv_is_coop(int64_t n, int R);     // does a level of n nodes at block class R run the cooperative kernel (16 / 32 / 64-row blocks, H = R)?
 int conv_pick_height(int64_t n, int R);  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
 
 // Tile lists of several levels in one pool (tiles.hip).  Level l is built from its parent level's cell map (par == nullptr:

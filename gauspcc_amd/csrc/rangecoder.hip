@@ -44,7 +44,6 @@ __device__ __forceinline__ void ring_dma_2xb32(const void *gsrc, uint32_t lds_ds
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst0), "s"(lds_dst1_minus4) : "memory");
 }
 template <int N> __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-constexpr int RC_RING_DEPTH = 16;
 
 __device__ __forceinline__ void ring_dma_b32(const void *gsrc, uint32_t lds_dst)
 {
@@ -424,7 +423,6 @@ __global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__
 //   d' = (d1 << k) | ones(k),  x' = (x1 << k) | next k bits   (the E3 flip adds 2^31 to low, high and value alike;
 //   d rather than the span itself because a span of 2^32 does occur: a symbol of probability 2^-16 renormalises to it),
 // k = n1 + n2 as in the kernels above.  ~40 instructions per binary symbol instead of ~75 (profiles/r03_rc_decode_isa.txt).
-constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
 
 __device__ __forceinline__ uint32_t ones_below(uint32_t k) { return (1u << (k & 31u)) - 1u; }
 
@@ -672,10 +670,10 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
 {
     if (nchunks <= 0) return GPCC_OK;
     // staged path: every lane's window (+ the two dwords the reader runs ahead) in LDS; as many lanes per wave as fit
-    const uint64_t rdw = ((uint64_t)max_bytes + 3u) / 4u + 3u;
-    const uint32_t ring_bytes = (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u);       // the row ring behind the windows
+    const uint64_t rdw = rc_window_dwords(max_bytes);
+    const uint32_t ring_bytes = rc_ring_bytes(lp);       // the row ring behind the windows
     const uint32_t cap = RC_LDS_CAP - ring_bytes;
-    if (rdw * 4u * (lp == 17 ? 4u : 1u) <= cap) {
+    if (rc_window_fits(lp, max_bytes)) {
         if (lp == 17) {
             k_rc_decode17_lds<<<(unsigned)cdiv(nchunks, 4), 64, (size_t)(4u * rdw * 4u) + ring_bytes, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
         } else {

@@ -194,6 +194,16 @@ static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_
     return nullptr;
 }
 
+// The staged decoders keep every lane's byte window (+ the dwords the reader runs ahead) in LDS, behind a ring of
+// RC_RING_DEPTH CDF rows per lane; the 16-ary kernel runs four coder states per wave.  A version-3 chunk must fit (both
+// lanes see the whole chunk): ~15 KiB for 16-ary, ~56 KiB for 4-ary, ~60 KiB for binary streams.  The encoder refuses to
+// write a chunk its decoder could not read (possible only at chunk_log2 >= 13 with a model that spends > 7 bits per symbol).
+constexpr int RC_RING_DEPTH = 16;
+constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
+static inline uint64_t rc_window_dwords(uint32_t max_bytes) { return ((uint64_t)max_bytes + 3u) / 4u + 3u; }
+static inline uint32_t rc_ring_bytes(int lp) { return (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u); }
+static inline bool rc_window_fits(int lp, uint32_t max_bytes) { return rc_window_dwords(max_bytes) * 4u * (lp == 17 ? 4u : 1u) <= RC_LDS_CAP - rc_ring_bytes(lp); }
+
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);

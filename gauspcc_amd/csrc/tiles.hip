@@ -532,7 +532,11 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         pool->alg_bytes = b;
     }
     int64_t cap;
+    int64_t rows_total = 0;
+    for (int l = 0; l < nlv; ++l) rows_total += lv[l].lv->n;
+    // (blocks of 32 / 64 rows of a small level -- the cooperative kernel's taller classes -- hold at most H / 16 tiles per offset)
     if (H <= 16) cap = nblk * K + CONV_HDR_PAD;
+    else if (H <= 64 && H % 16 == 0 && conv_is_coop(rows_total, R)) cap = nblk * K * (H / 16) + CONV_HDR_PAD;
     else {
         uint32_t total = 0;
         HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));

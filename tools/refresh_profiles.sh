@@ -21,6 +21,10 @@ f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
 python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
 rm -rf "$OUT/t" "$OUT/pmc"
+# 2b. convolutions per level (per-launch HIP events inside the library)
+{ echo "# tools/conv_log.py 1000000 (per-launch HIP events, GAUSPCC_CONV_LOG=1): convolutions of one encode + decode of the 1 M-point bench cloud, per level"
+  echo "# 'enc level 0 / 1' = the prior set (levels 0..L-2) / the target set (levels 1..L-1), all levels in one launch; 'dec level g' = the launches on level g's nodes"
+  timeout 300 python3 tools/conv_log.py 1000000 2>/dev/null | grep -E "^enc|^dec|^\{"; } > "$OUT/${R}_conv_levels.txt"
 # 3. SQ / TCP / GRBM counters of the conv kernels
 BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1
 cp "$OUT/pmc2/summary.txt" "$OUT/${R}_pmc_conv_counters.txt"; rm -rf "$OUT/pmc2"

@@ -41,8 +41,84 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->conv_products) (void)hipFree(c->conv_products);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
+    if (c->dbg_dev) (void)hipFree(c->dbg_dev);
+    for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
     delete c;
+}
+
+namespace gpcc {
+constexpr int DBG_MAX = 4096;
+__global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t *__restrict__ p, size_t words, unsigned long long *__restrict__ out)
+{
+    unsigned long long a = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < words; i += (size_t)gridDim.x * 256) a += (unsigned long long)p[i] * (2ull * i + 1ull);
+    atomicAdd(out, a);
+}
+int dbg_mark(gpcc_ctx *ctx, hipStream_t st, int tag, const void *p, size_t bytes)
+{
+    if (!ctx || !ctx->dbg_on || (int)ctx->dbg_tags.size() >= DBG_MAX) return GPCC_OK;
+    const size_t words = bytes / 4;
+    unsigned long long *slot = ctx->dbg_dev + ctx->dbg_tags.size();
+    HIP_TRY(hipMemsetAsync(slot, 0, 8, st));
+    if (words) k_dbg_sum<<<(unsigned)std::min<size_t>(1024, (words + 255) / 256), 256, 0, st>>>(static_cast<const uint32_t *>(p), words, slot);
+    LAUNCH_CHECK();
+    ctx->dbg_tags.push_back(tag);
+    if (ctx->dbg_capture_tag_mod >= 0 && tag % 100 == ctx->dbg_capture_tag_mod && bytes) {
+        gpcc_ctx::DbgCap *c = nullptr;
+        for (auto &e : ctx->dbg_caps) if (e.tag == tag) c = &e;
+        if (!c) { ctx->dbg_caps.push_back(gpcc_ctx::DbgCap{tag, nullptr, 0, 0}); c = &ctx->dbg_caps.back(); }
+        if (c->cap < bytes) {
+            if (c->dev) HIP_TRY(hipFree(c->dev));
+            c->dev = nullptr; c->cap = 0;
+            HIP_TRY(hipMalloc(&c->dev, bytes));
+            c->cap = bytes;
+        }
+        c->bytes = bytes;
+        HIP_TRY(hipMemcpyAsync(c->dev, p, bytes, hipMemcpyDeviceToDevice, st));
+    }
+    return GPCC_OK;
+}
+}  // namespace gpcc
+
+// developer trace: keep a device copy of every marked buffer whose tag % 100 == tag_mod (-1: none); _get copies one out
+extern "C" int gpcc_debug_capture(gpcc_ctx *ctx, int tag_mod)
+{
+    if (!ctx) return fail(GPCC_ERR_ARG, "null context");
+    ctx->dbg_capture_tag_mod = tag_mod;
+    return GPCC_OK;
+}
+extern "C" long long gpcc_debug_capture_get(gpcc_ctx *ctx, int tag, void *host, long long cap)
+{
+    if (!ctx) return -1;
+    for (auto &e : ctx->dbg_caps)
+        if (e.tag == tag) {
+            const size_t n = std::min<size_t>(e.bytes, (size_t)std::max<long long>(cap, 0));
+            if (n && hipMemcpy(host, e.dev, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+            return (long long)e.bytes;
+        }
+    return -1;
+}
+
+extern "C" int gpcc_debug_trace_enable(gpcc_ctx *ctx, int on)
+{
+    if (!ctx) return fail(GPCC_ERR_ARG, "null context");
+    if (on && !ctx->dbg_dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->dbg_dev), 8 * (size_t)DBG_MAX));
+    ctx->dbg_on = on != 0;
+    ctx->dbg_tags.clear();
+    return GPCC_OK;
+}
+// marks recorded since the last enable / get (the decode that recorded them has returned: its streams are idle); clears the list
+extern "C" int gpcc_debug_trace_get(gpcc_ctx *ctx, int *tags, unsigned long long *sums, int cap)
+{
+    if (!ctx || !ctx->dbg_dev) return 0;
+    const int n = std::min<int>(cap, (int)ctx->dbg_tags.size());
+    if (n > 0) {
+        if (hipMemcpy(sums, ctx->dbg_dev, 8 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        for (int i = 0; i < n; ++i) tags[i] = ctx->dbg_tags[(size_t)i];
+    }
+    ctx->dbg_tags.clear();
+    return n;
 }
 
 extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)

@@ -230,7 +230,10 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
+        GP_TRY(dbg_mark(ctx, st, 1, pA, (size_t)nP * 128)); GP_TRY(dbg_mark(ctx, st, 2, cA, (size_t)nC * 128));
+        for (int s = 0; s < 4; ++s) GP_TRY(dbg_mark(ctx, st, 3 + s, y[s], (size_t)nC * 128));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));   // ranks -> posC / slotsC
+        GP_TRY(dbg_mark(ctx, st, 7, posC, (size_t)nC * 4)); GP_TRY(dbg_mark(ctx, st, 8, slotsC, (size_t)nC * 4));
         ctx->arena.release_top_low();                       // what is enqueued on st from here on runs behind the rank pass: its temporaries are free
         StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
@@ -303,6 +306,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         HIP_TRY(hipMemcpyAsync(dchunks, hs + off_desc, sizeof(RcChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
         StageTimer tm(ctx, st, ST_CODER, (double)coded * 4 * 4);   // + 3 x the payload (written, compacted), added when it is known
         GP_TRY(rc_encode_launch(st, lohi, dchunks, nchunks, scratch, stride, dcnt));
+        GP_TRY(dbg_mark(ctx, st, 10, dcnt, (size_t)nchunks * 4));
         GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt + 4 * (size_t)nchunks, doff + nchunks, 4, hipMemcpyDeviceToHost, st));
@@ -592,7 +596,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         // ---- st: parent trunk
         TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 1, pF, (size_t)np * 128));
         GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 2, pA, (size_t)np * 128));
         // ---- side: the child level's structure
         HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
         Level chi;
@@ -626,6 +632,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             GP_TRY(tiles_view(ctx, sd, pool, 0, 1, zero_base, &tilesC));
             tm.add_bytes(pool.alg_bytes);
         }
+        GP_TRY(dbg_mark(ctx, sd, g * 100 + 3, chi.rkey, (size_t)nc * 8)); GP_TRY(dbg_mark(ctx, sd, g * 100 + 4, chi.parent, (size_t)nc * 4));
+        GP_TRY(dbg_mark(ctx, sd, g * 100 + 5, chi.m2r, (size_t)nc * 4)); GP_TRY(dbg_mark(ctx, sd, g * 100 + 6, tilesC.first, (size_t)(tilesC.nblk + 1) * 4));
+        GP_TRY(dbg_mark(ctx, sd, g * 100 + 7, tilesC.order, (size_t)tilesC.nblk * 4));
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
         // lane descriptors of this level's four streams (chunked containers: uploaded with the container, above)
@@ -647,7 +656,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         // ---- st: child trunk and the four stages
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 8, cX, (size_t)nc * 128));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 9, cA, (size_t)nc * 128));
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc + 4); sym[s] = sy; }   // + the last group of four of the last lane
@@ -661,19 +672,26 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
             GP_TRY(conv_chain_end(ctx, st));
+            GP_TRY(dbg_mark(ctx, st, g * 100 + 10 + 5 * s, xin, (size_t)nc * 128)); GP_TRY(dbg_mark(ctx, st, g * 100 + 11 + 5 * s, cX, (size_t)nc * 128));
+            GP_TRY(dbg_mark(ctx, st, g * 100 + 12 + 5 * s, cB, (size_t)nc * 128));
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = clog; ha.nch = (uint32_t)nch;
             const int row_bytes = STAGE_M[s] == 2 ? 2 : STAGE_M[s] == 4 ? 8 : 32;     // compact CDF row
+            const size_t cdf_bytes = (size_t)rc_rows_capacity(nch, S) * 16 * 2;
+            if (ctx->dbg_on) HIP_TRY(hipMemsetAsync(cdf, 0, cdf_bytes, st));   // developer trace: rows the head does not write read as zeros
             { StageTimer tm(ctx, st, ST_HEADS, (double)nc * (128 + 4 + row_bytes)); GP_TRY(head_cdf(st, ha)); }
+            GP_TRY(dbg_mark(ctx, st, g * 100 + 13 + 5 * s, cdf, cdf_bytes));
             if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
                 GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], pl.dual, sym[s]));
             }
+            GP_TRY(dbg_mark(ctx, st, g * 100 + 14 + 5 * s, sym[s], (size_t)nc));
         }
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ)); }
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 30, chi.occ, (size_t)nc));
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
         coded += nc;

@@ -194,6 +194,14 @@ struct gpcc_ctx {
     // ordered on one stream)
     float *conv_products = nullptr;
     size_t conv_products_cap = 0;   // floats
+    // developer trace (gpcc_debug_trace_*): checksums of intermediate buffers of a decode, one (tag, sum) per mark, computed
+    // on the stream that produced the buffer -- to find the first stage whose output differs between two runs
+    bool dbg_on = false;
+    unsigned long long *dbg_dev = nullptr;
+    std::vector<int> dbg_tags;
+    struct DbgCap { int tag; void *dev; size_t cap, bytes; };
+    std::vector<DbgCap> dbg_caps;   // gpcc_debug_capture: copies of selected buffers (tag -> device copy)
+    int dbg_capture_tag_mod = -1;   // capture buffers whose tag % 100 equals this (-1: none)
     int side_init()
     {
         if (side) return GPCC_OK;
@@ -207,6 +215,7 @@ struct gpcc_ctx {
 };
 
 namespace gpcc {
+int dbg_mark(gpcc_ctx *ctx, hipStream_t st, int tag, const void *p, size_t bytes);   // api.hip (developer trace)
 int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx);   // network.hip
 // RAII bracket of one HBM-bound stage on the stream its kernels are enqueued on; bytes = the stage's ALGORITHMIC traffic
 // (what an ideal layer-by-layer implementation reads and writes), accumulated beside the time

@@ -20,21 +20,30 @@ namespace gpcc {
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
 // ------------------------------------------------------------------ LDS-DMA ring (decoder: CDF rows; encoder: symbol words)
-// CDF rows run DEPTH symbols ahead of the coder through a ring -- in LDS, filled by LDS-DMA loads (global_load_lds_*: no
-// VGPR destination, so nothing the register allocator could copy, spill or reuse before the data lands; a sub-dword LDS-DMA load writes a zero-extended DWORD per lane -- tools/ubench/lds_dma_probe.hip).  A register ring
-// left to the compiler costs a full memory round trip per trip of the unrolled loop: it clusters the loads, renames the
-// ring across the back edge and waits with vmcnt(0) for loads it has just issued (measured: ~0.15 us per symbol whatever
-// the instruction count); the same ring as inline-asm loads into "=v" registers is not safe (hipcc copied a destination
+// CDF rows run ahead of the coder through a ring -- in LDS, filled by LDS-DMA loads (global_load_lds_dword: no VGPR
+// destination, so nothing the register allocator could copy, spill or reuse before the data lands).  A register ring left
+// to the compiler costs a full memory round trip per trip of the unrolled loop: it clusters the loads, renames the ring
+// across the back edge and waits with vmcnt(0) for loads it has just issued (measured: ~0.15 us per symbol whatever the
+// instruction count); the same ring as inline-asm loads into "=v" registers is not safe (hipcc copied a destination
 // register in front of the hand-written wait).  Slot s of the ring is 64 lanes x 4 bytes at ring + 256 s: lane l's
-// datum of row i sits at slot (i % DEPTH), offset 4 l.  Loads return in order, so with (DEPTH - 1) x LPR younger ring
-// loads in flight `vmcnt((DEPTH - 1) * LPR)` means "row i has landed" (the symbol stores count too and may retire early,
-// which only makes the wait conservative).  M0 carries the LDS destination and is compiler-reserved: saved and restored
-// inside the statement.  Single-wave workgroups and every lane reads what its own lane's DMA wrote: no barrier.
-__device__ __forceinline__ void ring_dma_u16(const void *gsrc, uint32_t lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_ushort %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
+// datum of row i sits at slot (i % RC_RING_DEPTH), offset 4 l.  M0 carries the LDS destination and is compiler-reserved:
+// saved and restored inside the statement.  Single-wave workgroups and every lane reads what its own lane's DMA wrote:
+// no barrier.
+//
+// WHEN a slot may be read (round 3, found with two scenes in flight on one GPU; tools/dbg/inflight_check.py):
+//  * LDS-DMA loads do NOT retire in issue order under load.  A counted wait -- "with N younger loads in flight row i has
+//    landed" -- holds on an idle device (tools/ubench/lds_dma_probe.hip) and failed in 1 of ~200 decodes beside a second
+//    scene: the first symbols of a lane, where the waits are binding, read slots whose rows had been overtaken by later
+//    ones (waiting three rows further and sleeping 256 cycles moved the first wrong symbol from 1 to 3, no more).
+//    The only wait used here is vmcnt(0).  The ring is two halves of RC_RING_PHASE rows: while the coder works through one
+//    half, the batch of loads that refills the other -- issued a whole phase (16 symbols, ~2 us) earlier -- lands; at the
+//    end of a phase ONE vmcnt(0) retires it, then the half just consumed is refilled.  The symbols of a phase leave in one
+//    16-byte store issued right behind that wait, so the store has a phase to complete before the next vmcnt(0) sees it.
+//  * `global_load_lds_ushort` is not used: beside a second scene the upper half of its dword was not always zero (wrong
+//    symbols in 2-6 % of the decodes when the consumer read the dword).  16-bit rows are fetched as dwords (the address
+//    need not be dword-aligned; the row buffers have look-ahead slack behind their last entry) and read with 16-bit LDS loads.
+constexpr int RING_PHASE = RC_RING_DEPTH / 2;
+static_assert(RING_PHASE == 16, "a phase's symbols leave as one 16-byte store");
 // an 8-byte row as two dwords into two slots (there is no 8-byte LDS-DMA).  The instruction offset of an LDS-DMA load
 // moves the LDS destination as well as the source: the caller passes the second slot's address minus 4.
 __device__ __forceinline__ void ring_dma_2xb32(const void *gsrc, uint32_t lds_dst0, uint32_t lds_dst1_minus4)
@@ -43,8 +52,8 @@ __device__ __forceinline__ void ring_dma_2xb32(const void *gsrc, uint32_t lds_ds
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst0), "s"(lds_dst1_minus4) : "memory");
 }
-template <int N> __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-
+__device__ __forceinline__ void ring_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void ring_settle() { __builtin_amdgcn_s_sleep(8); }   // ~512 cycles behind the one BINDING wait of a lane (the prologue's): margin between the counter and the LDS write
 __device__ __forceinline__ void ring_dma_b32(const void *gsrc, uint32_t lds_dst)
 {
     unsigned keep;
@@ -78,10 +87,10 @@ struct BitOut {
 __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ lohi, const RcChunk *__restrict__ chunks, int nchunks,
                                                   uint8_t *__restrict__ scratch, uint32_t sstride, uint32_t *__restrict__ cnt)
 {
-    // the packed (c_low | (c_high - 1) << 16) words of the lanes come through the LDS-DMA ring, RC_RING_DEPTH symbols ahead:
-    // one load per symbol fetched one symbol ahead was a memory round trip per symbol (0.42 us: the whole encode coder
-    // took as long as its longest lane times that)
-    constexpr int DEPTH = RC_RING_DEPTH;
+    // the packed (c_low | (c_high - 1) << 16) words of the lanes come through the LDS-DMA ring, up to RC_RING_DEPTH symbols
+    // ahead: one load per symbol fetched one symbol ahead was a memory round trip per symbol (0.42 us: the whole encode
+    // coder took as long as its longest lane times that)
+    constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
     extern __shared__ uint32_t ring[];        // DEPTH slots of 64 dwords (dynamic: its LDS address is the static size)
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 64 + lane;
@@ -99,41 +108,52 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_groupstaticsize());
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) ring_dma_b32(src((uint32_t)d), ring_lds + (uint32_t)d * 256u);
-    ring_wait<DEPTH - 1>();
+    ring_wait_all();
+    ring_settle();
     uint32_t next = ring[lane];
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const uint32_t i = i0 + (uint32_t)d;
-            const uint32_t cur = next;
-            ring_wait<DEPTH - 2>();
-            next = ring[((d + 1) % DEPTH) * 64 + lane];
-            ring_dma_b32(src(i + (uint32_t)DEPTH), ring_lds + (uint32_t)d * 256u);
-            if (i < ch.n) {
-                const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
-                const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-                high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
-                low = low + (uint32_t)((span * c_low) >> 16);
-                const int n1 = clz32(low ^ high);  // leading bits on which low and high agree (< 32: low < high)
-                if (n1) {
-                    const uint32_t bits = low >> (32 - n1);
-                    const uint32_t b = bits >> (n1 - 1);
-                    w.put(b, 1);
-                    if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
-                    if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), (uint32_t)n1 - 1u);
-                    low <<= n1;
-                    high = (high << n1) | ((1u << n1) - 1u);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int dd = 0; dd < PH; ++dd) {
+                const int d = h * PH + dd;
+                const uint32_t i = i0 + (uint32_t)d;
+                const uint32_t cur = next;
+                if (dd + 1 < PH) next = ring[(d + 1) * 64 + lane];   // (the first word of the other half is read behind the wait below)
+                if (i < ch.n) {
+                    const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
+                    const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+                    high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+                    low = low + (uint32_t)((span * c_low) >> 16);
+                    const int n1 = clz32(low ^ high);  // leading bits on which low and high agree (< 32: low < high)
+                    if (n1) {
+                        const uint32_t bits = low >> (32 - n1);
+                        const uint32_t b = bits >> (n1 - 1);
+                        w.put(b, 1);
+                        if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
+                        if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), (uint32_t)n1 - 1u);
+                        low <<= n1;
+                        high = (high << n1) | ((1u << n1) - 1u);
+                    }
+                    // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times
+                    const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
+                    if (n2) {
+                        pending += (uint32_t)n2;
+                        low = (low << n2) & 0x7FFFFFFFu;
+                        high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+                    }
                 }
-                // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times
-                const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-                if (n2) {
-                    pending += (uint32_t)n2;
-                    low = (low << n2) & 0x7FFFFFFFu;
-                    high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
-                }
+            }
+            // end of a phase: the batch behind the other half (issued a phase ago) has to have landed; refill this half
+            ring_wait_all();
+            next = ring[((h + 1) % 2) * PH * 64 + lane];
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) nothing is fetched that no lane will use: no load is in flight when the wave ends
+#pragma unroll
+                for (int dd = 0; dd < PH; ++dd) ring_dma_b32(src(i0 + (uint32_t)(DEPTH + h * PH + dd)), ring_lds + (uint32_t)(h * PH + dd) * 256u);
             }
         }
     }
+    ring_wait_all();   // an LDS-DMA load still in flight at s_endpgm would land in LDS that may already belong to another workgroup
     if (c >= nchunks) return;
     pending += 1;
     const uint32_t b = low < 0x40000000u ? 0u : 1u;
@@ -497,8 +517,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
 {
     static_assert(LP == 3 || LP == 5, "17-entry rows are decoded by k_rc_decode17_lds");
     constexpr int RS = LP == 3 ? 1 : 4;
-    constexpr int DEPTH = RC_RING_DEPTH;
-    constexpr int LPR = LP == 3 ? 1 : 2;                       // ring loads per row
+    constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
     constexpr uint32_t SLOT = 256u;                            // bytes of a ring slot: a dword per lane
     static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
     extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows, then the row ring
@@ -520,51 +539,66 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     uint32_t *ring = win + (size_t)lpw * rdw;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + (uint32_t)lpw * rdw * 4u));
     auto ring_load = [&](int slot) {
-        if (LP == 3) ring_dma_u16(rowp, ring_lds + (uint32_t)slot * SLOT);
+        if (LP == 3) ring_dma_b32(rowp, ring_lds + (uint32_t)slot * SLOT);   // a dword for a 16-bit row (header comment)
         else ring_dma_2xb32(rowp, ring_lds + (uint32_t)slot * SLOT, ring_lds + (uint32_t)(DEPTH + slot) * SLOT - 4u);
         rowp += rstep;
     };
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-    uint32_t pack = 0;
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
     uint8_t *out = sym + ch.out;
-    // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain)
+    // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain); 16-bit rows arrive as
+    // the low half of a dword whose upper half is the next entry in memory: read 16 bits
     auto ring_read = [&](int slot, uint32_t &a, uint32_t &b) {
-        a = ring[slot * 64 + lane];
-        if (LP != 3) b = ring[(DEPTH + slot) * 64 + lane];
+        if (LP == 3) a = reinterpret_cast<const uint16_t *>(ring)[2 * (slot * 64 + lane)];
+        else { a = ring[slot * 64 + lane]; b = ring[(DEPTH + slot) * 64 + lane]; }
     };
     uint32_t n0 = 0, n1r = 0;
-    ring_wait<(DEPTH - 1) * LPR>();
+    ring_wait_all();
+    ring_settle();
     ring_read(0, n0, n1r);
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) {
-            const uint32_t i = i0 + (uint32_t)dd;
-            const uint32_t r0 = n0, r1 = n1r;
-            ring_wait<(DEPTH - 2) * LPR>();                    // row i + 1 has landed: DEPTH - 2 younger rows in flight
-            ring_read((dd + 1) % DEPTH, n0, n1r);
-            ring_load(dd);          // slot dd (row i, read one symbol ago) takes row i + DEPTH
-            const uint32_t t = in.peek();
-            uint32_t s, lo, d1;
-            if (LP == 3) {
-                const uint32_t t1 = scale_d(d, r0);
-                const bool ge = t1 <= x;
-                s = ge; lo = ge ? t1 : 0u;
-                d1 = ge ? d - t1 : t1 - 1u;
-            } else {
-                const uint32_t t1 = scale_d(d, r0 & 0xFFFFu), t2 = scale_d(d, r0 >> 16), t3 = scale_d(d, r1 & 0xFFFFu);
-                // the scaled bounds are monotone: (t3 <= x) implies (t2 <= x) implies (t1 <= x).  Selects, no branches.
-                const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
-                lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
-                const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));              // scaled upper bound (mod 2^32: a span of 2^32 wraps to 0)
-                s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
-                d1 = hi + ~lo;                                                           // hi - lo - 1
+        for (int h = 0; h < 2; ++h) {
+            uint32_t pack[PH / 4];
+#pragma unroll
+            for (int dd = 0; dd < PH; ++dd) {
+                const uint32_t r0 = n0, r1 = n1r;
+                if (dd + 1 < PH) ring_read(h * PH + dd + 1, n0, n1r);   // (the first row of the other half is read behind the wait below)
+                const uint32_t t = in.peek();
+                uint32_t s, lo, d1;
+                if (LP == 3) {
+                    const uint32_t t1 = scale_d(d, r0);
+                    const bool ge = t1 <= x;
+                    s = ge; lo = ge ? t1 : 0u;
+                    d1 = ge ? d - t1 : t1 - 1u;
+                } else {
+                    const uint32_t t1 = scale_d(d, r0 & 0xFFFFu), t2 = scale_d(d, r0 >> 16), t3 = scale_d(d, r1 & 0xFFFFu);
+                    // the scaled bounds are monotone: (t3 <= x) implies (t2 <= x) implies (t1 <= x).  Selects, no branches.
+                    const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
+                    lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
+                    const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));              // scaled upper bound (mod 2^32: a span of 2^32 wraps to 0)
+                    s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
+                    d1 = hi + ~lo;                                                           // hi - lo - 1
+                }
+                if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
+                rc_renorm(low, d, x, lo, d1, t, k);
+                in.advance(k);
             }
-            if ((dd & 3) == 0) pack = s; else pack |= s << (8 * (dd & 3));
-            if ((dd & 3) == 3 && i - 3u < ch.n) *reinterpret_cast<uint32_t *>(out + (i - 3u)) = pack;
-            rc_renorm(low, d, x, lo, d1, t, k);
-            in.advance(k);
+            // end of a phase: retire the batch behind the other half, refill this one, write the phase's 16 symbols
+            ring_wait_all();
+            ring_read(((h + 1) % 2) * PH, n0, n1r);
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
+#pragma unroll
+                for (int dd = 0; dd < PH; ++dd) ring_load(h * PH + dd);
+            }
+            const uint32_t ib = i0 + (uint32_t)(h * PH);
+            if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
+            else {
+#pragma unroll
+                for (int q = 0; q < PH / 4; ++q)
+                    if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];   // the last group may run 3 bytes into the slack behind the stream
+            }
         }
     }
 }
@@ -573,7 +607,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
 __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                         int nchunks, uint32_t rdw, uint8_t *__restrict__ sym)
 {
-    constexpr int DEPTH = RC_RING_DEPTH;
+    constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
     static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
     extern __shared__ uint32_t win[];
     const int lane = threadIdx.x, grp = lane >> 4, kk = lane & 15;
@@ -594,36 +628,52 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     const size_t rstep = (size_t)ch.stride * 32;
     const uint32_t *ring = win + (size_t)4 * rdw;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + 4u * rdw * 4u));
-    auto ring_load = [&](int slot) { ring_dma_u16(rowp, ring_lds + (uint32_t)slot * 256u); rowp += rstep; };
+    auto ring_load = [&](int slot) { ring_dma_b32(rowp, ring_lds + (uint32_t)slot * 256u); rowp += rstep; };   // a dword for a 16-bit entry (header comment)
     const int g16 = grp << 4;
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-    uint32_t pack = 0;
 #pragma unroll
     for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
     uint8_t *out = sym + ch.out;
-    ring_wait<DEPTH - 1>();
-    uint32_t vnext = ring[lane];
+    ring_wait_all();
+    ring_settle();
+    const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);   // 16-bit reads: see k_rc_decode_lds
+    uint32_t vnext = ring16[2 * lane];
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int dd = 0; dd < DEPTH; ++dd) {
-            const uint32_t i = i0 + (uint32_t)dd;
-            const uint32_t v = vnext;
-            ring_wait<DEPTH - 2>();                            // row i + 1 has landed
-            vnext = ring[((dd + 1) % DEPTH) * 64 + lane];
-            ring_load(dd);
-            const uint32_t tw = in.peek();
-            const uint32_t t = kk ? scale_d(d, v) : 0u;
-            const uint64_t bal = __ballot(t <= x);
-            const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-            const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
-            const uint32_t s = ((uint32_t)__popc(bits) - 1u) & 15u;
-            const uint32_t lo = (uint32_t)__shfl((int)t, g16 + (int)s);
-            const uint32_t nx = (uint32_t)__shfl((int)t, g16 + (int)min(s + 1u, 15u));
-            const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
-            if ((dd & 3) == 0) pack = s; else pack |= s << (8 * (dd & 3));
-            if ((dd & 3) == 3 && kk == 0 && i - 3u < ch.n) *reinterpret_cast<uint32_t *>(out + (i - 3u)) = pack;
-            rc_renorm(low, d, x, lo, d1, tw, k);
-            in.advance(k);
+        for (int h = 0; h < 2; ++h) {
+            uint32_t pack[PH / 4];
+#pragma unroll
+            for (int dd = 0; dd < PH; ++dd) {
+                const uint32_t v = vnext;
+                if (dd + 1 < PH) vnext = ring16[2 * ((h * PH + dd + 1) * 64 + lane)];   // (the other half's first row: behind the wait below)
+                const uint32_t tw = in.peek();
+                const uint32_t t = kk ? scale_d(d, v) : 0u;
+                const uint64_t bal = __ballot(t <= x);
+                const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+                const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
+                const uint32_t s = ((uint32_t)__popc(bits) - 1u) & 15u;
+                const uint32_t lo = (uint32_t)__shfl((int)t, g16 + (int)s);
+                const uint32_t nx = (uint32_t)__shfl((int)t, g16 + (int)min(s + 1u, 15u));
+                const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
+                if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
+                rc_renorm(low, d, x, lo, d1, tw, k);
+                in.advance(k);
+            }
+            ring_wait_all();
+            vnext = ring16[2 * (((h + 1) % 2) * PH * 64 + lane)];
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
+#pragma unroll
+                for (int dd = 0; dd < PH; ++dd) ring_load(h * PH + dd);
+            }
+            const uint32_t ib = i0 + (uint32_t)(h * PH);
+            if (kk == 0) {
+                if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
+                else {
+#pragma unroll
+                    for (int q = 0; q < PH / 4; ++q)
+                        if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];
+                }
+            }
         }
     }
 }

@@ -140,6 +140,17 @@ typedef struct {
 } gpcc_stage;
 GPCC_API int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int *n_out);
 
+/* Developer trace (no reference counterpart): while enabled, gpcc_decode records a checksum of every intermediate buffer
+ * of every level (features, level structure, symbols) on the stream that produced it; _get returns the (tag, sum) pairs of
+ * the decode that just returned (tag = 100 x level + buffer id, codec.hip) and clears the list.  Two runs of one container
+ * must give identical lists: the first difference names the stage that misbehaved (tools/dbg/inflight_check.py). */
+GPCC_API int gpcc_debug_trace_enable(gpcc_ctx *ctx, int on);
+GPCC_API int gpcc_debug_trace_get(gpcc_ctx *ctx, int *tags, unsigned long long *sums, int cap);
+/* keep a device copy of every marked buffer whose tag % 100 == tag_mod (-1: none); _get copies the last copy of `tag` out and
+ * returns its size in bytes (-1: no such copy) */
+GPCC_API int gpcc_debug_capture(gpcc_ctx *ctx, int tag_mod);
+GPCC_API long long gpcc_debug_capture_get(gpcc_ctx *ctx, int tag, void *host, long long cap);
+
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */
 GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);

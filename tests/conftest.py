@@ -52,3 +52,23 @@ def synth_model_k3(orc):
     from gauspcc_amd.synth import synthetic_state_dict
 
     return orc.Model(tensor_table(synthetic_state_dict(32, 3), 32, 3), 32, 3)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _lds_polluter():
+    """Developer knob: GAUSPCC_TEST_POLLUTE=<path to tools/dbg/liblds_polluter.so> keeps the LDS of every CU full of a
+    non-zero pattern while the GPU tests run (a second stream launching a fill kernel over and over), so that a kernel which
+    reads LDS it has not written fails its parity test instead of passing on an idle device's zeros."""
+    path = os.environ.get("GAUSPCC_TEST_POLLUTE")
+    if not path:
+        yield
+        return
+    import ctypes
+
+    import torch
+
+    torch.cuda.init()
+    lib = ctypes.CDLL(os.path.abspath(path))
+    lib.pollute_start(0, int(os.environ.get("GAUSPCC_TEST_POLLUTE_PATTERN", "0x00010001"), 16))
+    yield
+    lib.pollute_stop()

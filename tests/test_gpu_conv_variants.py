@@ -4,7 +4,7 @@ The block height (and with it the kernel: cooperative 16-row kernel, wave-serial
 HIP C++ loop) is picked from the level size, so a 10 k-point test cloud only ever meets the small-level kernels.  The
 policy is read once per process from the environment; each variant therefore runs in its own interpreter:
 GAUSPCC_CONV_R forces the block height, GAUSPCC_CONV_ASM=0 the C++ loop, GAUSPCC_CONV_COOP=0 the wave-serial kernel on
-16-row blocks, GAUSPCC_CONV_BALANCE the block-height rule (0: the class height, 1: always equal blocks, default 2: equal
+16-row blocks, GAUSPCC_COOP_TALL=0 / GAUSPCC_CONV_SPLIT=0 / GAUSPCC_CONV_PAIR=0 switch the round-3 kernels off one at a time, GAUSPCC_CONV_BALANCE the block-height rule (0: the class height, 1: always equal blocks, default 2: equal
 blocks when the last round would be mostly empty)."""
 import os
 import subprocess
@@ -55,12 +55,15 @@ print("variant ok", pairs)
     {"GAUSPCC_CONV_R": "64"},
     {"GAUSPCC_CONV_R": "32"},
     {"GAUSPCC_CONV_R": "16", "GAUSPCC_CONV_COOP": "0"},
+    {"GAUSPCC_COOP_TALL": "0"},                              # the cooperative kernel on 16-row blocks only (default: 16 / 32 / 64 by level size)
+    {"GAUSPCC_CONV_SPLIT": "0"},                             # no products-over-the-chip kernels on the tiniest levels
+    {"GAUSPCC_CONV_PAIR": "0"},                              # one-tile asm loop everywhere
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "1"},
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_BALANCE": "1"},
-], ids=lambda e: ",".join(f"{k[13:]}={v}" for k, v in e.items()))
+], ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
 def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)
     e.update(env)

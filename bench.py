@@ -213,7 +213,19 @@ def main():
         stagger = (enc_s + dec_s) / args.steps / S   # scenes that start in lockstep stay in lockstep (both in their convolutions
         # at once: no gain at all); requests of a real server arrive out of phase, so scene i starts i / S of a step late
 
+        failed = []
+
         def scene(i):
+            try:
+                scene_body(i)
+            except BaseException as e:   # a thread's exception would otherwise vanish and leave its `took` at 0: an inflated figure
+                failed.append((i, repr(e)))
+                try:
+                    gate.abort()
+                except Exception:
+                    pass
+
+        def scene_body(i):
             def one():
                 pb, nb, s1 = C.c_void_p(), C.c_int64(), _lib.Stats()
                 sp = C.c_void_p(streams[i].cuda_stream)
@@ -239,6 +251,8 @@ def main():
             t.join()
         for h in ctxs[1:]:
             L.gpcc_ctx_destroy(h)
+        if failed:
+            raise SystemExit(f"scenes in flight: {failed}")
         el = max(took)
         inflight = {"scenes": S, "value": round(S * fsteps * args.points / el / 1e6, 4), "unit": "Mpoints/s", "steps": fsteps,
                     "ms_per_scene_step": round(1e3 * el / fsteps, 3)}

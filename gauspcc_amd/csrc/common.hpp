@@ -41,7 +41,16 @@ inline int fail(int code, const char *fmt, ...)
         if (s_ != GPCC_OK) return s_; \
     } while (0)
 
-#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+// GAUSPCC_DEBUG_SYNC=1 (developer): every launch site prints itself and waits for the device -- the last line on stderr
+// before a "Memory access fault" abort names the kernel that faulted
+inline bool debug_sync_on() { static const bool on = [] { const char *e = getenv("GAUSPCC_DEBUG_SYNC"); return e && atoi(e) != 0; }(); return on; }
+inline hipError_t launch_check(const char *file, int line)
+{
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && debug_sync_on()) { fprintf(stderr, "[launch] %s:%d\n", file, line); fflush(stderr); e = hipDeviceSynchronize(); }
+    return e;
+}
+#define LAUNCH_CHECK() HIP_TRY(gpcc::launch_check(__FILE__, __LINE__))
 
 constexpr int CB = 1 << 20;        // coordinate bias at level 0
 constexpr int CLIM = CB - 8;       // |coordinate| limit

@@ -654,17 +654,19 @@ __global__ __launch_bounds__(64 * PROD_WAVES) void k_conv_products(ConvJob J, Co
 }
 
 // developer check (GAUSPCC_DEBUG_LAUNCH): every tile of the set inside its bounds?
-__global__ void k_check_tiles(ConvTiles T, int64_t n, unsigned long long total_cap, int *bad)
+__global__ void k_check_tiles(ConvTiles T, int64_t n, unsigned long long total_cap, int *bad, int koff)
 {
+    // T.K = the most tiles a block may have, koff = kernel offsets
     const int blk = (int)T.lv_blk0[0] + (int)blockIdx.x;
     const uint32_t t0 = T.first[blk], t1 = T.first[blk + 1];
-    if (threadIdx.x == 0 && (t1 < t0 || t1 - t0 > (uint32_t)T.K || t1 > total_cap)) { printf("[check] block %d: tiles %u .. %u (K %d, cap %llu)\n", blk, t0, t1, T.K, total_cap); atomicAdd(bad, 1); }
+    if (threadIdx.x == 0 && (t1 < t0 || t1 - t0 > (uint32_t)T.K || t1 > total_cap)) { if (atomicAdd(bad, 1) < 8) printf("[check] block %d: tiles %u .. %u (at most %d, cap %llu)\n", blk, t0, t1, T.K, total_cap); }
     const uint32_t tend = t0 + min(t1 - t0, (uint32_t)T.K);
     for (uint32_t t = t0 + threadIdx.x / 16; t < tend && t < total_cap; t += blockDim.x / 16) {
         const int e = threadIdx.x & 15;
         const int32_t j = T.tj[(size_t)t * 16 + e];
         const uint32_t oc = T.toc[t];
-        if (j < 0 || j >= n || (oc & 0xFFFFu) >= (uint32_t)T.K || (oc >> 16) > 16u) { printf("[check] block %d tile %u entry %d: j %d (n %lld) toc %08x\n", blk, t, e, j, (long long)n, oc); atomicAdd(bad, 1); }
+        const uint32_t r = T.tr[(size_t)t * 16 + e];
+        if (j < 0 || j >= n || (oc & 0xFFFFu) >= (uint32_t)koff || (oc >> 16) > 16u || r > (uint32_t)T.H) { if (atomicAdd(bad, 1) < 8) printf("[check] block %d tile %u entry %d: j %d (n %lld) toc %08x slot %u\n", blk, t, e, j, (long long)n, oc, r); }
     }
 }
 
@@ -789,7 +791,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
                 int *bad = nullptr, hb = 0;
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bad), 4));
                 HIP_TRY(hipMemsetAsync(bad, 0, 4, st));
-                k_check_tiles<<<(unsigned)T.nblk, 256, 0, st>>>(T, n, (unsigned long long)((size_t)T.nblk * T.K + CONV_HDR_PAD), bad);
+                k_check_tiles<<<(unsigned)T.nblk, 256, 0, st>>>(T, n, (unsigned long long)((size_t)T.nblk * T.K + CONV_HDR_PAD), bad, T.K);
                 HIP_TRY(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 (void)hipFree(bad);
@@ -816,6 +818,19 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         LAUNCH_CHECK();
         if (prof) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
         return GPCC_OK;
+    }
+    if (debug_sync_on()) {   // developer: every tile of the set inside its bounds?
+        int *bad = nullptr, hb = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bad), 4));
+        HIP_TRY(hipMemsetAsync(bad, 0, 4, st));
+        ConvTiles Tc = T; Tc.K = T.K * ((T.H + 15) / 16);   // tiles a block may have
+        k_check_tiles<<<(unsigned)T.nblk, 256, 0, st>>>(Tc, n, ~0ull, bad, T.K);
+        HIP_TRY(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        (void)hipFree(bad);
+        fflush(stdout);
+        fprintf(stderr, "[conv] level %d n %lld R %d H %d blocks %lld paired %d: tile check %d bad\n", level, (long long)n, T.R, T.H, (long long)T.nblk, T.paired, hb); fflush(stderr);
+        if (hb) return fail(GPCC_ERR_FORMAT, "developer check: %d tile entries out of bounds at level %d", hb, level);
     }
     dim3 grid((unsigned)cdiv(T.nblk * njobs, SC_WAVES), 1u);   // work items = blocks x jobs, one per wave
     const size_t lds_bytes = (size_t)SC_WAVES * conv_lds_wave_floats(T.R) * 4;

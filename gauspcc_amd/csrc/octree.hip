@@ -584,6 +584,13 @@ __global__ __launch_bounds__(TB) void k_expand(const uint64_t *__restrict__ rkey
 // expansion + ranks of the child level: one launch for small levels, the two chains otherwise
 int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, int hb_level)
 {
+    // The child arrays are sized from the container header and the occupancy they are expanded from is whatever the range
+    // decoder produced: a corrupt stream (or a lying header) leaves their tail unwritten.  Ranks are INDICES (rows of the
+    // CDF and symbol arrays are addressed through m2r / r2m): stale arena bytes there become out-of-range addresses -- a
+    // memory fault at 10^6 nodes, where the small clouds of the corruption tests never left mapped memory.  Zero = valid.
+    HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)chi->n, st));
+    HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)chi->n, st));
+    HIP_TRY(hipMemsetAsync(chi->rkey, 0, 8 * (size_t)chi->n, st));
     if (small_level_fits(par, chi) && !no_fuse()) return small_level(ctx, st, par, chi, true, total_dev);
     GP_TRY(level_expand(ctx, st, par, chi, total_dev));
     return rank_level(ctx, st, par, chi, hb_level);

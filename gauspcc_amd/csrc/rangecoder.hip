@@ -30,7 +30,7 @@ __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32
 // saved and restored inside the statement.  Single-wave workgroups and every lane reads what its own lane's DMA wrote:
 // no barrier.
 //
-// WHEN a slot may be read (round 3, found with two scenes in flight on one GPU; tools/dbg/inflight_check.py):
+// WHEN a slot may be read (round 3, found with two scenes in flight on one GPU; tools/inflight_check.py):
 //  * LDS-DMA loads do NOT retire in issue order under load.  A counted wait -- "with N younger loads in flight row i has
 //    landed" -- holds on an idle device (tools/ubench/lds_dma_probe.hip) and failed in 1 of ~200 decodes beside a second
 //    scene: the first symbols of a lane, where the waits are binding, read slots whose rows had been overtaken by later

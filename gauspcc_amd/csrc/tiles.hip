@@ -167,12 +167,18 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
             uint32_t sv[CBATCH], ov[CBATCH];
 #pragma unroll
             for (int u = 0; u < CBATCH; ++u) {
-                const int32_t q = max(pn[u], 0);             // unconditional gathers (row 0 is always there): no branch between the loads
+                // unconditional gathers (row 0 is always there): no branch between the loads.  Clamped from above too: the cell map
+                // of a level decoded from a corrupt stream is built from whatever occupancy came out of the coder
+                const int32_t q = min(max(pn[u], 0), (int32_t)min(a.np - 1, (int64_t)INT32_MAX));
                 sv[u] = a.cstart_p[q]; ov[u] = a.occ_p[q];
             }
 #pragma unroll
             for (int u = 0; u < CBATCH; ++u)
-                if (pl && c0 + u < NP) { cst[lane * NP + c0 + u] = pn[u] >= 0 ? sv[u] : 0u; coc[lane * NP + c0 + u] = pn[u] >= 0 ? (uint8_t)ov[u] : (uint8_t)0; }
+                if (c0 + u < NP) {   // every slot is written: rows of an inconsistent level (a corrupt stream) may point at a parent outside the run, and what they
+                                     // read there must be the same in the count pass and in the fill pass -- not whatever the LDS held
+                    const bool have = pl && pn[u] >= 0;
+                    cst[lane * NP + c0 + u] = have ? sv[u] : 0u; coc[lane * NP + c0 + u] = have ? (uint8_t)ov[u] : (uint8_t)0;
+                }
         }
     }
     const uint64_t kc = a.rkey_c[i];

@@ -143,7 +143,7 @@ GPCC_API int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int *n
 /* Developer trace (no reference counterpart): while enabled, gpcc_decode records a checksum of every intermediate buffer
  * of every level (features, level structure, symbols) on the stream that produced it; _get returns the (tag, sum) pairs of
  * the decode that just returned (tag = 100 x level + buffer id, codec.hip) and clears the list.  Two runs of one container
- * must give identical lists: the first difference names the stage that misbehaved (tools/dbg/inflight_check.py). */
+ * must give identical lists: the first difference names the stage that misbehaved (tools/inflight_check.py). */
 GPCC_API int gpcc_debug_trace_enable(gpcc_ctx *ctx, int on);
 GPCC_API int gpcc_debug_trace_get(gpcc_ctx *ctx, int *tags, unsigned long long *sums, int cap);
 /* keep a device copy of every marked buffer whose tag % 100 == tag_mod (-1: none); _get copies the last copy of `tag` out and

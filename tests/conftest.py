@@ -56,7 +56,7 @@ def synth_model_k3(orc):
 
 @pytest.fixture(scope="session", autouse=True)
 def _lds_polluter():
-    """Developer knob: GAUSPCC_TEST_POLLUTE=<path to tools/dbg/liblds_polluter.so> keeps the LDS of every CU full of a
+    """Developer knob: GAUSPCC_TEST_POLLUTE=<path to tools/liblds_polluter.so> keeps the LDS of every CU full of a
     non-zero pattern while the GPU tests run (a second stream launching a fill kernel over and over), so that a kernel which
     reads LDS it has not written fails its parity test instead of passing on an idle device's zeros."""
     path = os.environ.get("GAUSPCC_TEST_POLLUTE")

@@ -6,7 +6,7 @@ import os
 import sys
 import threading
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import numpy as np

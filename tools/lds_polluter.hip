@@ -2,8 +2,8 @@
 // launching a fill kernel over and over on its own stream, so that a kernel of the library that reads LDS it has not
 // written -- harmless on an idle device, whose LDS reads as zeros or as the kernel's own leftovers -- computes a wrong
 // result under the parity tests.  (Found this way in round 3: 16-bit LDS-DMA loads leave the upper half of the dword alone.)
-//   hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/dbg/lds_polluter.hip -o tools/dbg/liblds_polluter.so
-//   GAUSPCC_TEST_POLLUTE=tools/dbg/liblds_polluter.so python -m pytest tests -m gpu ...   (tests/conftest.py starts it)
+//   hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/lds_polluter.hip -o tools/liblds_polluter.so
+//   GAUSPCC_TEST_POLLUTE=tools/liblds_polluter.so python -m pytest tests -m gpu ...   (tests/conftest.py starts it)
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <thread>

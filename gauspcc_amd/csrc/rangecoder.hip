@@ -44,13 +44,30 @@ __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32
 //    need not be dword-aligned; the row buffers have look-ahead slack behind their last entry) and read with 16-bit LDS loads.
 constexpr int RING_PHASE = RC_RING_DEPTH / 2;
 static_assert(RING_PHASE == 16, "a phase's symbols leave as one 16-byte store");
-// an 8-byte row as two dwords into two slots (there is no 8-byte LDS-DMA).  The instruction offset of an LDS-DMA load
-// moves the LDS destination as well as the source: the caller passes the second slot's address minus 4.
-__device__ __forceinline__ void ring_dma_2xb32(const void *gsrc, uint32_t lds_dst0, uint32_t lds_dst1_minus4)
+// A phase's refill in one statement: RING_PHASE loads of consecutive rows into consecutive slots, M0 saved and restored once,
+// the row pointer advanced in place (three instructions a row instead of seven; the VALU add between the scalar add to M0 and
+// the next load is the wait state that write needs).
+#define RC_DMA_ROW1 "global_load_lds_dword %[a], off\n\ts_add_u32 m0, m0, 0x100\n\tv_lshl_add_u64 %[a], %[a], 0, %[st]\n\t"
+#define RC_DMA_ROW2 "global_load_lds_dword %[a], off\n\ts_add_u32 m0, m0, %[d1]\n\ts_nop 0\n\tglobal_load_lds_dword %[a], off offset:4\n\ts_sub_u32 m0, m0, %[d2]\n\tv_lshl_add_u64 %[a], %[a], 0, %[st]\n\t"
+#define RC_REP16(x) x x x x x x x x x x x x x x x x
+// rows of one dword each (16-bit rows fetched as dwords): slot s of the phase at lds_first + 256 s
+__device__ __forceinline__ void ring_batch_b32(const char *&rowp, uint64_t rstep, uint32_t lds_first)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off offset:4\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst0), "s"(lds_dst1_minus4) : "memory");
+    uint64_t a = reinterpret_cast<uint64_t>(rowp);
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[b]\n\ts_nop 0\n\t" RC_REP16(RC_DMA_ROW1) "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [a] "+v"(a) : [b] "s"(lds_first), [st] "v"(rstep) : "memory", "scc");
+    rowp = reinterpret_cast<const char *>(a);
+}
+// rows of two dwords: the first into slot s, the second into slot RC_RING_DEPTH + s (its M0 is 4 short: the instruction
+// offset of an LDS-DMA load moves the LDS destination as well as the source)
+__device__ __forceinline__ void ring_batch_2xb32(const char *&rowp, uint64_t rstep, uint32_t lds_first)
+{
+    unsigned keep;
+    uint64_t a = reinterpret_cast<uint64_t>(rowp);
+    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[b]\n\ts_nop 0\n\t" RC_REP16(RC_DMA_ROW2) "s_mov_b32 m0, %[k]"
+                 : [k] "=&s"(keep), [a] "+v"(a) : [b] "s"(lds_first), [st] "v"(rstep), [d1] "n"(RC_RING_DEPTH * 256 - 4), [d2] "n"(RC_RING_DEPTH * 256 - 4 - 256) : "memory", "scc");
+    rowp = reinterpret_cast<const char *>(a);
 }
 __device__ __forceinline__ void ring_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void ring_settle() { __builtin_amdgcn_s_sleep(8); }   // ~512 cycles behind the one BINDING wait of a lane (the prologue's): margin between the counter and the LDS write
@@ -538,14 +555,13 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     const size_t rstep = (size_t)ch.stride * (2 * RS);
     uint32_t *ring = win + (size_t)lpw * rdw;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + (uint32_t)lpw * rdw * 4u));
-    auto ring_load = [&](int slot) {
-        if (LP == 3) ring_dma_b32(rowp, ring_lds + (uint32_t)slot * SLOT);   // a dword for a 16-bit row (header comment)
-        else ring_dma_2xb32(rowp, ring_lds + (uint32_t)slot * SLOT, ring_lds + (uint32_t)(DEPTH + slot) * SLOT - 4u);
-        rowp += rstep;
+    auto ring_fill = [&](int h) {   // rows of one phase into half h (a dword for a 16-bit row: header comment)
+        if (LP == 3) ring_batch_b32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * SLOT);
+        else ring_batch_2xb32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * SLOT);
     };
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
+    ring_fill(0);
+    ring_fill(1);
     uint8_t *out = sym + ch.out;
     // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain); 16-bit rows arrive as
     // the low half of a dword whose upper half is the next entry in memory: read 16 bits
@@ -588,10 +604,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
             // end of a phase: retire the batch behind the other half, refill this one, write the phase's 16 symbols
             ring_wait_all();
             ring_read(((h + 1) % 2) * PH, n0, n1r);
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
-#pragma unroll
-                for (int dd = 0; dd < PH; ++dd) ring_load(h * PH + dd);
-            }
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
             else {
@@ -628,11 +641,11 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     const size_t rstep = (size_t)ch.stride * 32;
     const uint32_t *ring = win + (size_t)4 * rdw;
     const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + 4u * rdw * 4u));
-    auto ring_load = [&](int slot) { ring_dma_b32(rowp, ring_lds + (uint32_t)slot * 256u); rowp += rstep; };   // a dword for a 16-bit entry (header comment)
+    auto ring_fill = [&](int h) { ring_batch_b32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * 256u); };   // a dword for a 16-bit entry (header comment)
     const int g16 = grp << 4;
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-#pragma unroll
-    for (int dd = 0; dd < DEPTH; ++dd) ring_load(dd);
+    ring_fill(0);
+    ring_fill(1);
     uint8_t *out = sym + ch.out;
     ring_wait_all();
     ring_settle();
@@ -661,10 +674,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
             }
             ring_wait_all();
             vnext = ring16[2 * (((h + 1) % 2) * PH * 64 + lane)];
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
-#pragma unroll
-                for (int dd = 0; dd < PH; ++dd) ring_load(h * PH + dd);
-            }
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (kk == 0) {
                 if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);

@@ -32,3 +32,11 @@ def test_two_scenes_in_flight_are_bit_identical_to_solo_runs():
 def test_corrupted_million_point_containers_never_fault():
     r = _run([os.path.join("tools", "fuzz_containers.py"), "1000000", "32"], 900)
     assert r.returncode == 0 and "fuzz done" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_side_paths_beside_a_geometry_scene_are_deterministic():
+    """conduct_encoding / conduct_decoding (files and decoded tensors hashed), generate_neural_gaussians + the rasteriser and
+    the fused Gaussian coder on one thread while another loops 1 M-point geometry encodes + decodes: every iteration equals
+    the first, and the geometry thread never fails."""
+    r = _run([os.path.join("tools", "inflight_side.py"), "8"], 900)
+    assert r.returncode == 0 and "8 iterations, 0 bad" in r.stdout and "steps, 0 bad" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -146,19 +146,27 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
                     if (n1) {
                         const uint32_t bits = low >> (32 - n1);
                         const uint32_t b = bits >> (n1 - 1);
-                        w.put(b, 1);
-                        if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
-                        if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), (uint32_t)n1 - 1u);
-                        low <<= n1;
-                        high = (high << n1) | ((1u << n1) - 1u);
+                        const uint32_t rest = bits & ((1u << (n1 - 1)) - 1u);
+                        if ((uint32_t)n1 + pending <= 32u) {
+                            // the common case in ONE put: b, `pending` copies of its complement, the other n1 - 1 agreed bits
+                            const uint32_t len = (uint32_t)n1 + pending;
+                            const uint32_t run = b ? 0u : ((pending >= 32u ? 0u : (1u << pending)) - 1u);
+                            w.put((b << (len - 1u)) | (run << (n1 - 1)) | rest, len);
+                        } else {
+                            w.put(b, 1);
+                            w.put_run(b ^ 1u, pending);
+                            if (n1 > 1) w.put(rest, (uint32_t)n1 - 1u);
+                        }
+                        pending = 0;
                     }
-                    // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times
+                    low <<= n1;                                   // (n1 = 0: no change)
+                    high = (high << n1) | ((1u << n1) - 1u);
+                    // underflow run: low = 01.., high = 10..  ->  drop the second bit n2 times (low's top bit is 0 and high's 1 here,
+                    // so the masks below change nothing when n2 = 0)
                     const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-                    if (n2) {
-                        pending += (uint32_t)n2;
-                        low = (low << n2) & 0x7FFFFFFFu;
-                        high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
-                    }
+                    pending += (uint32_t)n2;
+                    low = (low << n2) & 0x7FFFFFFFu;
+                    high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
                 }
             }
             // end of a phase: the batch behind the other half (issued a phase ago) has to have landed; refill this half

@@ -287,7 +287,17 @@ struct BitWin {
 
 __device__ __forceinline__ uint32_t scale(uint64_t span, uint32_t v) { return (uint32_t)((span * (uint64_t)v) >> 16); }
 // the same on d = span - 1 (fits 32 bits): (d + 1) * v = d * v + v -> one v_mad_u64_u32 and one v_alignbit
-__device__ __forceinline__ uint32_t scale_d(uint32_t d, uint32_t v) { return (uint32_t)(((uint64_t)d * (uint64_t)v + (uint64_t)v) >> 16); }
+// (d + 1) * v >> 16 for a 16-bit v, exactly.  Not `v_mad_u64_u32` (a quarter-rate 64-bit multiply on the symbol's critical
+// path): d = dh * 2^16 + dl, so (d v + v) >> 16 = dh v + ((dl + 1) v >> 16), both products below 2^32 and both 24-bit multiplies.
+__device__ __forceinline__ uint32_t scale_d(uint32_t d, uint32_t v)
+{
+#ifdef RC_SCALE_MUL64
+    return (uint32_t)(((uint64_t)d * (uint64_t)v + (uint64_t)v) >> 16);
+#else
+    const uint32_t dh = d >> 16, dl = d & 0xFFFFu;
+    return __umul24(dh, v) + ((__umul24(dl, v) + v) >> 16);
+#endif
+}
 
 // One lane per chunk.  The compact CDF rows of a chunk do not depend on decoded symbols, so they are fetched
 // DEPTH symbols ahead through a register ring (the loop is unrolled over the ring, nothing rotates): the

@@ -1,3 +1,5 @@
+// (self-check: pollute_probe() launches a kernel that only READS its 64 KiB -- 0 % pattern words on a fresh device, 100 % while the
+//  polluter runs and after it has stopped: LDS is not cleared between kernels.  Load the library AFTER torch has initialised HIP.)
 // Developer tool: keeps every CU's LDS (and a few KiB of VGPR-staged stores) full of a recognisable non-zero pattern by
 // launching a fill kernel over and over on its own stream, so that a kernel of the library that reads LDS it has not
 // written -- harmless on an idle device, whose LDS reads as zeros or as the kernel's own leftovers -- computes a wrong
@@ -15,6 +17,27 @@ __global__ __launch_bounds__(256) void k_pollute(unsigned pattern, unsigned *sin
     for (unsigned i = threadIdx.x; i < words; i += 256u) lds[i] = pattern;
     __syncthreads();
     if (lds[(threadIdx.x * 97u) % words] != pattern) sink[0] = 1;   // keeps the stores alive
+}
+
+// how much of a fresh workgroup's LDS holds the pattern right now: a kernel that only READS its 64 KiB (the tool's self-check)
+__global__ __launch_bounds__(256) void k_probe(unsigned pattern, unsigned *hits)
+{
+    extern __shared__ unsigned lds[];
+    unsigned n = 0;
+    for (unsigned i = threadIdx.x; i < 64u * 1024u / 4u; i += 256u) n += lds[i] == pattern;
+    atomicAdd(hits, n);
+}
+extern "C" double pollute_probe(unsigned pattern, int workgroups)
+{
+    unsigned *hits = nullptr, h = 0;
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess || hipMalloc(&hits, 4) != hipSuccess) return -1.0;
+    (void)hipMemsetAsync(hits, 0, 4, s);
+    k_probe<<<workgroups, 256, 64 * 1024, s>>>(pattern, hits);
+    (void)hipMemcpyAsync(&h, hits, 4, hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(hits); (void)hipStreamDestroy(s);
+    return (double)h / ((double)workgroups * 16384.0);
 }
 
 static std::atomic<bool> g_run{false};

@@ -403,16 +403,13 @@ int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Lev
     TAKE(cnt4, uint32_t, 4 * n); TAKE(walk, uint4, n);
     k_rr_flags<<<nblk(n), TB, 0, st>>>(par->rkey, par->r2m, n, fs, fw);
     LAUNCH_CHECK();
-    GP_TRY(exclusive_scan_u32(ctx, st, fs, es, n, nullptr));
-    GP_TRY(exclusive_scan_u32(ctx, st, fw, ew, n, nullptr));
+    GP_TRY(exclusive_scan_pair_u32(ctx, st, fs, es, fw, ew, n));
     k_rr_starts<<<nblk(n), TB, 0, st>>>(fs, fw, es, ew, n, sstart, wstart);
     LAUNCH_CHECK();
     k_rr_counts<<<nblk(n), TB, 0, st>>>(par->occ, par->r2m, fs, fw, es, ew, sstart, wstart, n, cnt4, walk);
     LAUNCH_CHECK();
     GP_TRY(exclusive_scan_u32(ctx, st, cnt4, cnt4, 4 * n, nullptr));
-    // a lying container header may leave ranks unwritten: keep both permutations valid (identity) underneath
-    HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)nc, st));
-    HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)nc, st));
+    // (a decoder's child arrays are zeroed by level_expand_rank: a corrupt stream may leave ranks unwritten; an encoder's tree writes them all)
     k_rr_assign<<<nblk(n * 8), TB, 0, st>>>(par->occ, par->cstart, walk, cnt4, n, nc, chi->m2r, chi->r2m);
     LAUNCH_CHECK();
     ctx->arena.rewind(mk);
@@ -588,15 +585,24 @@ int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uin
     // decoder produced: a corrupt stream (or a lying header) leaves their tail unwritten.  Ranks are INDICES (rows of the
     // CDF and symbol arrays are addressed through m2r / r2m): stale arena bytes there become out-of-range addresses -- a
     // memory fault at 10^6 nodes, where the small clouds of the corruption tests never left mapped memory.  Zero = valid.
-    HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)chi->n, st));
-    HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)chi->n, st));
-    HIP_TRY(hipMemsetAsync(chi->rkey, 0, 8 * (size_t)chi->n, st));
+    // One memset: the decoder carves a level's arrays from the arena back to back (codec.hip: alloc_level: rkey | occ | cstart |
+    // parent | m2r | r2m); occ and cstart are written in full later (assemble_occ, the next level's popcount scan).
+    {
+        char *lo = reinterpret_cast<char *>(chi->rkey), *hi = reinterpret_cast<char *>(chi->r2m + chi->n);
+        if (hi > lo && (size_t)(hi - lo) <= 64 * (size_t)chi->n + 4096) HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
+        else {   // (a caller with its own layout)
+            HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)chi->n, st));
+            HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)chi->n, st));
+            HIP_TRY(hipMemsetAsync(chi->rkey, 0, 8 * (size_t)chi->n, st));
+            HIP_TRY(hipMemsetAsync(chi->parent, 0, 4 * (size_t)chi->n, st));
+        }
+    }
     if (small_level_fits(par, chi) && !no_fuse()) return small_level(ctx, st, par, chi, true, total_dev);
-    GP_TRY(level_expand(ctx, st, par, chi, total_dev));
+    GP_TRY(level_expand(ctx, st, par, chi, total_dev, true));
     return rank_level(ctx, st, par, chi, hb_level);
 }
 
-int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev)
+int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, bool chi_zeroed)
 {
     const int64_t n = par->n;
     k_popc<<<nblk(n), TB, 0, st>>>(par->occ, n, par->cstart);
@@ -606,7 +612,7 @@ int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t
     if (chi) {
         // the child arrays were sized from the container header, which is verified only at the caller's next sync: keep
         // every parent index valid (0) where a lying header leaves children unwritten
-        HIP_TRY(hipMemsetAsync(chi->parent, 0, 4 * (size_t)chi->n, st));
+        if (!chi_zeroed) HIP_TRY(hipMemsetAsync(chi->parent, 0, 4 * (size_t)chi->n, st));
         k_expand<<<nblk(n * 8), TB, 0, st>>>(par->rkey, par->occ, par->cstart, n, chi->rkey, chi->parent, chi->n);
         LAUNCH_CHECK();
     }

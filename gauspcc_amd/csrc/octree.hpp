@@ -88,7 +88,7 @@ int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Lev
 int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int hb_level);
 
 // decode side: children of `par` (occupancy known) -> `chi` (rkey, parent; n must be known)
-int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev);
+int level_expand(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, bool chi_zeroed = false);   // chi_zeroed: the caller has cleared the child arrays
 // level_expand + rank_level; small levels (<= 1 k parents, <= 8 k children) in ONE single-workgroup launch (GAUSPCC_SMALL_FUSE=0: never)
 int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uint32_t *total_dev, int hb_level);
 

@@ -116,6 +116,44 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_single(const uint32_t *in, uint
     if (threadIdx.x == 0 && total_out) *total_out = carry;
 }
 constexpr int64_t SCAN_SINGLE_MAX = 16 * SCAN_TILE;
+// two independent short scans of the same length in ONE launch (workgroup 0 / 1): the two flag scans of the rank derivation
+__global__ __launch_bounds__(SCAN_T) void k_scan_single2(const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, int64_t n)
+{
+    __shared__ uint32_t lds[8];
+    const uint32_t *in = blockIdx.x ? in1 : in0;
+    uint32_t *out = blockIdx.x ? out1 : out0;
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += SCAN_TILE) {
+        const int64_t base = b0 + (int64_t)threadIdx.x * SCAN_E;
+        uint32_t v[SCAN_E];
+        uint32_t s = 0;
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            v[e] = base + e < n ? in[base + e] : 0;
+            s += v[e];
+        }
+        uint32_t total;
+        uint32_t ex = carry + block_excl_scan_256(s, &total, lds);
+#pragma unroll
+        for (int e = 0; e < SCAN_E; ++e) {
+            if (base + e < n) out[base + e] = ex;
+            ex += v[e];
+        }
+        carry += total;
+    }
+}
+
+int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev);
+int exclusive_scan_pair_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, int64_t n)
+{
+    if (n > 0 && n <= SCAN_SINGLE_MAX) {
+        k_scan_single2<<<2, SCAN_T, 0, st>>>(in0, out0, in1, out1, n);
+        LAUNCH_CHECK();
+        return GPCC_OK;
+    }
+    GP_TRY(exclusive_scan_u32(ctx, st, in0, out0, n, nullptr));
+    return exclusive_scan_u32(ctx, st, in1, out1, n, nullptr);
+}
 
 int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev)
 {

@@ -6,6 +6,7 @@ namespace gpcc {
 
 // out[i] = sum_{j<i} in[j] (uint32).  in == out allowed.  If total_dev != nullptr the grand
 // total is stored there.  Workspace comes from ctx->arena (released before return).
+int exclusive_scan_pair_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, int64_t n);   // two scans of one length (one launch when short)
 int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n,
                        uint32_t *total_dev);
 

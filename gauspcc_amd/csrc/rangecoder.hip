@@ -35,14 +35,22 @@ __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32
 //    landed" -- holds on an idle device (tools/ubench/lds_dma_probe.hip) and failed in 1 of ~200 decodes beside a second
 //    scene: the first symbols of a lane, where the waits are binding, read slots whose rows had been overtaken by later
 //    ones (waiting three rows further and sleeping 256 cycles moved the first wrong symbol from 1 to 3, no more).
-//    The only wait used here is vmcnt(0).  The ring is two halves of RC_RING_PHASE rows: while the coder works through one
-//    half, the batch of loads that refills the other -- issued a whole phase (16 symbols, ~2 us) earlier -- lands; at the
-//    end of a phase ONE vmcnt(0) retires it, then the half just consumed is refilled.  The symbols of a phase leave in one
-//    16-byte store issued right behind that wait, so the store has a phase to complete before the next vmcnt(0) sees it.
+//    The only wait used here is vmcnt(0).
+//  * ...and a slot is not read right behind the wait that retires it: beside a second scene, `s_waitcnt vmcnt(0)` released
+//    waves whose LDS-DMA data was not yet visible to their own `ds_read` (a ring of two halves that read the other half's
+//    first row right behind the phase-end wait was clean while that wait was rarely binding and failed in 16 % of the decodes
+//    once a faster symbol loop made it binding more often).  The ring is therefore THREE thirds of RING_PHASE rows.  At the
+//    end of phase p: ONE vmcnt(0) -- it retires the batch issued at the end of phase p - 1, which phase p + 2 will read --,
+//    then the third just consumed is refilled (rows of phase p + 3), then the 16 symbols of the phase leave in one 16-byte
+//    store (it has a phase to complete before the next vmcnt(0) sees it).  Phase p + 1 reads the third retired at the end
+//    of phase p - 1: a whole phase (16 symbols, ~2 us) lies between a retiring wait and the first read of what it retired.
+//    Rows no lane will use are not fetched and a final vmcnt(0) precedes s_endpgm: an LDS-DMA load in flight when its wave
+//    ends lands in LDS that may already belong to another workgroup.
 //  * `global_load_lds_ushort` is not used: beside a second scene the upper half of its dword was not always zero (wrong
 //    symbols in 2-6 % of the decodes when the consumer read the dword).  16-bit rows are fetched as dwords (the address
 //    need not be dword-aligned; the row buffers have look-ahead slack behind their last entry) and read with 16-bit LDS loads.
-constexpr int RING_PHASE = RC_RING_DEPTH / 2;
+constexpr int RING_NPH = 3;                      // thirds of the ring
+constexpr int RING_PHASE = RC_RING_DEPTH / RING_NPH;
 static_assert(RING_PHASE == 16, "a phase's symbols leave as one 16-byte store");
 // A phase's refill in one statement: RING_PHASE loads of consecutive rows into consecutive slots, M0 saved and restored once,
 // the row pointer advanced in place (three instructions a row instead of seven; the VALU add between the scalar add to M0 and
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
     uint32_t next = ring[lane];
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RING_NPH; ++h) {
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
                 const int d = h * PH + dd;
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
             }
             // end of a phase: the batch behind the other half (issued a phase ago) has to have landed; refill this half
             ring_wait_all();
-            next = ring[((h + 1) % 2) * PH * 64 + lane];
+            next = ring[((h + 1) % RING_NPH) * PH * 64 + lane];   // retired a phase ago
             if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) nothing is fetched that no lane will use: no load is in flight when the wave ends
 #pragma unroll
                 for (int dd = 0; dd < PH; ++dd) ring_dma_b32(src(i0 + (uint32_t)(DEPTH + h * PH + dd)), ring_lds + (uint32_t)(h * PH + dd) * 256u);
@@ -580,6 +588,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
     ring_fill(0);
     ring_fill(1);
+    ring_fill(2);
     uint8_t *out = sym + ch.out;
     // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain); 16-bit rows arrive as
     // the low half of a dword whose upper half is the next entry in memory: read 16 bits
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     ring_read(0, n0, n1r);
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RING_NPH; ++h) {
             uint32_t pack[PH / 4];
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
             }
             // end of a phase: retire the batch behind the other half, refill this one, write the phase's 16 symbols
             ring_wait_all();
-            ring_read(((h + 1) % 2) * PH, n0, n1r);
+            ring_read(((h + 1) % RING_NPH) * PH, n0, n1r);   // retired a phase ago
             if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
@@ -664,6 +673,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
     ring_fill(0);
     ring_fill(1);
+    ring_fill(2);
     uint8_t *out = sym + ch.out;
     ring_wait_all();
     ring_settle();
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     uint32_t vnext = ring16[2 * lane];
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RING_NPH; ++h) {
             uint32_t pack[PH / 4];
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
@@ -691,7 +701,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
                 in.advance(k);
             }
             ring_wait_all();
-            vnext = ring16[2 * (((h + 1) % 2) * PH * 64 + lane)];
+            vnext = ring16[2 * (((h + 1) % RING_NPH) * PH * 64 + lane)];   // retired a phase ago
             if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (kk == 0) {

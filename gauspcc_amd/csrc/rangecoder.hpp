@@ -29,7 +29,7 @@ __host__ __device__ __forceinline__ uint32_t rc_interleaved(uint32_t r, int chun
 
 // The decoder fetches compact rows RC_ROW_LOOKAHEAD symbols ahead without clamping: the row buffer of a stream of
 // nch chunks of (at most) S symbols must hold rc_rows_capacity(nch, S) rows (what lies past the last row is never used).
-constexpr int RC_ROW_LOOKAHEAD = 64;   // staged kernels: a ring of 32 rows, refilled half by half, + a last trip that runs up to 31 symbols past a lane of any length
+constexpr int RC_ROW_LOOKAHEAD = 96;   // staged kernels: the prologue fetches a whole ring of 48 rows whatever the lane's length; refills stop at the wave's longest lane
 static inline int64_t rc_rows_capacity(int64_t nch, int64_t S) { return (S + RC_ROW_LOOKAHEAD) * nch; }
 
 // How a stream of n symbols is cut (by container version).  A LANE is what one coder state covers: 2^llog consecutive
@@ -198,7 +198,7 @@ static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_
 // RC_RING_DEPTH CDF rows per lane; the 16-ary kernel runs four coder states per wave.  A version-3 chunk must fit (both
 // lanes see the whole chunk): ~15 KiB for 16-ary, ~56 KiB for 4-ary, ~60 KiB for binary streams.  The encoder refuses to
 // write a chunk its decoder could not read (possible only at chunk_log2 >= 13 with a model that spends > 7 bits per symbol).
-constexpr int RC_RING_DEPTH = 32;   // two halves of 16 rows (rangecoder.hip: LDS-DMA ring)
+constexpr int RC_RING_DEPTH = 48;   // three thirds of 16 rows (rangecoder.hip: LDS-DMA ring)
 constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
 static inline uint64_t rc_window_dwords(uint32_t max_bytes) { return ((uint64_t)max_bytes + 3u) / 4u + 3u; }
 static inline uint32_t rc_ring_bytes(int lp) { return (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u); }

@@ -100,8 +100,16 @@ def run(i, x, ctx, stream, ref):
 
 def worker(i, x, ctx, stream, barrier):
     ref = run(i, x, ctx, stream, None)
-    assert isinstance(ref, tuple), ref
-    barrier.wait()
+    if not isinstance(ref, tuple):   # the solo pass itself failed (it runs beside the other scenes' solo passes)
+        with lock:
+            bad.append((i, -1, ref))
+            print("  scene %d solo pass: %s" % (i, ref[:600]), flush=True)
+        barrier.abort()
+        return
+    try:
+        barrier.wait()
+    except threading.BrokenBarrierError:
+        return
     for k in range(steps):
         r = run(i, x, ctx, stream, ref)
         if r:

@@ -19,71 +19,26 @@ namespace gpcc {
 
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
-// ------------------------------------------------------------------ LDS-DMA ring (decoder: CDF rows; encoder: symbol words)
-// CDF rows run ahead of the coder through a ring -- in LDS, filled by LDS-DMA loads (global_load_lds_dword: no VGPR
-// destination, so nothing the register allocator could copy, spill or reuse before the data lands).  A register ring left
-// to the compiler costs a full memory round trip per trip of the unrolled loop: it clusters the loads, renames the ring
-// across the back edge and waits with vmcnt(0) for loads it has just issued (measured: ~0.15 us per symbol whatever the
-// instruction count); the same ring as inline-asm loads into "=v" registers is not safe (hipcc copied a destination
-// register in front of the hand-written wait).  Slot s of the ring is 64 lanes x 4 bytes at ring + 256 s: lane l's
-// datum of row i sits at slot (i % RC_RING_DEPTH), offset 4 l.  M0 carries the LDS destination and is compiler-reserved:
-// saved and restored inside the statement.  Single-wave workgroups and every lane reads what its own lane's DMA wrote:
-// no barrier.
+// ------------------------------------------------------------------ rows ahead of the coder: three register sets
+// CDF rows (decoders) and packed symbol words (encoder) do not depend on coded symbols, so they are fetched ahead of the
+// serial chain: three sets of RING_PHASE = 16 rows in REGISTERS, filled by ordinary global loads.  The symbol loop is
+// unrolled over one trip of the three sets (48 symbols), so every row has a fixed register, nothing rotates, and the set
+// just consumed is refilled at the end of its phase -- two phases (32 symbols, ~4 us) before it is read again.  The waits
+// are the compiler's own counted `s_waitcnt vmcnt` (ordinary loads retire in order), the 16 symbols of a phase leave in one
+// 16-byte store.
 //
-// WHEN a slot may be read (round 3, found with two scenes in flight on one GPU; tools/inflight_check.py):
-//  * LDS-DMA loads do NOT retire in issue order under load.  A counted wait -- "with N younger loads in flight row i has
-//    landed" -- holds on an idle device (tools/ubench/lds_dma_probe.hip) and failed in 1 of ~200 decodes beside a second
-//    scene: the first symbols of a lane, where the waits are binding, read slots whose rows had been overtaken by later
-//    ones (waiting three rows further and sleeping 256 cycles moved the first wrong symbol from 1 to 3, no more).
-//    The only wait used here is vmcnt(0).
-//  * ...and a slot is not read right behind the wait that retires it: beside a second scene, `s_waitcnt vmcnt(0)` released
-//    waves whose LDS-DMA data was not yet visible to their own `ds_read` (a ring of two halves that read the other half's
-//    first row right behind the phase-end wait was clean while that wait was rarely binding and failed in 16 % of the decodes
-//    once a faster symbol loop made it binding more often).  The ring is therefore THREE thirds of RING_PHASE rows.  At the
-//    end of phase p: ONE vmcnt(0) -- it retires the batch issued at the end of phase p - 1, which phase p + 2 will read --,
-//    then the third just consumed is refilled (rows of phase p + 3), then the 16 symbols of the phase leave in one 16-byte
-//    store (it has a phase to complete before the next vmcnt(0) sees it).  Phase p + 1 reads the third retired at the end
-//    of phase p - 1: a whole phase (16 symbols, ~2 us) lies between a retiring wait and the first read of what it retired.
-//    Rows no lane will use are not fetched and a final vmcnt(0) precedes s_endpgm: an LDS-DMA load in flight when its wave
-//    ends lands in LDS that may already belong to another workgroup.
-//  * `global_load_lds_ushort` is not used: beside a second scene the upper half of its dword was not always zero (wrong
-//    symbols in 2-6 % of the decodes when the consumer read the dword).  16-bit rows are fetched as dwords (the address
-//    need not be dword-aligned; the row buffers have look-ahead slack behind their last entry) and read with 16-bit LDS loads.
-constexpr int RING_NPH = 3;                      // thirds of the ring
+// Round 3 first built this ring in LDS, filled by LDS-DMA loads (`global_load_lds_*`, hand-counted waits), because a
+// ROLLED register ring had cost a memory round trip per trip (the compiler clusters the loads, renames the ring across the
+// back edge and waits with vmcnt(0)).  That version passed every parity test and decoded wrong symbols in 2-16 % of the
+// decodes as soon as a second scene shared the GPU (tools/inflight_check.py; DESIGN.md section 4 has the whole story):
+// under load LDS-DMA loads do not retire in issue order, `s_waitcnt vmcnt(0)` can release a wave before the data is visible
+// to its own ds_read, the upper half of the dword a 16-bit LDS-DMA load writes is not reliably zero, and a load still in
+// flight at s_endpgm lands in LDS that may belong to another workgroup.  A three-thirds LDS ring with a whole phase between
+// a retiring vmcnt(0) and the first read was clean in 4 000 scene-steps -- and the register sets below are as fast
+// (51.6 vs 53.1 us per binary launch, 74.2 vs 77.7 4-ary) on documented semantics only.  The LDS-DMA code is gone.
+constexpr int RING_NPH = 3;                       // register sets
 constexpr int RING_PHASE = RC_RING_DEPTH / RING_NPH;
 static_assert(RING_PHASE == 16, "a phase's symbols leave as one 16-byte store");
-// A phase's refill in one statement: RING_PHASE loads of consecutive rows into consecutive slots, M0 saved and restored once,
-// the row pointer advanced in place (three instructions a row instead of seven; the VALU add between the scalar add to M0 and
-// the next load is the wait state that write needs).
-#define RC_DMA_ROW1 "global_load_lds_dword %[a], off\n\ts_add_u32 m0, m0, 0x100\n\tv_lshl_add_u64 %[a], %[a], 0, %[st]\n\t"
-#define RC_DMA_ROW2 "global_load_lds_dword %[a], off\n\ts_add_u32 m0, m0, %[d1]\n\ts_nop 0\n\tglobal_load_lds_dword %[a], off offset:4\n\ts_sub_u32 m0, m0, %[d2]\n\tv_lshl_add_u64 %[a], %[a], 0, %[st]\n\t"
-#define RC_REP16(x) x x x x x x x x x x x x x x x x
-// rows of one dword each (16-bit rows fetched as dwords): slot s of the phase at lds_first + 256 s
-__device__ __forceinline__ void ring_batch_b32(const char *&rowp, uint64_t rstep, uint32_t lds_first)
-{
-    unsigned keep;
-    uint64_t a = reinterpret_cast<uint64_t>(rowp);
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[b]\n\ts_nop 0\n\t" RC_REP16(RC_DMA_ROW1) "s_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep), [a] "+v"(a) : [b] "s"(lds_first), [st] "v"(rstep) : "memory", "scc");
-    rowp = reinterpret_cast<const char *>(a);
-}
-// rows of two dwords: the first into slot s, the second into slot RC_RING_DEPTH + s (its M0 is 4 short: the instruction
-// offset of an LDS-DMA load moves the LDS destination as well as the source)
-__device__ __forceinline__ void ring_batch_2xb32(const char *&rowp, uint64_t rstep, uint32_t lds_first)
-{
-    unsigned keep;
-    uint64_t a = reinterpret_cast<uint64_t>(rowp);
-    asm volatile("s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[b]\n\ts_nop 0\n\t" RC_REP16(RC_DMA_ROW2) "s_mov_b32 m0, %[k]"
-                 : [k] "=&s"(keep), [a] "+v"(a) : [b] "s"(lds_first), [st] "v"(rstep), [d1] "n"(RC_RING_DEPTH * 256 - 4), [d2] "n"(RC_RING_DEPTH * 256 - 4 - 256) : "memory", "scc");
-    rowp = reinterpret_cast<const char *>(a);
-}
-__device__ __forceinline__ void ring_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void ring_settle() { __builtin_amdgcn_s_sleep(8); }   // ~512 cycles behind the one BINDING wait of a lane (the prologue's): margin between the counter and the LDS write
-__device__ __forceinline__ void ring_dma_b32(const void *gsrc, uint32_t lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
 
 // ------------------------------------------------------------------ encode
 struct BitOut {
@@ -112,11 +67,10 @@ struct BitOut {
 __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ lohi, const RcChunk *__restrict__ chunks, int nchunks,
                                                   uint8_t *__restrict__ scratch, uint32_t sstride, uint32_t *__restrict__ cnt)
 {
-    // the packed (c_low | (c_high - 1) << 16) words of the lanes come through the LDS-DMA ring, up to RC_RING_DEPTH symbols
-    // ahead: one load per symbol fetched one symbol ahead was a memory round trip per symbol (0.42 us: the whole encode
-    // coder took as long as its longest lane times that)
+    // the packed (c_low | (c_high - 1) << 16) words of the lanes are fetched up to RC_RING_DEPTH symbols ahead (header comment):
+    // one load per symbol fetched one symbol ahead was a memory round trip per symbol (0.42 us: the whole encode coder took as
+    // long as its longest lane times that)
     constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
-    extern __shared__ uint32_t ring[];        // DEPTH slots of 64 dwords (dynamic: its LDS address is the static size)
     const int lane = threadIdx.x;
     const int c = blockIdx.x * 64 + lane;
     RcChunk ch = {0, 0, 0, 0, 0, 0};
@@ -130,21 +84,20 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
     // loads run past a lane's last word: clamp the element index to the lane's own words (a finished lane re-reads its last one)
     const uint32_t last = ch.n ? ch.n - 1u : 0u;
     auto src = [&](uint32_t t) -> const uint32_t * { return lohi + ch.first + (size_t)min(t, last) * ch.stride; };
-    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_amdgcn_groupstaticsize());
+    uint32_t regs[RING_NPH][PH];
+    auto fill = [&](int h, uint32_t first) {
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) ring_dma_b32(src((uint32_t)d), ring_lds + (uint32_t)d * 256u);
-    ring_wait_all();
-    ring_settle();
-    uint32_t next = ring[lane];
+        for (int dd = 0; dd < PH; ++dd) regs[h][dd] = *src(first + (uint32_t)dd);
+    };
+#pragma unroll
+    for (int h = 0; h < RING_NPH; ++h) fill(h, (uint32_t)(h * PH));
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
         for (int h = 0; h < RING_NPH; ++h) {
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
-                const int d = h * PH + dd;
-                const uint32_t i = i0 + (uint32_t)d;
-                const uint32_t cur = next;
-                if (dd + 1 < PH) next = ring[(d + 1) * 64 + lane];   // (the first word of the other half is read behind the wait below)
+                const uint32_t i = i0 + (uint32_t)(h * PH + dd);
+                const uint32_t cur = regs[h][dd];
                 if (i < ch.n) {
                     const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
                     const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
@@ -177,16 +130,11 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
                     high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
                 }
             }
-            // end of a phase: the batch behind the other half (issued a phase ago) has to have landed; refill this half
-            ring_wait_all();
-            next = ring[((h + 1) % RING_NPH) * PH * 64 + lane];   // retired a phase ago
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) {   // (wave-uniform) nothing is fetched that no lane will use: no load is in flight when the wave ends
-#pragma unroll
-                for (int dd = 0; dd < PH; ++dd) ring_dma_b32(src(i0 + (uint32_t)(DEPTH + h * PH + dd)), ring_lds + (uint32_t)(h * PH + dd) * 256u);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) fill(h, i0 + (uint32_t)(DEPTH + h * PH));   // (wave-uniform) words no lane will use are not fetched
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
-    ring_wait_all();   // an LDS-DMA load still in flight at s_endpgm would land in LDS that may already belong to another workgroup
     if (c >= nchunks) return;
     pending += 1;
     const uint32_t b = low < 0x40000000u ? 0u : 1u;
@@ -552,8 +500,9 @@ __device__ __forceinline__ void rc_renorm(uint32_t &low, uint32_t &d, uint32_t &
     k_out = k;
 }
 
-// Lanes of 3- and 5-entry rows.  Symbols leave four at a time; a lane's first symbol sits on a multiple of 4 (lanes are
-// 2^llog >= 32 symbols) and `sym` has 3 bytes of slack behind the stream for the last group of its last lane.
+// Lanes of 3- and 5-entry rows, byte windows staged in LDS, rows in three register sets (header comment).  A lane's first
+// symbol sits on a multiple of 16 (lanes are 2^llog >= 32 symbols) and `sym` has 3 bytes of slack behind the stream for the
+// last group of its last lane.
 template <int LP>
 __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                       int nchunks, int lpw, uint32_t rdw, uint8_t *__restrict__ sym)
@@ -561,9 +510,7 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     static_assert(LP == 3 || LP == 5, "17-entry rows are decoded by k_rc_decode17_lds");
     constexpr int RS = LP == 3 ? 1 : 4;
     constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
-    constexpr uint32_t SLOT = 256u;                            // bytes of a ring slot: a dword per lane
-    static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
-    extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows, then the row ring
+    extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows
     const int lane = threadIdx.x;
     const int c = blockIdx.x * lpw + lane;
     RcChunk ch = {0, 0, 0, 0, 0, 0};
@@ -573,41 +520,33 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
     for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
     nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
     if (nmax == 0) return;
-    stage_windows(win, bytes, ch, lpw, rdw, 64, 1);   // lane j's descriptor lives in thread j
+    stage_windows(win, bytes, ch, lpw, rdw, 64, 1);
     __syncthreads();
     LaneWin in;
     in.init(win + (size_t)min(lane, lpw - 1) * rdw, rdw);
-    const char *rowp = reinterpret_cast<const char *>(cdf) + (size_t)ch.first * (2 * RS);   // this lane's row of the next ring load
-    const size_t rstep = (size_t)ch.stride * (2 * RS);
-    uint32_t *ring = win + (size_t)lpw * rdw;
-    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + (uint32_t)lpw * rdw * 4u));
-    auto ring_fill = [&](int h) {   // rows of one phase into half h (a dword for a 16-bit row: header comment)
-        if (LP == 3) ring_batch_b32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * SLOT);
-        else ring_batch_2xb32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * SLOT);
+    const uint16_t *rowp = cdf + (size_t)ch.first * RS;
+    const size_t rstep = (size_t)ch.stride * RS;
+    struct Row { uint32_t a, b; };
+    Row regs[RING_NPH][PH];
+    auto fill = [&](int h) {
+#pragma unroll
+        for (int dd = 0; dd < PH; ++dd) {
+            if (LP == 3) { regs[h][dd].a = rowp[0]; regs[h][dd].b = 0; }
+            else { const uint2 q = *reinterpret_cast<const uint2 *>(rowp); regs[h][dd].a = q.x; regs[h][dd].b = q.y; }
+            rowp += rstep;
+        }
     };
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-    ring_fill(0);
-    ring_fill(1);
-    ring_fill(2);
+#pragma unroll
+    for (int h = 0; h < RING_NPH; ++h) fill(h);
     uint8_t *out = sym + ch.out;
-    // the ring slot of row i + 1 is read while symbol i decodes (its LDS latency off the serial chain); 16-bit rows arrive as
-    // the low half of a dword whose upper half is the next entry in memory: read 16 bits
-    auto ring_read = [&](int slot, uint32_t &a, uint32_t &b) {
-        if (LP == 3) a = reinterpret_cast<const uint16_t *>(ring)[2 * (slot * 64 + lane)];
-        else { a = ring[slot * 64 + lane]; b = ring[(DEPTH + slot) * 64 + lane]; }
-    };
-    uint32_t n0 = 0, n1r = 0;
-    ring_wait_all();
-    ring_settle();
-    ring_read(0, n0, n1r);
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
         for (int h = 0; h < RING_NPH; ++h) {
             uint32_t pack[PH / 4];
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
-                const uint32_t r0 = n0, r1 = n1r;
-                if (dd + 1 < PH) ring_read(h * PH + dd + 1, n0, n1r);   // (the first row of the other half is read behind the wait below)
+                const uint32_t r0 = regs[h][dd].a, r1 = regs[h][dd].b;
                 const uint32_t t = in.peek();
                 uint32_t s, lo, d1;
                 if (LP == 3) {
@@ -617,33 +556,32 @@ __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict
                     d1 = ge ? d - t1 : t1 - 1u;
                 } else {
                     const uint32_t t1 = scale_d(d, r0 & 0xFFFFu), t2 = scale_d(d, r0 >> 16), t3 = scale_d(d, r1 & 0xFFFFu);
-                    // the scaled bounds are monotone: (t3 <= x) implies (t2 <= x) implies (t1 <= x).  Selects, no branches.
                     const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
                     lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
-                    const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));              // scaled upper bound (mod 2^32: a span of 2^32 wraps to 0)
+                    const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));
                     s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
-                    d1 = hi + ~lo;                                                           // hi - lo - 1
+                    d1 = hi + ~lo;
                 }
                 if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
                 rc_renorm(low, d, x, lo, d1, t, k);
                 in.advance(k);
             }
-            // end of a phase: retire the batch behind the other half, refill this one, write the phase's 16 symbols
-            ring_wait_all();
-            ring_read(((h + 1) % RING_NPH) * PH, n0, n1r);   // retired a phase ago
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
+            __builtin_amdgcn_sched_barrier(0);
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) fill(h);
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
             else {
 #pragma unroll
                 for (int q = 0; q < PH / 4; ++q)
-                    if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];   // the last group may run 3 bytes into the slack behind the stream
+                    if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];
             }
         }
     }
 }
 
-// 17-entry rows: a 16-lane group per coder lane as in k_rc_decode17, the byte windows staged in LDS.
+// 17-entry rows: a 16-lane group per coder lane as in k_rc_decode17, the byte windows staged in LDS, every lane's own entry
+// of the coming rows in three register sets.
 __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                         int nchunks, uint32_t rdw, uint8_t *__restrict__ sym)
 {
@@ -664,29 +602,25 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
     LaneWin in;
     in.init(win + (size_t)grp * rdw, rdw);
     // compact row: v[1..15] at [0..14]; lane 0 stands for v[0] = 0 and reads the unused slot 15
-    const char *rowp = reinterpret_cast<const char *>(cdf) + ((size_t)ch.first * 16 + (size_t)(kk ? kk - 1 : 15)) * 2;
-    const size_t rstep = (size_t)ch.stride * 32;
-    const uint32_t *ring = win + (size_t)4 * rdw;
-    const uint32_t ring_lds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_groupstaticsize() + 4u * rdw * 4u));
-    auto ring_fill = [&](int h) { ring_batch_b32(rowp, (uint64_t)rstep, ring_lds + (uint32_t)(h * PH) * 256u); };   // a dword for a 16-bit entry (header comment)
+    const uint16_t *rowp = cdf + (size_t)ch.first * 16 + (size_t)(kk ? kk - 1 : 15);
+    const size_t rstep = (size_t)ch.stride * 16;
+    uint32_t regs[RING_NPH][PH];
+    auto fill = [&](int h) {
+#pragma unroll
+        for (int dd = 0; dd < PH; ++dd) { regs[h][dd] = rowp[0]; rowp += rstep; }
+    };
     const int g16 = grp << 4;
     uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-    ring_fill(0);
-    ring_fill(1);
-    ring_fill(2);
+#pragma unroll
+    for (int h = 0; h < RING_NPH; ++h) fill(h);
     uint8_t *out = sym + ch.out;
-    ring_wait_all();
-    ring_settle();
-    const uint16_t *ring16 = reinterpret_cast<const uint16_t *>(ring);   // 16-bit reads: see k_rc_decode_lds
-    uint32_t vnext = ring16[2 * lane];
     for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
 #pragma unroll
         for (int h = 0; h < RING_NPH; ++h) {
             uint32_t pack[PH / 4];
 #pragma unroll
             for (int dd = 0; dd < PH; ++dd) {
-                const uint32_t v = vnext;
-                if (dd + 1 < PH) vnext = ring16[2 * ((h * PH + dd + 1) * 64 + lane)];   // (the other half's first row: behind the wait below)
+                const uint32_t v = regs[h][dd];
                 const uint32_t tw = in.peek();
                 const uint32_t t = kk ? scale_d(d, v) : 0u;
                 const uint64_t bal = __ballot(t <= x);
@@ -700,9 +634,9 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
                 rc_renorm(low, d, x, lo, d1, tw, k);
                 in.advance(k);
             }
-            ring_wait_all();
-            vnext = ring16[2 * (((h + 1) % RING_NPH) * PH * 64 + lane)];   // retired a phase ago
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) ring_fill(h);   // (wave-uniform) rows no lane will use are not fetched: no load is in flight when the wave ends
+            __builtin_amdgcn_sched_barrier(0);
+            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) fill(h);   // (wave-uniform) rows no lane will use are not fetched
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t ib = i0 + (uint32_t)(h * PH);
             if (kk == 0) {
                 if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
@@ -719,7 +653,7 @@ __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restri
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt)
 {
     if (nchunks <= 0) return GPCC_OK;
-    k_rc_encode<<<(unsigned)cdiv(nchunks, 64), 64, RC_RING_DEPTH * 256, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
+    k_rc_encode<<<(unsigned)cdiv(nchunks, 64), 64, 0, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

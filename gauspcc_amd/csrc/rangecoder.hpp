@@ -198,10 +198,10 @@ static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_
 // RC_RING_DEPTH CDF rows per lane; the 16-ary kernel runs four coder states per wave.  A version-3 chunk must fit (both
 // lanes see the whole chunk): ~15 KiB for 16-ary, ~56 KiB for 4-ary, ~60 KiB for binary streams.  The encoder refuses to
 // write a chunk its decoder could not read (possible only at chunk_log2 >= 13 with a model that spends > 7 bits per symbol).
-constexpr int RC_RING_DEPTH = 48;   // three thirds of 16 rows (rangecoder.hip: LDS-DMA ring)
+constexpr int RC_RING_DEPTH = 48;   // rows fetched ahead of the coder: three register sets of 16 (rangecoder.hip)
 constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
 static inline uint64_t rc_window_dwords(uint32_t max_bytes) { return ((uint64_t)max_bytes + 3u) / 4u + 3u; }
-static inline uint32_t rc_ring_bytes(int lp) { return (uint32_t)RC_RING_DEPTH * (lp == 5 ? 512u : 256u); }
+static inline uint32_t rc_ring_bytes(int) { return 0u; }   // (the row ring lives in registers: rangecoder.hip)
 static inline bool rc_window_fits(int lp, uint32_t max_bytes) { return rc_window_dwords(max_bytes) * 4u * (lp == 17 ? 4u : 1u) <= RC_LDS_CAP - rc_ring_bytes(lp); }
 
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }

@@ -194,10 +194,10 @@ static inline const char *rc_parse_table(const uint8_t *tab, int64_t off, int64_
     return nullptr;
 }
 
-// The staged decoders keep every lane's byte window (+ the dwords the reader runs ahead) in LDS, behind a ring of
-// RC_RING_DEPTH CDF rows per lane; the 16-ary kernel runs four coder states per wave.  A version-3 chunk must fit (both
-// lanes see the whole chunk): ~15 KiB for 16-ary, ~56 KiB for 4-ary, ~60 KiB for binary streams.  The encoder refuses to
-// write a chunk its decoder could not read (possible only at chunk_log2 >= 13 with a model that spends > 7 bits per symbol).
+// The staged decoders keep every lane's byte window (+ the dwords the reader runs ahead) in LDS; the 16-ary kernel runs four
+// coder states per wave.  A version-3 chunk must fit (both lanes see the whole chunk): ~16 KiB for 16-ary, ~64 KiB for the
+// other streams.  The encoder refuses to write a chunk its decoder could not read (possible only at chunk_log2 >= 13 with a
+// model that spends > 8 bits per 16-ary symbol).
 constexpr int RC_RING_DEPTH = 48;   // rows fetched ahead of the coder: three register sets of 16 (rangecoder.hip)
 constexpr uint32_t RC_LDS_CAP = 64u * 1024u;    // dynamic LDS of a decode workgroup (one wave)
 static inline uint64_t rc_window_dwords(uint32_t max_bytes) { return ((uint64_t)max_bytes + 3u) / 4u + 3u; }

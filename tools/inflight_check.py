@@ -23,13 +23,14 @@ model = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
 bad = []
 lock = threading.Lock()
 TRACE = os.environ.get("INFLIGHT_TRACE", "0") != "0"
+CHUNK_LOG2 = int(os.environ.get("INFLIGHT_CHUNK_LOG2", "11"))   # 0: the reference layout (one lane per stream: slow decodes)
 CAP = int(os.environ.get("INFLIGHT_CAPTURE", "-1"))     # capture the buffers whose tag % 100 is this (29: the 16-ary symbols)
 
 
 def run(i, x, ctx, stream, ref):
     sp = C.c_void_p(stream.cuda_stream)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
-    rc = L.gpcc_encode(ctx, model.handle, x.data_ptr(), x.shape[0], 11, runtime.f16_bits(1), C.byref(pb), C.byref(nb), C.byref(st), sp)
+    rc = L.gpcc_encode(ctx, model.handle, x.data_ptr(), x.shape[0], CHUNK_LOG2, runtime.f16_bits(1), C.byref(pb), C.byref(nb), C.byref(st), sp)
     if rc:
         return f"encode rc {rc}: {L.gpcc_last_error().decode(errors='replace')}"
     h = hashlib.sha1(C.string_at(pb, nb.value)).hexdigest()

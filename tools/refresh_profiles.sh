@@ -3,7 +3,7 @@
 # (every step under its own `timeout`; PMC passes never combined with tracing)
 set -u
 OUT=$1
-R=${2:-r02}
+R=${2:-r03}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__
 // half of a tree is launch-latency-bound: four launches per level otherwise).  The workgroup walks the children in tiles of
 // 1024 with the running count in a register.
 constexpr int LS_T = 256, LS_E = 4, LS_TILE = LS_T * LS_E;
-constexpr int64_t LEVEL_SINGLE_MAX = 16 * LS_TILE;
+constexpr int64_t LEVEL_SINGLE_MAX = 8 * LS_TILE;   // (one workgroup builds 8 k children in 44 us, 16 k in 81; the five-launch path takes ~40 at either size)
 __global__ __launch_bounds__(LS_T) void k_level_up_single(const uint64_t *__restrict__ key, int64_t n, uint64_t *__restrict__ key_up, uint64_t *__restrict__ rkey_up,
                                                          uint32_t *__restrict__ cstart_up, uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
 {

@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=11)
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="independent scenes each rank codes per step, one after the other (weak scaling: scene i of the "
                     "batch -> rank i mod N, gauspcc_amd.dist.scenes_for_rank; BASELINE configs[3] is --gpus 8 with one or more scenes per GPU)")
-    ap.add_argument("--cpu-threads", type=int, default=64, help="OpenMP threads of the CPU baseline (capped by the cores this process may use; the same at every --gpus)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = every core this process may use; a positive value pins the count, capped by those cores)")
     ap.add_argument("--measure-traffic", action="store_true", help="(informative) leave roofline.traffic null instead of quoting profiles/: run tools/pmc_traffic.sh for a fresh figure")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
     ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
@@ -356,7 +356,10 @@ def main():
             spec = importlib.util.spec_from_file_location("bench_side_paths", os.path.join(ROOT, "tools", "bench_side_paths.py"))
             mod = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(mod)
-            sp = mod.measure(args.side_anchors)
+            import contextlib
+
+            with contextlib.redirect_stdout(sys.stderr):   # the reference-compatible callers print progress lines (`Start encoding ...`,
+                sp = mod.measure(args.side_anchors)        # HAC/scene/gaussian_model.py:1095): stdout carries the ONE JSON line only
             out["side_paths"] = {
                 "scene": f"synthetic HAC-style scene, {sp['n_anchors']} anchors x 50 features x 10 offsets, {sp['image'][0]}x{sp['image'][1]} frame",
                 "attribute_loop": {k: sp["attribute_loop"][k] for k in ("anchors_coded", "files_bytes", "conduct_encoding_s", "conduct_decoding_s")},
@@ -370,7 +373,8 @@ def main():
             from gauspcc_amd.model import tensor_table
             from oracle import oracle as orc
 
-            threads = orc.set_threads(max(1, min(args.cpu_threads, len(os.sched_getaffinity(0)))))
+            host_cores = len(os.sched_getaffinity(0))
+            threads = orc.set_threads(max(1, min(args.cpu_threads, host_cores) if args.cpu_threads > 0 else host_cores))
             om = orc.Model(tensor_table(sd, 32, k), 32, k)
             sp = synthetic_cloud(args.cpu_sample, seed=seed)
             t0 = time.perf_counter()
@@ -382,11 +386,13 @@ def main():
             out["cpu_baseline"] = {
                 "value": round(args.cpu_sample / (t2 - t0) / 1e6, 5),
                 "unit": "Mpoints/s",
-                "cores": threads,
+                "cores": threads,            # the threads actually used (all cores of the box unless --cpu-threads pins fewer)
+                "threads": threads,
+                "host_cores": host_cores,
                 "kind": "port",
                 "sample": f"oracle encode+decode of a {args.cpu_sample}-point cloud from the same generator "
                           f"(enc {t1 - t0:.2f} s, dec {t2 - t1:.2f} s; {threads} OpenMP threads for the convolutions and heads, "
-                          f"single-thread range coder as torchac; the box has {len(os.sched_getaffinity(0))} cores)",
+                          f"single-thread range coder as torchac; the box has {host_cores} cores)",
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -134,9 +134,10 @@ def main(argv=None):
             xyz = quantise(pts, args.is_data_pre_quantized, args.posQ, device)
             r = pcc_utils.compress_point_cloud(xyz, args.ckpt, out_path, channels=args.channels,
                                                kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
+            io.note_workspace(device)
         return {"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in}
 
-    if args.jobs <= 1 or world > 1:
+    if args.jobs <= 1:
         for item in zip(my_files, xyz_ls):
             rows.append(one(item))
             if world == 1:
@@ -144,8 +145,11 @@ def main(argv=None):
     else:
         # files in flight share the GPU: a file's enc_time is its wall-clock span UNDER CONTENTION (longer than alone; the
         # batch finishes sooner).  The CSV grows as files complete, in input order, so a failing job loses only its own row.
+        # Under --gpus N every rank keeps --jobs files of ITS share in flight on its own GPU; only rank 0's single-rank runs
+        # write the CSV incrementally (with several ranks the rows are collated at the end).
         def done(results):
-            write_results_csv([r for r in results if r is not None], csvfile, with_avg=False)
+            if world == 1:
+                write_results_csv([r for r in results if r is not None], csvfile, with_avg=False)
 
         rows = io.run_jobs(one, zip(my_files, xyz_ls), args.jobs, on_progress=done)
     if world > 1:
@@ -159,10 +163,11 @@ def main(argv=None):
                          "file_size_bits": 8 * s.num_bytes, "num_points": s.num_points}
     if rank == 0:
         write_results_csv(rows, csvfile, with_avg=True)
-        mem = torch.cuda.max_memory_allocated() / 1024 / 1024 if device.type == "cuda" else 0.0
+        # torch's figure (the reference's column) cannot see the library's own workspace: add its high-water mark (this rank's contexts)
+        mem = (torch.cuda.max_memory_allocated() + io.workspace_peak()) / 1024 / 1024 if device.type == "cuda" else 0.0
         print("Total: {total_n:d} | Average bitrate:{bpp:.3f} | Encoding time:{enc_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
             total_n=len(rows), bpp=np.mean([r["bpp"] for r in rows]), enc_time=np.mean([r["enc_time"] for r in rows]), memory=mem)
-            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight (times under contention)" if args.jobs > 1 and world == 1 else ""))
+            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight" + (" per rank" if world > 1 else "") + " (times under contention)" if args.jobs > 1 else ""))
         print("Results saved to ", csvfile)
     if world > 1:
         import torch.distributed as td

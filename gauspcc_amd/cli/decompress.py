@@ -23,7 +23,20 @@ def build_parser():
     p.add_argument("--ckpt", help="Checkpoint loading path ('synthetic[:seed]' = seeded random weights)", default="./model/KITTIDetection/ckpt_ue_4stage_conv.pt")
     p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context)")
     p.add_argument("--gpus", type=int, default=1, help="extension: shard the files over this many GPUs of the node, one process per GPU (file i -> rank i mod N)")
+    p.add_argument("--selftest-stub", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the sharding / collation path without a GPU
     return p
+
+
+def _stub_codec(path, out_path):
+    """Inverse of compress._stub_codec (tests of the sharding path on CPU ranks): the zlib blob back to an ASCII PLY."""
+    import zlib
+
+    from ..pcc_utils import save_ply_ascii_geo
+
+    with open(path, "rb") as f:
+        a = np.frombuffer(zlib.decompress(f.read()), dtype=np.float64).reshape(-1, 3)
+    save_ply_ascii_geo(a, out_path)
+    return {"num_points": len(a), "dec_time": 0.001 * (1 + len(a) % 5)}
 
 
 def main(argv=None):
@@ -40,9 +53,10 @@ def main(argv=None):
     import torch
 
     from .. import dist as gdist
-    from .. import pcc_utils
 
-    rank, world, device = gdist.init_from_env()
+    rank, world, device = gdist.init_from_env(prefer_gpu=not args.selftest_stub)
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     os.makedirs(args.output_folder, exist_ok=True)
     all_files = sorted(glob(args.input_glob))
     if not all_files:
@@ -50,8 +64,14 @@ def main(argv=None):
     files = [all_files[i] for i in gdist.scenes_for_rank(len(all_files), rank, world)]
     def one(path):
         name = os.path.split(path)[-1]
-        r = pcc_utils.decompress_point_cloud(path, args.ckpt, os.path.join(args.output_folder, name + ".ply"), channels=args.channels,
-                                             kernel_size=args.kernel_size, is_data_pre_quantized=args.is_data_pre_quantized)
+        if args.selftest_stub:
+            r = _stub_codec(path, os.path.join(args.output_folder, name + ".ply"))
+        else:
+            from .. import pcc_utils
+
+            r = pcc_utils.decompress_point_cloud(path, args.ckpt, os.path.join(args.output_folder, name + ".ply"), channels=args.channels,
+                                                 kernel_size=args.kernel_size, is_data_pre_quantized=args.is_data_pre_quantized)
+            io.note_workspace(device)
         print(f"Points after decompression: {r['num_points']}")
         return r["dec_time"]
 
@@ -60,9 +80,11 @@ def main(argv=None):
         allst = gdist.collate_stats([gdist.SceneStats(dec_s=t) for t in dec_time_ls], device)
         dec_time_ls = [s.dec_s for s in allst]
     if rank == 0:
+        # torch's figure (the reference's column) cannot see the library's own workspace: add its high-water mark (this rank's contexts)
+        mem = (torch.cuda.max_memory_allocated() + io.workspace_peak()) / 1024 / 1024 if device.type == "cuda" else 0.0
         print("Total: {total_n:d} | Decoding time:{dec_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
-            total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=torch.cuda.max_memory_allocated() / 1024 / 1024)
-            + (f" | {world} ranks" if world > 1 else ""))
+            total_n=len(dec_time_ls), dec_time=np.array(dec_time_ls).mean(), memory=mem)
+            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight" + (" per rank" if world > 1 else "") if args.jobs > 1 else ""))
     if world > 1:
         import torch.distributed as td
 

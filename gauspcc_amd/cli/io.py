@@ -84,7 +84,11 @@ def run_jobs(fn, items, jobs=1, on_progress=None):
 
     tls = threading.local()
 
+    gpu = torch.cuda.is_available()   # (the CPU self-test of the sharding path runs the same thread pool without streams)
+
     def call(it):
+        if not gpu:
+            return fn(it)
         if not hasattr(tls, "stream"):
             tls.stream = torch.cuda.Stream()
         with torch.cuda.stream(tls.stream):
@@ -121,3 +125,23 @@ def export_hw_queues(jobs):
 
     if jobs > 1:
         os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(8, 4 * jobs)))
+
+
+_WS_PEAK = [0]
+
+
+def note_workspace(device=None):
+    """Record the high-water mark of the library's own device workspace (all live contexts of this process): job threads and
+    their contexts are gone by the time the summary line is printed."""
+    from .. import runtime
+
+    try:
+        d, _ = runtime.workspace_bytes(device)
+    except Exception:
+        return
+    if d > _WS_PEAK[0]:
+        _WS_PEAK[0] = d
+
+
+def workspace_peak():
+    return _WS_PEAK[0]

@@ -47,6 +47,18 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     delete c;
 }
 
+// what the context holds right now: device bytes (workspace arena + the small levels' product buffer + developer buffers) and
+// pinned host bytes.  torch.cuda.max_memory_allocated() cannot see any of it (the library allocates with hipMalloc itself).
+extern "C" int gpcc_ctx_bytes(const gpcc_ctx *c, int64_t *device_bytes, int64_t *pinned_bytes)
+{
+    if (!c) return fail(GPCC_ERR_ARG, "null argument");
+    size_t d = c->arena.cap + c->conv_products_cap * sizeof(float) + (c->dbg_dev ? 8 * (size_t)4096 : 0);
+    for (const auto &e : c->dbg_caps) d += e.cap;
+    if (device_bytes) *device_bytes = (int64_t)d;
+    if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap);
+    return GPCC_OK;
+}
+
 namespace gpcc {
 constexpr int DBG_MAX = 4096;
 __global__ __launch_bounds__(256) void k_dbg_sum(const uint32_t *__restrict__ p, size_t words, unsigned long long *__restrict__ out)

@@ -25,6 +25,10 @@ namespace {
 
 struct Trunk { float *x, *a, *b; };
 
+// internal return value of encode_body: a chunk came out larger than the staged decoder's LDS window (rangecoder.hpp:
+// rc_window_fits) -- the caller retries with chunk_log2 - 1 (the header records the value used)
+constexpr int ENC_RETRY_SMALLER_CHUNKS = -1000;
+
 // Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; kit/nn.py:18-22).  Result in t.a.
 int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const ConvTiles &tiles, int64_t n)
 {
@@ -264,6 +268,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
                 const int64_t base = pre + (int64_t)s * slots(nc);
                 gap += 4u;
                 table_bound += 6 * (size_t)pl.nchunks + 8;   // escape code: 48 bits a chunk; first count + k
+                if (pl.dual && ((base & 1) || pl.llog < 4)) return fail(GPCC_ERR_HIP, "internal: stream %d starts on an odd slot or has lanes below 16 symbols", si);   // k_rc_compact tells a chunk's backwards lane by the parity of RcChunk::first; k_rc_decode_lds stores 16 symbols at a time
                 for (uint32_t c = 0; c < pl.nlanes; ++c) {
                     const int64_t cn = pl.lane_syms(nc, c);
                     gaps.push_back(chunk_log2 ? (uint32_t)si : gap);
@@ -364,8 +369,11 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             const int stage_lp[4] = {STAGE_M[0] + 1, STAGE_M[1] + 1, STAGE_M[2] + 1, STAGE_M[3] + 1};
             uint32_t mb = 0;
             for (int c = c0; c < c1; c += 2) mb = std::max(mb, hcnt[c] + (c + 1 < c1 ? hcnt[c + 1] : 0u));
-            if (!rc_window_fits(stage_lp[si & 3], mb))
-                return fail(GPCC_ERR_ARG, "a chunk of stream %d takes %u bytes, more than the decoder's window holds at chunk_log2 = %d: use a smaller chunk_log2", si, mb, chunk_log2);
+            if (!rc_window_fits(stage_lp[si & 3], mb)) {
+                // (possible only at chunk_log2 >= 13 with a model that spends > 8 bits per 16-ary symbol: gpcc_encode codes the cloud again with smaller chunks)
+                (void)fail(GPCC_ERR_ARG, "a chunk of stream %d takes %u bytes, more than the decoder's window holds at chunk_log2 = %d: use a smaller chunk_log2", si, mb, chunk_log2);
+                return ENC_RETRY_SMALLER_CHUNKS;
+            }
         }
         if (chunk_log2)
             s_tab[(size_t)si] = rc_table_size([&](uint32_t c) { const int l = c0 + 2 * (int)c; return hcnt[l] + (l + 1 < c1 ? hcnt[l + 1] : 0u); }, (uint32_t)((c1 - c0 + 1) / 2));
@@ -503,6 +511,8 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         lv->n = n; lv->lvl = lvl;
         TAKE(rkey, uint64_t, n); TAKE(occ, uint8_t, n); TAKE(cstart, uint32_t, n + 1); TAKE(parent, uint32_t, n); TAKE(m2r, uint32_t, n); TAKE(r2m, uint32_t, n);
         lv->rkey = rkey; lv->occ = occ; lv->cstart = cstart; lv->parent = parent; lv->m2r = m2r; lv->r2m = r2m;
+        // the arrays are carved back to back: level_expand_rank zeroes them with ONE memset over this recorded span
+        lv->span0 = reinterpret_cast<char *>(rkey); lv->span_bytes = (size_t)(reinterpret_cast<char *>(r2m + n) - reinterpret_cast<char *>(rkey));
         return GPCC_OK;
     };
     // the container goes up on a stream of its own: the first reader is the range decoder of the first coded level, behind a
@@ -767,6 +777,14 @@ extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xy
     for (int attempt = 0; attempt < 6; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         rc = encode_body(ctx, m, xyz_dev, n, chunk_log2, posq_f16, bytes_out, nbytes_out, stats, st);
+        if (rc == ENC_RETRY_SMALLER_CHUNKS) {
+            // an oversize chunk (16-ary streams at chunk_log2 >= 13 under a high-entropy model): the staged decoder has no path
+            // for it, so the limit is part of the format -- code again with half the chunk size instead of failing the call
+            HIP_TRY(hipStreamSynchronize(st));
+            if (chunk_log2 <= 6) { rc = GPCC_ERR_ARG; break; }
+            chunk_log2 -= 1; attempt -= 1;
+            continue;
+        }
         if (rc != GPCC_ERR_NOMEM) break;
         HIP_TRY(hipStreamSynchronize(st));
         want *= 2;  // deep / very sparse trees: more nodes per point than the estimate

@@ -585,11 +585,10 @@ int level_expand_rank(gpcc_ctx *ctx, hipStream_t st, Level *par, Level *chi, uin
     // decoder produced: a corrupt stream (or a lying header) leaves their tail unwritten.  Ranks are INDICES (rows of the
     // CDF and symbol arrays are addressed through m2r / r2m): stale arena bytes there become out-of-range addresses -- a
     // memory fault at 10^6 nodes, where the small clouds of the corruption tests never left mapped memory.  Zero = valid.
-    // One memset: the decoder carves a level's arrays from the arena back to back (codec.hip: alloc_level: rkey | occ | cstart |
-    // parent | m2r | r2m); occ and cstart are written in full later (assemble_occ, the next level's popcount scan).
+    // One memset: the decoder carves a level's arrays from the arena back to back and records the span (codec.hip: alloc_level,
+    // Level::span0 / span_bytes); occ and cstart are written in full later (assemble_occ, the next level's popcount scan).
     {
-        char *lo = reinterpret_cast<char *>(chi->rkey), *hi = reinterpret_cast<char *>(chi->r2m + chi->n);
-        if (hi > lo && (size_t)(hi - lo) <= 64 * (size_t)chi->n + 4096) HIP_TRY(hipMemsetAsync(lo, 0, (size_t)(hi - lo), st));
+        if (chi->span0 && chi->span_bytes) HIP_TRY(hipMemsetAsync(chi->span0, 0, chi->span_bytes, st));   // the span alloc_level recorded: nothing else lives in it
         else {   // (a caller with its own layout)
             HIP_TRY(hipMemsetAsync(chi->m2r, 0, 4 * (size_t)chi->n, st));
             HIP_TRY(hipMemsetAsync(chi->r2m, 0, 4 * (size_t)chi->n, st));

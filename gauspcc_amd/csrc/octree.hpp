@@ -54,6 +54,10 @@ struct Level {
     uint32_t *parent = nullptr; // (n) index of the parent in the next coarser level
     uint32_t *m2r = nullptr;    // (n) Morton index -> raster rank
     uint32_t *r2m = nullptr;    // (n) raster rank  -> Morton index
+    // decoder: the byte span that holds ALL of the arrays above when they were carved back to back (codec.hip: alloc_level);
+    // nullptr = no such guarantee (level_expand_rank then zeroes array by array)
+    char *span0 = nullptr;
+    size_t span_bytes = 0;
 };
 
 struct Tree {

@@ -691,6 +691,8 @@ int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *to
 int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym)
 {
     if (nchunks <= 0) return GPCC_OK;
+    // (invariants the staged kernels rely on, enforced by gpcc_encode / gpcc_decode's chunk_log2 range of 6..14 -- checked by their
+    // callers: lanes of a chunked stream start on multiples of 16 symbols, ch.out is 16-byte aligned, `sym` has n + 4 bytes)
     // staged path: every lane's window (+ the two dwords the reader runs ahead) in LDS; as many lanes per wave as fit
     const uint64_t rdw = rc_window_dwords(max_bytes);
     const uint32_t ring_bytes = rc_ring_bytes(lp);       // the row ring behind the windows

@@ -71,6 +71,7 @@ static inline RcPlan rc_plan(int64_t n, int chunk_log2, int version)
     const int clog = rc_level_chunk_log2(n, chunk_log2, version);
     p.dual = version >= 3;
     p.llog = p.dual ? clog - 1 : clog;
+    if (p.llog < 4) p.llog = 4;   // the staged decoders store 16 symbols at a time: lanes of at least 16 symbols (the API's chunk_log2 >= 6 never gets here)
     const int64_t nl = (std::max<int64_t>(n, 1) + ((int64_t)1 << p.llog) - 1) >> p.llog;
     p.nlanes = (uint32_t)nl;
     p.nchunks = p.dual ? (uint32_t)((nl + 1) / 2) : (uint32_t)nl;

@@ -3,6 +3,7 @@ PyTorch supplies device memory and the current HIP stream)."""
 import ctypes as C
 import sys
 import threading
+import weakref
 
 import numpy as np
 import torch
@@ -12,6 +13,8 @@ from .model import load_state_dict, tensor_table
 
 _MODELS = {}
 _MODELS_LOCK = threading.Lock()
+_ALL = weakref.WeakSet()       # every live _Contexts (one per host thread that used the library); weak: a thread's contexts die with it
+_ALL_LOCK = threading.Lock()
 
 
 class _Contexts:
@@ -21,6 +24,8 @@ class _Contexts:
 
     def __init__(self):
         self.h = {}
+        with _ALL_LOCK:
+            _ALL.add(self)
 
     def __del__(self, _finalizing=sys.is_finalizing):
         try:
@@ -33,6 +38,24 @@ class _Contexts:
 
 
 _TLS = threading.local()
+
+
+def workspace_bytes(device=None):
+    """(device_bytes, pinned_bytes) held by every live context of this process (all host threads), optionally of one device:
+    the library's own hipMalloc / hipHostMalloc allocations, which torch.cuda.max_memory_allocated() cannot see."""
+    dev = pin = 0
+    idx = None if device is None else _device_index(device)
+    with _ALL_LOCK:
+        owners = list(_ALL)
+    for own in owners:
+        for i, h in list(own.h.items()):
+            if idx is not None and i != idx:
+                continue
+            d, p = C.c_int64(0), C.c_int64(0)
+            _lib.check(_lib.lib().gpcc_ctx_bytes(h, C.byref(d), C.byref(p)))
+            dev += d.value
+            pin += p.value
+    return dev, pin
 
 
 def _device_index(device=None) -> int:

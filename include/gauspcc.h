@@ -41,6 +41,10 @@ GPCC_API int gpcc_version(void);
 
 GPCC_API int gpcc_ctx_create(int device, gpcc_ctx **out);
 GPCC_API void gpcc_ctx_destroy(gpcc_ctx *ctx);
+/* bytes the context holds now: device (workspace arena, product buffer of the small levels) and pinned host staging.  The
+ * reference's CLIs print torch.cuda.max_memory_allocated() (compress_ue_4stage_conv.py:283); this library allocates its
+ * workspace itself, so its CLIs add this figure.  Either pointer may be null. */
+GPCC_API int gpcc_ctx_bytes(const gpcc_ctx *ctx, int64_t *device_bytes, int64_t *pinned_bytes);
 
 /* ---- a2  calculate_morton_order            src/gs_compress/HAC/utils/pcc_utils.py:12-22
  * perm_out[N] (int64, device): argsort of x + y*M + z*M^2 after the per-axis min shift
@@ -95,8 +99,11 @@ typedef struct {
 /* ---- a12  compress_point_cloud (the timed span :78-189 + container :192-203)
  * xyz_dev: (N,3) int32 device, duplicate-free, any order.  chunk_log2 = 0 writes the
  * reference container layout (one range-coder stream per level and stage, decoded by
- * a single lane); 6..14 writes container v1 whose streams are cut into
- * 2^chunk_log2-symbol chunks that decode in parallel.  posq_f16 = bits of np.float16(posQ).
+ * a single lane); 6..14 writes the chunked container whose streams are cut into
+ * chunks of at most 2^chunk_log2 symbols that decode in parallel.  A chunk must fit the staged decoder's LDS
+ * window (64 KiB; 16 KiB for the 16-ary streams): should one come out larger -- possible only at chunk_log2 >= 13 with
+ * a model that spends more than 8 bits per 16-ary symbol -- the cloud is coded again with chunk_log2 - 1 (the header
+ * records the value used; readers never see the request).  posq_f16 = bits of np.float16(posQ).
  * On success *bytes_out points at a context-owned host buffer valid until the next call. */
 GPCC_API int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz_dev, int64_t n,
                 int chunk_log2, uint16_t posq_f16, const uint8_t **bytes_out, int64_t *nbytes_out,

@@ -106,3 +106,43 @@ def test_batch_cli_two_ranks_write_the_csv_of_one_rank(tmp_path):
         assert np.allclose(a[col].to_numpy(), b[col].to_numpy(), rtol=1e-12), col
     for i in range(5):
         assert (tmp_path / "one" / "bin" / f"c{i}.npy.bin").read_bytes() == (tmp_path / "two" / "bin" / f"c{i}.npy.bin").read_bytes()
+
+
+def test_batch_cli_jobs_and_decompress_under_two_ranks(tmp_path):
+    """`--jobs` is honoured per rank under `--gpus N` (round 3 silently ignored it), and the decompress CLI shards like the
+    compressor (reference batch driver: decompress_ue_4stage_conv.py:46-192): two gloo ranks, two files in flight each,
+    give the CSV / .bin / .ply files and the one summary line of a single process.  Stub codec: no GPU here."""
+    import numpy as np
+    import pandas as pd
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.RandomState(11)
+    src = tmp_path / "in"
+    src.mkdir()
+    for i in range(7):
+        np.save(src / f"c{i}.npy", rng.randint(0, 512, size=(200 + 41 * i, 3)).astype(np.float64))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    csv, summary = {}, {}
+    for tag, extra in (("one", []), ("two", ["--gpus", "2", "--jobs", "2"])):
+        cmd = [sys.executable, "-m", "gauspcc_amd.cli.compress", "--input_glob", str(src), "--output_folder", str(tmp_path / tag / "bin"),
+               "--resultdir", str(tmp_path / tag / "res"), "--ckpt", "synthetic", "--selftest-stub"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert r.stdout.count("Total: 7 |") == 1, r.stdout
+        if extra:
+            assert "2 files in flight per rank" in r.stdout, r.stdout
+        csv[tag] = pd.read_csv(tmp_path / tag / "res" / "ue_4stage_conv_data7.csv")
+        cmd = [sys.executable, "-m", "gauspcc_amd.cli.decompress", "--input_glob", str(tmp_path / tag / "bin" / "*.bin"),
+               "--output_folder", str(tmp_path / tag / "ply"), "--ckpt", "synthetic", "--selftest-stub"] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("Total: 7 |")]
+        assert len(lines) == 1, r.stdout                          # one summary line, from rank 0, over all seven files
+        summary[tag] = lines[0].split("|")[1].strip()             # "Decoding time:0.00Xs": the mean over every rank's files
+    assert csv["one"]["filedir"].tolist() == csv["two"]["filedir"].tolist()
+    for col in ("bpp", "enc_time", "file_size_bits", "num_points"):
+        assert np.allclose(csv["one"][col].to_numpy(), csv["two"][col].to_numpy(), rtol=1e-12), col
+    assert summary["one"] == summary["two"]
+    for i in range(7):
+        for sub, ext in (("bin", ".npy.bin"), ("ply", ".npy.bin.ply")):
+            assert (tmp_path / "one" / sub / f"c{i}{ext}").read_bytes() == (tmp_path / "two" / sub / f"c{i}{ext}").read_bytes()

@@ -2,6 +2,7 @@
 // points used by the parity tests (include/gauspcc.h).
 #include <algorithm>
 
+#include "fused.hpp"
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
@@ -40,6 +41,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->conv_products) (void)hipFree(c->conv_products);
+    if (c->fused_state) (void)hipFree(c->fused_state);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
@@ -553,7 +555,15 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             LAUNCH_CHECK();
             ConvBatch cb = {};
             cb.job[0] = ConvJob{xin, dw, res_dev ? xres : nullptr, xout};
-            GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, tiles, n, relu));
+            if (relu & 2) {
+                // test knob: the pair-plan form of the decoder's small levels (fused.hpp) -- products + ordered sums on a level-wide plan
+                if (T.L < 2 || !fused_level_ok(n, kernel_size)) return fail(GPCC_ERR_ARG, "the pair-plan convolution takes levels of at most %lld nodes below a parent level", (long long)FUSE_MAX_NODES);
+                PairPlan plan;
+                GP_TRY(pairplan_build(ctx, st, &T.lv[T.L - 2], tl[T.L - 1].cell_par, fin, nullptr, kernel_size, &plan, nullptr));
+                TAKE(P, float, plan.pcap * 32);
+                GP_TRY(plan_conv(st, plan, cb.job[0], P, relu & 1));
+            } else
+            GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, tiles, n, relu & 1));
             k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
             LAUNCH_CHECK();
             unsigned long long hpairs = 0;

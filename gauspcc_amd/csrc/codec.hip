@@ -14,6 +14,7 @@
 #include <chrono>
 
 #include <functional>
+#include "fused.hpp"
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
@@ -28,13 +29,18 @@ struct Trunk { float *x, *a, *b; };
 // internal return value of encode_body: a chunk came out larger than the staged decoder's LDS window (rangecoder.hpp:
 // rc_window_fits) -- the caller retries with chunk_log2 - 1 (the header records the value used)
 constexpr int ENC_RETRY_SMALLER_CHUNKS = -1000;
+// internal return value of decode_body: a persistent small-level launch timed out (fused.hip) -- the caller decodes again on the
+// launch-per-layer path (ctx->fused_off is set)
+constexpr int DEC_RETRY_UNFUSED = -1001;
 
 // Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; kit/nn.py:18-22).  Result in t.a.
-int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const ConvTiles &tiles, int64_t n)
+int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const ConvTiles &tiles, int64_t n, const PairPlan *plan = nullptr,
+              float *P = nullptr)
 {
     ConvBatch cb = {};
     auto one = [&](const float *in, int ci, const float *res, float *out) {
         cb.job[0] = ConvJob{in, m->conv[ci], res, out};
+        if (plan) return plan_conv(st, *plan, cb.job[0], P, 1);
         return sparse_conv(ctx, level, st, cb, 1, tiles, n, 1);
     };
     GP_TRY(conv_chain_begin(ctx, st));
@@ -593,6 +599,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         GP_TRY(tiles_view(ctx, st, pool, 0, 1, zero_base, &tilesP));
     }
     int64_t coded = 0;
+    // Small levels (fused.hpp): a chunked container's levels of at most FUSE_MAX_NODES nodes get a pair plan instead of a tile list,
+    // their chain runs as one persistent launch (plus one for the finished level's prior trunk).  planP: the plan of `cur`.
+    const bool fuse_ctx = fused_enabled() && !ctx->fused_off && v1 && version >= 1;
+    const int fmode = fused_mode();
+    PairPlan planP;
+    bool any_fused = false;
     // Two streams.  `st` carries the network of a level (18 convolutions, heads, range decoder).  The octree work that only
     // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's tile list (and cell
     // map) -- runs on the context's side stream beside the parent trunk's five convolutions and fills the idle tails
@@ -605,9 +617,16 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const int64_t np = cur.n;
         // ---- st: parent trunk
         TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
-        GP_TRY(dbg_mark(ctx, st, g * 100 + 1, pF, (size_t)np * 128));
-        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
+        float *Pp = nullptr;
+        if (planP.valid()) { TAKE_TOP(pp, float, planP.pcap * 32); Pp = pp; }
+        if (planP.valid() && fmode == 1) {
+            GP_TRY(fused_parent_trunk(ctx, st, m, planP, cur.occ, pF, pA, pB, Pp));
+            any_fused = true;
+        } else {
+            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
+            GP_TRY(dbg_mark(ctx, st, g * 100 + 1, pF, (size_t)np * 128));
+            GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np, planP.valid() ? &planP : nullptr, Pp));
+        }
         GP_TRY(dbg_mark(ctx, st, g * 100 + 2, pA, (size_t)np * 128));
         // ---- side: the child level's structure
         HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
@@ -632,8 +651,16 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it
+        // lane descriptors of this level's four streams (chunked containers: all levels parsed and uploaded once, behind the container)
+        if (v1 && g == 0) GP_TRY(upload_tables());
+        const RcPlan pl = rc_plan(nc, chunk_log2, version);
         ConvTiles tilesC;
-        {
+        PairPlan planC;
+        const bool child_plan = fuse_ctx && fused_level_ok(nc, m->k) && pl.dual == (version >= 3) && fused_windows_fit(nc, pl.nlanes, win_bytes[g]);
+        if (child_plan) {
+            StageTimer tm(ctx, sd, ST_TILES, 0.0);
+            GP_TRY(pairplan_build(ctx, sd, &cur, cellP, &chi, cellC, m->k, &planC, pairs_dev + g + 1));
+        } else {
             const TileLevel tl = {&chi, &cur, cellP, cellC};
             const int R = conv_pick_rows(nc, m->k);
             TilePool pool;
@@ -643,18 +670,15 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             tm.add_bytes(pool.alg_bytes);
         }
         GP_TRY(dbg_mark(ctx, sd, g * 100 + 3, chi.rkey, (size_t)nc * 8)); GP_TRY(dbg_mark(ctx, sd, g * 100 + 4, chi.parent, (size_t)nc * 4));
-        GP_TRY(dbg_mark(ctx, sd, g * 100 + 5, chi.m2r, (size_t)nc * 4)); GP_TRY(dbg_mark(ctx, sd, g * 100 + 6, tilesC.first, (size_t)(tilesC.nblk + 1) * 4));
-        GP_TRY(dbg_mark(ctx, sd, g * 100 + 7, tilesC.order, (size_t)tilesC.nblk * 4));
+        GP_TRY(dbg_mark(ctx, sd, g * 100 + 5, chi.m2r, (size_t)nc * 4));
+        if (!child_plan) { GP_TRY(dbg_mark(ctx, sd, g * 100 + 6, tilesC.first, (size_t)(tilesC.nblk + 1) * 4)); GP_TRY(dbg_mark(ctx, sd, g * 100 + 7, tilesC.order, (size_t)tilesC.nblk * 4)); }
         HIP_TRY(hipEventRecord(ctx->ev_side, sd));
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_side, 0));
-        // lane descriptors of this level's four streams (chunked containers: uploaded with the container, above)
-        const RcPlan pl = rc_plan(nc, chunk_log2, version);
         const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : nc;   // symbols of a lane
         const int nch = (int)pl.nlanes;
         const int clog = pl.llog;
         const RcChunk *dchunks = nullptr;
         if (v1) {
-            if (g == 0) GP_TRY(upload_tables());
             dchunks = dchunks_all + desc_at[g];
         } else {
             size_t at = 0;
@@ -665,23 +689,40 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         // ---- st: child trunk and the four stages
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
-        GP_TRY(dbg_mark(ctx, st, g * 100 + 8, cX, (size_t)nc * 128));
-        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));  // -> cA
-        GP_TRY(dbg_mark(ctx, st, g * 100 + 9, cA, (size_t)nc * 128));
+        float *Pc = nullptr;
+        if (child_plan) { TAKE_TOP(pc, float, planC.pcap * 32); Pc = pc; }
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);  // interleaved rows + the decoder's look-ahead
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, nc + 4); sym[s] = sy; }   // + the last group of four of the last lane
+        if (child_plan && fmode == 1) {
+            // the level's whole chain in one persistent launch (fused.hip)
+            if (g == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
+            FusedChild fa = {};
+            fa.pA = pA; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
+            for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g][s]; fa.sym[s] = sym[s]; }
+            fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ;
+            GP_TRY(fused_child_level(ctx, st, m, planC, fa));
+            any_fused = true;
+        } else {
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 8, cX, (size_t)nc * 128));
+        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc, child_plan ? &planC : nullptr, Pc));  // -> cA
+        GP_TRY(dbg_mark(ctx, st, g * 100 + 9, cA, (size_t)nc * 128));
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
             if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
+            if (child_plan) {
+                GP_TRY(plan_conv(st, planC, ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX}, Pc, 1));
+                GP_TRY(plan_conv(st, planC, ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB}, Pc, 0));
+            } else {
             GP_TRY(conv_chain_begin(ctx, st));
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 1));
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
             GP_TRY(conv_chain_end(ctx, st));
+            }
             GP_TRY(dbg_mark(ctx, st, g * 100 + 10 + 5 * s, xin, (size_t)nc * 128)); GP_TRY(dbg_mark(ctx, st, g * 100 + 11 + 5 * s, cX, (size_t)nc * 128));
             GP_TRY(dbg_mark(ctx, st, g * 100 + 12 + 5 * s, cB, (size_t)nc * 128));
             HeadArgs ha = {};
@@ -701,11 +742,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             GP_TRY(dbg_mark(ctx, st, g * 100 + 14 + 5 * s, sym[s], (size_t)nc));
         }
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, chi.m2r, nc, chi.occ)); }
+        }
         GP_TRY(dbg_mark(ctx, st, g * 100 + 30, chi.occ, (size_t)nc));
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
         coded += nc;
-        cur = chi; cellP = cellC; tilesP = tilesC;
+        cur = chi; cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan();
         ht.mark("dec level queued", g + 1, nc);
     }
     // ---- leaves
@@ -730,8 +772,16 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     GP_TRY(leaves_reference_order(ctx, st, &cur, bias_leaf, xyz, npts));
     unsigned long long hpairs[MAXLV];
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
+    htotal[40] = 0;
+    if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(htotal + 40, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     ht.mark("dec leaves done (sync)");
+    if (htotal[40]) {
+        // a persistent launch gave up waiting for its workgroups (fused.hip: bounded spins): nothing it produced is trusted
+        ctx->fused_off = true;
+        GP_TRY(fused_reset(ctx, st));
+        return DEC_RETRY_UNFUSED;
+    }
     if (v1) {
         for (int g = 0; g + 1 < L; ++g)
             if (htotal[1 + g] != (uint32_t)lvl_n[g + 1])
@@ -816,6 +866,11 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
         if (npts < 1 || npts > 8 * prev) return fail(GPCC_ERR_FORMAT, "header: %lld points under %lld finest nodes", (long long)npts, (long long)prev);
         if (nodes > (nbytes << 13)) return fail(GPCC_ERR_FORMAT, "header: %lld nodes cannot come from %lld bytes", (long long)nodes, (long long)nbytes);
         want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
+        if (fused_enabled()) {   // small levels (fused.hpp): the product buffer n K + 1 rows, the plan and its build scratch
+            int64_t nf = 0;
+            for (int d = 0; d < L; ++d) { const int64_t v = get32(bytes + 8 + 4 * d); if (fused_level_ok(v, m->k)) nf = std::max(nf, v); }
+            want += (size_t)nf * (size_t)m->K * (128 + 10 + 9) + ((size_t)4 << 20);
+        }
     }
     want = arena_scaled(want);
     int rc = GPCC_OK;
@@ -823,6 +878,12 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
     for (int attempt = 0; attempt < 6; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         rc = decode_body(ctx, m, bytes, nbytes, &xyz, n_out, posq_f16_out, stats, st, out_user, out_cap);
+        if (rc == DEC_RETRY_UNFUSED) {
+            static const bool loud = getenv("GAUSPCC_FUSED_QUIET") == nullptr;
+            if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; this context decodes on the launch-per-layer path from now on\n", ctx->device);
+            attempt -= 1;
+            continue;
+        }
         if (rc != GPCC_ERR_NOMEM) break;
         HIP_TRY(hipStreamSynchronize(st));
         want *= 2;

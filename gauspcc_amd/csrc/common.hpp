@@ -203,6 +203,12 @@ struct gpcc_ctx {
     // ordered on one stream)
     float *conv_products = nullptr;
     size_t conv_products_cap = 0;   // floats
+    // persistent small-level launches of the decoder (fused.hip): two grid-barrier blocks that alternate between launches and a
+    // sticky timeout word; fused_off: a launch timed out on this context (its workgroups were not all resident) -- the
+    // launch-per-layer path from then on
+    void *fused_state = nullptr;
+    int fused_flip = 0;
+    bool fused_off = false;
     // developer trace (gpcc_debug_trace_*): checksums of intermediate buffers of a decode, one (tag, sum) per mark, computed
     // on the stream that produced the buffer -- to find the first stage whose output differs between two runs
     bool dbg_on = false;

@@ -125,6 +125,8 @@ int cell_map_entries(int k);
 // count pass per level -> scan -> (one stream sync unless H <= 16) -> fill pass per level.  pairs_dev (nullable): [nlv]
 // accumulators, += the (row, present neighbour) pairs of each level.  Arrays come from the arena.
 int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int k, int R, int H, TilePool *pool, unsigned long long *pairs_dev);
+// small levels (fused.hip): dense neighbour map + per-(offset, row) ranks + per-row counts; writes the level's own cell map too
+int tiles_dense_map(hipStream_t st, const Level *par, const int32_t *cell_par, const Level *chi, int32_t *cell_own, int k, int32_t *nbr, uint16_t *rk, uint32_t *rowcnt);
 // the levels [l0, l1) of a pool as the work list of one set; row_base[l - l0] = first row of level l in the set's arrays
 int tiles_view(gpcc_ctx *ctx, hipStream_t st, const TilePool &pool, int l0, int l1, const int64_t *row_base, ConvTiles *T);
 

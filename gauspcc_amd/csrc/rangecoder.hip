@@ -12,12 +12,11 @@
 //     and then the run of underflow bits in a second (leading ones of low<<1 / zeros of high<<1);
 //   * bits move through a 64-bit reservoir, memory is touched 4 bytes at a time.
 // Integer / byte work; latency-bound per lane, not bandwidth-bound.
-#include "rangecoder.hpp"
+#include "rangecoder_dev.hpp"
 #include <type_traits>
 
 namespace gpcc {
 
-__device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
 
 // ------------------------------------------------------------------ rows ahead of the coder: three register sets
 // CDF rows (decoders) and packed symbol words (encoder) do not depend on coded symbols, so they are fetched ahead of the
@@ -36,7 +35,6 @@ __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32
 // flight at s_endpgm lands in LDS that may belong to another workgroup.  A three-thirds LDS ring with a whole phase between
 // a retiring vmcnt(0) and the first read was clean in 4 000 scene-steps -- and the register sets below are as fast
 // (51.6 vs 53.1 us per binary launch, 74.2 vs 77.7 4-ary) on documented semantics only.  The LDS-DMA code is gone.
-constexpr int RING_NPH = 3;                       // register sets
 constexpr int RING_PHASE = RC_RING_DEPTH / RING_NPH;
 static_assert(RING_PHASE == 16, "a phase's symbols leave as one 16-byte store");
 
@@ -241,20 +239,6 @@ struct BitWin {
     __device__ __forceinline__ uint32_t take32() { const uint32_t t = peek32(); bp += 32u; return t; }
 };
 
-__device__ __forceinline__ uint32_t scale(uint64_t span, uint32_t v) { return (uint32_t)((span * (uint64_t)v) >> 16); }
-// the same on d = span - 1 (fits 32 bits): (d + 1) * v = d * v + v -> one v_mad_u64_u32 and one v_alignbit
-// (d + 1) * v >> 16 for a 16-bit v, exactly.  Not `v_mad_u64_u32` (a quarter-rate 64-bit multiply on the symbol's critical
-// path): d = dh * 2^16 + dl, so (d v + v) >> 16 = dh v + ((dl + 1) v >> 16), both products below 2^32 and both 24-bit multiplies.
-__device__ __forceinline__ uint32_t scale_d(uint32_t d, uint32_t v)
-{
-#ifdef RC_SCALE_MUL64
-    return (uint32_t)(((uint64_t)d * (uint64_t)v + (uint64_t)v) >> 16);
-#else
-    const uint32_t dh = d >> 16, dl = d & 0xFFFFu;
-    return __umul24(dh, v) + ((__umul24(dl, v) + v) >> 16);
-#endif
-}
-
 // One lane per chunk.  The compact CDF rows of a chunk do not depend on decoded symbols, so they are fetched
 // DEPTH symbols ahead through a register ring (the loop is unrolled over the ring, nothing rotates): the
 // serial part of a symbol is then ALU only.  The loop bound is the longest chunk of the wave, shorter lanes
@@ -435,219 +419,21 @@ __global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__
 //   d rather than the span itself because a span of 2^32 does occur: a symbol of probability 2^-16 renormalises to it),
 // k = n1 + n2 as in the kernels above.  ~40 instructions per binary symbol instead of ~75 (profiles/r03_rc_decode_isa.txt).
 
-__device__ __forceinline__ uint32_t ones_below(uint32_t k) { return (1u << (k & 31u)) - 1u; }
-
-struct LaneWin {
-    const uint32_t *w;      // the lane's window in LDS
-    uint32_t q;             // bits consumed - 1 (starts at 31: the first dword is the initial value)
-    uint32_t w0, w1;        // dwords q / 32 and q / 32 + 1
-    uint32_t last;          // the last dword pair a reader may touch: a lane past its symbols, or fed a corrupt stream, runs
-                            // on garbage and its position may run anywhere -- an LDS access outside the workgroup's
-                            // allocation raises a memory violation that the runtime turns into abort()
-    __device__ __forceinline__ void init(const uint32_t *p, uint32_t rdw) { w = p; q = 31u; w0 = p[0]; w1 = p[1]; last = rdw - 2u; }
-    // the next 32 unread bits: bits [s, s + 32) of w0:w1 with s = q % 32 + 1 in [1, 32]
-    __device__ __forceinline__ uint32_t peek() const { return __builtin_amdgcn_alignbit(w0, w1, ~q); }
-    __device__ __forceinline__ void advance(uint32_t k) { q += k; const uint32_t i = min(q >> 5, last); w0 = w[i]; w1 = w[i + 1u]; }
-};
-
-// stage the byte windows of the workgroup's lanes (thread j * owner_stride holds the descriptor of lane j): win[j * rdw + d] = logical bytes 4d .. 4d + 3 of lane j, first byte in the
-// most significant position; zero past the lane's byte count (what the reference's reader supplies past the end of a stream)
-__device__ __forceinline__ void stage_windows(uint32_t *win, const uint8_t *__restrict__ bytes, const RcChunk &ch, int nl, uint32_t rdw, int nthreads, int owner_stride)
-{
-    const uint32_t total = (uint32_t)nl * rdw;
-    const uint32_t nbf = ch.nbytes;
-    for (uint32_t f0 = 0; f0 < total; f0 += 4u * (uint32_t)nthreads) {
-        uint32_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t f = f0 + (uint32_t)u * (uint32_t)nthreads + threadIdx.x;
-            const uint32_t j = min(f / rdw, (uint32_t)nl - 1u), dq = f - (f / rdw) * rdw;
-            const uint32_t off = (uint32_t)__shfl((int)ch.byte_off, (int)j * owner_stride, 64);
-            const uint32_t nb = (uint32_t)__shfl((int)nbf, (int)j * owner_stride, 64);
-            const bool back = (nb & RC_BACKWARDS) != 0u;
-            const uint32_t n = nb & ~RC_BACKWARDS;
-            uint32_t raw = 0;
-            if (f < total && 4u * dq < n) {
-                const uint8_t *src = back ? bytes + (size_t)off - 4u * (size_t)dq - 3u : bytes + (size_t)off + 4u * (size_t)dq;
-                __builtin_memcpy(&raw, src, 4);
-                if (!back) raw = __builtin_bswap32(raw);
-                const uint32_t left = n - 4u * dq;                       // valid bytes of this dword: the top `left` of them
-                if (left < 4u) raw &= 0xFFFFFFFFu << (8u * (4u - left));
-            }
-            v[u] = raw;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t f = f0 + (uint32_t)u * (uint32_t)nthreads + threadIdx.x;
-            if (f < total) win[f] = v[u];
-        }
-    }
-}
-
-// one symbol of a lane: interval update + renormalisation on (low, d = span - 1, x); `t` = the next 32 unread bits.
-// lo / d1 = scaled lower bound and width - 1 of the decoded symbol's slice of [0, span).
-__device__ __forceinline__ uint32_t ffbh(uint32_t v) { uint32_t r; asm("v_ffbh_u32_e32 %0, %1" : "=v"(r) : "v"(v)); return r; }   // v != 0: no zero check
-__device__ __forceinline__ void rc_renorm(uint32_t &low, uint32_t &d, uint32_t &x, uint32_t lo, uint32_t d1, uint32_t t, uint32_t &k_out)
-{
-    const uint32_t x1 = x - lo, low1 = low + lo, high1 = low1 + d1;
-    const uint32_t n1 = ffbh(low1 ^ high1);                                          // low1 < high1 for every valid row: 0..31
-    const uint32_t l1 = low1 << n1, h1 = (high1 << n1) | ~(0xFFFFFFFFu << n1);
-    const uint32_t n2 = ffbh((((~l1) | h1) << 1) | 1u);                              // run of (low bit 1, high bit 0) behind the top bit
-    const uint32_t k = n1 + n2;                                                      // <= 19 for a valid row (shifts use the low 5 / 6 bits)
-    low = (l1 << n2) & 0x7FFFFFFFu;
-    d = (d1 << k) | ~(0xFFFFFFFFu << k);                                             // span - 1: a span of 2^32 (a certain symbol's bounds renormalised) fits
-    x = (uint32_t)(((((uint64_t)x1) << 32 | (uint64_t)t) << k) >> 32);
-    k_out = k;
-}
-
-// Lanes of 3- and 5-entry rows, byte windows staged in LDS, rows in three register sets (header comment).  A lane's first
-// symbol sits on a multiple of 16 (lanes are 2^llog >= 32 symbols) and `sym` has 3 bytes of slack behind the stream for the
-// last group of its last lane.
+// The staged decoders (byte windows in LDS, rows in three register sets) live in rangecoder_dev.hpp as functions of one
+// wave; these kernels are one wave per workgroup.
 template <int LP>
 __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                       int nchunks, int lpw, uint32_t rdw, uint8_t *__restrict__ sym)
 {
-    static_assert(LP == 3 || LP == 5, "17-entry rows are decoded by k_rc_decode17_lds");
-    constexpr int RS = LP == 3 ? 1 : 4;
-    constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
     extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows
-    const int lane = threadIdx.x;
-    const int c = blockIdx.x * lpw + lane;
-    RcChunk ch = {0, 0, 0, 0, 0, 0};
-    if (lane < lpw && c < nchunks) ch = chunks[c];
-    uint32_t nmax = ch.n;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
-    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-    if (nmax == 0) return;
-    stage_windows(win, bytes, ch, lpw, rdw, 64, 1);
-    __syncthreads();
-    LaneWin in;
-    in.init(win + (size_t)min(lane, lpw - 1) * rdw, rdw);
-    const uint16_t *rowp = cdf + (size_t)ch.first * RS;
-    const size_t rstep = (size_t)ch.stride * RS;
-    struct Row { uint32_t a, b; };
-    Row regs[RING_NPH][PH];
-    auto fill = [&](int h) {
-#pragma unroll
-        for (int dd = 0; dd < PH; ++dd) {
-            if (LP == 3) { regs[h][dd].a = rowp[0]; regs[h][dd].b = 0; }
-            else { const uint2 q = *reinterpret_cast<const uint2 *>(rowp); regs[h][dd].a = q.x; regs[h][dd].b = q.y; }
-            rowp += rstep;
-        }
-    };
-    uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-#pragma unroll
-    for (int h = 0; h < RING_NPH; ++h) fill(h);
-    uint8_t *out = sym + ch.out;
-    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
-#pragma unroll
-        for (int h = 0; h < RING_NPH; ++h) {
-            uint32_t pack[PH / 4];
-#pragma unroll
-            for (int dd = 0; dd < PH; ++dd) {
-                const uint32_t r0 = regs[h][dd].a, r1 = regs[h][dd].b;
-                const uint32_t t = in.peek();
-                uint32_t s, lo, d1;
-                if (LP == 3) {
-                    const uint32_t t1 = scale_d(d, r0);
-                    const bool ge = t1 <= x;
-                    s = ge; lo = ge ? t1 : 0u;
-                    d1 = ge ? d - t1 : t1 - 1u;
-                } else {
-                    const uint32_t t1 = scale_d(d, r0 & 0xFFFFu), t2 = scale_d(d, r0 >> 16), t3 = scale_d(d, r1 & 0xFFFFu);
-                    const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
-                    lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
-                    const uint32_t hi = g3 ? d + 1u : (g2 ? t3 : (g1 ? t2 : t1));
-                    s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
-                    d1 = hi + ~lo;
-                }
-                if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
-                rc_renorm(low, d, x, lo, d1, t, k);
-                in.advance(k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) fill(h);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t ib = i0 + (uint32_t)(h * PH);
-            if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
-            else {
-#pragma unroll
-                for (int q = 0; q < PH / 4; ++q)
-                    if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];
-            }
-        }
-    }
+    rc_decode_lds_wave<LP, RING_PHASE, true>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * lpw, (int)threadIdx.x, lpw, rdw, sym, win);
 }
 
-// 17-entry rows: a 16-lane group per coder lane as in k_rc_decode17, the byte windows staged in LDS, every lane's own entry
-// of the coming rows in three register sets.
 __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                         int nchunks, uint32_t rdw, uint8_t *__restrict__ sym)
 {
-    constexpr int DEPTH = RC_RING_DEPTH, PH = RING_PHASE;
-    static_assert(2 * DEPTH <= RC_ROW_LOOKAHEAD, "row look-ahead exceeds the capacity contract (rc_rows_capacity)");
     extern __shared__ uint32_t win[];
-    const int lane = threadIdx.x, grp = lane >> 4, kk = lane & 15;
-    const int c = blockIdx.x * 4 + grp;
-    RcChunk ch = {0, 0, 0, 0, 0, 0};
-    if (c < nchunks) ch = chunks[c];
-    uint32_t nmax = ch.n;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d));
-    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
-    if (nmax == 0) return;
-    stage_windows(win, bytes, ch, 4, rdw, 64, 16);   // coder lane j's descriptor lives in thread 16 j
-    __syncthreads();
-    LaneWin in;
-    in.init(win + (size_t)grp * rdw, rdw);
-    // compact row: v[1..15] at [0..14]; lane 0 stands for v[0] = 0 and reads the unused slot 15
-    const uint16_t *rowp = cdf + (size_t)ch.first * 16 + (size_t)(kk ? kk - 1 : 15);
-    const size_t rstep = (size_t)ch.stride * 16;
-    uint32_t regs[RING_NPH][PH];
-    auto fill = [&](int h) {
-#pragma unroll
-        for (int dd = 0; dd < PH; ++dd) { regs[h][dd] = rowp[0]; rowp += rstep; }
-    };
-    const int g16 = grp << 4;
-    uint32_t low = 0, d = 0xFFFFFFFFu, x = in.w0, k;
-#pragma unroll
-    for (int h = 0; h < RING_NPH; ++h) fill(h);
-    uint8_t *out = sym + ch.out;
-    for (uint32_t i0 = 0; i0 < nmax; i0 += DEPTH) {
-#pragma unroll
-        for (int h = 0; h < RING_NPH; ++h) {
-            uint32_t pack[PH / 4];
-#pragma unroll
-            for (int dd = 0; dd < PH; ++dd) {
-                const uint32_t v = regs[h][dd];
-                const uint32_t tw = in.peek();
-                const uint32_t t = kk ? scale_d(d, v) : 0u;
-                const uint64_t bal = __ballot(t <= x);
-                const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
-                const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
-                const uint32_t s = ((uint32_t)__popc(bits) - 1u) & 15u;
-                const uint32_t lo = (uint32_t)__shfl((int)t, g16 + (int)s);
-                const uint32_t nx = (uint32_t)__shfl((int)t, g16 + (int)min(s + 1u, 15u));
-                const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
-                if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
-                rc_renorm(low, d, x, lo, d1, tw, k);
-                in.advance(k);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (i0 + (uint32_t)(DEPTH + h * PH) < nmax) fill(h);   // (wave-uniform) rows no lane will use are not fetched
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t ib = i0 + (uint32_t)(h * PH);
-            if (kk == 0) {
-                if (ib + (uint32_t)PH <= ch.n) *reinterpret_cast<uint4 *>(out + ib) = make_uint4(pack[0], pack[1], pack[2], pack[3]);
-                else {
-#pragma unroll
-                    for (int q = 0; q < PH / 4; ++q)
-                        if (ib + 4u * (uint32_t)q < ch.n) *reinterpret_cast<uint32_t *>(out + ib + 4 * q) = pack[q];
-                }
-            }
-        }
-    }
+    rc_decode17_lds_wave<RING_PHASE, true>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * 4, (int)threadIdx.x, rdw, sym, win);
 }
 
 int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt)

@@ -37,6 +37,9 @@ struct LevelTilesArgs {
     // pass 2
     const uint32_t *first;      // [pool blocks + 1] first tile of each block
     int32_t *tj; uint8_t *tr; uint32_t *toc;
+    // DENSE count pass (small levels, fused.hip: the pair plan): the whole neighbour map and, per (offset, row), the rank of the
+    // offset among the row's present offsets; rowcnt[row] = its present offsets
+    int32_t *nbr; uint16_t *rk; uint32_t *rowcnt;
 };
 
 // How a 64-lane wave maps to blocks.  H = 16 / 32: the wave takes 64 consecutive rows = 4 / 2 whole blocks side by side as
@@ -131,9 +134,10 @@ __device__ __forceinline__ void chunk_tables(const uint8_t *__restrict__ cnt_blk
 // TALL: the wave is one 64-row chunk of a block taller than 64 rows; else its block(s) fit the wave.
 // The k^2 neighbours of a (dy, dx) plane are computed as one batch (independent LDS reads and integer chains in flight
 // together -- a wave alone on its SIMD has nothing else to hide their latency behind), then compacted one by one.
-template <int KS, bool FILL, bool TALL>
+template <int KS, bool FILL, bool TALL, bool DENSE = false>
 __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint32_t bid)
 {
+    static_assert(!DENSE || (!FILL && !TALL), "the dense map is a count-pass output of blocks that fit a wave");
     constexpr int r = KS / 2, K = KS * KS * KS, PR = (r + 1) / 2, PW = 2 * PR + 1, NP = PW * PW * PW;
     __shared__ uint32_t cst[64 * NP];     // child start of every staged cell
     __shared__ uint8_t coc[64 * NP];      // its occupancy (0 = the cell does not exist)
@@ -191,6 +195,7 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
     uint32_t t = (FILL && m.blk_live) ? a.first[m.blk] : 0u;   // running tile of my block (blocks that fit the wave)
     const uint32_t t0 = t;
     uint32_t npairs = 0;
+    uint32_t dcount = 0;   // DENSE: present offsets of my row so far
     const int nc32 = (int)min(a.nc, (int64_t)INT32_MAX);
     for (int dz = -r; dz <= r; ++dz) {
         const int tz = cz + dz;
@@ -231,6 +236,17 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
                     a.cell_c[(int64_t)((ix - r + PR) + PW * (iy - r + PR) + PW * PW * (dz + PR)) * a.nc + i] = jv[iy * KS + ix];
         }
         const int ob = (dz + r) * KS * KS;
+        if constexpr (DENSE) {
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < KS * KS; ++u) {
+                    a.nbr[(int64_t)(ob + u) * a.nc + i] = jv[u];
+                    a.rk[(int64_t)(ob + u) * a.nc + i] = (uint16_t)dcount;
+                    dcount += jv[u] >= 0 ? 1u : 0u;
+                }
+            }
+            continue;
+        }
         if (!TALL) {
 #pragma unroll
             for (int u = 0; u < KS * KS; ++u) pack_local<FILL>(a, m, ob + u, jv[u], t, npairs);
@@ -268,6 +284,10 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
 #ifdef TILES_TIMING
     const long long tc2 = clock64();
 #endif
+    if constexpr (DENSE) {
+        if (live) a.rowcnt[i] = dcount;
+        return;
+    }
     if (!FILL) {
         if (!TALL && m.ls == 0 && m.blk_live) a.per_block[m.blk] = t;
         // pairs: tall chunks hold partial sums in lanes 0 .. k^2 - 1; one atomic per wave on one of 64 counters (a single
@@ -288,6 +308,8 @@ __device__ __forceinline__ void chunk_tiles(const LevelTilesArgs &a, const uint3
 
 template <int KS, bool FILL, bool TALL>
 __global__ __launch_bounds__(64) void k_chunk_tiles(LevelTilesArgs a) { chunk_tiles<KS, FILL, TALL>(a, blockIdx.x); }
+template <int KS>
+__global__ __launch_bounds__(64) void k_chunk_dense(LevelTilesArgs a) { chunk_tiles<KS, false, false, true>(a, blockIdx.x); }
 
 // The fill pass of every level of a pool in ONE launch (an encode builds the tile lists of its whole tree; the passes of
 // different levels are independent once the counts are scanned, and ten of its fifteen levels are launch-latency-bound).
@@ -591,6 +613,26 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
             LAUNCH_CHECK();
         }
     }
+    return GPCC_OK;
+}
+
+// Small levels (fused.hip): the level's whole neighbour map nbr[K][n] (-1 = absent), rk[K][n] = rank of the offset among the
+// row's present offsets, rowcnt[n] -- and, as the count pass of tiles_build does, the level's own cell map for the level below.
+int tiles_dense_map(hipStream_t st, const Level *par, const int32_t *cell_par, const Level *chi, int32_t *cell_own, int k, int32_t *nbr, uint16_t *rk, uint32_t *rowcnt)
+{
+    if (!par) return fail(GPCC_ERR_ARG, "internal: dense map of a level without a parent");
+    LevelTilesArgs a = {};
+    a.H = 64; a.blk0 = 0; a.cell_c = cell_own; a.nbr = nbr; a.rk = rk; a.rowcnt = rowcnt;
+    a.rkey_c = chi->rkey; a.parent_c = chi->parent; a.nc = chi->n;
+    a.cell_p = cell_par; a.np = par->n; a.occ_p = par->occ; a.cstart_p = par->cstart;
+    const unsigned grid = (unsigned)cdiv(chi->n, 64);
+    switch (k) {
+    case 3: k_chunk_dense<3><<<grid, 64, 0, st>>>(a); break;
+    case 5: k_chunk_dense<5><<<grid, 64, 0, st>>>(a); break;
+    case 7: k_chunk_dense<7><<<grid, 64, 0, st>>>(a); break;
+    default: return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+    }
+    LAUNCH_CHECK();
     return GPCC_OK;
 }
 

@@ -180,7 +180,8 @@ GPCC_API int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz_dev, int64_t n,
 /* spnn.Conv3d (stride 1) on raster-sorted coordinates: torchsparse 2.1.0 (not in tree), call
  * sites network_ue_4stage_conv.py:17-62.  in/out (n,C) float32 device in LOGICAL channel
  * order; w = upstream (k^3,C,C) host; residual may be NULL.  Also returns the number of
- * (node, neighbour) pairs. */
+ * (node, neighbour) pairs.  relu: bit 0 = ReLU; bit 1 (test knob) = run the pair-plan form the decoder uses on its small levels
+ * (csrc/fused.hpp; at most 16384 points) instead of the block-tile kernels -- same sums in the same order, same bits. */
 GPCC_API int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted_dev, int64_t n, int channels, int kernel_size,
                 const float *in_dev, const float *w_host, const float *res_dev, int relu,
                 float *out_dev, int64_t *pairs_out, void *stream);

@@ -36,7 +36,7 @@ def build_octree(xyz: np.ndarray):
     return [(coords[d][: nodes[d]].copy(), occ[d][: nodes[d]].copy()) for d in range(levels.value)]
 
 
-def conv3d(xyz_sorted: np.ndarray, feats: np.ndarray, w: np.ndarray, k: int, res=None, relu=False):
+def conv3d(xyz_sorted: np.ndarray, feats: np.ndarray, w: np.ndarray, k: int, res=None, relu=False, plan=False):
     x = torch.tensor(np.ascontiguousarray(xyz_sorted, dtype=np.int32), device=dev())
     f = torch.tensor(np.ascontiguousarray(feats, dtype=np.float32), device=dev())
     r = None if res is None else torch.tensor(np.ascontiguousarray(res, dtype=np.float32), device=dev())
@@ -44,7 +44,7 @@ def conv3d(xyz_sorted: np.ndarray, feats: np.ndarray, w: np.ndarray, k: int, res
     w = np.ascontiguousarray(w, dtype=np.float32)
     pairs = C.c_int64()
     _lib.check(_lib.lib().gpcc_conv3d(runtime.context(dev()), x.data_ptr(), x.shape[0], 32, k, f.data_ptr(), w.ctypes.data,
-                                      None if r is None else r.data_ptr(), int(relu), out.data_ptr(), C.byref(pairs), _st()))
+                                      None if r is None else r.data_ptr(), int(relu) | (2 if plan else 0), out.data_ptr(), C.byref(pairs), _st()))
     return out.cpu().numpy(), pairs.value
 
 

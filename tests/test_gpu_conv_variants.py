@@ -67,6 +67,24 @@ print("variant ok", pairs)
 def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)
     e.update(env)
+    e.setdefault("GAUSPCC_FUSED", "0")   # these variants are about the block-tile kernels: keep the decoder's small levels on them
+    r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("env", [
+    {"GAUSPCC_FUSED": "1"},                                  # the default: persistent small-level launches (csrc/fused.hpp)
+    {"GAUSPCC_FUSED": "2"},                                  # the same pair plans, every phase its own launch
+    {"GAUSPCC_FUSED": "1", "GAUSPCC_FUSED_GRID": "8"},       # one workgroup per XCC
+    {"GAUSPCC_FUSED": "1", "GAUSPCC_FUSED_GRID": "37"},      # uneven XCC membership
+    {"GAUSPCC_FUSED": "1", "GAUSPCC_FUSED_GRID": "256"},     # every CU
+    {"GAUSPCC_FUSED": "1", "GAUSPCC_FUSED_MAX": "700"},      # only the tiniest levels fused: the hand-over to the block-tile path three levels earlier
+], ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+def test_fused_small_levels_variant_bit_exact(env):
+    """The decoder's small levels through the pair-plan path (reference chain: HAC/utils/pcc_utils.py:283-372): decoded geometry ==
+    the oracle's, whatever the grid of the persistent launch and wherever the hand-over to the block-tile kernels lies."""
+    e = dict(os.environ)
+    e.update(env)
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

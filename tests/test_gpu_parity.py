@@ -218,6 +218,29 @@ def test_conv3d_bit_exact(gh, orc, k, n):
     assert np.array_equal(out2, orc.conv(x, nb, w, res=res, relu=True))
 
 
+@pytest.mark.parametrize("k,n,spread", [(3, 40, 6), (3, 4000, 12), (5, 37, 4), (5, 300, 5), (5, 5000, 12), (5, 9000, 60), (5, 16000, 40), (7, 2500, 12)])
+def test_conv3d_pair_plan_bit_exact(gh, orc, k, n, spread):
+    """The pair-plan form of the convolution (csrc/fused.hpp: level-wide offset tiles -> product buffer -> ordered row sums), which
+    the decoder's persistent small-level kernels run in two phases, against the oracle's spnn.Conv3d restatement
+    (network_ue_4stage_conv.py:17-62): dense and sparse levels, with and without residual + ReLU."""
+    rng = np.random.RandomState(k * 1000 + n % 991)
+    pts = np.unique(rng.randint(-spread, spread, (n * 3, 3)), axis=0)
+    pts = pts[rng.permutation(len(pts))[:n]].astype(np.int32)
+    pts = pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))]
+    n = len(pts)
+    x = rng.randn(n, 32).astype(np.float32)
+    w = (rng.rand(k ** 3, 32, 32).astype(np.float32) - 0.5) * 0.2
+    res = rng.randn(n, 32).astype(np.float32)
+    nb = orc.nbr(pts, k)
+    out, _ = gh.conv3d(pts, x, w, k, plan=True)
+    ref = orc.conv(x, nb, w)
+    assert np.array_equal(out, ref), f"max abs diff {np.abs(out - ref).max()}"
+    out2, _ = gh.conv3d(pts, x, w, k, res=res, relu=True, plan=True)
+    assert np.array_equal(out2, orc.conv(x, nb, w, res=res, relu=True))
+    base, _ = gh.conv3d(pts, x, w, k, res=res, relu=True)
+    assert np.array_equal(out2, base)          # and the block-tile kernels of the big levels: the same bits
+
+
 def test_conv3d_transpose_detecting(gh, orc):
     """Asymmetric weights: a single non-zero (k_in, c_out) entry per offset catches any
     row/column or offset-order mix-up in the MFMA fragment layouts."""

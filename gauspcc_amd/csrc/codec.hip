@@ -604,6 +604,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     const bool fuse_ctx = fused_enabled() && !ctx->fused_off && v1 && version >= 1;
     const int fmode = fused_mode();
     PairPlan planP;
+    int64_t planP_np = 0;          // nodes of the level above planP's (the grid policy's density hint)
     bool any_fused = false;
     // Two streams.  `st` carries the network of a level (18 convolutions, heads, range decoder).  The octree work that only
     // needs the parent level's occupancy -- expansion into the child level, raster ranks, the child's tile list (and cell
@@ -620,7 +621,12 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         float *Pp = nullptr;
         if (planP.valid()) { TAKE_TOP(pp, float, planP.pcap * 32); Pp = pp; }
         if (planP.valid() && fmode == 1) {
-            GP_TRY(fused_parent_trunk(ctx, st, m, planP, cur.occ, pF, pA, pB, Pp));
+            // (profiling: a persistent launch counts as the convolutions it contains -- 5 here, 13 for a level's chain -- over its whole
+            // time, heads / coder phases and barriers included: the conv roofline figure stays conservative)
+            ConvRec rec = {0, 0, g, 1, 0, 0, (long long)np, 0, 5};
+            if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
+            GP_TRY(fused_parent_trunk(ctx, st, m, planP, planP_np, cur.occ, pF, pA, pB, Pp));
+            if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
             { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
@@ -656,7 +662,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const RcPlan pl = rc_plan(nc, chunk_log2, version);
         ConvTiles tilesC;
         PairPlan planC;
-        const bool child_plan = fuse_ctx && fused_level_ok(nc, m->k) && pl.dual == (version >= 3) && fused_windows_fit(nc, pl.nlanes, win_bytes[g]);
+        const bool child_plan = fuse_ctx && fused_level_ok(nc, m->k) && pl.dual == (version >= 3) && fused_windows_fit(nc, cur.n, pl.nlanes, win_bytes[g]);
         if (child_plan) {
             StageTimer tm(ctx, sd, ST_TILES, 0.0);
             GP_TRY(pairplan_build(ctx, sd, &cur, cellP, &chi, cellC, m->k, &planC, pairs_dev + g + 1));
@@ -698,10 +704,13 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             // the level's whole chain in one persistent launch (fused.hip)
             if (g == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             FusedChild fa = {};
-            fa.pA = pA; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
+            fa.pA = pA; fa.np = np; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
             for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g][s]; fa.sym[s] = sym[s]; }
             fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ;
+            ConvRec rec = {0, 0, g + 1, 1, 0, 0, (long long)nc, 0, 13};
+            if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
             GP_TRY(fused_child_level(ctx, st, m, planC, fa));
+            if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
@@ -747,7 +756,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
         coded += nc;
-        cur = chi; cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan();
+        cur = chi; cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan(); planP_np = np;
         ht.mark("dec level queued", g + 1, nc);
     }
     // ---- leaves

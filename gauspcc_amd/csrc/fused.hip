@@ -151,89 +151,154 @@ struct PlanV {
 };
 inline PlanV plan_view(const PairPlan &p) { return PlanV{p.rowstart, p.ot_j, p.ot_q, p.ot_o, p.ntiles, (int)p.n, p.K, (uint32_t)p.tcap, (uint32_t)p.pcap}; }
 
-// PRODUCTS: wave gw of NW takes tiles gw, gw + NW, ... two at a time (their loads in flight together).  Per tile the 16 x 32
-// products of its pairs -- 16 MFMAs from a zero accumulator, the transposed product D^T = W^T X^T of the asm conv loop, so
-// lane (g, e) holds four physically consecutive channels of tile row e per accumulator -- go to the pairs' rows of P.
+// PRODUCTS.  Per tile the 16 x 32 products of its pairs -- 16 MFMAs from a zero accumulator, the transposed product
+// D^T = W^T X^T of the asm conv loop, so lane (g, e) holds four physically consecutive channels of tile row e per accumulator
+// -- go to the pairs' rows of P.  Two tiles at a time (their loads in flight together).
 // in: the layer's input rows (written by other workgroups a grid barrier ago: no __restrict__ / const promises to the compiler).
-__device__ __forceinline__ void phase_products(const PlanV &pl, const float *in, const float *__restrict__ wt, float *P, uint32_t gw, uint32_t NW, int lane)
+struct TileHdr { uint32_t oc, j, q; };   // offset | count << 16; neighbour row and P row of this lane's entry (clamped)
+__device__ __forceinline__ TileHdr tile_hdr(const PlanV &pl, uint32_t t, int e)
 {
-    const uint32_t nt = min((uint32_t)__builtin_amdgcn_readfirstlane((int)*pl.ntiles), pl.tcap);
+    TileHdr h;
+    h.oc = pl.ot_o[t];
+    h.j = min((uint32_t)pl.ot_j[(size_t)t * 16 + e], (uint32_t)pl.n - 1u);
+    h.q = min(pl.ot_q[(size_t)t * 16 + e], pl.pcap - 1u);
+    return h;
+}
+#define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+__device__ __forceinline__ void tile_pair(const PlanV &pl, const TileHdr &ha, const TileHdr &hb, bool two, const float *in, const float *__restrict__ wt, float *P, int lane)
+{
     const int e = lane & 15, g = lane >> 4;
-    const uint32_t nm1 = (uint32_t)pl.n - 1u, km1 = (uint32_t)pl.K - 1u, pm1 = pl.pcap - 1u;
+    const uint32_t km1 = (uint32_t)pl.K - 1u;
     const float *inl = in + 4 * g;
     const float *wl = wt + lane * 4;
-#define MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
-    for (uint32_t t = gw; t < nt; t += 2u * NW) {
-        const bool two = t + NW < nt;                    // wave-uniform
-        const uint32_t tb = two ? t + NW : t;
-        const uint32_t oca = pl.ot_o[t], ocb = pl.ot_o[tb];
-        const uint32_t ja = min((uint32_t)pl.ot_j[(size_t)t * 16 + e], nm1), jb = min((uint32_t)pl.ot_j[(size_t)tb * 16 + e], nm1);
-        const uint32_t qa = min(pl.ot_q[(size_t)t * 16 + e], pm1), qb = min(pl.ot_q[(size_t)tb * 16 + e], pm1);
-        const float *pa = inl + (size_t)ja * 32, *pb = inl + (size_t)jb * 32;
-        const float *wa = wl + (size_t)min(oca & 0xFFFFu, km1) * 1024, *wb = wl + (size_t)min(ocb & 0xFFFFu, km1) * 1024;
-        const float4 xa0 = ld4(pa), xa1 = ld4(pa + 16), xb0 = ld4(pb), xb1 = ld4(pb + 16);
-        const float4 wa0 = ld4(wa), wa1 = ld4(wa + 256), wa2 = ld4(wa + 512), wa3 = ld4(wa + 768);
-        const float4 wb0 = ld4(wb), wb1 = ld4(wb + 256), wb2 = ld4(wb + 512), wb3 = ld4(wb + 768);
-        {
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-            MF(c0, wa0.x, xa0.x); MF(c1, wa2.x, xa0.x);
-            MF(c0, wa0.y, xa0.y); MF(c1, wa2.y, xa0.y);
-            MF(c0, wa0.z, xa0.z); MF(c1, wa2.z, xa0.z);
-            MF(c0, wa0.w, xa0.w); MF(c1, wa2.w, xa0.w);
-            MF(c0, wa1.x, xa1.x); MF(c1, wa3.x, xa1.x);
-            MF(c0, wa1.y, xa1.y); MF(c1, wa3.y, xa1.y);
-            MF(c0, wa1.z, xa1.z); MF(c1, wa3.z, xa1.z);
-            MF(c0, wa1.w, xa1.w); MF(c1, wa3.w, xa1.w);
-            if ((uint32_t)e < (oca >> 16)) {
-                float *dst = P + (size_t)qa * 32 + 4 * g;
-                *reinterpret_cast<float4 *>(dst) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-                *reinterpret_cast<float4 *>(dst + 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-            }
-        }
-        if (two) {
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-            MF(c0, wb0.x, xb0.x); MF(c1, wb2.x, xb0.x);
-            MF(c0, wb0.y, xb0.y); MF(c1, wb2.y, xb0.y);
-            MF(c0, wb0.z, xb0.z); MF(c1, wb2.z, xb0.z);
-            MF(c0, wb0.w, xb0.w); MF(c1, wb2.w, xb0.w);
-            MF(c0, wb1.x, xb1.x); MF(c1, wb3.x, xb1.x);
-            MF(c0, wb1.y, xb1.y); MF(c1, wb3.y, xb1.y);
-            MF(c0, wb1.z, xb1.z); MF(c1, wb3.z, xb1.z);
-            MF(c0, wb1.w, xb1.w); MF(c1, wb3.w, xb1.w);
-            if ((uint32_t)e < (ocb >> 16)) {
-                float *dst = P + (size_t)qb * 32 + 4 * g;
-                *reinterpret_cast<float4 *>(dst) = make_float4(c0[0], c0[1], c0[2], c0[3]);
-                *reinterpret_cast<float4 *>(dst + 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
-            }
+    const float *pa = inl + (size_t)ha.j * 32, *pb = inl + (size_t)hb.j * 32;
+    const float *wa = wl + (size_t)min(ha.oc & 0xFFFFu, km1) * 1024, *wb = wl + (size_t)min(hb.oc & 0xFFFFu, km1) * 1024;
+    const float4 xa0 = ld4(pa), xa1 = ld4(pa + 16), xb0 = ld4(pb), xb1 = ld4(pb + 16);
+    const float4 wa0 = ld4(wa), wa1 = ld4(wa + 256), wa2 = ld4(wa + 512), wa3 = ld4(wa + 768);
+    const float4 wb0 = ld4(wb), wb1 = ld4(wb + 256), wb2 = ld4(wb + 512), wb3 = ld4(wb + 768);
+    {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        MF(c0, wa0.x, xa0.x); MF(c1, wa2.x, xa0.x);
+        MF(c0, wa0.y, xa0.y); MF(c1, wa2.y, xa0.y);
+        MF(c0, wa0.z, xa0.z); MF(c1, wa2.z, xa0.z);
+        MF(c0, wa0.w, xa0.w); MF(c1, wa2.w, xa0.w);
+        MF(c0, wa1.x, xa1.x); MF(c1, wa3.x, xa1.x);
+        MF(c0, wa1.y, xa1.y); MF(c1, wa3.y, xa1.y);
+        MF(c0, wa1.z, xa1.z); MF(c1, wa3.z, xa1.z);
+        MF(c0, wa1.w, xa1.w); MF(c1, wa3.w, xa1.w);
+        if ((uint32_t)e < (ha.oc >> 16)) {
+            float *dst = P + (size_t)ha.q * 32 + 4 * g;
+            *reinterpret_cast<float4 *>(dst) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+            *reinterpret_cast<float4 *>(dst + 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
         }
     }
+    if (two) {
+        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+        MF(c0, wb0.x, xb0.x); MF(c1, wb2.x, xb0.x);
+        MF(c0, wb0.y, xb0.y); MF(c1, wb2.y, xb0.y);
+        MF(c0, wb0.z, xb0.z); MF(c1, wb2.z, xb0.z);
+        MF(c0, wb0.w, xb0.w); MF(c1, wb2.w, xb0.w);
+        MF(c0, wb1.x, xb1.x); MF(c1, wb3.x, xb1.x);
+        MF(c0, wb1.y, xb1.y); MF(c1, wb3.y, xb1.y);
+        MF(c0, wb1.z, xb1.z); MF(c1, wb3.z, xb1.z);
+        MF(c0, wb1.w, xb1.w); MF(c1, wb3.w, xb1.w);
+        if ((uint32_t)e < (hb.oc >> 16)) {
+            float *dst = P + (size_t)hb.q * 32 + 4 * g;
+            *reinterpret_cast<float4 *>(dst) = make_float4(c0[0], c0[1], c0[2], c0[3]);
+            *reinterpret_cast<float4 *>(dst + 16) = make_float4(c1[0], c1[1], c1[2], c1[3]);
+        }
+    }
+}
 #undef MF
+
+// wave gw of NW takes tiles gw, gw + NW, ... starting with tile number `first` of its sequence (the ones before are cached)
+__device__ __forceinline__ void phase_products(const PlanV &pl, const float *in, const float *__restrict__ wt, float *P, uint32_t gw, uint32_t NW, int lane, uint32_t first = 0u)
+{
+    const uint32_t nt = min((uint32_t)__builtin_amdgcn_readfirstlane((int)*pl.ntiles), pl.tcap);
+    const int e = lane & 15;
+    for (uint32_t t = gw + first * NW; t < nt; t += 2u * NW) {
+        const bool two = t + NW < nt;                    // wave-uniform
+        const TileHdr ha = tile_hdr(pl, t, e), hb = tile_hdr(pl, two ? t + NW : t, e);
+        tile_pair(pl, ha, hb, two, in, wt, P, lane);
+    }
+}
+
+// The persistent kernels run up to 18 convolutions on ONE plan: the headers of a wave's first two tiles and the P ranges of a
+// thread's first two (row, quad) items are loaded once per launch and stay in registers -- a phase then starts with the
+// loads that depend on the previous phase (gathered rows / product rows), not with a round trip for its own work list.
+struct PlanCache {
+    TileHdr ha, hb; uint32_t ntw;        // cached tiles of this wave (0, 1 or 2); more tiles than 2 NW: the rest streams
+    uint32_t q0[2], q1[2];               // P ranges of items tid, tid + 1024 of this workgroup's rows
+};
+__device__ __forceinline__ void sum_range(const PlanV &pl, int r, uint32_t *q0, uint32_t *q1)
+{
+    const uint32_t pm1 = pl.pcap - 1u;
+    *q0 = min(pl.rowstart[r], pm1);
+    *q1 = min(min(pl.rowstart[r + 1], pm1), *q0 + (uint32_t)pl.K);   // (a plan built from a corrupt level: stay inside P)
+}
+__device__ __forceinline__ PlanCache plan_cache(const PlanV &pl, uint32_t gw, uint32_t NW, int lane, int row0, int row1, int tid, int nthreads)
+{
+    PlanCache c;
+    const uint32_t nt = min((uint32_t)__builtin_amdgcn_readfirstlane((int)*pl.ntiles), pl.tcap);
+    c.ntw = gw < nt ? (gw + NW < nt ? 2u : 1u) : 0u;
+    const int e = lane & 15;
+    c.ha = tile_hdr(pl, c.ntw ? gw : 0u, e);
+    c.hb = tile_hdr(pl, c.ntw == 2u ? gw + NW : (c.ntw ? gw : 0u), e);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + i * nthreads;
+        c.q0[i] = c.q1[i] = 0u;
+        if (it < (row1 - row0) * 8) sum_range(pl, row0 + (it >> 3), &c.q0[i], &c.q1[i]);
+    }
+    return c;
+}
+__device__ __forceinline__ void phase_products_cached(const PlanV &pl, const PlanCache &c, const float *in, const float *__restrict__ wt, float *P, uint32_t gw, uint32_t NW, int lane)
+{
+    if (c.ntw) tile_pair(pl, c.ha, c.hb, c.ntw == 2u, in, wt, P, lane);
+    if (c.ntw == 2u) phase_products(pl, in, wt, P, gw, NW, lane, 2u);
 }
 
 // SUMS: rows [row0, row1) of the level, a thread per (row, 16-byte channel quad): the row's P rows added in ascending offset
-// order (= the order they lie in P), then + residual, ReLU.  `nthreads` threads with index tid share the rows.
-__device__ __forceinline__ void phase_sums(const PlanV &pl, const float *P, const float *res, float *out, int relu, int row0, int row1, int tid, int nthreads)
+// order (= the order they lie in P), then + residual, ReLU.  Sixteen loads in flight (a dense small level has 40-77 pairs per
+// row: the adds are a sequential chain by specification, the loads need not be).
+__device__ __forceinline__ void sum_item(const PlanV &pl, const float *P, const float *res, float *out, int relu, int r, int c4, uint32_t q0, uint32_t q1)
 {
     const uint32_t pm1 = pl.pcap - 1u;
-    for (int it = tid; it < (row1 - row0) * 8; it += nthreads) {
-        const int r = row0 + (it >> 3), c4 = it & 7;
-        const uint32_t q0 = min(pl.rowstart[r], pm1);
-        const uint32_t q1 = min(min(pl.rowstart[r + 1], pm1), q0 + (uint32_t)pl.K);   // (a plan built from a corrupt level: stay inside P)
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float *Pc = P + c4 * 4;
-        for (uint32_t q = q0; q < q1; q += 8u) {
-            float4 v[8];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *Pc = P + c4 * 4;
+    const size_t at = (size_t)r * 32 + c4 * 4;
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (res) rv = ld4(res + at);
+    for (uint32_t q = q0; q < q1; q += 16u) {
+        float4 v[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld4(Pc + (size_t)min(q + (uint32_t)u, pm1) * 32);   // unconditional: eight loads in flight
+        for (int u = 0; u < 16; ++u) v[u] = ld4(Pc + (size_t)min(q + (uint32_t)u, pm1) * 32);   // unconditional: sixteen loads in flight
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (q + (uint32_t)u < q1) { acc.x = acc.x + v[u].x; acc.y = acc.y + v[u].y; acc.z = acc.z + v[u].z; acc.w = acc.w + v[u].w; }
-        }
-        const size_t at = (size_t)r * 32 + c4 * 4;
-        if (res) { const float4 q = ld4(res + at); acc.x = acc.x + q.x; acc.y = acc.y + q.y; acc.z = acc.z + q.z; acc.w = acc.w + q.w; }
-        if (relu) { acc.x = acc.x > 0.f ? acc.x : 0.f; acc.y = acc.y > 0.f ? acc.y : 0.f; acc.z = acc.z > 0.f ? acc.z : 0.f; acc.w = acc.w > 0.f ? acc.w : 0.f; }
-        *reinterpret_cast<float4 *>(out + at) = acc;
+        for (int u = 0; u < 16; ++u)
+            if (q + (uint32_t)u < q1) { acc.x = acc.x + v[u].x; acc.y = acc.y + v[u].y; acc.z = acc.z + v[u].z; acc.w = acc.w + v[u].w; }
     }
+    if (res) { acc.x = acc.x + rv.x; acc.y = acc.y + rv.y; acc.z = acc.z + rv.z; acc.w = acc.w + rv.w; }
+    if (relu) { acc.x = acc.x > 0.f ? acc.x : 0.f; acc.y = acc.y > 0.f ? acc.y : 0.f; acc.z = acc.z > 0.f ? acc.z : 0.f; acc.w = acc.w > 0.f ? acc.w : 0.f; }
+    *reinterpret_cast<float4 *>(out + at) = acc;
+}
+// items first, first + 1, ... of the sequence tid, tid + nthreads, ... (the ones before `first` are the caller's cached ones)
+__device__ __forceinline__ void phase_sums(const PlanV &pl, const float *P, const float *res, float *out, int relu, int row0, int row1, int tid, int nthreads, int first = 0)
+{
+    for (int it = tid + first * nthreads; it < (row1 - row0) * 8; it += nthreads) {
+        uint32_t q0, q1;
+        sum_range(pl, row0 + (it >> 3), &q0, &q1);
+        sum_item(pl, P, res, out, relu, row0 + (it >> 3), it & 7, q0, q1);
+    }
+}
+__device__ __forceinline__ void phase_sums_cached(const PlanV &pl, const PlanCache &c, const float *P, const float *res, float *out, int relu, int row0, int row1, int tid, int nthreads)
+{
+    const int items = (row1 - row0) * 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int it = tid + i * nthreads;
+        if (it < items) sum_item(pl, P, res, out, relu, row0 + (it >> 3), it & 7, c.q0[i], c.q1[i]);
+    }
+    if (items > 2 * nthreads) phase_sums(pl, P, res, out, relu, row0, row1, tid, nthreads, 2);
 }
 
 __global__ __launch_bounds__(256) void k_plan_products(PlanV pl, const float *in, const float *wt, float *P)
@@ -290,7 +355,12 @@ __device__ __forceinline__ bool poll_ge(uint32_t *p, uint32_t want, uint32_t *tm
     return false;
 }
 
-struct BarCtx { FusedBar *b; uint32_t *tmo; uint32_t xcc, epoch; };
+struct BarCtx {
+    FusedBar *b; uint32_t *tmo; uint32_t xcc, epoch;
+#ifdef FUSED_TIMING
+    unsigned long long t_start, t_bar, t_poll;   // developer build: 100 MHz stamps of workgroup 0 (launch start, time inside barriers, of it polling)
+#endif
+};
 
 // start of a launch: who runs where (the workgroup -> XCC placement is observed, not promised: counted, not assumed), and the
 // other barrier block zeroed for the next launch of this context (stream-ordered behind this one)
@@ -298,6 +368,9 @@ __device__ __forceinline__ bool bar_begin(BarCtx &bc, FusedBar *b, FusedBar *b_n
 {
     __shared__ uint32_t ok_s;
     bc.b = b; bc.tmo = tmo; bc.xcc = xcc_id(); bc.epoch = 0;
+#ifdef FUSED_TIMING
+    bc.t_start = __builtin_amdgcn_s_memrealtime(); bc.t_bar = 0; bc.t_poll = 0;
+#endif
     if (blockIdx.x == 0) {
         uint32_t *z = reinterpret_cast<uint32_t *>(b_next);
         for (uint32_t i = threadIdx.x; i < sizeof(FusedBar) / 4; i += blockDim.x) z[i] = 0u;
@@ -324,6 +397,10 @@ __device__ __forceinline__ bool bar_begin(BarCtx &bc, FusedBar *b, FusedBar *b_n
 __device__ __forceinline__ bool grid_barrier(BarCtx &bc)
 {
     __shared__ uint32_t ok_s;
+#ifdef FUSED_TIMING
+    const unsigned long long tb0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tp0 = 0, tp1 = 0;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its own stores have reached the L2
     __syncthreads();
     const uint32_t epoch = ++bc.epoch;
@@ -339,11 +416,20 @@ __device__ __forceinline__ bool grid_barrier(BarCtx &bc)
             if (t + 1u == epoch * nx)
                 for (uint32_t x = 0; x < 8u; ++x) st_rlx(&b->xcc_gen[x * 32], epoch);
         }
+#ifdef FUSED_TIMING
+        tp0 = __builtin_amdgcn_s_memrealtime();
+#endif
         const bool ok = poll_ge(&b->xcc_gen[bc.xcc * 32], epoch, bc.tmo);
+#ifdef FUSED_TIMING
+        tp1 = __builtin_amdgcn_s_memrealtime();
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         ok_s = ok ? 1u : 0u;
     }
     __syncthreads();
+#ifdef FUSED_TIMING
+    bc.t_bar += __builtin_amdgcn_s_memrealtime() - tb0; bc.t_poll += tp1 - tp0;
+#endif
     return ok_s != 0u;
 }
 
@@ -365,11 +451,11 @@ struct FusedK {
 
 struct WgMap { uint32_t G, wg, gw, NW, gtid, NT; int row0, row1; int lane, wave; };
 
-__device__ __forceinline__ bool conv_phases(const FusedK &k, BarCtx &bc, const WgMap &m, const float *in, const float *wt, const float *res, float *out, int relu, bool barrier_after)
+__device__ __forceinline__ bool conv_phases(const FusedK &k, BarCtx &bc, const WgMap &m, const PlanCache &pc, const float *in, const float *wt, const float *res, float *out, int relu, bool barrier_after)
 {
-    phase_products(k.pl, in, wt, k.P, m.gw, m.NW, m.lane);
+    phase_products_cached(k.pl, pc, in, wt, k.P, m.gw, m.NW, m.lane);
     if (!grid_barrier(bc)) return false;
-    phase_sums(k.pl, k.P, res, out, relu, m.row0, m.row1, (int)threadIdx.x, FUSE_THREADS);
+    phase_sums_cached(k.pl, pc, k.P, res, out, relu, m.row0, m.row1, (int)threadIdx.x, FUSE_THREADS);
     if (barrier_after && !grid_barrier(bc)) return false;
     return true;
 }
@@ -420,6 +506,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
     const int rpw = (n + (int)m.G - 1) / (int)m.G;
     m.row0 = min(n, (int)m.wg * rpw); m.row1 = min(n, m.row0 + rpw);
     const int64_t n8 = (int64_t)n * 8;
+    const PlanCache pc = plan_cache(k.pl, m.gw, m.NW, m.lane, m.row0, m.row1, (int)threadIdx.x, FUSE_THREADS);   // (the plan is a previous launch's output)
     if (MODE == FUSED_PARENT) {
         // F = Emb256[occ]                                                   (pcc_utils.py:99)
         const float4 *emb = reinterpret_cast<const float4 *>(k.prior_emb);
@@ -439,11 +526,15 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
         if (!grid_barrier(bc)) return;
     }
     // Conv-ReLU-ResNet-ResNet (network_ue_4stage_conv.py:17-33; codec.hip: run_trunk) -> a
-    if (!conv_phases(k, bc, m, k.x, k.w[0], nullptr, k.a, 1, true)) return;
-    if (!conv_phases(k, bc, m, k.a, k.w[1], nullptr, k.b, 1, true)) return;
-    if (!conv_phases(k, bc, m, k.b, k.w[2], k.a, k.x, 1, true)) return;
-    if (!conv_phases(k, bc, m, k.x, k.w[3], nullptr, k.b, 1, true)) return;
-    if (!conv_phases(k, bc, m, k.b, k.w[4], k.x, k.a, 1, MODE == FUSED_CHILD)) return;
+    if (!conv_phases(k, bc, m, pc, k.x, k.w[0], nullptr, k.a, 1, true)) return;
+    if (!conv_phases(k, bc, m, pc, k.a, k.w[1], nullptr, k.b, 1, true)) return;
+    if (!conv_phases(k, bc, m, pc, k.b, k.w[2], k.a, k.x, 1, true)) return;
+    if (!conv_phases(k, bc, m, pc, k.x, k.w[3], nullptr, k.b, 1, true)) return;
+    if (!conv_phases(k, bc, m, pc, k.b, k.w[4], k.x, k.a, 1, MODE == FUSED_CHILD)) return;
+#ifdef FUSED_TIMING
+    if (MODE == FUSED_PARENT && blockIdx.x == 0 && threadIdx.x == 0)
+        printf("[fused] parent n %d G %u: %u barriers, total %.1f us, in barriers %.1f us (polling %.1f us)\n", n, gridDim.x, bc.epoch, (__builtin_amdgcn_s_memrealtime() - bc.t_start) / 100.0, bc.t_bar / 100.0, bc.t_poll / 100.0);
+#endif
     if (MODE == FUSED_PARENT) return;
     // the four stages (pcc_utils.py:313-366): input, conv-ReLU-conv, head -> CDF rows, range decoder
     for (int s = 0; s < 4; ++s) {
@@ -461,8 +552,8 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
             if (!grid_barrier(bc)) return;
             xin = k.u;
         }
-        if (!conv_phases(k, bc, m, xin, k.w[5 + 2 * s], nullptr, k.x, 1, true)) return;
-        if (!conv_phases(k, bc, m, k.x, k.w[6 + 2 * s], nullptr, k.b, 0, false)) return;
+        if (!conv_phases(k, bc, m, pc, xin, k.w[5 + 2 * s], nullptr, k.x, 1, true)) return;
+        if (!conv_phases(k, bc, m, pc, k.x, k.w[6 + 2 * s], nullptr, k.b, 0, false)) return;
         if (s < 2) head_rows<2>(k, m, s, reinterpret_cast<float *>(lds));
         else if (s == 2) head_rows<4>(k, m, s, reinterpret_cast<float *>(lds));
         else head_rows<16>(k, m, s, reinterpret_cast<float *>(lds));
@@ -477,13 +568,24 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
         const uint32_t r = k.m2r[i];
         k.occ[i] = (uint8_t)(k.sym[0][r] * 128 + k.sym[1][r] * 64 + k.sym[2][r] * 16 + k.sym[3][r]);
     }
+#ifdef FUSED_TIMING
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        printf("[fused] child  n %d G %u: %u barriers, total %.1f us, in barriers %.1f us (polling %.1f us)\n", n, gridDim.x, bc.epoch, (__builtin_amdgcn_s_memrealtime() - bc.t_start) / 100.0, bc.t_bar / 100.0, bc.t_poll / 100.0);
+#endif
 }
 
-int fused_grid(int64_t n)
+// Workgroups of a persistent launch (16 waves each).  A phase costs its barrier (2.2 / 2.7 / 3.9 us at 64 / 128 / 256 workgroups,
+// tools/ubench/grid_sync.hip) plus one or two memory round trips, so the grid is the smallest that gives every wave at most ~2 tiles:
+// a sparse level (most small levels: 2-5 neighbours per node) has ~n / 4 tiles, a dense one (the levels right below the base:
+// 40-77 neighbours per node) ~4 n.  The host knows the density only through the growth of the level (children per parent node).
+int fused_grid(int64_t n, int64_t np)
 {
     static const int forced = env_int("GAUSPCC_FUSED_GRID", 0);
     if (forced >= 1 && forced <= 256) return forced;
-    return n <= 1024 ? 16 : n <= 4096 ? 64 : 128;
+    const bool dense = np > 0 && n > 3 * np;
+    const int64_t tiles = dense ? 5 * n : n / 2 + 64;
+    const int64_t g = cdiv(tiles, 2 * (FUSE_THREADS / 64));   // two tiles per wave
+    return (int)std::min<int64_t>(256, std::max<int64_t>(16, (g + 15) / 16 * 16));
 }
 
 // barrier blocks + sticky timeout word of a context: [FusedBar][FusedBar][32 words]
@@ -526,16 +628,16 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
     for (int i = 0; i < 3; ++i) k.semb[i] = m->semb[i];
     for (int i = 0; i < 4; ++i) { k.hfrag[i] = m->hfrag[i]; k.sym[i] = a.sym[i]; k.rdw[i] = (uint32_t)rc_window_dwords(a.win_bytes[i]); }
     k.cdf = a.cdf; k.occ = a.occ; k.bytes = a.bytes; k.chunks = a.chunks; k.nlanes = a.nlanes; k.llog = a.llog;
-    const int G = fused_grid(plan.n);
+    const int G = fused_grid(plan.n, a.np);
     k_level_fused<FUSED_CHILD><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
 // can the range-decoder phases of a level keep their byte windows in the fused kernel's LDS?
-bool fused_windows_fit(int64_t n, uint32_t nlanes, const uint32_t win_bytes[4])
+bool fused_windows_fit(int64_t n, int64_t np, uint32_t nlanes, const uint32_t win_bytes[4])
 {
-    const uint32_t G = (uint32_t)fused_grid(n), LPW = (nlanes + G - 1u) / G;
+    const uint32_t G = (uint32_t)fused_grid(n, np), LPW = (nlanes + G - 1u) / G;
     for (int s = 0; s < 4; ++s) {
         const uint64_t rdw = rc_window_dwords(win_bytes[s]);
         const uint64_t lanes = s == 3 ? (uint64_t)((LPW + 3u) / 4u) * 4u : LPW;
@@ -545,7 +647,7 @@ bool fused_windows_fit(int64_t n, uint32_t nlanes, const uint32_t win_bytes[4])
     return true;
 }
 
-int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const PairPlan &plan, const uint8_t *occ, float *pF, float *pA, float *pB, float *P)
+int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const PairPlan &plan, int64_t np, const uint8_t *occ, float *pF, float *pA, float *pB, float *P)
 {
     FusedK k = {};
     k.pl = plan_view(plan);
@@ -555,7 +657,7 @@ int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const
     for (int i = 0; i < 5; ++i) k.w[i] = m->conv[i] + (size_t)m->K * 1024;
     k.prior_emb = m->prior_emb;
     k.occ = const_cast<uint8_t *>(occ);
-    const int G = fused_grid(plan.n);
+    const int G = fused_grid(plan.n, np);
     k_level_fused<FUSED_PARENT><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
     return GPCC_OK;

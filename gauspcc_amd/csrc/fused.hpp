@@ -26,7 +26,10 @@
 namespace gpcc {
 
 constexpr int64_t FUSE_MAX_NODES = 16384;
-constexpr int FUSE_THREADS = 1024;          // 16 waves per workgroup, one workgroup per CU
+#ifndef FUSE_THREADS_N
+#define FUSE_THREADS_N 512
+#endif
+constexpr int FUSE_THREADS = FUSE_THREADS_N;   // 8 waves per workgroup (256 VGPRs a wave: the chain's phases -- MFMA tiles, 16-deep sums, three range decoders, three heads -- share one register allocation; at 16 waves / 128 VGPRs it spilled 93 of them)
 constexpr int FUSE_HEAD_WAVES = 8;          // waves of a workgroup that may run a head (LDS: HEAD_LDS_FLOATS each)
 constexpr size_t FUSE_LDS_BYTES = (size_t)FUSE_HEAD_WAVES * (512 + 1024) * 4;   // 48 KiB: head buffers / range-decoder byte windows (phases apart)
 
@@ -67,7 +70,7 @@ int plan_conv(hipStream_t st, const PairPlan &plan, const ConvJob &job, float *P
 
 struct FusedChild {
     // inputs
-    const float *pA;                 // parent level's trunk output (np, 32)
+    const float *pA; int64_t np;     // parent level's trunk output (np, 32)
     const uint32_t *parent;          // (n) parent row
     const uint64_t *rkey;            // (n) raster key (octant bits)
     const uint32_t *m2r;             // (n) Morton row -> raster rank
@@ -86,11 +89,12 @@ struct FusedChild {
 int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const PairPlan &plan, const FusedChild &a);
 // can the range-decoder phases of the level keep their lanes' byte windows in the fused kernel's LDS?  (always, for containers this
 // library wrote: 64-symbol lanes; a foreign or corrupt table may claim more)
-bool fused_windows_fit(int64_t n, uint32_t nlanes, const uint32_t win_bytes[4]);
+bool fused_windows_fit(int64_t n, int64_t np, uint32_t nlanes, const uint32_t win_bytes[4]);
 // the context's sticky timeout word (device) -- the caller copies it out at its final sync; fused_reset: after a timeout
 uint32_t *fused_timeout_word(gpcc_ctx *ctx);
 int fused_reset(gpcc_ctx *ctx, hipStream_t st);
 // prior_resnet of a finished level (pcc_utils.py:99-101): F = Emb256[occ] -> 5 convolutions; result in pA
-int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const PairPlan &plan, const uint8_t *occ, float *pF, float *pA, float *pB, float *P);
+// np_of_level: nodes of the level ABOVE it (the density hint of fused_grid; the same value the level's own chain was launched with)
+int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const PairPlan &plan, int64_t np_of_level, const uint8_t *occ, float *pF, float *pA, float *pB, float *P);
 
 }  // namespace gpcc

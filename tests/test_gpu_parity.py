@@ -218,7 +218,7 @@ def test_conv3d_bit_exact(gh, orc, k, n):
     assert np.array_equal(out2, orc.conv(x, nb, w, res=res, relu=True))
 
 
-@pytest.mark.parametrize("k,n,spread", [(3, 40, 6), (3, 4000, 12), (5, 37, 4), (5, 300, 5), (5, 5000, 12), (5, 9000, 60), (5, 16000, 40), (7, 2500, 12)])
+@pytest.mark.parametrize("k,n,spread", [(3, 70, 6), (3, 4000, 12), (5, 90, 4), (5, 300, 5), (5, 5000, 12), (5, 9000, 60), (5, 16000, 40), (7, 2500, 12)])
 def test_conv3d_pair_plan_bit_exact(gh, orc, k, n, spread):
     """The pair-plan form of the convolution (csrc/fused.hpp: level-wide offset tiles -> product buffer -> ordered row sums), which
     the decoder's persistent small-level kernels run in two phases, against the oracle's spnn.Conv3d restatement

@@ -306,7 +306,7 @@ def main():
                 "scenes_per_gpu": K,
                 "channels": 32,
                 "kernel_size": k,
-                "container": f"v3 (per-level chunks of two coder lanes, chunk_log2<={args.chunk_log2})" if args.chunk_log2 else "v0 (reference layout)",
+                "container": f"v{data[2]} (per-level chunks of two coder lanes, chunk_log2<={args.chunk_log2}" + ("; carry-propagating range coder in the lanes)" if data[2] >= 4 else ")") if args.chunk_log2 else "v0 (reference layout)",
                 "weights": "seeded synthetic (reference initialisers, conv gain 4)",
             },
             "enc_ms": round(float(allstats[:, 1].mean()) * 1e3 / K, 3),     # per scene

@@ -41,7 +41,7 @@ class Stage(C.Structure):
 
 
 EXPORTS = [
-    "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_ctx_bytes", "gpcc_raster_order", "gpcc_voxelise",
+    "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_ctx_bytes", "gpcc_ctx_set_container_version", "gpcc_raster_order", "gpcc_voxelise",
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get",
@@ -69,6 +69,7 @@ def lib():
     L.gpcc_ctx_destroy.argtypes = [vp]
     L.gpcc_ctx_destroy.restype = None
     L.gpcc_ctx_bytes.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.gpcc_ctx_set_container_version.argtypes = [vp, i32]
     L.gpcc_raster_order.argtypes = [vp, vp, i32, i64, vp, vp]
     L.gpcc_voxelise.argtypes = [vp, vp, i32, i64, C.c_double, C.c_double, C.c_double, i32, vp, vp]
     L.gpcc_model_create.argtypes = [vp, i32, i32, vp, C.POINTER(vp)]

@@ -6,7 +6,7 @@
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
-#include "rangecoder.hpp"
+#include "rangecoder_dev.hpp"
 
 using namespace gpcc;
 
@@ -47,6 +47,16 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
     delete c;
+}
+
+// Version gpcc_encode (and the stage-level gpcc_rc_encode / gpcc_rc_decode) use for chunked containers: 4 (default: the
+// carry-propagating coder in the lanes) or 3 (torchac's coder in the lanes: what round 3 wrote).  Readers take 0-4.
+extern "C" int gpcc_ctx_set_container_version(gpcc_ctx *c, int version)
+{
+    if (!c) return fail(GPCC_ERR_ARG, "null argument");
+    if (version != 3 && version != 4) return fail(GPCC_ERR_ARG, "container version must be 3 or 4");
+    c->container_version = version;
+    return GPCC_OK;
 }
 
 // what the context holds right now: device bytes (workspace arena + the small levels' product buffer + developer buffers) and
@@ -609,7 +619,8 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const RcPlan pl = rc_plan(n, chunk_log2, 3);
+    const int version = ctx->container_version;
+    const RcPlan pl = rc_plan(n, chunk_log2, version);
     const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : n;
     const int nch = (int)pl.nlanes;
     const uint32_t stride = rc_scratch_stride((uint32_t)std::min<int64_t>(S, n));
@@ -622,7 +633,7 @@ extern "C" int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     GP_TRY(rc_pack_lohi(st, cdf_dev, lp, sym_dev, n, pl.llog, (uint32_t)nch, lohi));
-    GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt));
+    GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, stride, dcnt, chunk_log2 ? rc_coder_of_version(version) : RC_CODER_CARRYLESS));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
     GP_TRY(rc_compact_launch(st, scratch, stride, dcnt, doff, nullptr, nch, payload, pl.dual ? dch : nullptr));
     std::vector<uint32_t> hcnt((size_t)nch + 1);
@@ -649,7 +660,8 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     if (chunk_log2 != 0 && (chunk_log2 < 6 || chunk_log2 > 14)) return fail(GPCC_ERR_ARG, "chunk_log2 must be 0 or 6..14");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const RcPlan pl = rc_plan(n, chunk_log2, 3);
+    const int version = ctx->container_version;
+    const RcPlan pl = rc_plan(n, chunk_log2, version);
     const int64_t S = chunk_log2 ? (int64_t)1 << pl.llog : n;
     const int nch = (int)pl.nlanes;
     GP_TRY(ctx->arena.reserve((size_t)nbytes + sizeof(RcChunk) * (size_t)nch + (size_t)rc_rows_capacity(nch, S) * 32 + (size_t)n + ((size_t)4 << 20)));
@@ -657,7 +669,7 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     std::vector<RcChunk> chunks((size_t)nch);
     uint32_t win = 0;
     constexpr int64_t FRONT = 16;   // the uploaded copy starts 16 bytes into its buffer: a backwards lane's staging loads reach up to 3 bytes in front of its chunk
-    if (const char *err = rc_parse_table(bytes, FRONT, nbytes, pl, n, chunk_log2 ? 3 : 0, chunks.data(), &win)) return fail(GPCC_ERR_FORMAT, "%s", err);
+    if (const char *err = rc_parse_table(bytes, FRONT, nbytes, pl, n, chunk_log2 ? version : 0, chunks.data(), &win)) return fail(GPCC_ERR_FORMAT, "%s", err);
     TAKE(db, uint8_t, nbytes + FRONT + 16); TAKE(dch, RcChunk, nch);
     TAKE(rows, uint16_t, rc_rows_capacity(nch, S) * rc_row_stride(lp) + 64);
     TAKE(symbuf, uint8_t, n + 4);   // the decoder stores groups of four
@@ -666,7 +678,7 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     HIP_TRY(hipMemcpyAsync(db + FRONT, bytes, (size_t)nbytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dch, chunks.data(), sizeof(RcChunk) * (size_t)nch, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, pl.dual, symbuf));
+    GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, pl.dual, symbuf, chunk_log2 ? rc_coder_of_version(version) : RC_CODER_CARRYLESS));
     HIP_TRY(hipMemcpyAsync(sym_dev, symbuf, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;

@@ -18,7 +18,7 @@
 #include "network.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
-#include "rangecoder.hpp"
+#include "rangecoder_dev.hpp"
 
 using namespace gpcc;
 
@@ -127,7 +127,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     // layout pads the last chunk): offset 4 * sum_{d' < d} slots(d') + s * slots(d)
     // (container version 3: rangecoder.hpp -- a stream is cut into LANES of 2^llog symbols, one coder state each; two lanes,
     // one coded forwards and one backwards, share a byte-counted chunk)
-    constexpr int CONTAINER_VERSION = 3;
+    const int CONTAINER_VERSION = ctx->container_version;   // 4: the carry-propagating coder in the lanes; 3: torchac's (gpcc_ctx_set_container_version)
     auto plan = [&](int64_t nc) -> RcPlan { return rc_plan(nc, chunk_log2, CONTAINER_VERSION); };
     auto clog = [&](int64_t nc) -> int { return plan(nc).llog; };                       // lane size log2
     auto slots = [&](int64_t nc) -> int64_t { return chunk_log2 ? (int64_t)plan(nc).nlanes << clog(nc) : nc; };
@@ -316,7 +316,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         TAKE(scratch, uint8_t, (size_t)nchunks * stride);
         HIP_TRY(hipMemcpyAsync(dchunks, hs + off_desc, sizeof(RcChunk) * (size_t)nchunks, hipMemcpyHostToDevice, st));
         StageTimer tm(ctx, st, ST_CODER, (double)coded * 4 * 4);   // + 3 x the payload (written, compacted), added when it is known
-        GP_TRY(rc_encode_launch(st, lohi, dchunks, nchunks, scratch, stride, dcnt));
+        GP_TRY(rc_encode_launch(st, lohi, dchunks, nchunks, scratch, stride, dcnt, chunk_log2 ? rc_coder_of_version(CONTAINER_VERSION) : RC_CODER_CARRYLESS));
         GP_TRY(dbg_mark(ctx, st, 10, dcnt, (size_t)nchunks * 4));
         GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nchunks, doff + nchunks));
         HIP_TRY(hipMemcpyAsync(hs + off_cnt, dcnt, 4 * (size_t)nchunks, hipMemcpyDeviceToHost, st));
@@ -450,7 +450,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     if (v1) {
         NEED(8);
         version = in[2];
-        if (version < 1 || version > 3) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
+        if (version < 1 || version > 4) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
         chunk_log2 = in[3];
         if (chunk_log2 < 6 || chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "bad chunk_log2 %d", chunk_log2);
         *posq_out = (uint16_t)(in[4] | in[5] << 8);
@@ -706,7 +706,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             FusedChild fa = {};
             fa.pA = pA; fa.np = np; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
             for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g][s]; fa.sym[s] = sym[s]; }
-            fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ;
+            fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ; fa.coder = rc_coder_of_version(version);
             ConvRec rec = {0, 0, g + 1, 1, 0, 0, (long long)nc, 0, 13};
             if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
             GP_TRY(fused_child_level(ctx, st, m, planC, fa));
@@ -746,7 +746,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
-                GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], pl.dual, sym[s]));
+                GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], pl.dual, sym[s], rc_coder_of_version(version)));
             }
             GP_TRY(dbg_mark(ctx, st, g * 100 + 14 + 5 * s, sym[s], (size_t)nc));
         }

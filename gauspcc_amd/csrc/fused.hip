@@ -473,7 +473,7 @@ __device__ __forceinline__ void head_rows(const FusedK &k, const WgMap &m, int s
             head_wave<M, 1>(ha, r, m.row1, m.lane, lds + m.wave * HEAD_LDS_FLOATS, 0u);
 }
 
-template <int LP>
+template <int LP, int CODER>
 __device__ __forceinline__ void rc_rows(const FusedK &k, const WgMap &m, int stage, uint32_t *lds)
 {
     // lanes [wg * LPW, (wg + 1) * LPW) of the stream: 3- / 5-entry rows on wave 0, 17-entry rows four coder lanes to a wave
@@ -484,15 +484,16 @@ __device__ __forceinline__ void rc_rows(const FusedK &k, const WgMap &m, int sta
     const uint32_t rdw = k.rdw[stage];
     if (LP == 17) {
         const int cw = c0 + 4 * m.wave;
-        if (cw < cend) rc_decode17_lds_wave<4, false>(k.cdf, k.bytes, ch, cend, cw, m.lane, rdw, k.sym[stage], lds + (size_t)m.wave * 4u * rdw);
+        if (cw < cend) rc_decode17_lds_wave<4, false, CODER>(k.cdf, k.bytes, ch, cend, cw, m.lane, rdw, k.sym[stage], lds + (size_t)m.wave * 4u * rdw);
     } else if (m.wave == 0) {
-        rc_decode_lds_wave<LP == 17 ? 3 : LP, 4, false>(k.cdf, k.bytes, ch, cend, c0, m.lane, (int)LPW, rdw, k.sym[stage], lds);
+        rc_decode_lds_wave<LP == 17 ? 3 : LP, 4, false, CODER>(k.cdf, k.bytes, ch, cend, c0, m.lane, (int)LPW, rdw, k.sym[stage], lds);
     }
 }
 
 enum { FUSED_CHILD = 0, FUSED_PARENT = 1 };
 
-template <int MODE>
+// CODER: the lanes' coder of the container being decoded (CHILD only)
+template <int MODE, int CODER>
 __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
@@ -558,9 +559,9 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
         else if (s == 2) head_rows<4>(k, m, s, reinterpret_cast<float *>(lds));
         else head_rows<16>(k, m, s, reinterpret_cast<float *>(lds));
         if (!grid_barrier(bc)) return;
-        if (s < 2) rc_rows<3>(k, m, s, lds);
-        else if (s == 2) rc_rows<5>(k, m, s, lds);
-        else rc_rows<17>(k, m, s, lds);
+        if (s < 2) rc_rows<3, CODER>(k, m, s, lds);
+        else if (s == 2) rc_rows<5, CODER>(k, m, s, lds);
+        else rc_rows<17, CODER>(k, m, s, lds);
         if (!grid_barrier(bc)) return;
     }
     // occupancy byte from the four symbol arrays (raster order) -> Morton order (pcc_utils.py:369)
@@ -629,7 +630,8 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
     for (int i = 0; i < 4; ++i) { k.hfrag[i] = m->hfrag[i]; k.sym[i] = a.sym[i]; k.rdw[i] = (uint32_t)rc_window_dwords(a.win_bytes[i]); }
     k.cdf = a.cdf; k.occ = a.occ; k.bytes = a.bytes; k.chunks = a.chunks; k.nlanes = a.nlanes; k.llog = a.llog;
     const int G = fused_grid(plan.n, a.np);
-    k_level_fused<FUSED_CHILD><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
+    if (a.coder == RC_CODER_CARRY) k_level_fused<FUSED_CHILD, RC_CODER_CARRY><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
+    else k_level_fused<FUSED_CHILD, RC_CODER_CARRYLESS><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -658,7 +660,7 @@ int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const
     k.prior_emb = m->prior_emb;
     k.occ = const_cast<uint8_t *>(occ);
     const int G = fused_grid(plan.n, np);
-    k_level_fused<FUSED_PARENT><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
+    k_level_fused<FUSED_PARENT, RC_CODER_CARRYLESS><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

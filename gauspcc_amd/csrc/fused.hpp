@@ -78,6 +78,7 @@ struct FusedChild {
     const RcChunk *chunks;           // [4][nlanes] lane descriptors of the level's four streams
     uint32_t nlanes; int llog;       // lanes per stream, log2 symbols per lane
     uint32_t win_bytes[4];           // longest byte window of a lane, per stage
+    int coder;                       // the lanes' coder (rangecoder_dev.hpp: RC_CODER_*: container version 4 / versions 1-3)
     // work buffers (n, 32) and outputs
     float *cX, *cA, *cB, *cU, *P;
     uint16_t *cdf;                   // rc_rows_capacity(nlanes, 2^llog) * 16 u16

@@ -62,6 +62,26 @@ struct BitOut {
     }
 };
 
+// Carry into the bits already collected (container version 4, the carry-propagating coder): + 1 at the last bit of the string;
+// a carry out of the accumulator ripples through the words already stored (big-endian bit strings).
+__device__ __forceinline__ void bitout_carry(BitOut &w)
+{
+    if (w.n) {
+        const uint64_t unit = 1ull << (64u - w.n);
+        const uint64_t a2 = w.acc + unit;
+        const bool ovf = a2 < w.acc;
+        w.acc = a2;
+        if (!ovf) return;
+    }
+    uint32_t *mem = reinterpret_cast<uint32_t *>(w.out);
+    for (int i = (int)w.words - 1; i >= 0; --i) {
+        const uint32_t v = __builtin_bswap32(mem[i]) + 1u;
+        mem[i] = __builtin_bswap32(v);
+        if (v) break;
+    }
+}
+
+template <int CODER>
 __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ lohi, const RcChunk *__restrict__ chunks, int nchunks,
                                                   uint8_t *__restrict__ scratch, uint32_t sstride, uint32_t *__restrict__ cnt)
 {
@@ -96,6 +116,19 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
             for (int dd = 0; dd < PH; ++dd) {
                 const uint32_t i = i0 + (uint32_t)(h * PH + dd);
                 const uint32_t cur = regs[h][dd];
+                if (CODER == RC_CODER_CARRY) {
+                    // version 4 (oracle/gpcc_oracle.c: cp_encode_core): `high` holds the RANGE, normalised to [2^31, 2^32)
+                    if (i < ch.n) {
+                        const uint32_t c_lo = cur & 0xFFFFu, c_hi = (cur >> 16) + 1u;
+                        const uint32_t r = high >> 16, add = __umul24(r, c_lo);
+                        const uint32_t nl = low + add;
+                        if (nl < low) bitout_carry(w);
+                        low = nl;
+                        high = c_hi == 0x10000u ? high - add : __umul24(r, c_hi - c_lo);
+                        const int k = clz32(high | 0x8000u);   // (range >= 2^15 for every valid row)
+                        if (k) { w.put(low >> (32 - k), (uint32_t)k); low <<= k; high <<= k; }
+                    }
+                } else
                 if (i < ch.n) {
                     const uint64_t c_low = cur & 0xFFFFu, c_high = (uint64_t)(cur >> 16) + 1u;
                     const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
@@ -134,10 +167,17 @@ __global__ __launch_bounds__(64) void k_rc_encode(const uint32_t *__restrict__ l
         }
     }
     if (c >= nchunks) return;
+    if (CODER == RC_CODER_CARRY) {
+        // flush: the two top bits of the smallest multiple of 2^30 >= low (whatever bits follow decode to the same symbols)
+        const uint32_t q = (uint32_t)(((uint64_t)low + 0x3FFFFFFFull) >> 30);   // 0 .. 4
+        if (q == 4u) bitout_carry(w);
+        w.put(q & 3u, 2);
+    } else {
     pending += 1;
     const uint32_t b = low < 0x40000000u ? 0u : 1u;
     w.put(b, 1);
     w.put_run(b ^ 1u, pending);
+    }
     // flush the tail, zero padded to a byte boundary
     const uint32_t tail_bytes = (w.n + 7u) >> 3;
     for (uint32_t k = 0; k < tail_bytes; ++k) w.out[4 * w.words + k] = (uint8_t)(w.acc >> (56 - 8 * k));
@@ -421,25 +461,27 @@ __global__ __launch_bounds__(64) void k_rc_decode17(const uint16_t *__restrict__
 
 // The staged decoders (byte windows in LDS, rows in three register sets) live in rangecoder_dev.hpp as functions of one
 // wave; these kernels are one wave per workgroup.
-template <int LP>
+template <int LP, int CODER>
 __global__ __launch_bounds__(64) void k_rc_decode_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                       int nchunks, int lpw, uint32_t rdw, uint8_t *__restrict__ sym)
 {
     extern __shared__ uint32_t win[];                          // [lpw][rdw] byte windows
-    rc_decode_lds_wave<LP, RING_PHASE, true>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * lpw, (int)threadIdx.x, lpw, rdw, sym, win);
+    rc_decode_lds_wave<LP, RING_PHASE, true, CODER>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * lpw, (int)threadIdx.x, lpw, rdw, sym, win);
 }
 
+template <int CODER>
 __global__ __launch_bounds__(64) void k_rc_decode17_lds(const uint16_t *__restrict__ cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                         int nchunks, uint32_t rdw, uint8_t *__restrict__ sym)
 {
     extern __shared__ uint32_t win[];
-    rc_decode17_lds_wave<RING_PHASE, true>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * 4, (int)threadIdx.x, rdw, sym, win);
+    rc_decode17_lds_wave<RING_PHASE, true, CODER>(cdf, bytes, chunks, nchunks, (int)blockIdx.x * 4, (int)threadIdx.x, rdw, sym, win);
 }
 
-int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt)
+int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt, int coder)
 {
     if (nchunks <= 0) return GPCC_OK;
-    k_rc_encode<<<(unsigned)cdiv(nchunks, 64), 64, 0, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
+    if (coder == RC_CODER_CARRY) k_rc_encode<RC_CODER_CARRY><<<(unsigned)cdiv(nchunks, 64), 64, 0, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
+    else k_rc_encode<RC_CODER_CARRYLESS><<<(unsigned)cdiv(nchunks, 64), 64, 0, st>>>(lohi, chunks, nchunks, scratch, stride, cnt);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -474,7 +516,7 @@ int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *to
     return GPCC_OK;
 }
 
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym)
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym, int coder)
 {
     if (nchunks <= 0) return GPCC_OK;
     // (invariants the staged kernels rely on, enforced by gpcc_encode / gpcc_decode's chunk_log2 range of 6..14 -- checked by their
@@ -484,15 +526,20 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
     const uint32_t ring_bytes = rc_ring_bytes(lp);       // the row ring behind the windows
     const uint32_t cap = RC_LDS_CAP - ring_bytes;
     if (rc_window_fits(lp, max_bytes)) {
+        const bool cp = coder == RC_CODER_CARRY;
         if (lp == 17) {
-            k_rc_decode17_lds<<<(unsigned)cdiv(nchunks, 4), 64, (size_t)(4u * rdw * 4u) + ring_bytes, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
+            const size_t lds = (size_t)(4u * rdw * 4u) + ring_bytes;
+            if (cp) k_rc_decode17_lds<RC_CODER_CARRY><<<(unsigned)cdiv(nchunks, 4), 64, lds, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
+            else k_rc_decode17_lds<RC_CODER_CARRYLESS><<<(unsigned)cdiv(nchunks, 4), 64, lds, st>>>(cdf, bytes, chunks, nchunks, (uint32_t)rdw, sym);
         } else {
             int lpw = 64;
             while ((uint64_t)lpw * rdw * 4u > cap) lpw >>= 1;
             const unsigned g = (unsigned)cdiv(nchunks, lpw);
             const size_t lds = (size_t)lpw * rdw * 4u + ring_bytes;
-            if (lp == 3) k_rc_decode_lds<3><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
-            else if (lp == 5) k_rc_decode_lds<5><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            if (lp == 3 && cp) k_rc_decode_lds<3, RC_CODER_CARRY><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            else if (lp == 3) k_rc_decode_lds<3, RC_CODER_CARRYLESS><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            else if (lp == 5 && cp) k_rc_decode_lds<5, RC_CODER_CARRY><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
+            else if (lp == 5) k_rc_decode_lds<5, RC_CODER_CARRYLESS><<<g, 64, lds, st>>>(cdf, bytes, chunks, nchunks, lpw, (uint32_t)rdw, sym);
             else return fail(GPCC_ERR_ARG, "rc_decode: Lp must be 3, 5 or 17");
         }
         LAUNCH_CHECK();
@@ -500,7 +547,7 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
     }
     // lanes too long for LDS (the reference layout: one lane per stream) read their bytes through a window in memory;
     // forwards only (backwards lanes exist in version-3 chunks, which are short by construction)
-    if (dual) return fail(GPCC_ERR_FORMAT, "a chunk of %u bytes is beyond the decoder's LDS window", max_bytes);
+    if (dual || coder != RC_CODER_CARRYLESS) return fail(GPCC_ERR_FORMAT, "a chunk of %u bytes is beyond the decoder's LDS window", max_bytes);
     const unsigned g = (unsigned)cdiv(nchunks, 64);
     switch (lp) {
     case 3: k_rc_decode<3><<<g, 64, 0, st>>>(cdf, bytes, chunks, nchunks, sym); break;

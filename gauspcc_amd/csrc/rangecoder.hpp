@@ -207,7 +207,9 @@ static inline bool rc_window_fits(int lp, uint32_t max_bytes) { return rc_window
 
 static inline uint32_t rc_scratch_stride(uint32_t max_syms) { return (2u * max_syms + 32u + 15u) & ~15u; }
 
-int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt);
+// coder: 0 = torchac's carry-less coder (the reference layout, container versions 1-3), 1 = the carry-propagating coder of container
+// version 4 (rangecoder_dev.hpp: RC_CODER_*, rc_coder_of_version)
+int rc_encode_launch(hipStream_t st, const uint32_t *lohi, const RcChunk *chunks, int nchunks, uint8_t *scratch, uint32_t stride, uint32_t *cnt, int coder = 0);
 // dual_lanes (the device lane descriptors, version 3): the bytes of a stream's odd lanes are written in reverse order (the backwards half of a chunk)
 int rc_compact_launch(hipStream_t st, const uint8_t *scratch, uint32_t stride, const uint32_t *cnt, const uint32_t *off, const uint32_t *gap, int nchunks, uint8_t *payload, const RcChunk *dual_lanes = nullptr);
 // payload[0 .. *total + extra (+ *extra_dev)) -> dst in 16-byte words (both 16-byte aligned; dst may be pinned host memory): the size stays on the device
@@ -216,7 +218,7 @@ int rc_to_host_launch(hipStream_t st, const uint8_t *payload, const uint32_t *to
 // max_bytes: the longest byte window of the lanes (rc_parse_table); lanes whose windows fit the LDS are decoded from a staged
 // copy, one lane of any size (the reference layout) straight from memory
 // dual: the lanes are version-3 chunk halves (some run backwards: staged path only)
-int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym);
+int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t *bytes, const RcChunk *chunks, int nchunks, uint32_t max_bytes, bool dual, uint8_t *sym, int coder = 0);
 // version-3 streams: the bytes in front of every lane's payload (stream lengths + varint tables) depend on the byte counts
 // and are worked out on the device: lane_stream[l] = stream of lane l, stream_first[s] = first lane of stream s (nstreams + 1
 // entries), dual: lanes pair up into chunks.  gap[l] and *gap_total come out.

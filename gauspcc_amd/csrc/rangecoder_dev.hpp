@@ -89,6 +89,22 @@ __device__ __forceinline__ void rc_renorm(uint32_t &low, uint32_t &d, uint32_t &
     k_out = k;
 }
 
+// Container version 4: the lanes' coder is a carry-PROPAGATING range coder (oracle/gpcc_oracle.c: cp_encode_core has the
+// definition).  The encoder resolves carries in the bits it has written, so the decoder's state is (range, x = value - low):
+// no `low`, no underflow bookkeeping -- a shift, a multiply, a compare, a subtract and one count-leading-zeros per binary symbol.
+// lo / r1 = scaled lower bound and width of the decoded symbol's slice; `t` = the next 32 unread bits.
+__device__ __forceinline__ void cp_renorm(uint32_t &range, uint32_t &x, uint32_t lo, uint32_t r1, uint32_t t, uint32_t &k_out)
+{
+    const uint32_t x1 = x - lo;
+    const uint32_t k = ffbh(r1 | 0x8000u);   // a valid row leaves r1 >= 2^15; the OR keeps garbage rows (r1 = 0) at a defined shift
+    range = r1 << k;
+    x = (uint32_t)(((((uint64_t)x1) << 32 | (uint64_t)t) << k) >> 32);
+    k_out = k;
+}
+
+constexpr int RC_CODER_CARRYLESS = 0, RC_CODER_CARRY = 1;   // torchac's coder (reference layout, versions 1-3) / version 4
+__host__ __device__ inline int rc_coder_of_version(int version) { return version >= 4 ? RC_CODER_CARRY : RC_CODER_CARRYLESS; }
+
 // Lanes of 3- and 5-entry rows, byte windows staged in LDS, rows in three register sets (header comment).  A lane's first
 // symbol sits on a multiple of 16 (lanes are 2^llog >= 32 symbols) and `sym` has 3 bytes of slack behind the stream for the
 // last group of its last lane.
@@ -102,7 +118,7 @@ template <bool SOLO> __device__ __forceinline__ void rc_wave_sync()
     else { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 }
 
-template <int LP, int PH, bool SOLO>
+template <int LP, int PH, bool SOLO, int CODER = RC_CODER_CARRYLESS>
 __device__ __forceinline__ void rc_decode_lds_wave(const uint16_t *cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                    int nchunks, int c0, int lane, int lpw, uint32_t rdw, uint8_t *sym, uint32_t *win)
 {
@@ -147,6 +163,25 @@ __device__ __forceinline__ void rc_decode_lds_wave(const uint16_t *cdf, const ui
                 const uint32_t r0 = regs[h][dd].a, r1 = regs[h][dd].b;
                 const uint32_t t = in.peek();
                 uint32_t s, lo, d1;
+                if constexpr (CODER == RC_CODER_CARRY) {
+                    // (d holds the RANGE here; low is unused)
+                    const uint32_t r = d >> 16;
+                    if (LP == 3) {
+                        const uint32_t t1 = __umul24(r, r0);
+                        const bool ge = t1 <= x;
+                        s = ge; lo = ge ? t1 : 0u;
+                        d1 = ge ? d - t1 : t1;
+                    } else {
+                        const uint32_t t1 = __umul24(r, r0 & 0xFFFFu), t2 = __umul24(r, r0 >> 16), t3 = __umul24(r, r1 & 0xFFFFu);
+                        const bool g1 = t1 <= x, g2 = t2 <= x, g3 = t3 <= x;
+                        lo = g3 ? t3 : (g2 ? t2 : (g1 ? t1 : 0u));
+                        const uint32_t hi = g3 ? d : (g2 ? t3 : (g1 ? t2 : t1));
+                        s = (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u);
+                        d1 = hi - lo;
+                    }
+                    if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
+                    cp_renorm(d, x, lo, d1, t, k);
+                } else {
                 if (LP == 3) {
                     const uint32_t t1 = scale_d(d, r0);
                     const bool ge = t1 <= x;
@@ -162,6 +197,7 @@ __device__ __forceinline__ void rc_decode_lds_wave(const uint16_t *cdf, const ui
                 }
                 if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
                 rc_renorm(low, d, x, lo, d1, t, k);
+                }
                 in.advance(k);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -184,7 +220,7 @@ __device__ __forceinline__ void rc_decode_lds_wave(const uint16_t *cdf, const ui
 
 // 17-entry rows: a 16-lane group per coder lane as in k_rc_decode17, the byte windows staged in LDS, every lane's own entry
 // of the coming rows in three register sets.
-template <int PH, bool SOLO>
+template <int PH, bool SOLO, int CODER = RC_CODER_CARRYLESS>
 __device__ __forceinline__ void rc_decode17_lds_wave(const uint16_t *cdf, const uint8_t *__restrict__ bytes, const RcChunk *__restrict__ chunks,
                                                      int nchunks, int c0, int lane, uint32_t rdw, uint8_t *sym, uint32_t *win)
 {
@@ -225,16 +261,20 @@ __device__ __forceinline__ void rc_decode17_lds_wave(const uint16_t *cdf, const 
             for (int dd = 0; dd < PH; ++dd) {
                 const uint32_t v = regs[h][dd];
                 const uint32_t tw = in.peek();
-                const uint32_t t = kk ? scale_d(d, v) : 0u;
+                const uint32_t t = kk ? (CODER == RC_CODER_CARRY ? __umul24(d >> 16, v) : scale_d(d, v)) : 0u;   // (CARRY: d holds the range)
                 const uint64_t bal = __ballot(t <= x);
                 const uint32_t half = (grp & 2) ? (uint32_t)(bal >> 32) : (uint32_t)bal;
                 const uint32_t bits = (half >> ((grp & 1) * 16)) & 0xFFFFu;      // this group's lanes with t <= x: lanes 0..s
                 const uint32_t s = ((uint32_t)__popc(bits) - 1u) & 15u;
                 const uint32_t lo = (uint32_t)__shfl((int)t, g16 + (int)s);
                 const uint32_t nx = (uint32_t)__shfl((int)t, g16 + (int)min(s + 1u, 15u));
-                const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
                 if ((dd & 3) == 0) pack[dd >> 2] = s; else pack[dd >> 2] |= s << (8 * (dd & 3));
-                rc_renorm(low, d, x, lo, d1, tw, k);
+                if constexpr (CODER == RC_CODER_CARRY) {
+                    cp_renorm(d, x, lo, (s == 15u ? d : nx) - lo, tw, k);
+                } else {
+                    const uint32_t d1 = (s == 15u ? d : nx - 1u) - lo;
+                    rc_renorm(low, d, x, lo, d1, tw, k);
+                }
                 in.advance(k);
             }
             __builtin_amdgcn_sched_barrier(0);

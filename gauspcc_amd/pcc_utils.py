@@ -10,9 +10,10 @@ Deliberate differences, all on the error side:
   * a bare file name as output_path works (reference: os.makedirs('') raises, :47);
   * decompress_point_cloud(output_path=...) really writes the ASCII PLY (reference: NameError,
     `io` is never imported, :392).
-The container written by default is the chunked one (version 3: per-level chunk sizes, two coder lanes per byte-counted
-chunk, parallel decode); chunk_log2=0 writes the reference's exact layout.  Every layout this library
-ever wrote (versions 1-3) and the reference's are read back transparently.
+The container written by default is the chunked one (version 4: per-level chunk sizes, two coder lanes per byte-counted
+chunk, a carry-propagating range coder in the lanes, parallel decode); chunk_log2=0 writes the
+reference's exact layout.  Every layout this library ever wrote (versions 1-4) and the reference's are read back transparently;
+`gauspcc_amd.pcc_utils.CONTAINER_VERSION = 3` (or GAUSPCC_CONTAINER_VERSION=3) keeps writing round 3's layout.
 """
 import ctypes as C
 import os
@@ -24,6 +25,11 @@ import torch
 from . import _lib, runtime
 
 DEFAULT_CHUNK_LOG2 = int(os.environ.get("GAUSPCC_CHUNK_LOG2", "11"))
+CONTAINER_VERSION = int(os.environ.get("GAUSPCC_CONTAINER_VERSION", "4"))   # chunked containers: 4, or 3 (torchac's coder in the lanes: round 3's files)
+
+
+def _set_version(ctx, version=None):
+    _lib.check(_lib.lib().gpcc_ctx_set_container_version(ctx, CONTAINER_VERSION if version is None else int(version)))
 
 _DTYPES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3}
 
@@ -70,8 +76,9 @@ def voxelise(xyz: torch.Tensor, is_data_pre_quantized: bool = True, posQ=1) -> t
     return out
 
 
-def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ, ideal_bits: bool = False):
+def _encode_to_bytes(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ, ideal_bits: bool = False, version=None):
     ctx = runtime.context(xyz_int32.device)
+    _set_version(ctx, version)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
     st.flags = 1 if ideal_bits else 0   # GPCC_STATS_IDEAL_BITS: the bpp estimator next to the coder (diagnostic, ~4 % of an encode)
     _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
@@ -153,6 +160,7 @@ def _encode_view(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
     and every gsac_encode* (the attribute coders of arithmetic.py / encodings_cuda.py share it).  Write it to a file or hand
     it to _decode_bytes first; _encode_to_bytes returns an owned copy."""
     ctx = runtime.context(xyz_int32.device)
+    _set_version(ctx)
     pb, nb, st = C.c_void_p(), C.c_int64(), _lib.Stats()
     _lib.check(_lib.lib().gpcc_encode(ctx, model.handle, xyz_int32.data_ptr(), xyz_int32.shape[0], chunk_log2, runtime.f16_bits(posQ),
                                       C.byref(pb), C.byref(nb), C.byref(st), runtime.stream_ptr(xyz_int32.device)))

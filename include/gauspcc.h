@@ -41,6 +41,11 @@ GPCC_API int gpcc_version(void);
 
 GPCC_API int gpcc_ctx_create(int device, gpcc_ctx **out);
 GPCC_API void gpcc_ctx_destroy(gpcc_ctx *ctx);
+/* Chunked containers (chunk_log2 != 0) are this library's own layout: version 4 (default) runs a
+ * carry-propagating range coder in the lanes of a stream -- same 16-bit CDF rows and rate as torchac's coder, a third of the
+ * decoder's dependent chain --, version 3 torchac's coder (arithmetic_kernel.cu:94-163) itself.  Sets what gpcc_encode and
+ * gpcc_rc_encode / gpcc_rc_decode use; gpcc_decode reads versions 0 (the reference layout, pcc_utils.py:198-203) to 4. */
+GPCC_API int gpcc_ctx_set_container_version(gpcc_ctx *ctx, int version);
 /* bytes the context holds now: device (workspace arena, product buffer of the small levels) and pinned host staging.  The
  * reference's CLIs print torch.cuda.max_memory_allocated() (compress_ue_4stage_conv.py:283); this library allocates its
  * workspace itself, so its CLIs add this figure.  Either pointer may be null. */

@@ -48,6 +48,9 @@ def lib():
         L.orc_rc_encode.restype = i64
         L.orc_rc_encode.argtypes = [vp, i32, vp, i64, vp, i64]
         L.orc_rc_decode.argtypes = [vp, i32, vp, i64, i64, vp]
+        L.orc_cp_encode.restype = i64
+        L.orc_cp_encode.argtypes = [vp, i32, vp, i64, vp, i64]
+        L.orc_cp_decode.argtypes = [vp, i32, vp, i64, i64, vp]
         L.orc_stream_encode.restype = i64
         L.orc_stream_encode.argtypes = [vp, i32, vp, i64, i32, i32, vp, i64]
         L.orc_stream_decode.argtypes = [vp, i32, vp, i64, i64, i32, i32, vp]
@@ -212,9 +215,29 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes) -> np.ndarray:
     return out
 
 
-def stream_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version: int = 3) -> bytes:
+def cp_encode(cdf_u16: np.ndarray, sym: np.ndarray) -> bytes:
+    """One lane of a version-4 container: the carry-propagating range coder (gpcc_oracle.c: cp_encode_core)."""
+    cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
+    sym = np.ascontiguousarray(sym, dtype=np.uint8)
+    cap = sym.size * 4 + 16
+    out = np.empty(cap, dtype=np.uint8)
+    n = lib().orc_cp_encode(_p(cdf), cdf.shape[1], _p(sym), sym.size, _p(out), cap)
+    assert n <= cap
+    return out[:n].tobytes()
+
+
+def cp_decode(cdf_u16: np.ndarray, data: bytes) -> np.ndarray:
+    cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(cdf.shape[0], dtype=np.uint8)
+    lib().orc_cp_decode(_p(cdf), cdf.shape[1], _p(buf), buf.size, cdf.shape[0], _p(out))
+    return out
+
+
+def stream_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version: int = 4) -> bytes:
     """One (level, stage) stream of the container as the codec writes it for a level of len(sym) nodes: the chunk table and
-    the chunks (version 3: Rice-coded counts, forward + reversed backward lane per chunk); chunk_log2 = 0: the bare coder bytes."""
+    the chunks (versions 3 / 4: Rice-coded counts, forward + reversed backward lane per chunk; version 4: the carry-propagating
+    coder in the lanes); chunk_log2 = 0: the bare bytes of torchac's coder."""
     cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
     sym = np.ascontiguousarray(sym, dtype=np.uint8)
     cap = sym.size * 4 + 64 + 8 * (sym.size // 32 + 1)
@@ -224,7 +247,7 @@ def stream_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version
     return out[:n].tobytes()
 
 
-def stream_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int, version: int = 3) -> np.ndarray:
+def stream_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int, version: int = 4) -> np.ndarray:
     cdf = np.ascontiguousarray(cdf_u16).view(np.uint16)
     buf = np.frombuffer(data, dtype=np.uint8)
     out = np.empty(cdf.shape[0], dtype=np.uint8)
@@ -250,8 +273,8 @@ def chunk_table_parse(data: bytes, nch: int):
     return out, int(k)
 
 
-def set_container_version(v: int = 3) -> int:
-    """Version orc.encode writes for chunk_log2 != 0 (default 3); returns the version in force."""
+def set_container_version(v: int = 4) -> int:
+    """Version orc.encode writes for chunk_log2 != 0 (default 4); returns the version in force."""
     return int(lib().orc_set_container_version(int(v)))
 
 

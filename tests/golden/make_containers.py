@@ -28,5 +28,15 @@ for k in (5, 3):
     orc.set_container_version(3)
     for cl in (6, 11):
         out[f"k{k}_chunk{cl}_v3"] = np.frombuffer(orc.encode(m, pts, chunk_log2=cl), dtype=np.uint8)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "containers.npz"), **out)
+    # k*_chunk*_v4: version 4 (round 4: the version-3 layout with the carry-propagating coder in the lanes), what the encoder writes now
+    orc.set_container_version(4)
+    for cl in (6, 11):
+        out[f"k{k}_chunk{cl}_v4"] = np.frombuffer(orc.encode(m, pts, chunk_log2=cl), dtype=np.uint8)
+# what earlier rounds stored must come out again byte for byte: a new layout is ADDED, the old streams never change
+path = os.path.join(ROOT, "tests", "golden", "containers.npz")
+if os.path.exists(path):
+    old = np.load(path)
+    for key in old.files:
+        assert key in out and np.array_equal(old[key], out[key]), f"stored fixture {key} would change"
+np.savez_compressed(path, **out)
 print({k: v.shape for k, v in out.items()})

@@ -59,7 +59,12 @@ def head_cdf(x: np.ndarray, w1, b1, w2, b2):
     return prob.cpu().numpy(), cdf.cpu().numpy().view(np.uint16)
 
 
-def rc_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int) -> bytes:
+def set_version(version: int = 4):
+    _lib.check(_lib.lib().gpcc_ctx_set_container_version(runtime.context(dev()), version))
+
+
+def rc_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int, version: int = 4) -> bytes:
+    set_version(version)
     c = torch.tensor(np.ascontiguousarray(cdf_u16).view(np.int16), device=dev())
     s = torch.tensor(np.ascontiguousarray(sym, dtype=np.uint8), device=dev())
     pb, nb = C.c_void_p(), C.c_int64()
@@ -68,7 +73,8 @@ def rc_encode(cdf_u16: np.ndarray, sym: np.ndarray, chunk_log2: int) -> bytes:
     return C.string_at(pb, nb.value)
 
 
-def rc_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int) -> np.ndarray:
+def rc_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int, version: int = 4) -> np.ndarray:
+    set_version(version)
     c = torch.tensor(np.ascontiguousarray(cdf_u16).view(np.int16), device=dev())
     out = torch.empty(c.shape[0], dtype=torch.uint8, device=dev())
     buf = (C.c_char * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
@@ -77,11 +83,11 @@ def rc_decode(cdf_u16: np.ndarray, data: bytes, chunk_log2: int) -> np.ndarray:
     return out.cpu().numpy()
 
 
-def encode(model, xyz: np.ndarray, chunk_log2=11, posq=1, ideal_bits=False):
+def encode(model, xyz: np.ndarray, chunk_log2=11, posq=1, ideal_bits=False, version=None):
     from gauspcc_amd.pcc_utils import _encode_to_bytes
 
     x = torch.tensor(np.ascontiguousarray(xyz, dtype=np.int32), device=dev())
-    return _encode_to_bytes(x, model, chunk_log2, posq, ideal_bits)
+    return _encode_to_bytes(x, model, chunk_log2, posq, ideal_bits, version)
 
 
 def decode(model, data: bytes):

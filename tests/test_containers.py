@@ -10,6 +10,7 @@ import pytest
 
 CASES = [(k, cl) for k in (5, 3) for cl in (0, 6, 10)]          # stored with the version-2 writer (0: reference layout)
 CASES_V3 = [(k, cl) for k in (5, 3) for cl in (6, 11)]
+CASES_V4 = CASES_V3                                               # version 4: the same layout, the carry-propagating coder in the lanes
 
 
 def _rows(a):
@@ -29,7 +30,7 @@ def test_oracle_reproduces_stored_stream(orc, fixture, synth_model_k5, synth_mod
     try:
         assert orc.encode(model, fixture["points"], chunk_log2=cl) == stored
     finally:
-        orc.set_container_version(3)
+        orc.set_container_version(4)
     dec, posq = orc.decode(model, stored)
     assert float(posq) == 1.0
     assert np.array_equal(_rows(dec), _rows(fixture["points"]))
@@ -39,10 +40,29 @@ def test_oracle_reproduces_stored_stream(orc, fixture, synth_model_k5, synth_mod
 def test_oracle_reproduces_stored_stream_v3(orc, fixture, synth_model_k5, synth_model_k3, k, cl):
     model = synth_model_k5 if k == 5 else synth_model_k3
     stored = fixture[f"k{k}_chunk{cl}_v3"].tobytes()
+    orc.set_container_version(3)
+    try:
+        assert orc.encode(model, fixture["points"], chunk_log2=cl) == stored
+    finally:
+        orc.set_container_version(4)
+    dec, posq = orc.decode(model, stored)
+    assert float(posq) == 1.0
+    assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+
+
+@pytest.mark.parametrize("k,cl", CASES_V4)
+def test_oracle_reproduces_stored_stream_v4(orc, fixture, synth_model_k5, synth_model_k3, k, cl):
+    """Version 4 = the version-3 layout with the carry-propagating range coder in the lanes (oracle/gpcc_oracle.c: cp_encode_core;
+    the reference's coder -- arithmetic_kernel.cu:94-163 -- stays in the reference layout and in versions 1-3)."""
+    model = synth_model_k5 if k == 5 else synth_model_k3
+    stored = fixture[f"k{k}_chunk{cl}_v4"].tobytes()
     assert orc.encode(model, fixture["points"], chunk_log2=cl) == stored
     dec, posq = orc.decode(model, stored)
     assert float(posq) == 1.0
     assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+    # the same tables, lanes and symbols as version 3: sizes differ by the coders' flush bytes only
+    v3 = fixture[f"k{k}_chunk{cl}_v3"]
+    assert abs(len(stored) - len(v3)) <= 0.004 * len(v3) + 8
 
 
 def test_stored_headers(fixture):
@@ -53,6 +73,7 @@ def test_stored_headers(fixture):
         assert fixture[f"k5_chunk{cl}"][:4].tolist() == [0xFF, 0xFF, 2, cl]
     for cl in (6, 11):
         assert fixture[f"k5_chunk{cl}_v3"][:4].tolist() == [0xFF, 0xFF, 3, cl]
+        assert fixture[f"k5_chunk{cl}_v4"][:4].tolist() == [0xFF, 0xFF, 4, cl]
     # version 3 is never larger than version 2 at the same lane length (chunk_log2 one higher: two lanes per chunk)
     assert len(fixture["k5_chunk11_v3"]) < len(fixture["k5_chunk10"]) and len(fixture["k3_chunk11_v3"]) < len(fixture["k3_chunk10"])
 
@@ -164,17 +185,17 @@ def test_device_reads_version1(fixture):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,cl,tag", [(k, cl, "") for k, cl in CASES] + [(k, cl, "_v3") for k, cl in CASES_V3])
+@pytest.mark.parametrize("k,cl,tag", [(k, cl, "") for k, cl in CASES] + [(k, cl, "_v3") for k, cl in CASES_V3] + [(k, cl, "_v4") for k, cl in CASES_V4])
 def test_device_reproduces_stored_stream(fixture, k, cl, tag):
-    """The device writes the reference layout and version 3 byte for byte; it READS every stored layout (version 2 too)."""
+    """The device writes the reference layout, version 3 and version 4 byte for byte; it READS every stored layout (version 2 too)."""
     from gauspcc_amd import runtime
     from gauspcc_amd.synth import synthetic_state_dict
     from tests import gpu_helpers as gh
 
     model = runtime.Model(synthetic_state_dict(32, k), 32, k, 0)
     stored = fixture[f"k{k}_chunk{cl}{tag}"].tobytes()
-    if tag == "_v3" or cl == 0:
-        data, _ = gh.encode(model, fixture["points"], cl)
+    if tag in ("_v3", "_v4") or cl == 0:
+        data, _ = gh.encode(model, fixture["points"], cl, version=3 if tag == "_v3" else 4)
         assert data == stored
     dec, posq, _ = gh.decode(model, stored)
     assert float(posq) == 1.0

@@ -271,12 +271,16 @@ def test_head_cdf_bit_exact(gh, orc, m):
 
 
 # ---------------------------------------------------------------- a10 range coder
+@pytest.mark.parametrize("version", [3, 4])
 @pytest.mark.parametrize("lp", [3, 5, 17])
 @pytest.mark.parametrize("chunk_log2", [0, 6, 10, 11])
-def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2):
+def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2, version):
     """gpcc_rc_encode writes ONE stream as the container holds it (chunk_log2 = 0: the bare torchac-compatible coder bytes;
-    else version 3: chunk table, forward + reversed backward lane per chunk): bytes == the oracle's stream encoder,
+    else versions 3 / 4: chunk table, forward + reversed backward lane per chunk -- torchac's coder in the lanes of version 3
+    (arithmetic_kernel.cu:94-163), the carry-propagating coder in version 4): bytes == the oracle's stream encoder,
     either side decodes the other's stream.  n = 7001 at chunk_log2 = 11 is one short last chunk with an odd lane count."""
+    if chunk_log2 == 0 and version == 3:
+        pytest.skip("the reference layout has one coder: covered by the version-4 case")
     rng = np.random.RandomState(lp * 31 + chunk_log2)
     n = 7001
     logits = rng.randn(n, lp - 1).astype(np.float32) * 2.5
@@ -285,14 +289,14 @@ def test_range_coder_bytes_and_roundtrip(gh, orc, lp, chunk_log2):
     cdf = np.concatenate([np.zeros((n, 1), np.float32), np.cumsum(p, 1)], 1).clip(0, 1).astype(np.float32)
     cdf_i = orc.cdf_to_int16(cdf).view(np.uint16)
     sym = np.array([rng.choice(lp - 1, p=pi / pi.sum()) for pi in p.astype(np.float64)], dtype=np.uint8)
-    data = gh.rc_encode(cdf_i, sym, chunk_log2)
+    data = gh.rc_encode(cdf_i, sym, chunk_log2, version)
     if chunk_log2 == 0:
         assert data == orc.rc_encode(cdf_i, sym)
         assert np.array_equal(orc.rc_decode(cdf_i, data), sym)
-    ref = orc.stream_encode(cdf_i, sym, chunk_log2)
+    ref = orc.stream_encode(cdf_i, sym, chunk_log2, version)
     assert data == ref, f"first differing byte at {next((i for i, (a, b) in enumerate(zip(data, ref)) if a != b), min(len(data), len(ref)))} of {len(data)} / {len(ref)}"
-    assert np.array_equal(orc.stream_decode(cdf_i, data, chunk_log2), sym)
-    dec = gh.rc_decode(cdf_i, data, chunk_log2)
+    assert np.array_equal(orc.stream_decode(cdf_i, data, chunk_log2, version), sym)
+    dec = gh.rc_decode(cdf_i, data, chunk_log2, version)
     assert np.array_equal(dec, sym)
 
 
@@ -306,10 +310,11 @@ def test_range_coder_long_lanes_and_high_rates(gh, orc, lp):
     cdf = np.concatenate([np.zeros((n, 1), np.float32), np.cumsum(p, 1)], 1).clip(0, 1).astype(np.float32)
     cdf_i = orc.cdf_to_int16(cdf).view(np.uint16)
     sym = rng.randint(0, lp - 1, size=n).astype(np.uint8)          # symbols against the model: ~log2(Lp - 1) + bits each
-    for chunk_log2 in (14, 8):
-        data = gh.rc_encode(cdf_i, sym, chunk_log2)
-        assert data == orc.stream_encode(cdf_i, sym, chunk_log2)
-        assert np.array_equal(gh.rc_decode(cdf_i, data, chunk_log2), sym)
+    for version in (3, 4):
+        for chunk_log2 in (14, 8):
+            data = gh.rc_encode(cdf_i, sym, chunk_log2, version)
+            assert data == orc.stream_encode(cdf_i, sym, chunk_log2, version)
+            assert np.array_equal(gh.rc_decode(cdf_i, data, chunk_log2, version), sym)
 
 
 def test_range_coder_chunk_table_escape(gh, orc):
@@ -325,13 +330,16 @@ def test_range_coder_chunk_table_escape(gh, orc):
     rng = np.random.RandomState(11)
     sym = np.zeros(n, np.uint8)
     sym[half:] = rng.randint(0, 16, size=half)
-    data = gh.rc_encode(cdf_i, sym, 12)
-    ref = orc.stream_encode(cdf_i, sym, 12)
+    data = gh.rc_encode(cdf_i, sym, 12, 3)
+    ref = orc.stream_encode(cdf_i, sym, 12, 3)
     counts, used = orc.chunk_table_parse(ref, n >> 12)
     # 127 differences: 126 zeros (one bit each at k = 0) and one of 2048 bytes (48 bits: the escape), behind the first count and k
     assert int(np.abs(np.diff(counts.astype(np.int64))).max()) == 2048 and used == 2 + (126 + 48 + 7) // 8
     assert data == ref
-    assert np.array_equal(gh.rc_decode(cdf_i, data, 12), sym)
+    assert np.array_equal(gh.rc_decode(cdf_i, data, 12, 3), sym)
+    d4 = gh.rc_encode(cdf_i, sym, 12, 4)                          # the same jump under the version-4 coder
+    assert d4 == orc.stream_encode(cdf_i, sym, 12, 4)
+    assert np.array_equal(gh.rc_decode(cdf_i, d4, 12, 4), sym)
 
 
 def test_range_coder_extreme_rows(gh, orc):
@@ -355,12 +363,18 @@ def _sorted_rows(a):
 
 
 @pytest.mark.parametrize("k", [5, 3])
-@pytest.mark.parametrize("chunk_log2", [10, 0])
-def test_codec_bitstream_identical_to_oracle(gh, orc, k, chunk_log2, dev_model_k5, dev_model_k3, synth_model_k5, synth_model_k3):
+@pytest.mark.parametrize("chunk_log2,version", [(10, 4), (10, 3), (0, 4)])
+def test_codec_bitstream_identical_to_oracle(gh, orc, k, chunk_log2, version, dev_model_k5, dev_model_k3, synth_model_k5, synth_model_k3):
     dm, om = (dev_model_k5, synth_model_k5) if k == 5 else (dev_model_k3, synth_model_k3)
     pts = _cloud(10_000)
-    data, st = gh.encode(dm, pts, chunk_log2)
-    ref = orc.encode(om, pts, chunk_log2=chunk_log2)
+    data, st = gh.encode(dm, pts, chunk_log2, version=version)
+    orc.set_container_version(version)
+    try:
+        ref = orc.encode(om, pts, chunk_log2=chunk_log2)
+    finally:
+        orc.set_container_version(4)
+    if chunk_log2:
+        assert data[2] == version
     assert len(data) == len(ref), (len(data), len(ref))
     assert data == ref, f"first differing byte at {next(i for i, (a, b) in enumerate(zip(data, ref)) if a != b)}"
     assert st.num_points == len(pts)
@@ -385,7 +399,7 @@ def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_m
 
 
 def test_codec_bitstream_identical_to_oracle_1m(gh, orc, dev_model_k5, synth_model_k5):
-    """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v3 with chunk_log2 = 11 (bench.py's default).  The device
+    """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v4 with chunk_log2 = 11 (bench.py's default).  The device
     writes the oracle's bytes and decodes to the oracle's points in the oracle's order (the oracle needs ~15 s of the box's
     host cores for each direction)."""
     pts = _cloud(1_000_000, seed=1234)

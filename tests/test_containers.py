@@ -130,11 +130,19 @@ def test_v3_table_oracle_matches_the_restatement(orc):
                 orc.chunk_table_parse(bytes(bad), len(counts))                   # k > 7
 
 
-def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5):
-    """Version 3 by hand: a stream is its chunk table, then per chunk the forward lane's coder bytes followed by the
-    backward lane's coder bytes reversed -- checked against the plain coder (orc.rc_encode) on the traced CDFs / symbols."""
+@pytest.mark.parametrize("version", [3, 4])
+def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5, version):
+    """Versions 3 and 4 by hand: a stream is its chunk table, then per chunk the forward lane's coder bytes followed by the
+    backward lane's coder bytes reversed -- checked against the plain coders (version 3: orc.rc_encode, torchac's; version 4:
+    orc.cp_encode, the carry-propagating one) on the traced CDFs / symbols."""
     pts = fixture["points"]
-    data = orc.encode(synth_model_k5, pts, chunk_log2=6, trace=True)
+    lane_coder = orc.rc_encode if version == 3 else orc.cp_encode
+    orc.set_container_version(version)
+    try:
+        data = orc.encode(synth_model_k5, pts, chunk_log2=6, trace=True)
+    finally:
+        orc.set_container_version(4)
+    assert data[2] == version
     levels = orc.trace()
     L = data[6]
     pos = 8 + 4 * L + 4
@@ -151,7 +159,7 @@ def test_v3_chunk_table_and_lane_layout(orc, fixture, synth_model_k5):
             ln = int.from_bytes(data[pos:pos + 4], "little")
             body = data[pos + 4:pos + 4 + ln]
             pos += 4 + ln
-            lanes = [orc.rc_encode(lv["cdf"][s][l * S:(l + 1) * S], lv["sym"][s][l * S:(l + 1) * S]) for l in range(nl)]
+            lanes = [lane_coder(lv["cdf"][s][l * S:(l + 1) * S], lv["sym"][s][l * S:(l + 1) * S]) for l in range(nl)]
             counts, want_pay = [], b""
             for c in range(0, nl, 2):
                 counts.append(len(lanes[c]) + (len(lanes[c + 1]) if c + 1 < nl else 0))

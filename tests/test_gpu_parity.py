@@ -465,7 +465,7 @@ def test_codec_rejects_bad_input(gh, dev_model_k5):
             gh.decode(dev_model_k5, data[:cut])
     # a header whose level sizes do not match the coded occupancy (the device expands into arrays sized from the header
     # and verifies at its final sync): an error, never an out-of-bounds access
-    assert data[:2] == b"\xff\xff" and data[2] == 3
+    assert data[:2] == b"\xff\xff" and data[2] == 4
     L = data[6]
     for lvl, delta in ((L - 1, +3), (L - 1, -3), (L - 2, +1), (2, -1)):
         bad = bytearray(data)

@@ -26,6 +26,10 @@ __device__ __forceinline__ uint32_t scale_d(uint32_t d, uint32_t v)
 
 __device__ __forceinline__ uint32_t ones_below(uint32_t k) { return (1u << (k & 31u)) - 1u; }
 
+// (Round 4 measured a register-resident window of four dwords -- shifted on a dword crossing, one LDS dword requested per symbol
+// and first needed a whole symbol later -- against this two-dword re-read: +6 VALU per symbol and 3-4 % SLOWER on both coders
+// (2.71 -> 2.81 ms of coder stage with the version-4 coder): a lone wave is bound by the instructions it issues, not by this LDS
+// round trip, which already overlaps the next symbol's compare chain.)
 struct LaneWin {
     const uint32_t *w;      // the lane's window in LDS
     uint32_t q;             // bits consumed - 1 (starts at 31: the first dword is the initial value)

@@ -1,0 +1,139 @@
+// hostcoder.hip -- torchac's coder on HOST arrays (plain C++; no kernel in this file).
+//
+// torchac.encode_int16_normalized_cdf / decode_int16_normalized_cdf (requirements.txt:6; torchac 0.9.3's C++ extension) code a
+// WHOLE tensor as one range-coder stream on one CPU thread; TC-GS and CAT-3DGS call it that way for every attribute
+// (TC-GS/utils/encodings.py:84-176: the CDF table is built with torch.distributions on the GPU, moved to the CPU, coded there).
+// A single stream is one dependent chain: on the MI355X it decodes on ONE lane at ~2 Msymbols/s (round 3's torchac shim: 4.8 /
+// 2.2 Msymbols/s encode / decode, slower than any CPU), while a host core runs the same chain at > 10 Msymbols/s.  So the
+// drop-in for torchac runs the coder here, on the host, and leaves the GPU what it is good at (building the integer CDF rows:
+// gauspcc_amd/torchac.py); callers that can choose their format use the chunked device coders (gsac_encode*, gpcc_rc_*).
+//
+// The loops are the lane loops of rangecoder.hip (carry-less 32-bit coder, 16-bit counts: arithmetic_kernel.cu:94-163,
+// 237-356) with the same shortcuts -- renormalisation by count-leading-zeros instead of bit by bit, a
+// division-free symbol search on the scaled bounds -- and produce / consume torchac's bytes exactly (tests: bytes == the
+// oracle's restatement of the reference loop).
+#include <stdint.h>
+#include <string.h>
+
+#include "../../include/gauspcc.h"
+#include "common.hpp"
+
+namespace {
+
+struct BitSink {
+    uint8_t *out; int64_t cap, len;
+    uint64_t acc; int n;   // n valid bits at the top of acc
+    inline void put(uint32_t bits, int k)   // k in [1, 32]
+    {
+        acc |= (uint64_t)bits << (64 - n - k);
+        n += k;
+        while (n >= 8) { if (len < cap) out[len] = (uint8_t)(acc >> 56); ++len; acc <<= 8; n -= 8; }
+    }
+    inline void put_run(uint32_t bit, uint64_t k)
+    {
+        const uint32_t pat = bit ? 0xFFFFFFFFu : 0u;
+        while (k >= 32) { put(pat, 32); k -= 32; }
+        if (k) put(pat >> (32 - k), (int)k);
+    }
+};
+
+inline int clz32h(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+
+}  // namespace
+
+extern "C" int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+{
+    if (!sym || !cdf || !out || !nbytes_out || n < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    BitSink w = {out, cap, 0, 0, 0};
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint64_t pending = 0;
+    const int top = lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const int s = sym[i];
+        if (s < 0 || s > top) return gpcc::fail(GPCC_ERR_ARG, "symbol %d at %lld outside [0, %d]", s, (long long)i, top);
+        const uint16_t *row = cdf + i * lp;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+        const uint32_t c_low = row[s], c_high = s == top ? 0x10000u : row[s + 1];
+        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        // E1 / E2: the n1 leading bits on which low and high agree leave at once (the first with the pending run behind it)
+        const int n1 = clz32h(low ^ high);
+        if (n1) {
+            const uint32_t bits = n1 == 32 ? low : low >> (32 - n1);
+            const uint32_t b = bits >> (n1 - 1);
+            w.put(b, 1);
+            if (pending) { w.put_run(b ^ 1u, pending); pending = 0; }
+            if (n1 > 1) w.put(bits & ((1u << (n1 - 1)) - 1u), n1 - 1);
+            low = n1 == 32 ? 0u : low << n1;
+            high = n1 == 32 ? 0xFFFFFFFFu : (high << n1) | ((1u << n1) - 1u);
+        }
+        // E3: low = 01.., high = 10.. -- drop the second bit n2 times
+        int n2 = clz32h(~(low << 1));
+        const int h2 = clz32h(high << 1);
+        n2 = n2 < h2 ? n2 : h2;
+        n2 = n2 < 31 ? n2 : 31;
+        if (n2) {
+            pending += (uint64_t)n2;
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+        }
+    }
+    pending += 1;
+    const uint32_t b = low < 0x40000000u ? 0u : 1u;
+    w.put(b, 1);
+    w.put_run(b ^ 1u, pending);
+    if (w.n) w.put(0u, 8 - w.n);
+    *nbytes_out = w.len;
+    if (w.len > cap) return gpcc::fail(GPCC_ERR_ARG, "output buffer of %lld bytes, the stream takes %lld", (long long)cap, (long long)w.len);
+    return GPCC_OK;
+}
+
+extern "C" int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
+{
+    if (!cdf || (!bytes && nbytes) || !sym_out || n < 0 || nbytes < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    // bit reservoir: `value` holds the 32 bits at the read position; bits past the end read as zero (arithmetic_kernel.cu:244-262)
+    uint64_t res = 0; int nres = 0; int64_t ptr = 0;
+    auto take = [&](int k) -> uint32_t {   // k in [0, 32]
+        if (k == 0) return 0u;
+        while (nres < k) { const uint64_t byte = ptr < nbytes ? bytes[ptr] : 0u; ++ptr; res |= byte << (56 - nres); nres += 8; }
+        const uint32_t v = (uint32_t)(res >> (64 - k));
+        res <<= k; nres -= k;
+        return v;
+    };
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = take(32);
+    const int top = lp - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t *row = cdf + i * lp;
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+        const uint32_t x = value - low;
+        // the reference picks the largest s with row[s] <= count, count = ((x + 1) 2^16 - 1) / span; row[s] <= count  <=>
+        // (span row[s]) >> 16 <= x, exactly (rangecoder.hip header): search on the scaled bounds, no division
+        int lo_i = 0, hi_i = top + 1;
+        while (lo_i + 1 < hi_i) {
+            const int m = (lo_i + hi_i) >> 1;
+            if ((uint32_t)((span * row[m]) >> 16) <= x) lo_i = m; else hi_i = m;
+        }
+        const int s = lo_i;
+        sym_out[i] = (int16_t)s;
+        const uint32_t c_low = row[s], c_high = s == top ? 0x10000u : row[s + 1];
+        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        const int n1 = clz32h(low ^ high);
+        if (n1) {
+            low = n1 == 32 ? 0u : low << n1;
+            high = n1 == 32 ? 0xFFFFFFFFu : (high << n1) | ((1u << n1) - 1u);
+            value = n1 == 32 ? take(32) : (value << n1) | take(n1);
+        }
+        int n2 = clz32h(~(low << 1));
+        const int h2 = clz32h(high << 1);
+        n2 = n2 < h2 ? n2 : h2;
+        n2 = n2 < 31 ? n2 : 31;
+        if (n2) {
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+            // every underflow step maps value -> 2 (value - 2^30) + next bit: n2 of them keep the top bit and shift the rest
+            value = ((value << n2) | take(n2)) ^ 0x80000000u;
+        }
+    }
+    return GPCC_OK;
+}

@@ -7,59 +7,72 @@ in pcc_utils.py:174-177, 322-366 and the TC-GS / CAT-3DGS attribute codecs
     encode_int16_normalized_cdf(cdf_int, sym) -> bytes
     decode_int16_normalized_cdf(cdf_int, byte_stream) -> int16 tensor
 
-Byte-compatible with torchac (one range-coder stream for the whole tensor), computed on the MI355X.
-torchac takes CPU tensors; here CPU tensors are moved to the current GPU and CUDA tensors are used in
-place.  A single stream decodes on a single lane, so for large tensors prefer the chunked
-gauspcc_amd.arithmetic interface (the reference's own CUDA coder format).
+Byte-compatible with torchac: ONE range-coder stream for the whole tensor.  That format is a single dependent chain, so
+the coder itself runs where such a chain runs fastest -- on a host core, in libgauspcc's plain C++ twin of the device lane
+loop (csrc/hostcoder.hip: gsac_host_encode_u16 / gsac_host_decode_u16; round 3 ran it on one GPU lane at 4.8 / 2.2 Msymbols/s,
+slower than torchac's own CPU loop).  What the GPU does is the part that is data-parallel: the float CDF table is turned into
+torchac's int16 rows with torch ops on the device the table lives on (`_convert_to_int_and_normalize`, torchac.py of the
+package = kit/op.py:67-79) and crosses PCIe once, as 2 bytes per entry instead of 4.  torchac takes CPU tensors; CUDA tensors
+work too.  Callers that can choose their format get parallel decode from the chunked device coders (gauspcc_amd.arithmetic,
+the reference's own CUDA coder format).
 """
 import ctypes as C
 
 import numpy as np
 import torch
 
-from . import _lib, runtime
+from . import _lib
 
-
-def _dev(t):
-    return t if t.is_cuda else t.to(torch.device("cuda", torch.cuda.current_device()))
+PRECISION = 16
 
 
 def _flatten(cdf, sym=None):
     lp = cdf.shape[-1]
-    cdf2 = cdf.reshape(-1, lp).contiguous()
+    cdf2 = cdf.reshape(-1, lp)
     if sym is not None:
         if tuple(sym.shape) != tuple(cdf.shape[:-1]):
             raise ValueError(f"Invalid shapes of cdf={tuple(cdf.shape)}, sym={tuple(sym.shape)}! The first m elements of cdf.shape must be equal to sym.shape")
         if sym.dtype != torch.int16:
             raise ValueError(f"sym must be int16, got {sym.dtype}")
-        sym = sym.reshape(-1).contiguous()
+        sym = sym.reshape(-1)
     return cdf2, sym, lp
 
 
-def _encode(cdf, sym, is_u16):
-    cdf, sym = _dev(cdf), _dev(sym)
+def _to_int_rows(cdf_float):
+    """torchac's _convert_to_int_and_normalize(cdf_float, needs_normalization=True) on the tensor's own device:
+    round(cdf * (2^16 - (Lp - 1))) + arange(Lp), kept as the int16 bit pattern.  Through int32 (exact for values up to 2^16):
+    a float -> int16 conversion of 32768 .. 65536 is not the same on every backend, the int32 -> int16 truncation is."""
+    lp = cdf_float.shape[-1]
+    scaled = cdf_float.to(torch.float32).mul(float(2 ** PRECISION - (lp - 1))).round().to(torch.int32)
+    return (scaled + torch.arange(lp, dtype=torch.int32, device=cdf_float.device)).to(torch.int16)
+
+
+def _host(t):
+    """contiguous numpy view of a tensor's data on the host (a CUDA tensor is copied once)"""
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+def _encode(cdf_i16, sym):
     n = sym.numel()
     if n == 0:
         return b""
-    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-    fn = _lib.lib().gsac_encode_u16 if is_u16 else _lib.lib().gsac_encode
-    _lib.check(fn(runtime.context(cdf.device), sym.data_ptr(), cdf.data_ptr(), n, n, cdf.shape[1], C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc),
-                  runtime.stream_ptr(cdf.device)))
-    return C.string_at(pb, nb.value)
+    rows, syms = _host(cdf_i16), _host(sym)
+    cap = 4 * n + 64
+    out = np.empty(cap, dtype=np.uint8)
+    nb = C.c_int64()
+    _lib.check(_lib.lib().gsac_host_encode_u16(syms.ctypes.data, rows.ctypes.data, n, rows.shape[1], out.ctypes.data, cap, C.byref(nb)))
+    return out[: nb.value].tobytes()
 
 
-def _decode(cdf, byte_stream, is_u16, out_shape, out_device):
-    cdf = _dev(cdf)
-    n = cdf.shape[0]
-    out = torch.zeros(n, dtype=torch.int16, device=cdf.device)
+def _decode(cdf_i16, byte_stream, out_shape, out_device):
+    rows = _host(cdf_i16)
+    n = rows.shape[0]
+    out = np.zeros(n, dtype=np.int16)
     if n:
         data = np.frombuffer(byte_stream, dtype=np.uint8)
-        cnt = np.array([data.size], dtype=np.int32)
         buf = np.ascontiguousarray(data) if data.size else np.zeros(1, np.uint8)
-        fn = _lib.lib().gsac_decode_u16 if is_u16 else _lib.lib().gsac_decode
-        _lib.check(fn(runtime.context(cdf.device), cdf.data_ptr(), buf.ctypes.data, data.size, cnt.ctypes.data, n, n, cdf.shape[1], out.data_ptr(),
-                      runtime.stream_ptr(cdf.device)))
-    return out.reshape(out_shape).to(out_device)
+        _lib.check(_lib.lib().gsac_host_decode_u16(rows.ctypes.data, buf.ctypes.data, data.size, n, rows.shape[1], out.ctypes.data))
+    return torch.from_numpy(out).reshape(out_shape).to(out_device)
 
 
 def encode_float_cdf(cdf_float, sym, needs_normalization=True, check_input_bounds=False):
@@ -73,26 +86,26 @@ def encode_float_cdf(cdf_float, sym, needs_normalization=True, check_input_bound
             raise ValueError("sym.max() >= Lp - 1!")
     if not needs_normalization:
         raise NotImplementedError("needs_normalization=False is not used by the reference")
-    cdf2, sym2, _ = _flatten(cdf_float.to(torch.float32), sym)
-    return _encode(cdf2, sym2, False)
+    cdf2, sym2, _ = _flatten(cdf_float, sym)
+    return _encode(_to_int_rows(cdf2), sym2)
 
 
 def decode_float_cdf(cdf_float, byte_stream, needs_normalization=True):
     if not needs_normalization:
         raise NotImplementedError("needs_normalization=False is not used by the reference")
-    cdf2, _, _ = _flatten(cdf_float.to(torch.float32))
-    return _decode(cdf2, byte_stream, False, tuple(cdf_float.shape[:-1]), cdf_float.device)
+    cdf2, _, _ = _flatten(cdf_float)
+    return _decode(_to_int_rows(cdf2), byte_stream, tuple(cdf_float.shape[:-1]), cdf_float.device)
 
 
 def encode_int16_normalized_cdf(cdf_int, sym):
     if cdf_int.dtype != torch.int16:
         raise ValueError(f"cdf must be int16, got {cdf_int.dtype}")
     cdf2, sym2, _ = _flatten(cdf_int, sym)
-    return _encode(cdf2, sym2, True)
+    return _encode(cdf2, sym2)
 
 
 def decode_int16_normalized_cdf(cdf_int, byte_stream):
     if cdf_int.dtype != torch.int16:
         raise ValueError(f"cdf must be int16, got {cdf_int.dtype}")
     cdf2, _, _ = _flatten(cdf_int)
-    return _decode(cdf2, byte_stream, True, tuple(cdf_int.shape[:-1]), cdf_int.device)
+    return _decode(cdf2, byte_stream, tuple(cdf_int.shape[:-1]), cdf_int.device)

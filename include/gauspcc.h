@@ -231,6 +231,15 @@ GPCC_API int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym_dev, const uint16
 GPCC_API int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
                              int64_t n, int lp, int16_t *sym_out_dev, void *stream);
 
+/* torchac's coder itself, on HOST arrays and one host thread -- the drop-in for torchac.encode_int16_normalized_cdf /
+ * decode_int16_normalized_cdf (torchac 0.9.3; call sites TC-GS/utils/encodings.py:84-176, CAT-3DGS/utils/encodings.py:39-175,
+ * HAC/utils/pcc_utils.py:174-177): ONE stream for the whole tensor, byte-identical to torchac's.  A single stream is a single
+ * dependent chain, which a host core runs several times faster than one GPU lane; gauspcc_amd.torchac builds the integer rows
+ * where the caller's tensors live and codes here.  cdf (n, lp) uint16 rows, sym (n) int16, all host memory; out: cap bytes
+ * (4 n + 64 always suffice).  No context, no GPU call. */
+GPCC_API int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out);
+GPCC_API int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out);
+
 /* encoder_gaussian / decoder_gaussian in one call each, WITHOUT the (n, max-min+2) float CDF table of
  * arithmetic.calculate_cdf (src/gs_compress/HAC/utils/encodings_cuda.py:336-371, 399-433):
  *   encode: x_int = round(x / Q), min/max over the slice, the two CDF entries of every symbol evaluated on the fly,

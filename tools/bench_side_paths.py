@@ -126,8 +126,14 @@ def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None
     sym_t = torch.multinomial(pt, 1).view(-1).to(torch.int16).to(dev)
     t_te, blob = timed(lambda: tac.encode_float_cdf(cdf_t, sym_t), 2)
     t_td, sd = timed(lambda: tac.decode_float_cdf(cdf_t, blob), 2)
+    # ... and with CPU tensors, torchac's own calling convention (TC-GS/utils/encodings.py:84-129 moves the table to the CPU first)
+    cdf_c, sym_c = cdf_t.cpu(), sym_t.cpu()
+    t_ce, blob_c = timed(lambda: tac.encode_float_cdf(cdf_c, sym_c), 2)
+    t_cd, _ = timed(lambda: tac.decode_float_cdf(cdf_c, blob_c), 2)
     out["torchac_shim"] = {"symbols": nt, "encode_Msym_per_s": round(nt / t_te / 1e6, 2), "decode_Msym_per_s": round(nt / t_td / 1e6, 2),
-                           "roundtrip": bool(torch.equal(sd.to(dev), sym_t))}
+                           "cpu_tensors_encode_Msym_per_s": round(nt / t_ce / 1e6, 2), "cpu_tensors_decode_Msym_per_s": round(nt / t_cd / 1e6, 2),
+                           "coder": "host thread (csrc/hostcoder.hip): one stream is one dependent chain; int16 rows built on the tensor's device",
+                           "roundtrip": bool(torch.equal(sd.to(dev), sym_t)) and blob == blob_c}
     return out
 
 

@@ -45,7 +45,7 @@ EXPORTS = [
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get",
-    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gshac_mlp2", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
+    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gsac_encode_gaussian_mixed_slices", "gsac_decode_gaussian_mixed_slices", "gshac_mlp2", "gshac_mlp2_act", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
 ]
 
 
@@ -109,6 +109,9 @@ def lib():
     L.gsac_encode_gaussian_slices.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
     L.gsac_decode_gaussian_slices.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, i32, vp, vp]
     L.gshac_mlp2.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, vp, vp]
+    L.gshac_mlp2_act.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, C.c_float, vp, vp]
+    L.gsac_encode_gaussian_mixed_slices.argtypes = [vp, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
+    L.gsac_decode_gaussian_mixed_slices.argtypes = [vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i64, vp, i32, vp, vp]
     L.gsge_forward.argtypes = [vp, vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, vp, vp]
     f32 = C.c_float
     L.gsr_visible_filter.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp]

@@ -200,3 +200,35 @@ def decode_gaussian_mixed(mean_list, scale_list, prob_list, Q, min_value, max_va
                                                      data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size), out.data_ptr(),
                                                      runtime.stream_ptr(q32.device)))
     return out
+
+
+def encode_gaussian_mixed_slices(x, mean_list, scale_list, prob_list, Q, slice_start, chunk_size):
+    """All slices of one mixture-coded attribute in one call (gsac_encode_gaussian_mixed_slices): HAC++ codes `feat` as five
+    ten-channel groups per 3000-anchor slice, each group under a two-component mixture (HAC-plus/scene/gaussian_model.py:1300-1321).
+    Returns (mins, maxs, bytes, cnt) as numpy arrays, as encode_gaussian_slices does."""
+    _chk(x, "x")
+    k, keep, pm, ps, pp, q32 = _mix_args(mean_list, scale_list, prob_list, Q)
+    (x32,) = _f32(x)
+    ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
+    ns = ss.size - 1
+    mins, maxs = np.empty(ns, dtype=np.float32), np.empty(ns, dtype=np.float32)
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode_gaussian_mixed_slices(runtime.context(x.device), x32.data_ptr(), pm, ps, pp, k, q32.data_ptr(), ss.ctypes.data, ns,
+                                                            int(chunk_size), mins.ctypes.data, maxs.ctypes.data, C.byref(pb), C.byref(nb), C.byref(pc),
+                                                            C.byref(nc), runtime.stream_ptr(x.device)))
+    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
+    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    return mins, maxs, out, cnt
+
+
+def decode_gaussian_mixed_slices(mean_list, scale_list, prob_list, Q, slice_start, mins, maxs, data, cnt, chunk_size):
+    """Inverse of encode_gaussian_mixed_slices."""
+    k, keep, pm, ps, pp, q32 = _mix_args(mean_list, scale_list, prob_list, Q)
+    ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
+    mins = np.ascontiguousarray(mins, dtype=np.float32); maxs = np.ascontiguousarray(maxs, dtype=np.float32)
+    data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    out = torch.empty(int(ss[-1]), dtype=torch.float32, device=q32.device)
+    _lib.check(_lib.lib().gsac_decode_gaussian_mixed_slices(runtime.context(q32.device), pm, ps, pp, k, q32.data_ptr(), ss.ctypes.data, ss.size - 1,
+                                                            mins.ctypes.data, maxs.ctypes.data, data.ctypes.data, data.size, cnt.ctypes.data,
+                                                            int(chunk_size), out.data_ptr(), runtime.stream_ptr(q32.device)))
+    return out

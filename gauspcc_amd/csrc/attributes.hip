@@ -219,13 +219,16 @@ __global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *
 // its own alphabet): one wave per chunk of any slice, CDF entries from the element's Gaussian parameters, the decoded
 // value (sym + min) * Q written directly (encodings_cuda.py:431-432).
 struct SliceChunk { int64_t base; int32_t n, slice; uint32_t byte_off, nbytes; };
-__global__ __launch_bounds__(64) void k_hac_decode_slices(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ q,
-                                                          const SliceChunk *__restrict__ chunks, const int32_t *__restrict__ smin,
+// CT = GaussTable (HAC) or MixTable (HAC++'s mixture: the feat groups); its min_value is the slice's
+template <typename CT>
+__global__ __launch_bounds__(64) void k_hac_decode_slices(CT table, const SliceChunk *__restrict__ chunks, const int32_t *__restrict__ smin,
                                                           const int32_t *__restrict__ slp, const uint8_t *__restrict__ bytes, float *__restrict__ x)
 {
     const SliceChunk ch = chunks[blockIdx.x];
     const int mn = smin[ch.slice];
-    hac_decode_chunk(GaussTable{mean, scale, q, mn}, bytes + ch.byte_off, ch.nbytes, ch.base, ch.n, slp[ch.slice],
+    table.min_value = mn;
+    const float *__restrict__ q = table.q;
+    hac_decode_chunk(table, bytes + ch.byte_off, ch.nbytes, ch.base, ch.n, slp[ch.slice],
                      [&](int64_t r, int s) { x[r] = ((float)s + (float)mn) * q[r]; });
 }
 
@@ -464,7 +467,7 @@ namespace {
 constexpr int MLP_ROWS = 16;
 __global__ __launch_bounds__(TB) void k_mlp2(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
                                              const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, int din, int dh, int dout,
-                                             float *__restrict__ y)
+                                             float slope, float *__restrict__ y)
 {
     extern __shared__ float sm[];
     float *xs = sm, *hs = sm + MLP_ROWS * din;
@@ -477,7 +480,7 @@ __global__ __launch_bounds__(TB) void k_mlp2(const float *__restrict__ x, const 
         const float *w = w1 + (size_t)c * din, *xr = xs + r * din;
         float acc = b1[c];
         for (int k = 0; k < din; ++k) acc = __builtin_fmaf(xr[k], w[k], acc);
-        hs[i] = acc > 0.0f ? acc : 0.0f;
+        hs[i] = acc > 0.0f ? acc : (slope != 0.0f ? acc * slope : 0.0f);   // ReLU (slope 0) or LeakyReLU(slope): x > 0 ? x : x * slope
     }
     __syncthreads();
     for (int i = threadIdx.x; i < rows * dout; i += TB) {
@@ -502,9 +505,15 @@ namespace {
 // back over them, no block barrier after the weights have landed.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
 constexpr int MLPM_WAVES = 4;
+// DIN / DH / DOUT are the CLASS of the kernel (register arrays and LDS pitches are compile-time); the layer's own sizes din <= DIN,
+// dh <= DH, dout <= DOUT are run-time: weights, biases and input columns beyond them are zeros in LDS, so the chain of an output
+// is its own k = 0 .. din - 1 steps followed by fmaf(0, 0, acc) steps, which leave acc unchanged.  HAC's 96-100-175 runs in its
+// exact class (no padding); HAC++'s mlp_grid (48-100-195 / 225) and its five channel-context MLPs (150 + 10 c - 40 - 30,
+// LeakyReLU) in classes <48, 100, 240> and <192, 40, 32> (HAC-plus/scene/gaussian_model.py:117-168, 370-374).
 template <int DIN, int DH, int DOUT>
 __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
-                                                              const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, float *__restrict__ y)
+                                                              const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, int din, int dh, int dout,
+                                                              float slope, float *__restrict__ y)
 {
     static_assert(DIN % 4 == 0 && DH % 4 == 0, "whole MFMA k-steps");
     constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2, PX = (DIN > DH ? DIN : DH) + 2;
@@ -512,20 +521,27 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
     float *W1s = sm, *W2s = W1s + NT1 * 16 * P1, *B1s = W2s + NT2 * 16 * P2, *B2s = B1s + NT1 * 16, *XS = B2s + NT2 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e = lane & 15, g = lane >> 4;
-    for (int i = tid; i < NT1 * 16 * DIN; i += 64 * MLPM_WAVES) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = c < DH ? w1[(size_t)c * DIN + k] : 0.0f; }
-    for (int i = tid; i < NT2 * 16 * DH; i += 64 * MLPM_WAVES) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = c < DOUT ? w2[(size_t)c * DH + k] : 0.0f; }
-    for (int i = tid; i < NT1 * 16; i += 64 * MLPM_WAVES) B1s[i] = i < DH ? b1[i] : 0.0f;
-    for (int i = tid; i < NT2 * 16; i += 64 * MLPM_WAVES) B2s[i] = i < DOUT ? b2[i] : 0.0f;
+    for (int i = tid; i < NT1 * 16 * DIN; i += 64 * MLPM_WAVES) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = (c < dh && k < din) ? w1[(size_t)c * din + k] : 0.0f; }
+    for (int i = tid; i < NT2 * 16 * DH; i += 64 * MLPM_WAVES) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = (c < dout && k < dh) ? w2[(size_t)c * dh + k] : 0.0f; }
+    for (int i = tid; i < NT1 * 16; i += 64 * MLPM_WAVES) B1s[i] = i < dh ? b1[i] : 0.0f;
+    for (int i = tid; i < NT2 * 16; i += 64 * MLPM_WAVES) B2s[i] = i < dout ? b2[i] : 0.0f;
     __syncthreads();
     float *xs = XS + wave * 16 * PX;
     const int64_t ntiles = (n + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * MLPM_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * MLPM_WAVES) {
         const int64_t row0 = tile * 16;
         // the tile's rows: coalesced float2 loads (rows past n: the last row again), the wave's own LDS slice
-        for (int i = lane; i < 16 * DIN / 2; i += 64) {
-            const int r = i / (DIN / 2), c2 = i - r * (DIN / 2);
-            const float2 v = *reinterpret_cast<const float2 *>(x + (size_t)min(row0 + r, n - 1) * DIN + 2 * c2);
-            *reinterpret_cast<float2 *>(xs + r * PX + 2 * c2) = v;
+        if (din == DIN) {
+            for (int i = lane; i < 16 * DIN / 2; i += 64) {
+                const int r = i / (DIN / 2), c2 = i - r * (DIN / 2);
+                const float2 v = *reinterpret_cast<const float2 *>(x + (size_t)min(row0 + r, n - 1) * DIN + 2 * c2);
+                *reinterpret_cast<float2 *>(xs + r * PX + 2 * c2) = v;
+            }
+        } else {   // a narrower layer in this class: column by column, zeros beyond din
+            for (int i = lane; i < 16 * DIN; i += 64) {
+                const int r = i / DIN, c = i - r * DIN;
+                xs[r * PX + c] = c < din ? x[(size_t)min(row0 + r, n - 1) * din + c] : 0.0f;
+            }
         }
         float a[DIN / 4 > DH / 4 ? DIN / 4 : DH / 4];
 #pragma unroll
@@ -546,7 +562,7 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
         for (int t = 0; t < NT1; ++t)
             if (16 * t + e < DH) {                 // the padding outputs of the last tile have no slot (and no reader)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + 16 * t + e] = hid[t][i] > 0.0f ? hid[t][i] : 0.0f;
+                for (int i = 0; i < 4; ++i) { const float h = hid[t][i]; xs[(4 * g + i) * PX + 16 * t + e] = h > 0.0f ? h : (slope != 0.0f ? h * slope : 0.0f); }
             }
 #pragma unroll
         for (int kk = 0; kk < DH / 4; ++kk) a[kk] = xs[e * PX + 4 * kk + g];
@@ -558,10 +574,10 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
 #pragma unroll
             for (int kk = 0; kk < DH / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wr[4 * kk], acc, 0, 0, 0);
             const int c = 16 * t + e;
-            if (c < DOUT) {
+            if (c < dout) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (row0 + 4 * g + i < n) y[(size_t)(row0 + 4 * g + i) * DOUT + c] = acc[i];
+                    if (row0 + 4 * g + i < n) y[(size_t)(row0 + 4 * g + i) * dout + c] = acc[i];
             }
         }
     }
@@ -574,30 +590,51 @@ static size_t mlpm_lds_bytes()
 }
 }  // namespace
 
-extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh,
-                          int dout, float *y, void *stream)
+template <int DIN, int DH, int DOUT>
+static int mlp2_mfma_launch(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh, int dout,
+                            float slope, float *y, hipStream_t st)
 {
-    if (!ctx || !x || !w1 || !b1 || !w2 || !b2 || !y) return fail(GPCC_ERR_ARG, "null argument");
-    if (n <= 0) return GPCC_OK;
-    if (din <= 0 || dh <= 0 || dout <= 0 || (size_t)MLP_ROWS * (size_t)(din + dh) * 4 > 64 * 1024) return fail(GPCC_ERR_ARG, "mlp2: unsupported layer sizes");
-    HIP_TRY(hipSetDevice(ctx->device));
-    static const bool use_mfma = [] { const char *e = getenv("GAUSPCC_MLP2_MFMA"); return !e || atoi(e) != 0; }();
-    if (use_mfma && din == 96 && dh == 100 && dout == 175) {   // HAC's mlp_grid (HAC/scene/gaussian_model.py:258-262)
-        static PerDeviceOnce attr;
-        const size_t lds = mlpm_lds_bytes<96, 100, 175>();
-        GP_TRY(attr.run(ctx->device, [&]() -> int {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<96, 100, 175>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            return GPCC_OK;
-        }));
-        const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), MLPM_WAVES));
-        k_mlp2_mfma<96, 100, 175><<<grid, 64 * MLPM_WAVES, lds, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, y);
-        LAUNCH_CHECK();
+    static PerDeviceOnce attr;
+    const size_t lds = mlpm_lds_bytes<DIN, DH, DOUT>();
+    GP_TRY(attr.run(ctx->device, [&]() -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<DIN, DH, DOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         return GPCC_OK;
-    }
-    k_mlp2<<<(unsigned)cdiv(n, MLP_ROWS), TB, (size_t)MLP_ROWS * (size_t)(din + dh) * 4, (hipStream_t)stream>>>(x, w1, b1, w2, b2, n, din, dh, dout, y);
+    }));
+    const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), MLPM_WAVES));
+    k_mlp2_mfma<DIN, DH, DOUT><<<grid, 64 * MLPM_WAVES, lds, st>>>(x, w1, b1, w2, b2, n, din, dh, dout, slope, y);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
+
+// act: 0 = ReLU, 1 = LeakyReLU(slope) between the two layers
+extern "C" int gshac_mlp2_act(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh,
+                              int dout, int act, float slope, float *y, void *stream)
+{
+    if (!ctx || !x || !w1 || !b1 || !w2 || !b2 || !y) return fail(GPCC_ERR_ARG, "null argument");
+    if (act != 0 && act != 1) return fail(GPCC_ERR_ARG, "mlp2: activation must be 0 (ReLU) or 1 (LeakyReLU)");
+    if (n <= 0) return GPCC_OK;
+    if (din <= 0 || dh <= 0 || dout <= 0 || (size_t)MLP_ROWS * (size_t)(din + dh) * 4 > 64 * 1024) return fail(GPCC_ERR_ARG, "mlp2: unsupported layer sizes");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const float sl = act == 1 ? slope : 0.0f;
+    hipStream_t st = (hipStream_t)stream;
+    static const bool use_mfma = [] { const char *e = getenv("GAUSPCC_MLP2_MFMA"); return !e || atoi(e) != 0; }();
+    if (use_mfma) {
+        // the smallest class that holds the layer (HAC's mlp_grid in its exact class)
+        if (din == 96 && dh == 100 && dout == 175) return mlp2_mfma_launch<96, 100, 175>(ctx, x, w1, b1, w2, b2, n, din, dh, dout, sl, y, st);
+        if (din <= 192 && dh <= 40 && dout <= 32) return mlp2_mfma_launch<192, 40, 32>(ctx, x, w1, b1, w2, b2, n, din, dh, dout, sl, y, st);
+        if (din <= 48 && dh <= 100 && dout <= 240) return mlp2_mfma_launch<48, 100, 240>(ctx, x, w1, b1, w2, b2, n, din, dh, dout, sl, y, st);
+    }
+    k_mlp2<<<(unsigned)cdiv(n, MLP_ROWS), TB, (size_t)MLP_ROWS * (size_t)(din + dh) * 4, st>>>(x, w1, b1, w2, b2, n, din, dh, dout, sl, y);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+extern "C" int gshac_mlp2(gpcc_ctx *ctx, const float *x, const float *w1, const float *b1, const float *w2, const float *b2, int64_t n, int din, int dh,
+                          int dout, float *y, void *stream)
+{
+    return gshac_mlp2_act(ctx, x, w1, b1, w2, b2, n, din, dh, dout, 0, 0.0f, y, stream);
+}
+
 
 // ------------------------------------------------------------------ fused Gaussian coder (no CDF table)
 namespace {
@@ -811,8 +848,8 @@ __global__ __launch_bounds__(TB) void k_quantise_minmax_slices(const float *__re
 }
 
 // (symbol, Gaussian parameters) -> the coder's two integers, in the chunk-interleaved layout of the element's slice
-__global__ __launch_bounds__(TB) void k_hac_pack_slices(const float *__restrict__ mean, const float *__restrict__ scale, const float *__restrict__ q,
-                                                        const int32_t *__restrict__ xi, int64_t n, const int64_t *__restrict__ start, int nslices,
+template <typename CT>
+__global__ __launch_bounds__(TB) void k_hac_pack_slices(CT table, const int32_t *__restrict__ xi, int64_t n, const int64_t *__restrict__ start, int nslices,
                                                         const int32_t *__restrict__ mm, const int64_t *__restrict__ lohi_base,
                                                         const int32_t *__restrict__ slice_nch, int chunk, uint32_t *__restrict__ lohi)
 {
@@ -822,7 +859,8 @@ __global__ __launch_bounds__(TB) void k_hac_pack_slices(const float *__restrict_
     const int mn = mm[2 * sl], lp = mm[2 * sl + 1] - mn + 2;
     const float sc = (float)(65536 - (lp - 1));
     const int s = xi[r] - mn;
-    const GaussRow row{mean[r], scale[r], q[r], mn};
+    table.min_value = mn;
+    const auto row = row_of(table, r, lp);
     const uint32_t lo = cdf_int(row, s, sc);
     const uint32_t hi = s == lp - 2 ? 0x10000u : cdf_int(row, s + 1, sc);
     const int64_t e = r - start[sl];
@@ -831,11 +869,12 @@ __global__ __launch_bounds__(TB) void k_hac_pack_slices(const float *__restrict_
 }
 }  // namespace
 
-extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const float *mean, const float *scale, const float *Q, const int64_t *slice_start,
-                                           int nslices, int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out,
-                                           const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+template <typename CT>
+static int encode_slices_impl(gpcc_ctx *ctx, const float *x, CT table, const float *Q, const int64_t *slice_start,
+                              int nslices, int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out,
+                              const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
-    if (!ctx || !x || !mean || !scale || !Q || !slice_start || !min_out || !max_out || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out)
+    if (!ctx || !x || !Q || !slice_start || !min_out || !max_out || !bytes_out || !nbytes_out || !cnt_out || !nchunks_out)
         return fail(GPCC_ERR_ARG, "null argument");
     if (nslices <= 0 || chunk_size <= 0) return fail(GPCC_ERR_ARG, "bad size");
     for (int s = 0; s < nslices; ++s)
@@ -879,7 +918,7 @@ extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const 
     HIP_TRY(hipStreamSynchronize(st));   // the host vectors above go out of scope before the stream drains otherwise
     k_quantise_minmax_slices<<<dim3(SLICE_PARTS, (unsigned)nslices), TB, 0, st>>>(x, Q, dstart, xi, mm);
     LAUNCH_CHECK();
-    k_hac_pack_slices<<<(unsigned)cdiv(n, TB), TB, 0, st>>>(mean, scale, Q, xi, n, dstart, nslices, mm, dlbase, dsnch, chunk_size, lohi);
+    k_hac_pack_slices<CT><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(table, xi, n, dstart, nslices, mm, dlbase, dsnch, chunk_size, lohi);
     LAUNCH_CHECK();
     GP_TRY(rc_encode_launch(st, lohi, dch, nch, scratch, sstride, dcnt));
     GP_TRY(exclusive_scan_u32(ctx, st, dcnt, doff, nch, doff + nch));
@@ -904,11 +943,32 @@ extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const 
     return GPCC_OK;
 }
 
-extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, const int64_t *slice_start, int nslices,
-                                           const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt,
-                                           int chunk_size, float *x_out, void *stream)
+extern "C" int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x, const float *mean, const float *scale, const float *Q, const int64_t *slice_start,
+                                           int nslices, int chunk_size, float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out,
+                                           const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
-    if (!ctx || !mean || !scale || !Q || !slice_start || !min_value || !max_value || !bytes || !cnt || !x_out) return fail(GPCC_ERR_ARG, "null argument");
+    if (!mean || !scale) return fail(GPCC_ERR_ARG, "null argument");
+    return encode_slices_impl(ctx, x, GaussTable{mean, scale, Q, 0}, Q, slice_start, nslices, chunk_size, min_out, max_out, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+}
+
+static int mix_table(const float *const *mean, const float *const *scale, const float *const *prob, int k, const float *Q, int min_value, MixTable *t);
+
+// HAC++: the slices of ONE channel group of `feat` under the two-component mixture (HAC-plus/scene/gaussian_model.py:1306-1321)
+extern "C" int gsac_encode_gaussian_mixed_slices(gpcc_ctx *ctx, const float *x, const float *const *mean, const float *const *scale, const float *const *prob, int k,
+                                                 const float *Q, const int64_t *slice_start, int nslices, int chunk_size, float *min_out, float *max_out,
+                                                 const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    MixTable t;
+    GP_TRY(mix_table(mean, scale, prob, k, Q, 0, &t));
+    return encode_slices_impl(ctx, x, t, Q, slice_start, nslices, chunk_size, min_out, max_out, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+}
+
+template <typename CT>
+static int decode_slices_impl(gpcc_ctx *ctx, CT table, const float *Q, const int64_t *slice_start, int nslices,
+                              const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt,
+                              int chunk_size, float *x_out, void *stream)
+{
+    if (!ctx || !Q || !slice_start || !min_value || !max_value || !bytes || !cnt || !x_out) return fail(GPCC_ERR_ARG, "null argument");
     if (nslices <= 0 || chunk_size <= 0 || slice_start[0] != 0) return fail(GPCC_ERR_ARG, "bad size");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
@@ -944,10 +1004,27 @@ extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, con
     HIP_TRY(hipMemcpyAsync(dmin, smin.data(), 4 * (size_t)nslices, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(dlp, slp.data(), 4 * (size_t)nslices, hipMemcpyHostToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    k_hac_decode_slices<<<(unsigned)nch, 64, 0, st>>>(mean, scale, Q, dch, dmin, dlp, db, x_out);
+    k_hac_decode_slices<CT><<<(unsigned)nch, 64, 0, st>>>(table, dch, dmin, dlp, db, x_out);
     LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
+}
+
+extern "C" int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean, const float *scale, const float *Q, const int64_t *slice_start, int nslices,
+                                           const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt,
+                                           int chunk_size, float *x_out, void *stream)
+{
+    if (!mean || !scale) return fail(GPCC_ERR_ARG, "null argument");
+    return decode_slices_impl(ctx, GaussTable{mean, scale, Q, 0}, Q, slice_start, nslices, min_value, max_value, bytes, nbytes, cnt, chunk_size, x_out, stream);
+}
+
+extern "C" int gsac_decode_gaussian_mixed_slices(gpcc_ctx *ctx, const float *const *mean, const float *const *scale, const float *const *prob, int k, const float *Q,
+                                                 const int64_t *slice_start, int nslices, const float *min_value, const float *max_value, const uint8_t *bytes,
+                                                 int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out, void *stream)
+{
+    MixTable t;
+    GP_TRY(mix_table(mean, scale, prob, k, Q, 0, &t));
+    return decode_slices_impl(ctx, t, Q, slice_start, nslices, min_value, max_value, bytes, nbytes, cnt, chunk_size, x_out, stream);
 }
 
 extern "C" int gsge_forward(gpcc_ctx *ctx, const float *inputs, const float *embeddings, const int32_t *offsets, const int32_t *resolutions,

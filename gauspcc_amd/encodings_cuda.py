@@ -166,6 +166,49 @@ def decoder_gaussian_slices(mean, scale, Q, slice_start, file_names):
                                              np.concatenate(cnts), chunk_size_cuda)
 
 
+def encoder_gaussian_mixed_slices(x, mean_list, scale_list, prob_list, Q, slice_start, file_names, chunk_size=1000_0000):
+    """encoder_gaussian_mixed_chunk (HAC-plus/utils/encodings_cuda.py:177-225) for MANY slices in one device call: slice s =
+    elements [slice_start[s], slice_start[s+1]) goes to file_names[s] (as in the reference the file written is `*_0.b`) with its
+    own min / max.  Same files as calling encoder_gaussian_mixed_chunk slice by slice; no slice may be empty or longer than
+    chunk_size.  Returns the bit count per slice."""
+    ss = np.asarray(slice_start, dtype=np.int64)
+    lens = np.diff(ss)
+    assert lens.min(initial=1) > 0 and lens.max(initial=0) <= chunk_size
+    cont = lambda lst: [t.contiguous() for t in lst]
+    mins, maxs, data, cnt = arithmetic.encode_gaussian_mixed_slices(x.contiguous(), cont(mean_list), cont(scale_list), cont(prob_list), Q.contiguous(), ss - ss[0],
+                                                                    chunk_size_cuda)
+    bits, jobs = [], []
+    c0 = b0 = 0
+    for i, ln in enumerate(lens):
+        nch = -(-int(ln) // chunk_size_cuda)
+        c = cnt[c0:c0 + nch]
+        nb = int(c.sum())
+        blob = b"".join((np.float32(mins[i]).tobytes(), np.float32(maxs[i]).tobytes(), np.array([4 * len(c)]).astype(np.int32).tobytes(),
+                         c.tobytes(), data[b0:b0 + nb].tobytes()))
+        jobs.append((file_names[i].replace('.b', '_0.b'), blob))
+        bits.append((nb + 4 * len(c)) * 8 + 32 * 3)
+        c0 += nch; b0 += nb
+    _write_files(jobs)
+    return bits
+
+
+def decoder_gaussian_mixed_slices(mean_list, scale_list, prob_list, Q, slice_start, file_names):
+    """Inverse of encoder_gaussian_mixed_slices: every chunk of every slice decoded concurrently; the decoded values of all
+    slices concatenated in slice order."""
+    ss = np.asarray(slice_start, dtype=np.int64)
+    mins, maxs, cnts, datas = [], [], [], []
+    for fn in file_names:
+        with open(fn.replace('.b', '_0.b'), 'rb') as fin:
+            mins.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+            maxs.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+            len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+            cnts.append(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32))
+            datas.append(np.frombuffer(fin.read(), dtype=np.uint8))
+    cont = lambda lst: [t.contiguous() for t in lst]
+    return arithmetic.decode_gaussian_mixed_slices(cont(mean_list), cont(scale_list), cont(prob_list), Q.contiguous(), ss - ss[0], np.array(mins), np.array(maxs),
+                                                   np.concatenate(datas), np.concatenate(cnts), chunk_size_cuda)
+
+
 # ---------------------------------------------------------------- `.b` container shared by the Gaussian-family coders
 def _write_b(file_name, min_value, max_value, byte_stream_torch, cnt_torch):
     """f32 min | f32 max | i32 len(cnt bytes) | cnt | payload  (HAC/utils/encodings_cuda.py:366-376); returns the bit count"""

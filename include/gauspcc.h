@@ -283,6 +283,16 @@ GPCC_API int gsac_encode_gaussian_slices(gpcc_ctx *ctx, const float *x_dev, cons
 GPCC_API int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean_dev, const float *scale_dev, const float *q_dev, const int64_t *slice_start,
                                          int nslices, const float *min_value, const float *max_value, const uint8_t *bytes, int64_t nbytes,
                                          const int32_t *cnt, int chunk_size, float *x_out_dev, void *stream);
+/* The same for HAC++'s K-component mixture (gsac_encode_gaussian_mixed): all 3000-anchor slices of ONE ten-channel group of `feat` in one
+ * call -- conduct_encoding / conduct_decoding code feat as five such groups per slice, every group's second component coming from the
+ * channel-context MLP on the groups already coded (HAC-plus/scene/gaussian_model.py:1300-1321, 1484-1504). */
+GPCC_API int gsac_encode_gaussian_mixed_slices(gpcc_ctx *ctx, const float *x_dev, const float *const *mean_dev, const float *const *scale_dev,
+                                               const float *const *prob_dev, int k, const float *q_dev, const int64_t *slice_start, int nslices, int chunk_size,
+                                               float *min_out, float *max_out, const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out,
+                                               int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_gaussian_mixed_slices(gpcc_ctx *ctx, const float *const *mean_dev, const float *const *scale_dev, const float *const *prob_dev, int k,
+                                               const float *q_dev, const int64_t *slice_start, int nslices, const float *min_value, const float *max_value,
+                                               const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, float *x_out_dev, void *stream);
 
 /* GaussianModel.mlp_grid = nn.Sequential(Linear(din, dh), ReLU, Linear(dh, dout)) (src/gs_compress/HAC/scene/gaussian_model.py:258-262,
  * called through get_grid_mlp at :1152-1153 and :1281-1282): y = W2 relu(W1 x + b1) + b2 for n rows.
@@ -290,6 +300,12 @@ GPCC_API int gsac_decode_gaussian_slices(gpcc_ctx *ctx, const float *mean_dev, c
  * (bias, then fmaf over k ascending), so the encoder and the decoder see the same context parameters. */
 GPCC_API int gshac_mlp2(gpcc_ctx *ctx, const float *x_dev, const float *w1_dev, const float *b1_dev, const float *w2_dev, const float *b2_dev,
                         int64_t n, int din, int dh, int dout, float *y_dev, void *stream);
+/* The same with the activation as an argument: act 0 = ReLU, 1 = LeakyReLU(slope) -- HAC++'s channel-context MLPs
+ * (Channel_CTX_fea.MLP_d0..4: Linear(150 + 10 c, 40) - LeakyReLU - Linear(40, 30), HAC-plus/scene/gaussian_model.py:117-168, called through
+ * get_deform_mlp.forward(feat, mean_scale, to_dec=c) at :1306 and :1490): context MLPs too -- encoder and decoder must obtain the same
+ * bits, hence the same specified fp32 order. */
+GPCC_API int gshac_mlp2_act(gpcc_ctx *ctx, const float *x_dev, const float *w1_dev, const float *b1_dev, const float *w2_dev, const float *b2_dev,
+                            int64_t n, int din, int dh, int dout, int act, float slope, float *y_dev, void *stream);
 
 /* _gridencoder.grid_encode_forward (inputs (N,D) in [0,1], embeddings (sO,F), offsets (L+1), resolutions (L),
  * outputs (L,N,F), ..., Rb, binary_vxl, min_level_id)   gridencoder.zip!gridencoder/src/gridencoder.h:12-22,

@@ -378,15 +378,16 @@ def hac_decode(cdf: np.ndarray, data: np.ndarray, cnt: np.ndarray, chunk: int = 
     return out
 
 
-def mlp2(x, w1, b1, w2, b2) -> np.ndarray:
-    """mlp_grid (HAC/scene/gaussian_model.py:258-262): Linear - ReLU - Linear in the normative fp32 order."""
+def mlp2(x, w1, b1, w2, b2, slope: float = 0.0) -> np.ndarray:
+    """mlp_grid (HAC/scene/gaussian_model.py:258-262): Linear - ReLU - Linear in the normative fp32 order; slope != 0: LeakyReLU(slope)
+    between the layers (HAC++'s channel-context MLPs, HAC-plus/scene/gaussian_model.py:117-168)."""
     x = np.ascontiguousarray(x, dtype=np.float32)
     w1, b1, w2, b2 = (np.ascontiguousarray(a, dtype=np.float32) for a in (w1, b1, w2, b2))
     n, din = x.shape
     dh, dout = w1.shape[0], w2.shape[0]
     assert dh <= 1024
     y = np.empty((n, dout), dtype=np.float32)
-    lib().orc_mlp2(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), C.c_int64(n), din, dh, dout, _p(y))
+    lib().orc_mlp2_act(_p(x), _p(w1), _p(b1), _p(w2), _p(b2), C.c_int64(n), din, dh, dout, C.c_float(slope), _p(y))
     return y
 
 

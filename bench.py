@@ -189,7 +189,10 @@ def main():
             ms, by = arr[i].ms, arr[i].bytes
             stages.append({"stage": arr[i].name.decode(), "bound": "hbm", "ms_per_step": round(ms, 3), "algorithmic_bytes": int(by),
                            "achieved": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                           "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms > 0 else 0.0, "event_brackets": int(arr[i].brackets)})
+                           "frac": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if ms > 0 else 0.0, "event_brackets": int(arr[i].brackets),
+                           # ms_per_step is the bracketed stream time (the octree / tile-list brackets of a decode run BESIDE the parent trunk's
+                           # convolutions); critical_ms is the part of it during which no convolution bracket was open: what the step waits for
+                           "critical_ms": round(arr[i].critical_ms, 3)})
         data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
 
     # Throughput mode (informative, not `value`): S independent scenes in flight on this GPU, each with its own context,
@@ -273,13 +276,20 @@ def main():
     if rank == 0:
         # HBM traffic of the conv kernel comes from separate rocprofv3 --pmc passes of this same command
         # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
-        traffic, traffic_source = None, None
+        traffic, traffic_source, pmc_extra = None, None, {}
         if not args.measure_traffic:
-            for name in ("r03_pmc_conv.json", "r02_pmc_conv.json"):
+            for name in ("r04_pmc_conv.json", "r03_pmc_conv.json", "r02_pmc_conv.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic = round(json.load(f)["hbm_bytes_per_launch"])
+                        pj = json.load(f)
+                    traffic = round(pj["hbm_bytes_per_launch"])
                     traffic_source = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/pmc_traffic.sh; not measured in this run)"
+                    # the other factors of frac, from the SQ / GRBM counter passes of the same round (labelled like traffic: replayed, not live)
+                    for key in ("mfma_busy", "tile_fill"):
+                        if key in pj:
+                            pmc_extra[key] = pj[key]
+                    if pmc_extra:
+                        pmc_extra["counters_source"] = f"profiles/{name} (tools/pmc_conv2.sh passes of this command; not measured in this run)"
                     break
                 except Exception:
                     pass
@@ -335,6 +345,7 @@ def main():
                 "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
                 "traffic": traffic,
                 "traffic_source": traffic_source,
+                **pmc_extra,
                 "algorithmic_per_launch": conv_flops / max(prof.conv_launches, 1),
                 "launches": int(prof.conv_launches),
                 "avg_launch_us": round(prof.conv_ms * 1e3 / max(prof.conv_launches, 1), 2),
@@ -346,6 +357,14 @@ def main():
                 # the HBM-bound stages either side of the convolutions: algorithmic bytes over the
                 # event-bracketed time of one extra untimed step; latency- / launch-bound at this size, not bandwidth-bound
                 "stages": stages,
+                # the decoder's levels of at most 16 k nodes run as persistent launches (csrc/fused.hpp), not as k_sparse_conv: their time
+                # covers whole chains of layers (heads, coder phases and grid barriers too), so they are reported apart from `achieved`
+                "small_levels": {
+                    "kernel": "k_level_fused",
+                    "ms_per_step": round(prof.fused_ms / max(ev_steps, 1), 3),
+                    "convolutions": int(prof.fused_launches),
+                    "algorithmic_flops_per_step": 2.0 * 32 * 32 * prof.fused_pair_jobs / max(ev_steps, 1),
+                },
             },
         }
         if args.side_anchors > 0 and world == 1:

@@ -33,11 +33,12 @@ class Stats(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_pair_jobs", C.c_int64)]
+    _fields_ = [("conv_ms", C.c_double), ("conv_launches", C.c_int64), ("conv_pair_jobs", C.c_int64),
+                ("fused_ms", C.c_double), ("fused_launches", C.c_int64), ("fused_pair_jobs", C.c_int64)]
 
 
 class Stage(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("bytes", C.c_double), ("brackets", C.c_int64)]
+    _fields_ = [("name", C.c_char * 48), ("ms", C.c_double), ("bytes", C.c_double), ("brackets", C.c_int64), ("critical_ms", C.c_double)]
 
 
 EXPORTS = [

@@ -152,8 +152,9 @@ extern "C" int gpcc_profile_enable(gpcc_ctx *ctx, int on)
     ctx->prof.on = on != 0;
     ctx->prof.stages = on >= 2;
     ctx->prof.conv_ms = 0.0; ctx->prof.conv_launches = 0; ctx->prof.conv_pair_jobs = 0;
+    ctx->prof.fused_ms = 0.0; ctx->prof.fused_launches = 0; ctx->prof.fused_pair_jobs = 0;
     ctx->prof.recs.clear(); ctx->prof.srecs.clear(); ctx->prof.used = 0; ctx->prof.chain_open = false;
-    for (int i = 0; i < 8; ++i) { ctx->prof.stage_ms[i] = 0.0; ctx->prof.stage_bytes[i] = 0.0; ctx->prof.stage_n[i] = 0; }
+    for (int i = 0; i < 8; ++i) { ctx->prof.stage_ms[i] = 0.0; ctx->prof.stage_bytes[i] = 0.0; ctx->prof.stage_n[i] = 0; ctx->prof.stage_crit_ms[i] = 0.0; }
     return GPCC_OK;
 }
 
@@ -166,7 +167,7 @@ extern "C" int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int 
     for (int i = 0; i < ST_COUNT && n < cap; ++i, ++n) {
         memset(&out[n], 0, sizeof out[n]);
         strncpy(out[n].name, names[i], sizeof out[n].name - 1);
-        out[n].ms = ctx->prof.stage_ms[i]; out[n].bytes = ctx->prof.stage_bytes[i]; out[n].brackets = ctx->prof.stage_n[i];
+        out[n].ms = ctx->prof.stage_ms[i]; out[n].bytes = ctx->prof.stage_bytes[i]; out[n].brackets = ctx->prof.stage_n[i]; out[n].critical_ms = ctx->prof.stage_crit_ms[i];
     }
     *n_out = n;
     return GPCC_OK;
@@ -178,6 +179,9 @@ extern "C" int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out)
     out->conv_ms = ctx->prof.conv_ms;
     out->conv_launches = ctx->prof.conv_launches;
     out->conv_pair_jobs = ctx->prof.conv_pair_jobs;
+    out->fused_ms = ctx->prof.fused_ms;
+    out->fused_launches = ctx->prof.fused_launches;
+    out->fused_pair_jobs = ctx->prof.fused_pair_jobs;
     return GPCC_OK;
 }
 

@@ -623,7 +623,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         if (planP.valid() && fmode == 1) {
             // (profiling: a persistent launch counts as the convolutions it contains -- 5 here, 13 for a level's chain -- over its whole
             // time, heads / coder phases and barriers included: the conv roofline figure stays conservative)
-            ConvRec rec = {0, 0, g, 1, 0, 0, (long long)np, 0, 5};
+            ConvRec rec = {0, 0, g, 1, 0, 0, (long long)np, 0, 5, 1};
             if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
             GP_TRY(fused_parent_trunk(ctx, st, m, planP, planP_np, cur.occ, pF, pA, pB, Pp));
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
@@ -707,7 +707,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             fa.pA = pA; fa.np = np; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
             for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g][s]; fa.sym[s] = sym[s]; }
             fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ; fa.coder = rc_coder_of_version(version);
-            ConvRec rec = {0, 0, g + 1, 1, 0, 0, (long long)nc, 0, 13};
+            ConvRec rec = {0, 0, g + 1, 1, 0, 0, (long long)nc, 0, 13, 1};
             if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
             GP_TRY(fused_child_level(ctx, st, m, planC, fa));
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }

@@ -148,7 +148,7 @@ namespace gpcc {
 // HIP-event timing of the dominant kernel (k_sparse_conv), on the stream it is launched on.  Convolutions that are
 // enqueued back to back with nothing between them (a trunk's five, a stage's two) share ONE pair of events: an event
 // costs ~3 us of stream time, and one pair per launch slowed a decode by 1.5 ms.
-struct ConvRec { int e0, e1, level, njobs, R, H; long long n, nblk; int launches; };
+struct ConvRec { int e0, e1, level, njobs, R, H; long long n, nblk; int launches; int fused = 0; };   // fused: a persistent small-level launch (fused.hip), `launches` = the convolutions inside
 struct Prof {
     bool on = false;
     bool chain_open = false;   // between conv_chain_begin and conv_chain_end: sparse_conv records no events of its own
@@ -158,12 +158,15 @@ struct Prof {
     std::vector<ConvRec> recs;
     double conv_ms = 0.0;
     int64_t conv_launches = 0, conv_pair_jobs = 0;
+    double fused_ms = 0.0;
+    int64_t fused_launches = 0, fused_pair_jobs = 0;
     // gpcc_profile_enable(ctx, 2): the HBM-bound stages of the path are bracketed by events too (a handful per level: the
     // brackets cost stream time, so bench.py measures them in a pass of their own behind the timed region)
     bool stages = false;
     struct StageRec { int id, e0, e1; };
     std::vector<StageRec> srecs;
     double stage_ms[8] = {0}, stage_bytes[8] = {0};
+    double stage_crit_ms[8] = {0};   // of stage_ms: the part during which no convolution bracket (either family) was open -- stream time the step really waits for
     int64_t stage_n[8] = {0};
 };
 enum { ST_OCTREE = 0, ST_TILES, ST_ELEM, ST_HEADS, ST_CODER, ST_COUNT };

@@ -15,6 +15,10 @@
 //                 Bound: fp32 MFMA (2*32*32 flop per pair); gathers come from L2/MALL.
 // k_head          Linear-ReLU-Linear-softmax-cumsum-integerise, one node per lane, weights through
 //                 the scalar cache.  Negligible next to the convolutions.
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "network_dev.hpp"
 #include "octree.hpp"
 #include "primitives.hpp"
@@ -913,9 +917,32 @@ int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
             for (int q = 0; q < r.launches; ++q)
                 fprintf(stderr, "[conv] level %2d n %8lld R %3d H %3d blocks %6lld jobs %d  %8.1f us pairs %llu\n", r.level, r.n, r.R, r.H, r.nblk, r.njobs, ms * 1e3 / r.launches,
                         (r.level >= 0 && r.level < nlevels) ? pairs[r.level] : 0ull);
+        if (r.fused) {
+            p.fused_ms += ms;
+            p.fused_launches += r.launches;
+            if (r.level >= 0 && r.level < nlevels) p.fused_pair_jobs += (int64_t)pairs[r.level] * r.njobs * r.launches;
+            continue;
+        }
         p.conv_ms += ms;
         p.conv_launches += r.launches;
         if (r.level >= 0 && r.level < nlevels) p.conv_pair_jobs += (int64_t)pairs[r.level] * r.njobs * r.launches;
+    }
+    // the convolution brackets of this call on a common time axis (events of any stream against the first event of the pool):
+    // a stage bracket's critical time is what lies outside all of them
+    std::vector<std::pair<float, float>> busy;
+    if (!p.srecs.empty() && p.used > 0) {
+        for (const ConvRec &r : p.recs) {
+            float a = 0.f, b = 0.f;
+            if (hipEventElapsedTime(&a, p.pool[0], p.pool[(size_t)r.e0]) != hipSuccess || hipEventElapsedTime(&b, p.pool[0], p.pool[(size_t)r.e1]) != hipSuccess) { busy.clear(); break; }
+            busy.emplace_back(a, b);
+        }
+        std::sort(busy.begin(), busy.end());
+        size_t w = 0;
+        for (size_t i = 0; i < busy.size(); ++i) {   // merge
+            if (w && busy[i].first <= busy[w - 1].second) busy[w - 1].second = std::max(busy[w - 1].second, busy[i].second);
+            else busy[w++] = busy[i];
+        }
+        busy.resize(w);
     }
     p.recs.clear();
     for (const Prof::StageRec &r : p.srecs) {
@@ -923,6 +950,11 @@ int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs, int nlevels)
         HIP_TRY(hipEventElapsedTime(&ms, p.pool[(size_t)r.e0], p.pool[(size_t)r.e1]));
         p.stage_ms[r.id] += ms;
         p.stage_n[r.id] += 1;
+        float a = 0.f, b = 0.f, cov = 0.f;
+        if (p.used > 0 && hipEventElapsedTime(&a, p.pool[0], p.pool[(size_t)r.e0]) == hipSuccess && hipEventElapsedTime(&b, p.pool[0], p.pool[(size_t)r.e1]) == hipSuccess) {
+            for (const auto &iv : busy) cov += std::max(0.f, std::min(b, iv.second) - std::max(a, iv.first));
+            p.stage_crit_ms[r.id] += std::max(0.f, (b - a) - cov);
+        } else p.stage_crit_ms[r.id] += ms;
     }
     p.srecs.clear();
     p.used = 0;

@@ -137,6 +137,12 @@ typedef struct {
     double conv_ms;
     int64_t conv_launches;
     int64_t conv_pair_jobs;
+    /* the decoder's persistent small-level launches (csrc/fused.hpp), kept apart from the k_sparse_conv family above: their time
+     * covers whole chains of layers (heads, range-decoder phases and grid barriers included); fused_launches counts the
+     * convolutions they contain (13 per level chain, 5 per prior trunk), fused_pair_jobs their (pair, convolution) products */
+    double fused_ms;
+    int64_t fused_launches;
+    int64_t fused_pair_jobs;
 } gpcc_profile;
 GPCC_API int gpcc_profile_enable(gpcc_ctx *ctx, int on);   /* 0 off, 1 the convolution, 2 also the stages below (these reset the accumulators); 3 = stop recording, keep what was collected */
 GPCC_API int gpcc_profile_get(gpcc_ctx *ctx, gpcc_profile *out);
@@ -149,6 +155,8 @@ typedef struct {
     double ms;
     double bytes;
     int64_t brackets;
+    double critical_ms;   /* of ms: the part during which no convolution bracket was open on any stream of the call -- the octree / tile-list
+                           * work of a decode runs beside the parent trunk's convolutions, the encoder's rank pass beside its first trunk */
 } gpcc_stage;
 GPCC_API int gpcc_profile_stages(gpcc_ctx *ctx, gpcc_stage *out, int cap, int *n_out);
 

@@ -23,9 +23,11 @@ def env():
 
 
 def _get(_lib, ctx):
+    """(ms, convolutions, pair jobs) over BOTH families: the k_sparse_conv launches and the decoder's persistent small-level
+    launches (csrc/fused.hpp), which count as the convolutions they contain"""
     p = _lib.Profile()
     _lib.check(_lib.lib().gpcc_profile_get(ctx, C.byref(p)))
-    return p.conv_ms, p.conv_launches, p.conv_pair_jobs
+    return p.conv_ms + p.fused_ms, p.conv_launches + p.fused_launches, p.conv_pair_jobs + p.fused_pair_jobs
 
 
 def test_conv_brackets_count_every_launch_and_pair(env):

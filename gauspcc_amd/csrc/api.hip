@@ -42,6 +42,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->conv_products) (void)hipFree(c->conv_products);
     if (c->fused_state) (void)hipFree(c->fused_state);
+    for (auto &ss : c->scan_states) if (ss.status) (void)hipFree(ss.status);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);

@@ -209,6 +209,10 @@ struct gpcc_ctx {
     // persistent small-level launches of the decoder (fused.hip): two grid-barrier blocks that alternate between launches and a
     // sticky timeout word; fused_off: a launch timed out on this context (its workgroups were not all resident) -- the
     // launch-per-layer path from then on
+    // single-pass scans (primitives.hip: k_scan_lookback): per stream of the context one tile-status array, a ticket word and a launch
+    // epoch (status words of earlier launches are invalid by their epoch: no reset between launches)
+    struct ScanState { hipStream_t st; unsigned long long *status; uint32_t *ticket; uint32_t epoch; };
+    std::vector<ScanState> scan_states;
     int container_version = 4;     // what gpcc_encode / gpcc_rc_encode write for chunk_log2 != 0 (gpcc_ctx_set_container_version: 3 or 4)
     void *fused_state = nullptr;
     int fused_flip = 0;

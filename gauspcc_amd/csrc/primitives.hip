@@ -190,6 +190,7 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
         if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, tile == 0 ? LB_INC : LB_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tile > 0) {
             int64_t j = (int64_t)tile - 1;       // nearest predecessor not yet accounted for
+            uint32_t idle = 0;
             for (;;) {
                 const int64_t idx = j - lane;
                 // before tile 0: a virtual inclusive prefix of 0
@@ -205,7 +206,12 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
                 excl += part;
                 if (first_inc < first_bad) break;
                 j -= take;
-                if (take == 0) __builtin_amdgcn_s_sleep(1);
+                if (take == 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    // predecessors are running workgroups (tickets are drawn in start order): no progress for ~10 s means the launch's
+                    // state was damaged -- end the launch loudly (the stream reports an error) rather than spin for ever
+                    if (++idle > (1u << 24)) __builtin_trap();
+                } else idle = 0;
             }
             if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, LB_INC, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -237,7 +243,10 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + 256));
-    HIP_TRY(hipMemset(p, 0, 8 * (size_t)LB_MAX_TILES + 256));
+    // ON THE STREAM that will use it: a hipMemset on the null stream is not ordered with a non-blocking stream, and may return before it
+    // has run -- it then zeroed the ticket word under a running scan (found with tools/inflight_side.py: tiles drawn twice, others
+    // never, their successors spinning for ever)
+    HIP_TRY(hipMemsetAsync(p, 0, 8 * (size_t)LB_MAX_TILES + 256, st));
     ns.status = static_cast<unsigned long long *>(p);
     ns.ticket = reinterpret_cast<uint32_t *>(ns.status + LB_MAX_TILES);
     ctx->scan_states.push_back(ns);

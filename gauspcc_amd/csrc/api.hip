@@ -41,6 +41,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->conv_products) (void)hipFree(c->conv_products);
+    fused_ctx_release(c);
     if (c->fused_state) (void)hipFree(c->fused_state);
     for (auto &ss : c->scan_states) if (ss.status) (void)hipFree(ss.status);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);

@@ -217,6 +217,7 @@ struct gpcc_ctx {
     void *fused_state = nullptr;
     int fused_flip = 0;
     bool fused_off = false;
+    hipEvent_t fused_ev = nullptr;   // recorded behind every persistent launch of this context while other contexts use the device (fused.hip: FusedGate)
     // developer trace (gpcc_debug_trace_*): checksums of intermediate buffers of a decode, one (tag, sum) per mark, computed
     // on the stream that produced the buffer -- to find the first stage whose output differs between two runs
     bool dbg_on = false;

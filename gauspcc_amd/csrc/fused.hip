@@ -1,6 +1,8 @@
 // fused.hip -- pair plans and the persistent small-level kernels of the decoder (fused.hpp has the design).
 #include "fused.hpp"
 
+#include <mutex>
+
 #include "network_dev.hpp"
 #include "primitives.hpp"
 #include "rangecoder_dev.hpp"
@@ -589,6 +591,34 @@ int fused_grid(int64_t n, int64_t np)
     return (int)std::min<int64_t>(256, std::max<int64_t>(16, (g + 15) / 16 * 16));
 }
 
+// Two persistent launches whose workgroups spin on grid barriers must not share the device: each may hold CUs the other's missing
+// workgroups need (observed with two scenes in flight: both spin until their bounded polls give up, ~2 s, and their contexts fall
+// back to the launch-per-layer path).  Contexts of one process therefore CHAIN their persistent launches per device: a launch
+// waits for the event behind the previous context's launch.  One context alone pays nothing (no event calls).  Other
+// processes on the same GPU are beyond this gate: for them the bounded spins and the fallback remain.
+struct FusedGate {
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static hipEvent_t &last(int dev) { static hipEvent_t e[64] = {}; return e[dev & 63]; }
+    static int &users(int dev) { static int n[64] = {}; return n[dev & 63]; }
+    std::unique_lock<std::mutex> lk;
+    gpcc_ctx *ctx; hipStream_t st; bool chain;
+    FusedGate(gpcc_ctx *c, hipStream_t s) : lk(mu()), ctx(c), st(s), chain(users(c->device) > 1) {}
+    int begin()
+    {
+        if (!chain) return GPCC_OK;
+        hipEvent_t prev = last(ctx->device);
+        if (prev && prev != ctx->fused_ev) HIP_TRY(hipStreamWaitEvent(st, prev, 0));
+        return GPCC_OK;
+    }
+    int end()
+    {
+        if (!chain) return GPCC_OK;
+        HIP_TRY(hipEventRecord(ctx->fused_ev, st));
+        last(ctx->device) = ctx->fused_ev;
+        return GPCC_OK;
+    }
+};
+
 // barrier blocks + sticky timeout word of a context: [FusedBar][FusedBar][32 words]
 int fused_state(gpcc_ctx *ctx, hipStream_t st, FusedBar **cur, FusedBar **next, uint32_t **tmo)
 {
@@ -598,6 +628,9 @@ int fused_state(gpcc_ctx *ctx, hipStream_t st, FusedBar **cur, FusedBar **next, 
         HIP_TRY(hipMemsetAsync(p, 0, 2 * sizeof(FusedBar) + 128, st));
         ctx->fused_state = p;
         ctx->fused_flip = 0;
+        HIP_TRY(hipEventCreateWithFlags(&ctx->fused_ev, hipEventDisableTiming));
+        std::lock_guard<std::mutex> g(FusedGate::mu());
+        FusedGate::users(ctx->device) += 1;
     }
     FusedBar *b = static_cast<FusedBar *>(ctx->fused_state);
     *cur = b + ctx->fused_flip; *next = b + (ctx->fused_flip ^ 1);
@@ -607,6 +640,15 @@ int fused_state(gpcc_ctx *ctx, hipStream_t st, FusedBar **cur, FusedBar **next, 
 }
 
 }  // namespace
+
+void fused_ctx_release(gpcc_ctx *ctx)
+{
+    if (!ctx->fused_state) return;
+    std::lock_guard<std::mutex> g(FusedGate::mu());
+    FusedGate::users(ctx->device) -= 1;
+    if (FusedGate::last(ctx->device) == ctx->fused_ev) FusedGate::last(ctx->device) = nullptr;
+    if (ctx->fused_ev) { (void)hipEventDestroy(ctx->fused_ev); ctx->fused_ev = nullptr; }
+}
 
 uint32_t *fused_timeout_word(gpcc_ctx *ctx) { return ctx->fused_state ? reinterpret_cast<uint32_t *>(static_cast<FusedBar *>(ctx->fused_state) + 2) : nullptr; }
 int fused_reset(gpcc_ctx *ctx, hipStream_t st)
@@ -630,10 +672,12 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
     for (int i = 0; i < 4; ++i) { k.hfrag[i] = m->hfrag[i]; k.sym[i] = a.sym[i]; k.rdw[i] = (uint32_t)rc_window_dwords(a.win_bytes[i]); }
     k.cdf = a.cdf; k.occ = a.occ; k.bytes = a.bytes; k.chunks = a.chunks; k.nlanes = a.nlanes; k.llog = a.llog;
     const int G = fused_grid(plan.n, a.np);
+    FusedGate gate(ctx, st);
+    GP_TRY(gate.begin());
     if (a.coder == RC_CODER_CARRY) k_level_fused<FUSED_CHILD, RC_CODER_CARRY><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     else k_level_fused<FUSED_CHILD, RC_CODER_CARRYLESS><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
-    return GPCC_OK;
+    return gate.end();
 }
 
 // can the range-decoder phases of a level keep their byte windows in the fused kernel's LDS?
@@ -660,9 +704,11 @@ int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const
     k.prior_emb = m->prior_emb;
     k.occ = const_cast<uint8_t *>(occ);
     const int G = fused_grid(plan.n, np);
+    FusedGate gate(ctx, st);
+    GP_TRY(gate.begin());
     k_level_fused<FUSED_PARENT, RC_CODER_CARRYLESS><<<(unsigned)G, FUSE_THREADS, FUSE_LDS_BYTES, st>>>(k);
     LAUNCH_CHECK();
-    return GPCC_OK;
+    return gate.end();
 }
 
 }  // namespace gpcc

@@ -91,6 +91,8 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
 // can the range-decoder phases of the level keep their lanes' byte windows in the fused kernel's LDS?  (always, for containers this
 // library wrote: 64-symbol lanes; a foreign or corrupt table may claim more)
 bool fused_windows_fit(int64_t n, int64_t np, uint32_t nlanes, const uint32_t win_bytes[4]);
+// a context is going away: its event leaves the per-device chain of persistent launches (api.hip: gpcc_ctx_destroy)
+void fused_ctx_release(gpcc_ctx *ctx);
 // the context's sticky timeout word (device) -- the caller copies it out at its final sync; fused_reset: after a timeout
 uint32_t *fused_timeout_word(gpcc_ctx *ctx);
 int fused_reset(gpcc_ctx *ctx, hipStream_t st);

@@ -40,3 +40,25 @@ def test_side_paths_beside_a_geometry_scene_are_deterministic():
     the first, and the geometry thread never fails."""
     r = _run([os.path.join("tools", "inflight_side.py"), "8"], 900)
     assert r.returncode == 0 and "8 iterations, 0 bad" in r.stdout and "steps, 0 bad" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_at_four_million_points():
+    """DESIGN quotes a 4 M-point figure (size dependence of the step): the driver's own harness at that size -- levels beyond 2^21
+    nodes, 32-bit tile addressing near its first million tiles, a 10 GB workspace -- must round-trip bit-identically and print ONE
+    JSON line on a clean stdout (bench.py verifies decoded geometry == input geometry before it prints)."""
+    import json
+
+    r = _run(["bench.py", "--points", "4000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--side-anchors", "0", "--scenes-in-flight", "0",
+              "--skip-v0", "--skip-stages"], 900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout)                       # the whole of stdout is the one line
+    assert line["roundtrip_bit_identical"] is True and line["config"]["points_per_scene"] == 4_000_000
+    assert line["coded_nodes"] > 8_000_000 and line["value"] > 5.0
+
+
+def test_two_contexts_never_spin_on_each_other(tmp_path):
+    """Two contexts with persistent small-level launches on one GPU (csrc/fused.hip: FusedGate): their launches are chained per device,
+    so neither ever runs into the bounded spin (which would print the fall-back notice and cost ~2 s)."""
+    r = _run([os.path.join("tools", "inflight_check.py"), "2", "12"], 600)
+    assert r.returncode == 0 and "0 bad" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "timed out" not in r.stderr, r.stderr[-2000:]

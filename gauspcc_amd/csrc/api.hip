@@ -235,9 +235,10 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     for (int ci = 0; ci < 18; ++ci) {  // (K, C, C) -> MFMA B fragments per offset
         off.push_back(h.size());
         size_t b = h.size();
-        h.resize(b + 2 * (size_t)K * C * C);
+        h.resize(b + 3 * (size_t)K * C * C);
         conv_weight_fragments(t[GPCC_T_CONV0 + ci], K, h.data() + b);
         conv_weight_fragments_t(t[GPCC_T_CONV0 + ci], K, h.data() + b + (size_t)K * C * C);
+        conv_weight_fragments_q(t[GPCC_T_CONV0 + ci], K, h.data() + b + 2 * (size_t)K * C * C);
     }
     push_rows_phys(t[GPCC_T_TEMB], 8);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW1 + s], (size_t)C * C);
@@ -560,10 +561,11 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             const int64_t zero_base[1] = {0};
             GP_TRY(tiles_view(ctx, st, pool, T.L - 1, T.L, zero_base, &tiles));
             // weights -> B-fragment order
-            std::vector<float> wf((size_t)K * 2048);
+            std::vector<float> wf((size_t)K * 3072);
             conv_weight_fragments(w_host, K, wf.data());
             conv_weight_fragments_t(w_host, K, wf.data() + (size_t)K * 1024);
-            TAKE(dw, float, (size_t)K * 2048); TAKE(xin, float, n * 32); TAKE(xres, float, n * 32); TAKE(xout, float, n * 32);
+            conv_weight_fragments_q(w_host, K, wf.data() + (size_t)K * 2048);
+            TAKE(dw, float, (size_t)K * 3072); TAKE(xin, float, n * 32); TAKE(xres, float, n * 32); TAKE(xout, float, n * 32);
             HIP_TRY(hipMemcpyAsync(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
             k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(in_dev, fin->m2r, n, xin);

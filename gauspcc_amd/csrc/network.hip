@@ -28,7 +28,9 @@
 #endif
 #include CONV_LOOP_INC
 #include "conv_loop2_gfx950.inc"               // generated: tools/gen_conv_loop2.py (the pair-step loop of paired tile lists)
+#include "conv_loop3_gfx950.inc"               // generated: tools/gen_conv_loop3.py (the same step on v_mfma_f32_32x32x2_f32)
 static_assert(CONV_LOOP2_ROW_BYTES == CONV_LDS_ROW_BYTES, "both asm loops address the running sums at one LDS row pitch");
+static_assert(CONV_LOOP3_ROW_BYTES == CONV_LDS_ROW_BYTES, "all asm loops address the running sums at one LDS row pitch");
 
 namespace gpcc {
 
@@ -81,6 +83,13 @@ bool conv_is_coop(int64_t n, int R)
     if (!use_coop) return false;
     if (R == 16) return true;
     return (R == 32 || R == 64) && !conv_rows_forced() && n < conv_tall_min() && n <= 64 * 256;
+}
+
+// GAUSPCC_CONV_QUAD: the paired blocks of the 255-row class run the 32x32x2 pair step (1) or the 16x16x4 one (0)
+bool conv_quad()
+{
+    static const bool q = env_int("GAUSPCC_CONV_QUAD", 0) != 0;
+    return q;
 }
 
 int conv_pick_rows(int64_t n, int k)
@@ -136,7 +145,8 @@ __device__ unsigned long long g_conv_timing[16];
 // PAIR (with ASM): the pool holds paired lists (tiles.hip: every run an even number of tiles) for the blocks whose runs are long
 // enough (T.pflag); those run the pair-step loop of conv_loop2_gfx950.inc -- two tiles of one kernel offset per step, one
 // weight fragment for both -- the others the one-tile loop.
-template <int R, int DIST, bool ASM, bool PAIR = false>
+// PAIR = 2: the pair-step loop on v_mfma_f32_32x32x2_f32 (conv_loop3_gfx950.inc) for the paired blocks
+template <int R, int DIST, bool ASM, int PAIR = 0>
 __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
 {
 #ifdef CONV_ONE_PER_SIMD
@@ -296,7 +306,13 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
                 atomicAdd(&g_conv_timing[14], (unsigned long long)sw2); atomicAdd(&g_conv_timing[15], (unsigned long long)sw3);
             }
 #else
-            if (PAIR && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
+            if (PAIR == 2 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
+                asm volatile(CONV_LOOP3_ASM
+                             : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
+                             : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 2048), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
+                               [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
+                             : CONV_LOOP3_CLOBBERS);
+            else if (PAIR == 1 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
                 asm volatile(CONV_LOOP2_ASM
                              : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
                              : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
@@ -751,7 +767,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         const int bytes = SC_WAVES * conv_lds_wave_floats(128) * 4;
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -842,7 +859,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
     case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
     case 255:
-        if (asm_ok && T.paired) k_sparse_conv<255, 1, true, true><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
+        if (asm_ok && T.paired && conv_quad()) k_sparse_conv<255, 1, true, 2><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
+        else if (asm_ok && T.paired) k_sparse_conv<255, 1, true, 1><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
         else if (asm_ok) CONV_LAUNCH(255, 1, true);
         else CONV_LAUNCH(255, 1, false);
         break;

@@ -15,7 +15,7 @@ struct gpcc_model {
     int C = 32, k = 5, K = 125;
     float *slab = nullptr;         // one allocation
     const float *prior_emb = nullptr;   // (256, 32) physical order
-    const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order, followed by the same in the transposed (A-fragment) order
+    const float *conv[18] = {0};        // (K, 2 halves, 64 lanes, 8) MFMA B-fragment order, followed by the same in the transposed (A-fragment) order and in the 32x32x2 A order
     const float *temb = nullptr;        // (8, 32) physical
     const float *hw1[4] = {0}, *hb1[4] = {0}, *hw2[4] = {0}, *hb2[4] = {0};  // upstream layouts (logical)
     const float *hfrag[4] = {0};        // per head: W1 as 2 x 512 B-fragment floats, W2 (columns padded to 16) as 512, b1 (32), b2 padded (16)
@@ -63,11 +63,24 @@ inline void conv_weight_fragments_t(const float *W, int K, float *out)
                     }
 }
 
+// The same kernel as the A operand of the 32x32x2 pair step (tools/gen_conv_loop3.py): MFMA row m = PHYSICAL output channel m (lane
+// l supplies row l % 32), MFMA number s of a step multiplies logical input channels k = 2 s + l / 32:
+// [o][q][lane][r] = W[o][2 (4 q + r) + lane / 32][logical_of(lane % 32)]      (four coalesced 1 KiB loads per offset, as the others)
+inline void conv_weight_fragments_q(const float *W, int K, float *out)
+{
+    for (int o = 0; o < K; ++o)
+        for (int q = 0; q < 4; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r)
+                    out[(((size_t)o * 4 + q) * 64 + lane) * 4 + r] = W[((size_t)o * 32 + (2 * (4 * q + r) + (lane >> 5))) * 32 + logical_of(lane & 31)];
+}
+
 constexpr int STAGE_M[4] = {2, 2, 4, 16};
 
 struct ConvJob {
     const float *in;   // (n,32) physical
-    const float *w;    // K x 1024 floats in B-fragment order, then K x 1024 in the transposed order (conv_weight_fragments_t)
+    const float *w;    // K x 1024 floats in B-fragment order, then K x 1024 in the transposed order (conv_weight_fragments_t), then K x 1024 in the
+                       // 32x32x2 order (conv_weight_fragments_q)
     const float *res;  // nullable, physical
     float *out;        // physical
 };

@@ -58,6 +58,8 @@ print("variant ok", pairs)
     {"GAUSPCC_COOP_TALL": "0"},                              # the cooperative kernel on 16-row blocks only (default: 16 / 32 / 64 by level size)
     {"GAUSPCC_CONV_SPLIT": "0"},                             # no products-over-the-chip kernels on the tiniest levels
     {"GAUSPCC_CONV_PAIR": "0"},                              # one-tile asm loop everywhere
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "1"},    # the pair step on v_mfma_f32_32x32x2_f32 (tools/gen_conv_loop3.py)
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "0"},
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "0"},

@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=11)
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="independent scenes each rank codes per step, one after the other (weak scaling: scene i of the "
                     "batch -> rank i mod N, gauspcc_amd.dist.scenes_for_rank; BASELINE configs[3] is --gpus 8 with one or more scenes per GPU)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = every core this process may use; a positive value pins the count, capped by those cores)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = the fastest of 8 / 16 / 32 / 64 / 128 / all cores on a short calibration run; a positive value pins the count, capped by the cores this process may use)")
     ap.add_argument("--measure-traffic", action="store_true", help="(informative) leave roofline.traffic null instead of quoting profiles/: run tools/pmc_traffic.sh for a fresh figure")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
     ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
@@ -393,8 +393,23 @@ def main():
             from oracle import oracle as orc
 
             host_cores = len(os.sched_getaffinity(0))
-            threads = orc.set_threads(max(1, min(args.cpu_threads, host_cores) if args.cpu_threads > 0 else host_cores))
             om = orc.Model(tensor_table(sd, 32, k), 32, k)
+            calib = {}
+            if args.cpu_threads > 0:
+                threads = orc.set_threads(max(1, min(args.cpu_threads, host_cores)))
+            else:
+                # the baseline must not be handicapped by its thread count in either direction: every core of a 256-core box ran the
+                # oracle 10x SLOWER than 64 threads (round 4, first try: 56.8 s against 5.7 s per 1 M-point encode), a fixed 64 may
+                # be too few elsewhere -- so a short calibration (encode of a 100 k-point cloud) picks among a few counts
+                small = synthetic_cloud(min(100_000, args.cpu_sample), seed=seed + 1)
+                for cand in sorted({c for c in (8, 16, 32, 64, 128, host_cores) if c <= host_cores}):
+                    orc.set_threads(cand)
+                    c0 = time.perf_counter()
+                    orc.encode(om, small, chunk_log2=args.chunk_log2)
+                    calib[cand] = round(time.perf_counter() - c0, 3)
+                    if calib[cand] > 4.0 * min(calib.values()):
+                        break
+                threads = orc.set_threads(min(calib, key=calib.get))
             sp = synthetic_cloud(args.cpu_sample, seed=seed)
             t0 = time.perf_counter()
             ref = orc.encode(om, sp, chunk_log2=args.chunk_log2)
@@ -405,13 +420,14 @@ def main():
             out["cpu_baseline"] = {
                 "value": round(args.cpu_sample / (t2 - t0) / 1e6, 5),
                 "unit": "Mpoints/s",
-                "cores": threads,            # the threads actually used (all cores of the box unless --cpu-threads pins fewer)
+                "cores": threads,            # the threads actually used: the fastest of the calibrated counts unless --cpu-threads pins one
                 "threads": threads,
                 "host_cores": host_cores,
+                "thread_calibration_s": calib or None,   # seconds per 100 k-point oracle encode at each candidate thread count
                 "kind": "port",
                 "sample": f"oracle encode+decode of a {args.cpu_sample}-point cloud from the same generator "
                           f"(enc {t1 - t0:.2f} s, dec {t2 - t1:.2f} s; {threads} OpenMP threads for the convolutions and heads, "
-                          f"single-thread range coder as torchac; the box has {host_cores} cores)",
+                          f"single-thread range coder as torchac; the box has {host_cores} cores; thread count {'pinned' if args.cpu_threads > 0 else 'picked by calibration'})",
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -15,6 +15,8 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/gauspcc.h"
 #include "common.hpp"
 
@@ -39,11 +41,27 @@ struct BitSink {
 
 inline int clz32h(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
-}  // namespace
+// rows of the table as the coder wants them: either the caller's int16 rows, or -- torchac's own calling convention, a float
+// table on the host (encode_float_cdf / decode_float_cdf on CPU tensors) -- integerised on the fly, one row per symbol, as
+// torchac's _convert_to_int_and_normalize does it: rint(cdf * (2^16 - (Lp - 1))) + j, kept modulo 2^16 (kit/op.py:67-79 is the
+// same statement).  fp32 multiply, round-half-even: the values torch computes for `cdf.mul(f).round()`.
+struct RowsU16 {
+    const uint16_t *cdf; int lp;
+    inline const uint16_t *row(int64_t i) { return cdf + i * lp; }
+};
+struct RowsF32 {
+    const float *cdf; int lp; uint16_t *tmp; float scale;
+    inline const uint16_t *row(int64_t i)
+    {
+        const float *r = cdf + i * lp;
+        for (int j = 0; j < lp; ++j) tmp[j] = (uint16_t)((int32_t)__builtin_rintf(r[j] * scale) + j);
+        return tmp;
+    }
+};
 
-extern "C" int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+template <typename ROWS>
+int host_encode(const int16_t *sym, ROWS rows, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
 {
-    if (!sym || !cdf || !out || !nbytes_out || n < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
     BitSink w = {out, cap, 0, 0, 0};
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint64_t pending = 0;
@@ -51,7 +69,7 @@ extern "C" int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int
     for (int64_t i = 0; i < n; ++i) {
         const int s = sym[i];
         if (s < 0 || s > top) return gpcc::fail(GPCC_ERR_ARG, "symbol %d at %lld outside [0, %d]", s, (long long)i, top);
-        const uint16_t *row = cdf + i * lp;
+        const uint16_t *row = rows.row(i);
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
         const uint32_t c_low = row[s], c_high = s == top ? 0x10000u : row[s + 1];
         high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
@@ -88,9 +106,9 @@ extern "C" int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int
     return GPCC_OK;
 }
 
-extern "C" int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
+template <typename ROWS>
+int host_decode(ROWS rows, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
 {
-    if (!cdf || (!bytes && nbytes) || !sym_out || n < 0 || nbytes < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
     // bit reservoir: `value` holds the 32 bits at the read position; bits past the end read as zero (arithmetic_kernel.cu:244-262)
     uint64_t res = 0; int nres = 0; int64_t ptr = 0;
     auto take = [&](int k) -> uint32_t {   // k in [0, 32]
@@ -103,7 +121,7 @@ extern "C" int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, i
     uint32_t low = 0, high = 0xFFFFFFFFu, value = take(32);
     const int top = lp - 2;
     for (int64_t i = 0; i < n; ++i) {
-        const uint16_t *row = cdf + i * lp;
+        const uint16_t *row = rows.row(i);
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
         const uint32_t x = value - low;
         // the reference picks the largest s with row[s] <= count, count = ((x + 1) 2^16 - 1) / span; row[s] <= count  <=>
@@ -136,4 +154,32 @@ extern "C" int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, i
         }
     }
     return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+{
+    if (!sym || !cdf || !out || !nbytes_out || n < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    return host_encode(sym, RowsU16{cdf, lp}, n, lp, out, cap, nbytes_out);
+}
+
+extern "C" int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
+{
+    if (!cdf || (!bytes && nbytes) || !sym_out || n < 0 || nbytes < 0 || lp < 2) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    return host_decode(RowsU16{cdf, lp}, bytes, nbytes, n, lp, sym_out);
+}
+
+extern "C" int gsac_host_encode_f32(const int16_t *sym, const float *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+{
+    if (!sym || !cdf || !out || !nbytes_out || n < 0 || lp < 2 || lp > 65536) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    std::vector<uint16_t> tmp((size_t)lp);
+    return host_encode(sym, RowsF32{cdf, lp, tmp.data(), (float)(65536 - (lp - 1))}, n, lp, out, cap, nbytes_out);
+}
+
+extern "C" int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
+{
+    if (!cdf || (!bytes && nbytes) || !sym_out || n < 0 || nbytes < 0 || lp < 2 || lp > 65536) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    std::vector<uint16_t> tmp((size_t)lp);
+    return host_decode(RowsF32{cdf, lp, tmp.data(), (float)(65536 - (lp - 1))}, bytes, nbytes, n, lp, sym_out);
 }

@@ -52,26 +52,39 @@ def _host(t):
     return np.ascontiguousarray(t.detach().cpu().numpy())
 
 
-def _encode(cdf_i16, sym):
+def _rows(cdf2):
+    """(host array, float?) the coder reads: a float table that already lives on the host goes in as it is (the coder integerises
+    row by row: gsac_host_*_f32); a float table on a GPU is integerised there and crosses PCIe as int16; int16 rows as they are"""
+    if cdf2.dtype == torch.int16:
+        return _host(cdf2), False
+    if cdf2.device.type == "cpu" and cdf2.dtype == torch.float32:
+        return _host(cdf2), True
+    return _host(_to_int_rows(cdf2)), False
+
+
+def _encode(cdf2, sym):
     n = sym.numel()
     if n == 0:
         return b""
-    rows, syms = _host(cdf_i16), _host(sym)
+    rows, is_float = _rows(cdf2)
+    syms = _host(sym)
     cap = 4 * n + 64
     out = np.empty(cap, dtype=np.uint8)
     nb = C.c_int64()
-    _lib.check(_lib.lib().gsac_host_encode_u16(syms.ctypes.data, rows.ctypes.data, n, rows.shape[1], out.ctypes.data, cap, C.byref(nb)))
+    fn = _lib.lib().gsac_host_encode_f32 if is_float else _lib.lib().gsac_host_encode_u16
+    _lib.check(fn(syms.ctypes.data, rows.ctypes.data, n, rows.shape[1], out.ctypes.data, cap, C.byref(nb)))
     return out[: nb.value].tobytes()
 
 
-def _decode(cdf_i16, byte_stream, out_shape, out_device):
-    rows = _host(cdf_i16)
+def _decode(cdf2, byte_stream, out_shape, out_device):
+    rows, is_float = _rows(cdf2)
     n = rows.shape[0]
     out = np.zeros(n, dtype=np.int16)
     if n:
         data = np.frombuffer(byte_stream, dtype=np.uint8)
         buf = np.ascontiguousarray(data) if data.size else np.zeros(1, np.uint8)
-        _lib.check(_lib.lib().gsac_host_decode_u16(rows.ctypes.data, buf.ctypes.data, data.size, n, rows.shape[1], out.ctypes.data))
+        fn = _lib.lib().gsac_host_decode_f32 if is_float else _lib.lib().gsac_host_decode_u16
+        _lib.check(fn(rows.ctypes.data, buf.ctypes.data, data.size, n, rows.shape[1], out.ctypes.data))
     return torch.from_numpy(out).reshape(out_shape).to(out_device)
 
 
@@ -87,14 +100,14 @@ def encode_float_cdf(cdf_float, sym, needs_normalization=True, check_input_bound
     if not needs_normalization:
         raise NotImplementedError("needs_normalization=False is not used by the reference")
     cdf2, sym2, _ = _flatten(cdf_float, sym)
-    return _encode(_to_int_rows(cdf2), sym2)
+    return _encode(cdf2, sym2)
 
 
 def decode_float_cdf(cdf_float, byte_stream, needs_normalization=True):
     if not needs_normalization:
         raise NotImplementedError("needs_normalization=False is not used by the reference")
     cdf2, _, _ = _flatten(cdf_float)
-    return _decode(_to_int_rows(cdf2), byte_stream, tuple(cdf_float.shape[:-1]), cdf_float.device)
+    return _decode(cdf2, byte_stream, tuple(cdf_float.shape[:-1]), cdf_float.device)
 
 
 def encode_int16_normalized_cdf(cdf_int, sym):

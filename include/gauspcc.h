@@ -247,6 +247,12 @@ GPCC_API int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf_dev, const uint8
  * (4 n + 64 always suffice).  No context, no GPU call. */
 GPCC_API int gsac_host_encode_u16(const int16_t *sym, const uint16_t *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out);
 GPCC_API int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out);
+/* The same for torchac.encode_float_cdf / decode_float_cdf on a HOST float table (torchac's own calling convention: CPU tensors;
+ * TC-GS/utils/encodings.py:84-129 moves its table to the CPU first): row i is integerised on the fly as torchac's
+ * _convert_to_int_and_normalize does -- rint(cdf * (2^16 - (lp - 1))) + j modulo 2^16, fp32 -- so the table is read once,
+ * 4 bytes per entry, and no int16 copy of it is ever built.  Bytes == the _u16 form on the pre-integerised rows.  lp <= 65536. */
+GPCC_API int gsac_host_encode_f32(const int16_t *sym, const float *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out);
+GPCC_API int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out);
 
 /* encoder_gaussian / decoder_gaussian in one call each, WITHOUT the (n, max-min+2) float CDF table of
  * arithmetic.calculate_cdf (src/gs_compress/HAC/utils/encodings_cuda.py:336-371, 399-433):

@@ -59,6 +59,28 @@ def test_extreme_rows_long_carry_runs_and_shapes(orc):
         torchac.encode_int16_normalized_cdf(torch.tensor(orc.cdf_to_int16(cdf)), torch.tensor(np.full(6000, 8, np.int16)))   # symbol == Lp - 1
 
 
+def test_float_rows_on_the_fly_equal_torch_rounding(orc):
+    """A float32 table on the host is integerised inside the coder (gsac_host_*_f32); every other table goes through torch ops
+    (_to_int_rows).  Same rows, ties included: cdf values placed exactly on k + 0.5 of the scaled grid round half to even in both."""
+    from gauspcc_amd import torchac
+
+    lp, n = 9, 4000
+    scale = float(2 ** 16 - (lp - 1))
+    rng = np.random.RandomState(5)
+    k = np.sort(rng.randint(0, 65000, size=(n, lp - 2)), axis=1).astype(np.float64)
+    inner = ((k + 0.5) / scale).astype(np.float32)                 # as close to a tie as fp32 gets; many are exact ties after the fp32 multiply
+    cdf = np.concatenate([np.zeros((n, 1), np.float32), inner, np.ones((n, 1), np.float32)], 1)
+    sym = rng.randint(0, lp - 1, size=n).astype(np.int16)
+    t32 = torch.tensor(cdf)
+    rows_torch = torchac._to_int_rows(t32).numpy()
+    assert np.array_equal(rows_torch, orc.cdf_to_int16(cdf))
+    b_fly = torchac.encode_float_cdf(t32, torch.tensor(sym))       # float32 on the host: on the fly
+    b_rows = torchac.encode_int16_normalized_cdf(torch.tensor(rows_torch), torch.tensor(sym))
+    b_f64 = torchac.encode_float_cdf(t32.double(), torch.tensor(sym))   # any other dtype: torch ops first
+    assert b_fly == b_rows == b_f64
+    assert np.array_equal(torchac.decode_float_cdf(t32, b_fly).numpy(), torchac.decode_int16_normalized_cdf(torch.tensor(rows_torch), b_fly).numpy())
+
+
 def test_faster_than_one_gpu_lane():
     """Round 3's shim ran the single stream on one GPU lane: 4.8 / 2.2 Msymbols/s.  The host loop must beat that on any core
     (the oracle's bit-by-bit restatement does ~15 / 10 on the build box)."""

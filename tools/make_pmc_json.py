@@ -37,7 +37,7 @@ if len(sys.argv) > 4:
         if m and not ln.startswith(" "):
             kern = m.group(1)
         m = re.match(r"\s+(\w+)\s+([0-9.e+]+)\s+\(dispatches (\d+)\)", ln)
-        if m and kern and "k_sparse_conv<255" in kern and "true, true" in kern:
+        if m and kern and "k_sparse_conv<255" in kern and ("true, true" in kern or "true, 1>" in kern):
             cnt[m.group(1)] = float(m.group(2))
     bench = None
     for ln in open(sys.argv[4]):
@@ -46,7 +46,7 @@ if len(sys.argv) > 4:
     if cnt.get("GRBM_GUI_ACTIVE") and cnt.get("SQ_VALU_MFMA_BUSY_CYCLES"):
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
         out["mfma_busy"] = round(cnt["SQ_VALU_MFMA_BUSY_CYCLES"] / (cnt["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
-        out["mfma_busy_source"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the dispatches of k_sparse_conv<255, 1, true, true> (the pair-step build), one encode + decode step"
+        out["mfma_busy_source"] = "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) over the dispatches of k_sparse_conv<255, 1, true, 1> (the pair-step build), one encode + decode step"
     if cnt.get("SQ_INSTS_MFMA") and bench:
         # a 16-pair tile is 16 v_mfma_f32_16x16x4_f32 = 16 x 2048 flop; SQ_INSTS_MFMA counts wave instructions.  The dominant kernel's
         # share of the step's pair jobs is taken from its share of the conv time (it IS >= 92 % of both)

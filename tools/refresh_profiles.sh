@@ -3,7 +3,7 @@
 # (every step under its own `timeout`; PMC passes never combined with tracing)
 set -u
 OUT=$1
-R=${2:-r03}
+R=${2:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
@@ -13,6 +13,12 @@ BENCH_ARGS="$QUIET" bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log
 cp "$OUT/pmc/summary_conv.txt" "$OUT/${R}_pmc_conv_fetch_write.txt"
 python3 tools/make_pmc_json.py "$OUT/${R}_pmc_conv_fetch_write.txt" "$OUT/${R}_pmc_conv.json" > /dev/null
 cp "$OUT/${R}_pmc_conv.json" profiles/${R}_pmc_conv.json     # bench.py reads the per-launch traffic from here
+# 1b. SQ / TCP / GRBM counters of the conv kernels; with a bench line they give roofline.mfma_busy / tile_fill
+BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1
+cp "$OUT/pmc2/summary.txt" "$OUT/${R}_pmc_conv_counters.txt"; rm -rf "$OUT/pmc2"
+timeout 600 python3 bench.py $QUIET > "$OUT/bench_quiet.json" 2> /dev/null
+python3 tools/make_pmc_json.py "$OUT/${R}_pmc_conv_fetch_write.txt" "$OUT/${R}_pmc_conv.json" "$OUT/${R}_pmc_conv_counters.txt" "$OUT/bench_quiet.json" > /dev/null
+cp "$OUT/${R}_pmc_conv.json" profiles/${R}_pmc_conv.json
 # 2. the bench line (default flags) and the same command under the kernel tracer
 timeout 600 python3 bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py $QUIET > "$OUT/bench_traced.log" 2>&1
@@ -20,14 +26,12 @@ cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_kernel_stats.
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
 python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
+python3 tools/level_breakdown.py "$f" > "$OUT/${R}_decode_levels.txt" 2>&1
 rm -rf "$OUT/t" "$OUT/pmc"
 # 2b. convolutions per level (per-launch HIP events inside the library)
 { echo "# tools/conv_log.py 1000000 (per-launch HIP events, GAUSPCC_CONV_LOG=1): convolutions of one encode + decode of the 1 M-point bench cloud, per level"
   echo "# 'enc level 0 / 1' = the prior set (levels 0..L-2) / the target set (levels 1..L-1), all levels in one launch; 'dec level g' = the launches on level g's nodes"
   timeout 300 python3 tools/conv_log.py 1000000 2>/dev/null | grep -E "^enc|^dec|^\{"; } > "$OUT/${R}_conv_levels.txt"
-# 3. SQ / TCP / GRBM counters of the conv kernels
-BENCH_ARGS="$QUIET" bash tools/pmc_conv2.sh "$OUT/pmc2" > "$OUT/pmc_counters.log" 2>&1
-cp "$OUT/pmc2/summary.txt" "$OUT/${R}_pmc_conv_counters.txt"; rm -rf "$OUT/pmc2"
 # 4. the callers either side of the path (attribute loop, Gaussian coder, generate_neural_gaussians + rasteriser)
 timeout 600 python3 tools/bench_side_paths.py 1000000 2> "$OUT/side.err" | tail -1 > "$OUT/${R}_side_paths.json"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/ts" -o tr -- python3 tools/bench_side_paths.py 1000000 > /dev/null 2>&1
@@ -37,4 +41,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/pmc_summary.py "$OUT" "k_" > "$OUT/${R}_side_pmc_fetch_write.txt"
 rm -rf "$OUT"/sp_*
+# 4b. the rasteriser's compute side: VALU instructions and busy cycles of k_render / k_preprocess (one pass)
+timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq_r" -o pmc -- python3 tools/bench_side_paths.py 1000000 > /dev/null 2>&1
+python3 tools/pmc_summary.py "$OUT/sq_r" "k_render" > "$OUT/${R}_render_counters.txt"; python3 tools/pmc_summary.py "$OUT/sq_r" "k_preprocess" >> "$OUT/${R}_render_counters.txt"
+rm -rf "$OUT/sq_r"
+# 5. the grid-barrier / launch-chain microbenchmark behind the small-level fusion decision (built by tools/build_variants.sh or by hand)
+[ -x tools/ubench/grid_sync ] && timeout 300 ./tools/ubench/grid_sync > "$OUT/${R}_grid_sync.txt" 2>&1
 tail -1 "$OUT/${R}_bench.json"

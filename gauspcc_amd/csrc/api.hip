@@ -38,7 +38,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); }
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); (void)hipEventDestroy(c->ev_main); (void)hipEventDestroy(c->ev_side); (void)hipEventDestroy(c->ev_bytes); (void)hipEventDestroy(c->ev_tables); }
     if (c->arena.base) (void)hipFree(c->arena.base);
     if (c->conv_products) (void)hipFree(c->conv_products);
     fused_ctx_release(c);

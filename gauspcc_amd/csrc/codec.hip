@@ -562,10 +562,16 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         TAKE(dca, RcChunk, std::max<size_t>(desc_total, 1));
         dchunks_all = dca;
     }
-    auto upload_tables = [&]() -> int {
-        for (int g = 0; g + 1 < L; ++g) GP_TRY(level_chunks(g, lvl_n[g + 1], &desc_at[g]));
-        HIP_TRY(hipMemcpyAsync(dchunks_all, hdesc, sizeof(RcChunk) * desc_used, hipMemcpyHostToDevice, ctx->xfer));
-        HIP_TRY(hipEventRecord(ctx->ev_bytes, ctx->xfer));   // replaces the record behind the container alone
+    // Two batches (round 4: the host parsed ALL tables between the first level's launches and the second level's, ~0.15 ms with the
+    // device idle): the tables of the first TAB_EARLY coded levels -- small levels, a tenth of the chunks -- go up in front of the first
+    // coded level; the rest is parsed once that level's chain is queued and goes up behind its own event, which level TAB_EARLY waits for.
+    constexpr int TAB_EARLY = 6;
+    int tab_parsed = 0;
+    auto upload_tables = [&](int g_end, hipEvent_t ev) -> int {
+        const size_t from = desc_used;
+        for (; tab_parsed < g_end && tab_parsed + 1 < L; ++tab_parsed) GP_TRY(level_chunks(tab_parsed, lvl_n[tab_parsed + 1], &desc_at[tab_parsed]));
+        if (desc_used > from) HIP_TRY(hipMemcpyAsync(dchunks_all + from, hdesc + from, sizeof(RcChunk) * (desc_used - from), hipMemcpyHostToDevice, ctx->xfer));
+        HIP_TRY(hipEventRecord(ev, ctx->xfer));   // (ev_bytes: replaces the record behind the container alone)
         return GPCC_OK;
     };
     Level cur;
@@ -658,7 +664,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it
         // lane descriptors of this level's four streams (chunked containers: all levels parsed and uploaded once, behind the container)
-        if (v1 && g == 0) GP_TRY(upload_tables());
+        if (v1 && g == 0) GP_TRY(upload_tables(TAB_EARLY, ctx->ev_bytes));
         const RcPlan pl = rc_plan(nc, chunk_log2, version);
         ConvTiles tilesC;
         PairPlan planC;
@@ -703,6 +709,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         if (child_plan && fmode == 1) {
             // the level's whole chain in one persistent launch (fused.hip)
             if (g == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
+            if (g == TAB_EARLY) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_tables, 0));
             FusedChild fa = {};
             fa.pA = pA; fa.np = np; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = clog;
             for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g][s]; fa.sym[s] = sym[s]; }
@@ -744,6 +751,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             { StageTimer tm(ctx, st, ST_HEADS, (double)nc * (128 + 4 + row_bytes)); GP_TRY(head_cdf(st, ha)); }
             GP_TRY(dbg_mark(ctx, st, g * 100 + 13 + 5 * s, cdf, cdf_bytes));
             if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
+            if (g == TAB_EARLY && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_tables, 0));
             {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
                 GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], pl.dual, sym[s], rc_coder_of_version(version)));
@@ -754,6 +762,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         }
         GP_TRY(dbg_mark(ctx, st, g * 100 + 30, chi.occ, (size_t)nc));
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
+        if (v1 && g == 0) GP_TRY(upload_tables(L, ctx->ev_tables));   // the other levels' tables: parsed while the device runs the first coded level
         ctx->arena.top_rewind(top_mk);
         coded += nc;
         cur = chi; cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan(); planP_np = np;

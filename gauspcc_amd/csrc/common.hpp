@@ -200,7 +200,7 @@ struct gpcc_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the codec: octree / tile-list work of the next step runs beside the convolutions of this one
     hipStream_t side = nullptr, xfer = nullptr;   // xfer: the container's host -> device copy of a decode, beside both
-    hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_bytes = nullptr;
+    hipEvent_t ev_main = nullptr, ev_side = nullptr, ev_bytes = nullptr, ev_tables = nullptr;
     // partial products of the two-launch convolution of the small levels (network.hip: k_conv_products / k_conv_sum): one
     // buffer per context, grown on demand, used by one convolution at a time (the launches of a context's convolutions are
     // ordered on one stream)
@@ -234,6 +234,7 @@ struct gpcc_ctx {
         HIP_TRY(hipEventCreateWithFlags(&ev_main, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_side, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_bytes, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_tables, hipEventDisableTiming));
         return GPCC_OK;
     }
 };

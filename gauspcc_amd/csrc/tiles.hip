@@ -566,11 +566,24 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     if (H <= 16) cap = nblk * K + CONV_HDR_PAD;
     else if (H <= 64 && H % 16 == 0 && conv_is_coop(rows_total, R)) cap = nblk * K * (H / 16) + CONV_HDR_PAD;
     else {
-        uint32_t total = 0;
-        HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        cap = (int64_t)total + CONV_HDR_PAD;   // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
-        pool->alg_bytes += 84.0 * total;
+        // A single level (the decoder builds one per level, beside the parent trunk) CAN be sized by the bound as well -- a (block, offset)
+        // run holds at most ceil(H / 16) tiles, one more where odd runs are padded to pairs: ~660 B per node at 255 rows -- so that the host
+        // never waits for the count pass (GAUSPCC_TILES_BOUND=1).  Measured in round 4 (S1M, 10 steps, same box): dec_ms 26.93 with the
+        // bound, 26.95 with the five syncs -- they fall on the second stream while the first runs a parent trunk, and the host is ahead
+        // either way.  Off by default: the exact size keeps the workspace smaller.
+        static const bool by_bound = env_int("GAUSPCC_TILES_BOUND", 0) != 0;
+        int64_t tpr = cdiv(H, 16);
+        if (pool->paired) tpr = (tpr + 1) & ~(int64_t)1;
+        const int64_t bound = nblk * K * tpr;
+        if (!batch && by_bound && bound < (int64_t)1 << 27) {
+            cap = bound + CONV_HDR_PAD;   // (profiling: the 84 B per tile written are not counted for a list whose length stays on the device)
+        } else {
+            uint32_t total = 0;
+            HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            cap = (int64_t)total + CONV_HDR_PAD;   // the conv kernel streams whole header batches: zeroed padding (row 0, offset 0)
+            pool->alg_bytes += 84.0 * total;
+        }
     }
     if (cap >= (int64_t)1 << 28) return fail(GPCC_ERR_ARG, "too many conv tiles (%lld): clouds beyond ~10^8 points need 64-bit tile addressing", (long long)cap);
     TAKE(tj, int32_t, cap * 16);

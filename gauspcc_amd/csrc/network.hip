@@ -395,6 +395,10 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     // with vmcnt(0) -- a batch loop that loads its residuals per batch waits for the previous batch's stores every time
     // (measured: 33 k cycles per 255-row block with a residual, 18 k without -- the short last batch went through a
     // dword-by-dword predicated path; now ~5 k / ~3 k).
+#ifdef CONV_NO_EPILOGUE   // developer ablation (WRONG results): what the copy-out costs -- one store keeps the block's work alive
+    if (lane == 0 && nrows > 0) J.out[(size_t)row0 * 32] = acc[ROWF];
+    if (false)
+#endif
     {
         const int nvec = nrows * 8;   // float4 elements of this block
         const bool has_res = J.res != nullptr;

@@ -1,0 +1,100 @@
+"""The torchac-based attribute coders of TC-GS and CAT-3DGS (src/gs_compress/TC-GS/utils/encodings.py:84-176,
+src/gs_compress/CAT-3DGS/utils/encodings.py:39-175 -- the two files agree on these functions), SURVEY.md §8(f) row 4:
+
+    from gauspcc_amd.torchac_encodings import encoder_gaussian, decoder_gaussian, encoder, decoder
+
+Same signatures, same `.b` files (ONE torchac stream per file), same return values.  What differs from the reference is
+where things run: the reference builds the float CDF table with `torch.distributions` on the GPU, moves the whole table
+to the CPU (4 bytes per entry) and lets torchac integerise and code it there; here the table is integerised on the device
+it was built on (2 bytes per entry cross PCIe, `gauspcc_amd.torchac`) and coded by libgauspcc's host-side coder
+(csrc/hostcoder.hip) -- a single stream is one dependent chain, which a host core runs faster than a GPU lane.  Tables are
+built in slabs of rows so that an attribute of millions of symbols never materialises n x (range + 2) floats at once.
+CPU tensors work as well (torchac's own convention); nothing here needs a GPU.
+"""
+import torch
+
+from . import torchac
+
+_SLAB_ENTRIES = 1 << 26          # table entries built at a time (256 MB of float32)
+
+
+def _as_q(Q, like):
+    if not isinstance(Q, torch.Tensor):
+        Q = torch.tensor([Q], dtype=like.dtype, device=like.device).repeat(like.shape[0])     # encodings.py:86-87
+    return Q
+
+
+def _int_rows(mean, scale, Q, min_value, max_value):
+    """int16 rows of the table `Normal(mean, scale).cdf((samples - 0.5) * Q)`, samples = min_value .. max_value + 1
+    (encodings.py:92-99), integerised as torchac does (`_convert_to_int_and_normalize`), slab by slab, on mean's device"""
+    lo, hi = int(min_value), int(max_value)
+    samples = torch.arange(lo, hi + 2, device=mean.device).to(torch.float)
+    lp = samples.numel()
+    rows_per = max(1, _SLAB_ENTRIES // lp)
+    out = []
+    for a in range(0, mean.shape[0], rows_per):
+        m = mean[a: a + rows_per].unsqueeze(-1)
+        s = scale[a: a + rows_per].unsqueeze(-1)
+        q = Q[a: a + rows_per].unsqueeze(-1)
+        lower = torch.distributions.normal.Normal(m, s).cdf((samples.unsqueeze(0) - 0.5) * q)
+        out.append(torchac._to_int_rows(lower))
+    return torch.cat(out, dim=0) if out else torch.zeros((0, lp), dtype=torch.int16, device=mean.device)
+
+
+def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
+    """encodings.py:84-120.  Returns (bit_len, min_value, max_value) -- the two bounds as 0-d tensors, as the reference's."""
+    assert file_name.endswith('.b')
+    Q = _as_q(Q, mean)
+    assert x.shape == mean.shape == scale.shape == Q.shape
+    x_int_round = torch.round(x / Q)
+    max_value = x_int_round.max()
+    min_value = x_int_round.min()
+    x_int_round_idx = (x_int_round - min_value).to(torch.int16)
+    assert (x_int_round_idx.to(torch.int32) == x_int_round - min_value).all()
+    rows = _int_rows(mean, scale, Q, min_value.item(), max_value.item())
+    byte_stream = torchac.encode_int16_normalized_cdf(rows, x_int_round_idx)
+    with open(file_name, 'wb') as fout:
+        fout.write(byte_stream)
+    return len(byte_stream) * 8, min_value, max_value
+
+
+def decoder_gaussian(mean, scale, Q, file_name='tmp.b', min_value=-100, max_value=100):
+    """encodings.py:123-146.  min_value / max_value: what encoder_gaussian returned (tensors or numbers)."""
+    assert file_name.endswith('.b')
+    Q = _as_q(Q, mean)
+    assert mean.shape == scale.shape == Q.shape
+    lo = min_value.item() if isinstance(min_value, torch.Tensor) else min_value
+    hi = max_value.item() if isinstance(max_value, torch.Tensor) else max_value
+    rows = _int_rows(mean, scale, Q, lo, hi)
+    with open(file_name, 'rb') as fin:
+        byte_stream_d = fin.read()
+    sym_out = torchac.decode_int16_normalized_cdf(rows, byte_stream_d).to(mean.device).to(torch.float32)
+    x = sym_out + min_value
+    return x * Q
+
+
+def _binary_cdf(p):
+    p_u = 1 - p.unsqueeze(-1)
+    return torch.cat([torch.zeros_like(p_u), p_u, torch.ones_like(p_u)], dim=-1)      # encodings.py:153-157
+
+
+def encoder(x, p, file_name):
+    """encodings.py:149-165: x in {-1, +1} with P(x = +1) = p, one torchac stream"""
+    assert file_name[-2:] == '.b'
+    x = x.detach()
+    p = p.detach()
+    sym = torch.floor((x + 1) / 2).to(torch.int16)
+    byte_stream = torchac.encode_float_cdf(_binary_cdf(p), sym, check_input_bounds=True)
+    with open(file_name, 'wb') as fout:
+        fout.write(byte_stream)
+    return len(byte_stream) * 8
+
+
+def decoder(p, file_name):
+    """encodings.py:167-183"""
+    dvc = p.device
+    assert file_name[-2:] == '.b'
+    with open(file_name, 'rb') as fin:
+        byte_stream = fin.read()
+    sym_out = torchac.decode_float_cdf(_binary_cdf(p.detach()), byte_stream)
+    return (sym_out * 2 - 1).to(torch.float32).to(dvc)

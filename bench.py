@@ -365,6 +365,9 @@ def main():
                     "convolutions": int(prof.fused_launches),
                     "algorithmic_flops_per_step": 2.0 * 32 * 32 * prof.fused_pair_jobs / max(ev_steps, 1),
                 },
+                # the same fraction with those launches counted WHOLE as convolution time (comparable with the lines of rounds 1-3, where
+                # `frac` covered every level; conservative: their heads, coder phases and barriers are in the denominator)
+                "frac_all_levels": round((conv_flops + 2.0 * 32 * 32 * prof.fused_pair_jobs) / max((prof.conv_ms + prof.fused_ms) * 1e-3, 1e-9) / 1e12 / 157.3, 4),
             },
         }
         if args.side_anchors > 0 and world == 1:

@@ -385,6 +385,7 @@ def main():
             out["side_paths"] = {
                 "scene": f"synthetic HAC-style scene, {sp['n_anchors']} anchors x 50 features x 10 offsets, {sp['image'][0]}x{sp['image'][1]} frame",
                 "attribute_loop": {k: sp["attribute_loop"][k] for k in ("anchors_coded", "files_bytes", "conduct_encoding_s", "conduct_decoding_s")},
+                "attribute_loop_hac_plus": {k: v for k, v in sp.get("attribute_loop_hac_plus", {}).items() if k != "log"},
                 "gaussian_coder": {k: sp["gaussian_coder"][k] for k in ("symbols", "encode_fused_ms", "decode_fused_ms", "Msymbols_per_s_encode", "Msymbols_per_s_decode",
                                                                         "fused_bytes_equal_table_bytes")},
                 "mlp_grid": sp["mlp_grid"],

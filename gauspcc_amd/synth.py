@@ -214,3 +214,57 @@ class SyntheticGaussianModel:
 
     def calc_interp_feat(self, x):
         return self.encoding_xyz((x - self.x_bound_min) / (self.x_bound_max - self.x_bound_min))
+
+
+class SyntheticGaussianModelPlus(SyntheticGaussianModel):
+    """What HAC++ adds to the slice of GaussianModel its codec touches (src/gs_compress/HAC-plus/scene/gaussian_model.py): `mlp_grid`
+    with the extra `prob` head and two more adjustments (:370-374), the channel-context MLP `Channel_CTX_fea` behind `get_deform_mlp`
+    (:117-168, :377: five MLPs Linear(150 + 10 c, 40) - LeakyReLU - Linear(40, 30) on the groups already coded + mean_scale), one more
+    mask slot per anchor and `get_mask_anchor` of shape (N, 1) (:465-476).  Seeded random weights, as the base class."""
+
+    def __init__(self, n_anchors, seed=0, **kw):
+        import numpy as np
+        import torch
+
+        super().__init__(n_anchors, seed=seed, **kw)
+        nn = torch.nn
+        dev = self._anchor.device
+        g = torch.Generator(device="cpu").manual_seed(seed + 1000)
+        F, K = self.feat_dim, self.n_offsets
+        torch.manual_seed(seed + 1)
+        self.mlp_grid = nn.Sequential(nn.Linear(self.encoding_xyz.output_dim, F * 2), nn.ReLU(True), nn.Linear(F * 2, (F + 6 + 3 * K) * 2 + F + 1 + 1 + 1)).to(dev)
+
+        class ChannelCtx(nn.Module):
+            def __init__(self):
+                super().__init__()
+                for c in range(5):
+                    setattr(self, f"MLP_d{c}", nn.Sequential(nn.Linear(F * 3 + 10 * c, 40), nn.LeakyReLU(inplace=True), nn.Linear(40, 30)))
+
+            def forward(self, fea_q, mean_scale, to_dec=-1):
+                d = torch.split(fea_q, [10] * 5, dim=-1)
+                outs = [torch.chunk(getattr(self, f"MLP_d{c}")(torch.cat(list(d[:c]) + [mean_scale], dim=-1)), chunks=3, dim=-1) for c in range(5)]
+                if 0 <= to_dec < 5:
+                    return outs[to_dec]
+                return tuple(torch.cat([o[i] for o in outs], dim=-1) for i in range(3))
+
+        m = ChannelCtx()
+        for p in m.parameters():
+            p.data = torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else 1.0 / float(np.sqrt(p.shape[-1])))
+        self.mlp_deform = m.to(dev)
+        self._mask = torch.cat([self._mask, torch.zeros(self._mask.shape[0], 1, 1, device=dev)], dim=1)   # (N, K + 1, 1)
+
+    @property
+    def get_mask(self):
+        import torch
+        if self.decoded_version:
+            return self._mask[:, :self.n_offsets, :]
+        s = torch.sigmoid(self._mask[:, :self.n_offsets, :])
+        return ((s > 0.01).float() - s).detach() + s
+
+    @property
+    def get_mask_anchor(self):
+        import torch
+        rate = torch.mean(self.get_mask, dim=1)
+        return ((rate > 0.0).float() - rate).detach() + rate          # (N, 1)
+
+    get_deform_mlp = property(lambda self: self.mlp_deform)

@@ -48,12 +48,12 @@ def test_bench_at_four_million_points():
     JSON line on a clean stdout (bench.py verifies decoded geometry == input geometry before it prints)."""
     import json
 
-    r = _run(["bench.py", "--points", "4000000", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--side-anchors", "0", "--scenes-in-flight", "0",
+    r = _run(["bench.py", "--points", "4000000", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--side-anchors", "0", "--scenes-in-flight", "0",
               "--skip-v0", "--skip-stages"], 900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout)                       # the whole of stdout is the one line
     assert line["roundtrip_bit_identical"] is True and line["config"]["points_per_scene"] == 4_000_000
-    assert line["coded_nodes"] > 8_000_000 and line["value"] > 5.0
+    assert line["coded_nodes"] > 8_000_000 and line["value"] > 10.0    # (warm: ~24 Mpoints/s; the first call of a process grows a 10 GB workspace)
 
 
 def test_two_contexts_never_spin_on_each_other(tmp_path):

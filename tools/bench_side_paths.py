@@ -79,6 +79,30 @@ def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None
     out["attribute_loop"] = {"anchors_coded": patched[1], "files_bytes": size, "conduct_encoding_s": round(t1 - t0, 3), "conduct_decoding_s": round(t3 - t2, 3),
                              "log": log.strip()}
 
+    # ---- the same loop of HAC++ (hac_plus_codec.py: five feat groups under the mixture whose second component comes from the channel-context MLP)
+    try:
+        from gauspcc_amd import hac_plus_codec
+        from gauspcc_amd.synth import SyntheticGaussianModelPlus
+        encp = SyntheticGaussianModelPlus(n_anchors, seed=3)
+        with tempfile.TemporaryDirectory() as d:
+            hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")
+        with tempfile.TemporaryDirectory() as d:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            logp = hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            decp = SyntheticGaussianModelPlus(64, seed=9)
+            decp.encoding_xyz, decp.mlp_grid, decp.mlp_deform = encp.encoding_xyz, encp.mlp_grid, encp.mlp_deform
+            decp._anchor_feat = torch.zeros(1, encp.feat_dim, device=dev)
+            t2 = time.perf_counter()
+            hac_plus_codec.conduct_decoding(decp, d, ckpt_path="synthetic")
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            sizep = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+        out["attribute_loop_hac_plus"] = {"anchors_coded": int(decp._anchor.shape[0]), "files_bytes": sizep, "conduct_encoding_s": round(t1 - t0, 3),
+                                          "conduct_decoding_s": round(t3 - t2, 3), "log": logp.strip()}
+        del encp, decp
+    except Exception as e:   # a side figure must not take the line down
+        out["attribute_loop_hac_plus"] = {"error": repr(e)}
+
     # camera on an orbit around the scene, looking at its centre (HAC/scene/cameras.py conventions: transposed matrices)
     ctr = enc._anchor.mean(dim=0); ext = float((enc._anchor.max(dim=0).values - enc._anchor.min(dim=0).values).max())
     eye = ctr + torch.tensor([0.0, 0.0, -1.4 * ext], device=dev)

@@ -28,7 +28,8 @@ Registers v16.. are fixed here (declared as clobbers).
 import os
 
 DX, DW = 3, 3
-EXP2 = int(os.environ.get("CONV_ASM_EXP2", "0"))   # developer ablations of the pair loop: 1 = conflict-free LDS slots (WRONG results)
+EXP2 = int(os.environ.get("CONV_ASM_EXP2", "0"))   # developer ablations of the pair loop (WRONG results): 1 = conflict-free LDS slots, 2 = no running sums
+                                                     # (no LDS read / add / write), 4 = no weight loads in the loop, 8 = no gathers in the loop, 16 = no header reads
 NX, NW = DX + 1, DW + 1
 ROWB = int(os.environ.get("CONV_ASM_ROWB", "144"))
 _x0 = 16
@@ -231,15 +232,17 @@ def step(du):
             b += mf(C(p, 1), ws, X(xs, 1), 0, True)
         # the step's only VALU burst
         b += (ring_pointers() if du == 0 else [])
-        b += sum_adds(q, 0) + sum_adds(q, 1) + addr_x(0) + addr_x(1) + addr_w()
+        b += ([] if EXP2 & 2 else sum_adds(q, 0) + sum_adds(q, 1)) + addr_x(0) + addr_x(1) + addr_w()
         if EXP2 & 1:   # ablation (WRONG results): every tile's rows are LDS slots 0..15 -- what the bank conflicts of gathered slots cost
             b += [f"v_mad_u32_u24 v{V['ra'][p][0]}, v{V['sgo']}, {ROWB // 4}, v{V['accb']}",
                   f"v_mad_u32_u24 v{V['ra'][p][1]}, v{V['sgo']}, {ROWB // 4}, v{V['accb']}"]
         else:
             b += [f"v_mad_u32_u24 v{V['ra'][p][0]}, v{V['rb'][0]}, %[t1], v{V['accb']}",
                   f"v_mad_u32_u24 v{V['ra'][p][1]}, v{V['rb'][1]}, %[t1], v{V['accb']}"]
-        mem = (sum_writes(q, 0) + sum_writes(q, 1) + sum_reads(p, 0) + sum_reads(p, 1) + header_reads(du)
-               + loads_x(nsx, 0) + loads_x(nsx, 1) + loads_w(nsw))
+        nop = lambda lst: ["s_nop 0"] * len(lst)
+        sw, sr = sum_writes(q, 0) + sum_writes(q, 1), sum_reads(p, 0) + sum_reads(p, 1)
+        hr, lx, lw = header_reads(du), loads_x(nsx, 0) + loads_x(nsx, 1), loads_w(nsw)
+        mem = ((nop(sw) + nop(sr) if EXP2 & 2 else sw + sr) + (nop(hr) if EXP2 & 16 else hr) + (nop(lx) if EXP2 & 8 else lx) + (nop(lw) if EXP2 & 4 else lw))
         rest = []
         for kk in range(1, 8):
             rest += mf(C(p, 0), ws, X(xs, 0), kk)

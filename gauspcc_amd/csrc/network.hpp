@@ -116,7 +116,8 @@ struct ConvTiles {
 };
 int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides)
 bool conv_is_coop(int64_t n, int R);     // does a level of n nodes at block class R run the cooperative kernel (16 / 32 / 64-row blocks, H = R)?
-int conv_pick_height(int64_t n, int R);  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
+int conv_pick_height(int64_t n, int R);
+bool conv_half_level(int64_t n, int R);   // the level runs on half-channel waves (k_sparse_conv_half): its tile list is not paired  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
 
 // Tile lists of several levels in one pool (tiles.hip).  Level l is built from its parent level's cell map (par == nullptr:
 // a base level of < 64 nodes, searched directly); cell_own, when not null, receives the level's own cell map

@@ -513,7 +513,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     LevelTilesArgs a = {};
     static const bool pair_on = [] { const char *e = getenv("GAUSPCC_CONV_PAIR"); return !e || atoi(e) != 0; }();
     static const int pair_min = env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
-    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block)
+    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on && !(nlv == 1 && conv_half_level(lv[0].lv->n, R))) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block); half-channel levels run the one-tile loop
     pool->pflag = nullptr;
     if (pool->paired) {
         TAKE(pf, uint8_t, nblk);

@@ -60,6 +60,8 @@ print("variant ok", pairs)
     {"GAUSPCC_CONV_PAIR": "0"},                              # one-tile asm loop everywhere
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "1"},    # the pair step on v_mfma_f32_32x32x2_f32 (tools/gen_conv_loop3.py)
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "0"},
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_HALF": "1"},    # half-channel waves: two waves per block, 16 output channels each (k_sparse_conv_half)
+    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_HALF": "1", "GAUSPCC_CONV_HALF_BLOCKS": "64"},   # ... on tall blocks
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "0"},

@@ -43,8 +43,10 @@ EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no s
                                                  # 32 as 16, but the odd tiles still issue four loads -- of one 16-byte address for all lanes, into scratch registers (issue slots kept, L1 traffic gone)
 DX = int(os.environ.get("CONV_ASM_DX", "3"))     # issue distance of the gathered rows (steps); X ring = DX + 1 sets (7: measured, no gain)
 DW = 3                                           # issue distance of the weight fragments; W ring = DW + 1 sets
-ROWB = int(os.environ.get("CONV_ASM_ROWB", "144"))   # LDS bytes per row of running sums (128 + one 16-byte pad: bank rotation, network.hip)
-assert DX in (3, 7) and ROWB % 16 == 0 and ROWB >= 128
+HALF = int(os.environ.get("CONV_ASM_HALF", "0"))   # 1: the HALF-CHANNEL loop (round 4): the wave computes 16 of the 32 output channels of its block -- 8 MFMAs a tile, one
+                                                     # 16-byte piece of running sums per lane, half a weight fragment (two loads); two such waves share a block's tile list
+ROWB = int(os.environ.get("CONV_ASM_ROWB", "64" if HALF else "144"))   # LDS bytes per row of running sums (128 + one 16-byte pad: bank rotation, network.hip; half rows: 64, no pad)
+assert DX in (3, 7) and ROWB % 16 == 0 and ROWB >= (64 if HALF else 128)
 NX, NW = DX + 1, DW + 1
 _x0 = 16
 _w0 = _x0 + 8 * NX
@@ -67,7 +69,8 @@ V = dict(
 )
 CLOBBER_V = list(range(16, _m0 + 28 + (20 if EXP & 32 else 0)))
 NSTEP = NX                             # a multiple of NX, NW and 2
-WINDOW = 6 * (DW - 1)                  # tile loads that may stay in flight across a step start
+LPS = 4 if HALF else 6                 # loads a step issues: 2 gathers + the (half) weight fragment
+WINDOW = LPS * (DW - 1)                # tile loads that may stay in flight across a step start
 # Header ring: 32 slots = two batches of 16 tiles, followed by a mirror of slots 0..15 so that the NSTEP steps of an
 # iteration reach every slot they read by immediate offsets from pointers that move once per iteration.
 # Byte offsets inside the ring (must match network.hip: HDR_R, HDR_O):
@@ -93,8 +96,8 @@ def loads_x(xset):
 
 def loads_w(wset):
     W = V["W"][wset]
-    o = [f"global_load_dwordx4 {vr(W + 4 * i, 4)}, v{V['bo']}, %[w]" + (f" offset:{1024 * i}" if i else "") for i in range(4)]
-    return ["s_nop 0"] * 4 if EXP & 2 else o
+    o = [f"global_load_dwordx4 {vr(W + 4 * i, 4)}, v{V['bo']}, %[w]" + (f" offset:{1024 * i}" if i else "") for i in range(2 if HALF else 4)]
+    return ["s_nop 0"] * len(o) if EXP & 2 else o
 
 
 def loads_w_dummy():
@@ -116,21 +119,21 @@ def sum_adds(sset, cp):
     S = V["S"][sset]
     if os.environ.get("CONV_ASM_PK", "1") == "0":      # experiment: eight scalar adds instead of four packed ones
         return [f"v_add_f32 v{S + i}, v{S + i}, v{cp + i}" for i in range(8)]
-    return [f"v_pk_add_f32 {vr(S + 2 * i, 2)}, {vr(S + 2 * i, 2)}, {vr(cp + 2 * i, 2)}" for i in range(4)]
+    return [f"v_pk_add_f32 {vr(S + 2 * i, 2)}, {vr(S + 2 * i, 2)}, {vr(cp + 2 * i, 2)}" for i in range(2 if HALF else 4)]
 
 
 def sum_writes(sset):
     if EXP & 1:
         return []
     S, ra = V["S"][sset], V["ra"][sset]
-    return [f"ds_write_b128 v{ra}, {vr(S, 4)}", f"ds_write_b128 v{ra}, {vr(S + 4, 4)} offset:64"]
+    return [f"ds_write_b128 v{ra}, {vr(S, 4)}"] + ([] if HALF else [f"ds_write_b128 v{ra}, {vr(S + 4, 4)} offset:64"])
 
 
 def sum_reads(sset):
     if EXP & 1:
         return []
     S, ra = V["S"][sset], V["ra"][sset]
-    return [f"ds_read_b128 {vr(S, 4)}, v{ra}", f"ds_read_b128 {vr(S + 4, 4)}, v{ra} offset:64"]
+    return [f"ds_read_b128 {vr(S, 4)}, v{ra}"] + ([] if HALF else [f"ds_read_b128 {vr(S + 4, 4)}, v{ra} offset:64"])
 
 
 def header_reads(du):
@@ -250,13 +253,17 @@ def step(du):
     label = f"s{du}"
 
     def mf(kk, first=False):
-        return [mfma(CC, W + kk, X + kk, first), mfma(CC + 4, W + 8 + kk, X + kk, first)]
+        return [mfma(CC, W + kk, X + kk, first)] + ([] if HALF else [mfma(CC + 4, W + 8 + kk, X + kk, first)])
 
     nsx, nsw = (du + DX) % NX, (du + DW) % NW    # the sets consumed by the previous step receive tiles u+du+DX / u+du+DW
     o = [f"; ---- step: tile u+{du}: X set {du % NX}, W set {du % NW}, C/S set {cur}"] + stamp("sa", cur) + step_wait(du, label) + stamp("sb", cur) + stamp_collect(cur)
     # slot multiplier of this tile: the row pitch if it exists, 0 (the dummy slot) past the end of the block's list
     o += [f"s_add_u32 %[t0], %[u], {du}", "s_cmp_lt_u32 %[t0], %[nt]", f"s_cselect_b32 %[t1], {ROWB}, 0"]
     o += mf(0, True)
+    if HALF:
+        # one accumulator chain: the previous step's LAST MFMA (which wrote the products the burst below adds) was issued one MFMA ago --
+        # a second MFMA of the new chain in front of the burst keeps the 11 wait states an 8-pass MFMA result needs before a VALU read
+        o += mf(1)
     # the step's only VALU burst: previous tile's products onto its rows' sums, addresses of the loads and of this tile's slot
     o += (ring_pointers() if du == 0 else [])
     o += sum_adds(prv, CP) + addr_x() + addr_w()
@@ -264,20 +271,23 @@ def step(du):
     # memory instructions issue slowly (measured: ~20 cycles an LDS, ~13 a global load instruction, during which an in-order
     # wave issues nothing else) but, unlike VALU work, they do overlap a running MFMA: one in front of each remaining MFMA
     mem = sum_writes(prv) + sum_reads(cur) + header_reads(du) + loads_x(nsx) + ((loads_w_dummy() if EXP & 32 else []) if (EXP & 48) and (du + DW) % 2 == 1 else loads_w(nsw))
-    rest = [m for kk in range(1, 8) for m in mf(kk)]
+    rest = [m for kk in range(2 if HALF else 1, 8) for m in mf(kk)]
     spread = os.environ.get("CONV_ASM_SPREAD", "1") != "0"
     if not spread:
         o += mem[:-6] + stamp("sc", cur) + rest[:2] + mem[-6:] + (staging_fetch(label) if du == 0 else []) + stamp("sd", cur)
-        o += rest[2:10] + (staging_store(label, WINDOW + 6) if du == 0 else []) + rest[10:]
+        o += rest[2:10] + (staging_store(label, WINDOW + LPS) if du == 0 else []) + rest[10:]
         return o
+    stag = (staging_fetch(label) + staging_store(label, (8 if EXP & 16 and not EXP & 32 else WINDOW) + (2 if EXP & 16 and not EXP & 32 else LPS)) if du == 0 else [])
     for i, m in enumerate(rest):
         if i < len(mem):
             o.append(mem[i])
         if i == len(mem):
-            o += (staging_fetch(label) + staging_store(label, (8 if EXP & 16 and not EXP & 32 else WINDOW) + (2 if EXP & 16 and not EXP & 32 else 6)) if du == 0 else [])
+            o += stag
         if i == 7:
             o += stamp("sc", cur)
         o.append(m)
+    if len(mem) >= len(rest):    # (the half-channel loop has fewer MFMAs than memory instructions: the rest of them, and the staging, behind the last MFMA)
+        o += mem[len(rest):] + stag
     o += stamp("sd", cur)
     return o
 
@@ -337,19 +347,20 @@ def build():
 
 
 def main():
-    path = os.environ.get("CONV_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gauspcc_amd", "csrc", "conv_loop_gfx950.inc")
+    path = os.environ.get("CONV_ASM_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gauspcc_amd", "csrc", "conv_looph_gfx950.inc" if HALF else "conv_loop_gfx950.inc")
+    sfx = "H" if HALF else ""
     with open(path, "w") as f:
-        f.write("// GENERATED by tools/gen_conv_loop.py -- do not edit.  gfx950 ISA of the k_sparse_conv tile loops.\n")
-        for name in ("CONV_LOOP_ASM",):
+        f.write("// GENERATED by tools/gen_conv_loop.py" + (" (CONV_ASM_HALF=1)" if HALF else "") + " -- do not edit.  gfx950 ISA of the k_sparse_conv tile loops.\n")
+        for name in (f"CONV_LOOP{sfx}_ASM",):
             o = build()
             f.write(f"#define {name} \\\n")
             for ln in o:
                 f.write('    "' + ln + '\\n" \\\n')
             f.write('    ""\n')
             print(f"{name}: {len(o)} lines")
-        f.write("#define CONV_LOOP_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + (", " + ", ".join(f'"s{i}"' for i in range(60, 76)) if EXP & 8 else "")
+        f.write(f"#define CONV_LOOP{sfx}_CLOBBERS " + ", ".join(f'"v{i}"' for i in CLOBBER_V) + (", " + ", ".join(f'"s{i}"' for i in range(60, 76)) if EXP & 8 else "")
                 + ', "vcc", "scc", "memory"\n')
-        f.write(f"#define CONV_LDS_ROW_BYTES {ROWB}\n")
+        f.write(f"#define CONV_LDS_ROW_BYTES{'_H' if HALF else ''} {ROWB}\n")
         if EXP & 8:
             f.write("#define CONV_LOOP_STAMPS 1\n")
     print(f"wrote {path}")

@@ -1,6 +1,8 @@
 // fused.hip -- pair plans and the persistent small-level kernels of the decoder (fused.hpp has the design).
 #include "fused.hpp"
 
+#include <atomic>
+
 #include <mutex>
 
 #include "network_dev.hpp"
@@ -449,7 +451,17 @@ struct FusedK {
     uint16_t *cdf; uint8_t *sym[4];
     uint8_t *occ;                    // CHILD: out; PARENT: in
     const uint8_t *bytes; const RcChunk *chunks; uint32_t nlanes; int llog; uint32_t rdw[4];
+    uint32_t desert;                 // test hook (GAUSPCC_FUSED_TEST_DESERT): the launch's last workgroup leaves before the census -- the others must time out
 };
+
+// GAUSPCC_FUSED_TEST_DESERT=N: the N-th persistent launch of the process loses a workgroup (tests/test_gpu_robustness.py: the bounded spins, the
+// sticky timeout word and the decoder's retry on the block-tile kernels are a recovery path that must be seen working)
+uint32_t fused_test_desert()
+{
+    static const int nth = env_int("GAUSPCC_FUSED_TEST_DESERT", 0);
+    static std::atomic<int> count{0};
+    return nth > 0 && ++count == nth ? 1u : 0u;
+}
 
 struct WgMap { uint32_t G, wg, gw, NW, gtid, NT; int row0, row1; int lane, wave; };
 
@@ -500,6 +512,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     BarCtx bc;
+    if (k.desert && gridDim.x > 1 && blockIdx.x == gridDim.x - 1) return;
     if (!bar_begin(bc, k.bar, k.bar_next, k.tmo)) return;
     WgMap m;
     m.G = gridDim.x; m.wg = blockIdx.x; m.lane = (int)(threadIdx.x & 63); m.wave = (int)(threadIdx.x >> 6);
@@ -663,6 +676,7 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
     FusedK k = {};
     k.pl = plan_view(plan);
     GP_TRY(fused_state(ctx, st, &k.bar, &k.bar_next, &k.tmo));
+    k.desert = fused_test_desert();
     k.P = a.P;
     k.pA = a.pA; k.parent = a.parent; k.rkey = a.rkey; k.m2r = a.m2r;
     k.x = a.cX; k.a = a.cA; k.b = a.cB; k.u = a.cU;
@@ -698,6 +712,7 @@ int fused_parent_trunk(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const
     FusedK k = {};
     k.pl = plan_view(plan);
     GP_TRY(fused_state(ctx, st, &k.bar, &k.bar_next, &k.tmo));
+    k.desert = fused_test_desert();
     k.P = P;
     k.x = pF; k.a = pA; k.b = pB;
     for (int i = 0; i < 5; ++i) k.w[i] = m->conv[i] + (size_t)m->K * 1024;

@@ -94,3 +94,36 @@ for i in range(3):
     r = subprocess.run([sys.executable, "-c", snippet], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.count("ok") == 3, r.stdout[-2000:] + r.stderr[-3000:]
     assert r.stderr.count("timed out") == 1, r.stderr[-3000:]
+
+
+def test_oversize_chunk_is_recoded_with_smaller_chunks():
+    """A chunk whose bytes exceed the staged decoder's LDS window cannot be written (the limit is part of the format: include/gauspcc.h);
+    gpcc_encode codes the cloud again with chunk_log2 - 1 until every chunk fits.  The real limit needs a model that spends > 8 bits per
+    16-ary symbol at chunk_log2 >= 13; GAUSPCC_TEST_CHUNK_BYTES stands in for the window here.  The container says which chunk_log2 was
+    used, equals the oracle's container at that value, and decodes."""
+    snippet = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests import gpu_helpers as gh
+from oracle import oracle as orc
+from gauspcc_amd import runtime
+from gauspcc_amd.model import tensor_table
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+sd = synthetic_state_dict(32, 5)
+dm = runtime.Model(sd, 32, 5, 0)
+om = orc.Model(tensor_table(sd, 32, 5), 32, 5)
+pts = synthetic_cloud(120000, seed=5)
+data, st = gh.encode(dm, pts, 11)
+used = data[3]
+assert data[0] == 0xFF and data[1] == 0xFF and 7 <= used < 11, used
+assert data == orc.encode(om, pts, chunk_log2=used), "container differs from the oracle's at the chunk size the retry settled on"
+dec, _, _ = gh.decode(dm, data)
+assert np.array_equal(dec, orc.decode(om, data)[0])
+print("recoded at chunk_log2", used)
+""" % ROOT
+    e = dict(os.environ)
+    e["GAUSPCC_TEST_CHUNK_BYTES"] = "400"
+    r = subprocess.run([sys.executable, "-c", snippet], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "recoded at chunk_log2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

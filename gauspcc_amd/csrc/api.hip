@@ -114,6 +114,22 @@ extern "C" int gpcc_debug_capture(gpcc_ctx *ctx, int tag_mod)
     ctx->dbg_capture_tag_mod = tag_mod;
     return GPCC_OK;
 }
+extern "C" int gpcc_debug_exclusive_scan(gpcc_ctx *ctx, const uint32_t *in_dev, uint32_t *out_dev, const uint32_t *in2_dev, uint32_t *out2_dev, int64_t n,
+                                         uint32_t *total_dev, void *stream)
+{
+    if (!ctx || !in_dev || !out_dev || n < 0 || (in2_dev == nullptr) != (out2_dev == nullptr)) return fail(GPCC_ERR_ARG, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    GP_TRY(ctx->arena.reserve((size_t)n / 64 + ((size_t)1 << 20)));   // (the three-launch scan of unaligned arrays keeps its block sums there)
+    ctx->arena.reset();
+    if (in2_dev) {
+        GP_TRY(exclusive_scan_pair_u32(ctx, st, in_dev, out_dev, in2_dev, out2_dev, n));
+        if (total_dev) return fail(GPCC_ERR_ARG, "no total with a pair of scans");
+        return GPCC_OK;
+    }
+    return exclusive_scan_u32(ctx, st, in_dev, out_dev, n, total_dev);
+}
+
 extern "C" long long gpcc_debug_capture_get(gpcc_ctx *ctx, int tag, void *host, long long cap)
 {
     if (!ctx) return -1;

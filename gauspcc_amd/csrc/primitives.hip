@@ -40,6 +40,86 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t *to
     return base + inc - v;
 }
 
+// ------------------------------------------------------------------ one-wave tiles: scans WITHOUT an LDS allocation
+// Round 4: the scans of the octree stage run on the context's second stream beside a convolution whose four waves hold all 160 KiB of
+// every CU's LDS -- a workgroup that wants even the 40 bytes of block_excl_scan_256 waits for a conv workgroup to retire (the same
+// launch: 5.6 us on a free device, 40-160 us beside a convolution; tools/scan_hist.py).  A 64-thread workgroup needs none: a tile is
+// 4 096 elements = 16 coalesced 16-byte loads per lane (row i = elements 256 i .. 256 i + 255, lane l its elements 4 l .. 4 l + 3), the
+// 16 row sums are scanned across the wave with cross-lane shuffles (no LDS memory involved), rows chained through a register.
+constexpr int WT_ROWS = 16, WT_TILE = 64 * 4 * WT_ROWS;
+__device__ __forceinline__ void wave_tile_load(const uint32_t *__restrict__ in, int64_t base, int64_t n, int lane, uint4 v[WT_ROWS])
+{
+    if (base + WT_TILE <= n) {
+        const uint4 *p = reinterpret_cast<const uint4 *>(in + base) + lane;
+#pragma unroll
+        for (int i = 0; i < WT_ROWS; ++i) v[i] = p[i * 64];
+    } else {
+#pragma unroll
+        for (int i = 0; i < WT_ROWS; ++i) {
+            const int64_t e = base + (int64_t)(i * 64 + lane) * 4;
+            v[i].x = e < n ? in[e] : 0u; v[i].y = e + 1 < n ? in[e + 1] : 0u; v[i].z = e + 2 < n ? in[e + 2] : 0u; v[i].w = e + 3 < n ? in[e + 3] : 0u;
+        }
+    }
+}
+// ex[i] = sum of the tile's elements in front of this lane's first element of row i; returns the tile's sum (in every lane)
+__device__ __forceinline__ uint32_t wave_tile_scan(const uint4 v[WT_ROWS], int lane, uint32_t ex[WT_ROWS])
+{
+    uint32_t s[WT_ROWS], inc[WT_ROWS];
+#pragma unroll
+    for (int i = 0; i < WT_ROWS; ++i) { s[i] = v[i].x + v[i].y + v[i].z + v[i].w; inc[i] = s[i]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {      // the 16 rows' scans side by side: 16 independent shuffles per step
+        uint32_t t[WT_ROWS];
+#pragma unroll
+        for (int i = 0; i < WT_ROWS; ++i) t[i] = (uint32_t)__shfl_up((int)inc[i], d, 64);
+#pragma unroll
+        for (int i = 0; i < WT_ROWS; ++i) inc[i] += lane >= d ? t[i] : 0u;
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < WT_ROWS; ++i) {
+        ex[i] = carry + inc[i] - s[i];
+        carry += (uint32_t)__shfl((int)inc[i], 63, 64);
+    }
+    return carry;
+}
+__device__ __forceinline__ void wave_tile_store(uint32_t *__restrict__ out, int64_t base, int64_t n, int lane, const uint4 v[WT_ROWS], const uint32_t ex[WT_ROWS], uint32_t carry)
+{
+    const bool full = base + WT_TILE <= n;
+    uint4 *p = reinterpret_cast<uint4 *>(out + base) + lane;
+#pragma unroll
+    for (int i = 0; i < WT_ROWS; ++i) {
+        uint4 o;
+        o.x = carry + ex[i]; o.y = o.x + v[i].x; o.z = o.y + v[i].y; o.w = o.z + v[i].z;
+        if (full) p[i * 64] = o;
+        else {
+            const int64_t e = base + (int64_t)(i * 64 + lane) * 4;
+            if (e < n) out[e] = o.x;
+            if (e + 1 < n) out[e + 1] = o.y;
+            if (e + 2 < n) out[e + 2] = o.z;
+            if (e + 3 < n) out[e + 3] = o.w;
+        }
+    }
+}
+
+// one wave walks the whole array (n <= SCAN_SINGLE_MAX: at most four tiles); blockIdx.x picks one of two independent scans
+__global__ __launch_bounds__(64) void k_scan_wave(const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, int64_t n, uint32_t *total_out)
+{
+    const uint32_t *in = blockIdx.x ? in1 : in0;
+    uint32_t *out = blockIdx.x ? out1 : out0;
+    const int lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < n; b0 += WT_TILE) {
+        uint4 v[WT_ROWS];
+        uint32_t ex[WT_ROWS];
+        wave_tile_load(in, b0, n, lane, v);
+        const uint32_t total = wave_tile_scan(v, lane, ex);
+        wave_tile_store(out, b0, n, lane, v, ex, carry);      // in == out allowed: the tile is in registers
+        carry += total;
+    }
+    if (lane == 0 && total_out && blockIdx.x == 0) *total_out = carry;
+}
+
 __global__ __launch_bounds__(SCAN_T) void k_scan_reduce(const uint32_t *__restrict__ in, uint32_t *__restrict__ bsum, int64_t n)
 {
     __shared__ uint32_t lds[8];
@@ -150,7 +230,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_single2(const uint32_t *in0, ui
 // that are running or done --, scans it, publishes (epoch | AGGREGATE | sum) as ONE 8-byte agent-scope word (the value is the
 // flag: no fence), looks back over its predecessors' words 64 at a time until it meets an INCLUSIVE prefix, publishes its own
 // inclusive prefix and writes the tile.  The status words carry the launch's epoch: no reset between launches.
-constexpr int LB_T = 256, LB_TILE = LB_T * 16;
+constexpr int LB_T = 64, LB_TILE = WT_TILE;    // one wave per tile: no LDS allocation (see "one-wave tiles" above)
 constexpr int64_t LB_MAX_TILES = 65536;
 constexpr unsigned long long LB_AGG = 1ull << 32, LB_INC = 2ull << 32;
 __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag, uint32_t v) { return ((unsigned long long)epoch << 34) | flag | v; }
@@ -158,81 +238,49 @@ __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned l
 __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n, unsigned long long *status, uint32_t *ticket,
                                                         uint32_t epoch, uint32_t *__restrict__ total_out)
 {
-    __shared__ uint32_t lds[8];
-    __shared__ uint32_t tile_s, excl_s;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) {
-        const uint32_t t = atomicAdd(ticket, 1u);
+    const int lane = threadIdx.x;
+    uint32_t t = 0;
+    if (lane == 0) {
+        t = atomicAdd(ticket, 1u);
         if (t == gridDim.x - 1u) atomicExch(ticket, 0u);     // every ticket of this launch is taken: ready for the next launch on this stream
-        tile_s = t;
     }
-    __syncthreads();
-    const uint32_t tile = tile_s;
-    const int64_t base = (int64_t)tile * LB_TILE + (int64_t)tid * 16;
-    uint4 v[4];
-    if (base + 16 <= n) {
+    const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    const int64_t base = (int64_t)tile * LB_TILE;
+    uint4 v[WT_ROWS];
+    uint32_t ex[WT_ROWS];
+    wave_tile_load(in, base, n, lane, v);
+    const uint32_t total = wave_tile_scan(v, lane, ex);
+    uint32_t excl = 0;
+    if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, tile == 0 ? LB_INC : LB_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile > 0) {
+        int64_t j = (int64_t)tile - 1;       // nearest predecessor not yet accounted for
+        uint32_t idle = 0;
+        for (;;) {
+            const int64_t idx = j - lane;
+            // before tile 0: a virtual inclusive prefix of 0
+            const unsigned long long w = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lb_pack(epoch, LB_INC, 0u);
+            const bool valid = (uint32_t)(w >> 34) == epoch && (w & (LB_AGG | LB_INC)) != 0ull;
+            const bool inc = valid && (w & LB_INC) != 0ull;
+            const unsigned long long bad = __ballot(!valid), pre = __ballot(inc);
+            const int first_bad = bad ? __builtin_ctzll(bad) : 64, first_inc = pre ? __builtin_ctzll(pre) : 64;
+            const int take = first_inc < first_bad ? first_inc + 1 : first_bad;   // lanes 0 .. take - 1 are usable in order
+            uint32_t part = lane < take ? (uint32_t)w : 0u;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const uint4 *>(in + base)[q];
-    } else {
-        uint32_t e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = base + i < n ? in[base + i] : 0u;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = make_uint4(e[4 * q], e[4 * q + 1], e[4 * q + 2], e[4 * q + 3]);
-    }
-    uint32_t s = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s += v[q].x + v[q].y + v[q].z + v[q].w;
-    uint32_t total;
-    uint32_t ex = block_excl_scan_256(s, &total, lds);
-    if (tid < 64) {   // wave 0: publish, look back
-        uint32_t excl = 0;
-        if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, tile == 0 ? LB_INC : LB_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tile > 0) {
-            int64_t j = (int64_t)tile - 1;       // nearest predecessor not yet accounted for
-            uint32_t idle = 0;
-            for (;;) {
-                const int64_t idx = j - lane;
-                // before tile 0: a virtual inclusive prefix of 0
-                const unsigned long long w = idx >= 0 ? __hip_atomic_load(status + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lb_pack(epoch, LB_INC, 0u);
-                const bool valid = (uint32_t)(w >> 34) == epoch && (w & (LB_AGG | LB_INC)) != 0ull;
-                const bool inc = valid && (w & LB_INC) != 0ull;
-                const unsigned long long bad = __ballot(!valid), pre = __ballot(inc);
-                const int first_bad = bad ? __builtin_ctzll(bad) : 64, first_inc = pre ? __builtin_ctzll(pre) : 64;
-                const int take = first_inc < first_bad ? first_inc + 1 : first_bad;   // lanes 0 .. take - 1 are usable in order
-                uint32_t part = lane < take ? (uint32_t)w : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
-                excl += part;
-                if (first_inc < first_bad) break;
-                j -= take;
-                if (take == 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    // predecessors are running workgroups (tickets are drawn in start order): no progress for ~10 s means the launch's
-                    // state was damaged -- end the launch loudly (the stream reports an error) rather than spin for ever
-                    if (++idle > (1u << 24)) __builtin_trap();
-                } else idle = 0;
-            }
-            if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, LB_INC, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int d = 32; d >= 1; d >>= 1) part += (uint32_t)__shfl_xor((int)part, d, 64);
+            excl += part;
+            if (first_inc < first_bad) break;
+            j -= take;
+            if (take == 0) {
+                __builtin_amdgcn_s_sleep(1);
+                // predecessors are running workgroups (tickets are drawn in start order): no progress for ~10 s means the launch's
+                // state was damaged -- end the launch loudly (the stream reports an error) rather than spin for ever
+                if (++idle > (1u << 24)) __builtin_trap();
+            } else idle = 0;
         }
-        if (lane == 0) { excl_s = excl; if (total_out && tile == gridDim.x - 1u) *total_out = excl + total; }
+        if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, LB_INC, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
-    ex += excl_s;
-    uint4 o[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        o[q].x = ex; ex += v[q].x; o[q].y = ex; ex += v[q].y; o[q].z = ex; ex += v[q].z; o[q].w = ex; ex += v[q].w;
-    }
-    if (base + 16 <= n) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<uint4 *>(out + base)[q] = o[q];
-    } else {
-        const uint32_t e[16] = {o[0].x, o[0].y, o[0].z, o[0].w, o[1].x, o[1].y, o[1].z, o[1].w, o[2].x, o[2].y, o[2].z, o[2].w, o[3].x, o[3].y, o[3].z, o[3].w};
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (base + i < n) out[base + i] = e[i];
-    }
+    if (lane == 0 && total_out && tile == gridDim.x - 1u) *total_out = excl + total;
+    wave_tile_store(out, base, n, lane, v, ex, excl);
 }
 
 // the scan state of (context, stream): created on first use (one hipMalloc + memset per stream of a context)
@@ -254,11 +302,19 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
     return GPCC_OK;
 }
 
+// the one-wave kernels move 16-byte words (GAUSPCC_SCAN_WAVE=0: the 256-thread kernels with their LDS words, kept as the cross-check)
+static bool scan_wave_ok(const uint32_t *in, const uint32_t *out)
+{
+    static const bool on = env_int("GAUSPCC_SCAN_WAVE", 1) != 0;
+    return on && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
+}
+
 int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev);
 int exclusive_scan_pair_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in0, uint32_t *out0, const uint32_t *in1, uint32_t *out1, int64_t n)
 {
     if (n > 0 && n <= SCAN_SINGLE_MAX) {
-        k_scan_single2<<<2, SCAN_T, 0, st>>>(in0, out0, in1, out1, n);
+        if (scan_wave_ok(in0, out0) && scan_wave_ok(in1, out1)) k_scan_wave<<<2, 64, 0, st>>>(in0, out0, in1, out1, n, nullptr);
+        else k_scan_single2<<<2, SCAN_T, 0, st>>>(in0, out0, in1, out1, n);
         LAUNCH_CHECK();
         return GPCC_OK;
     }
@@ -273,7 +329,8 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
         return GPCC_OK;
     }
     if (n <= SCAN_SINGLE_MAX) {
-        k_scan_single<<<1, SCAN_T, 0, st>>>(in, out, n, total_dev);
+        if (scan_wave_ok(in, out)) k_scan_wave<<<1, 64, 0, st>>>(in, out, in, out, n, total_dev);
+        else k_scan_single<<<1, SCAN_T, 0, st>>>(in, out, n, total_dev);
         LAUNCH_CHECK();
         return GPCC_OK;
     }

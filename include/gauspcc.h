@@ -171,6 +171,13 @@ GPCC_API int gpcc_debug_trace_get(gpcc_ctx *ctx, int *tags, unsigned long long *
 GPCC_API int gpcc_debug_capture(gpcc_ctx *ctx, int tag_mod);
 GPCC_API long long gpcc_debug_capture_get(gpcc_ctx *ctx, int tag, void *host, long long cap);
 
+/* The library's exclusive prefix sum of uint32 values (every level build, rank derivation, sort pass and tile list runs on it: no
+ * reference counterpart, torch.cumsum / unique do this job upstream).  in / out device arrays of n values (in == out allowed), in2 /
+ * out2 optional: a second independent scan of the same length in the same launch where the size allows; total_dev (nullable)
+ * receives the sum of `in`.  Exported for the unit tests of the scan kernels (tests/test_gpu_primitives.py). */
+GPCC_API int gpcc_debug_exclusive_scan(gpcc_ctx *ctx, const uint32_t *in_dev, uint32_t *out_dev, const uint32_t *in2_dev, uint32_t *out2_dev, int64_t n,
+                                       uint32_t *total_dev, void *stream);
+
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */
 GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);

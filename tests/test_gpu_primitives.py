@@ -1,0 +1,71 @@
+"""The scan kernels on their own (csrc/primitives.hip): one-wave tiles without an LDS allocation for arrays up to 16 k elements, the
+decoupled look-back scan above that -- against numpy's cumsum at the sizes where a tile, a row or the launch path changes, in place
+and out of place, on aligned and unaligned arrays (the unaligned ones take the 256-thread kernels), the pair form, and many launches
+back to back on one stream (the look-back state is reused with an epoch)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 3, 63, 64, 65, 255, 256, 257, 1023, 1024, 4095, 4096, 4097, 8191, 16384, 16385, 20000, 65536, 65537, 262144 + 5, 1_000_003, 4_200_001]
+
+
+def _scan(x, off_in=0, off_out=0, inplace=False, with_total=True):
+    from gauspcc_amd import _lib, runtime
+
+    dev = torch.device("cuda", 0)
+    ctx = runtime.context(dev)
+    n = len(x)
+    buf_in = torch.zeros(n + 8, dtype=torch.int32, device=dev)
+    a = buf_in[off_in: off_in + n]
+    a.copy_(torch.from_numpy(x.astype(np.int32)))
+    out = a if inplace else torch.full((n + 8,), -1, dtype=torch.int32, device=dev)[off_out: off_out + n]
+    total = torch.full((1,), -1, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().gpcc_debug_exclusive_scan(ctx, a.data_ptr(), out.data_ptr(), None, None, n, total.data_ptr() if with_total else None, st))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().astype(np.uint32), int(total.cpu().numpy().astype(np.uint32)[0])
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_exclusive_scan_matches_cumsum(n):
+    rng = np.random.RandomState(n % 9973)
+    x = rng.randint(0, 9, size=n).astype(np.uint32)
+    ref = np.concatenate([[0], np.cumsum(x[:-1], dtype=np.uint64)]).astype(np.uint32)
+    for off_in, off_out, inplace in ((0, 0, False), (0, 0, True), (1, 0, False), (0, 3, False)):
+        if n > 1_000_003 and (off_in or off_out):
+            continue
+        out, total = _scan(x, off_in, off_out, inplace)
+        assert np.array_equal(out, ref), (n, off_in, off_out, inplace, int(np.argmax(out != ref)))
+        assert total == int(x.sum(dtype=np.uint64) & 0xFFFFFFFF)
+
+
+def test_scan_wraps_modulo_2_32_and_pair_form():
+    from gauspcc_amd import _lib, runtime
+
+    dev = torch.device("cuda", 0)
+    ctx = runtime.context(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    for n in (100, 5000, 16384, 70000):
+        rng = np.random.RandomState(n)
+        x0 = rng.randint(0, 2 ** 31, size=n, dtype=np.int64).astype(np.uint32)
+        x1 = rng.randint(0, 4, size=n).astype(np.uint32)
+        a0 = torch.from_numpy(x0.view(np.int32)).to(dev); a1 = torch.from_numpy(x1.view(np.int32)).to(dev)
+        o0 = torch.empty_like(a0); o1 = torch.empty_like(a1)
+        _lib.check(_lib.lib().gpcc_debug_exclusive_scan(ctx, a0.data_ptr(), o0.data_ptr(), a1.data_ptr(), o1.data_ptr(), n, None, st))
+        torch.cuda.synchronize()
+        for x, o in ((x0, o0), (x1, o1)):
+            ref = (np.concatenate([[0], np.cumsum(x[:-1], dtype=np.uint64)]).astype(np.uint64) & np.uint64(0xFFFFFFFF)).astype(np.uint32)     # modulo 2^32
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), ref), n
+
+
+def test_many_lookback_scans_back_to_back_reuse_their_state():
+    rng = np.random.RandomState(3)
+    for it in range(40):
+        n = int(rng.randint(16385, 600000))
+        x = rng.randint(0, 3, size=n).astype(np.uint32)
+        out, total = _scan(x)
+        assert total == int(x.sum()) and out[-1] == total - int(x[-1]) and out[n // 2] == int(x[: n // 2].sum()), (it, n)

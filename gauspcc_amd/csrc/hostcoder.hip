@@ -15,6 +15,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <atomic>
+#include <cstdio>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/gauspcc.h"
@@ -182,4 +186,35 @@ extern "C" int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int6
     if (!cdf || (!bytes && nbytes) || !sym_out || n < 0 || nbytes < 0 || lp < 2 || lp > 65536) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
     std::vector<uint16_t> tmp((size_t)lp);
     return host_decode(RowsF32{cdf, lp, tmp.data(), (float)(65536 - (lp - 1))}, bytes, nbytes, n, lp, sym_out);
+}
+
+// ---- many small files on native threads (the per-slice `.b` files of the attribute loops: include/gauspcc.h)
+extern "C" int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads)
+{
+    if (n < 0 || (n > 0 && (!paths || !data || !sizes))) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    if (threads <= 0) threads = 8;
+    threads = threads < n ? threads : (n > 0 ? n : 1);
+    std::atomic<int> next{0}, bad{-1};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            bool ok = paths[i] && sizes[i] >= 0 && (sizes[i] == 0 || data[i]);
+            if (ok) {
+                FILE *f = fopen(paths[i], "wb");
+                ok = f != nullptr;
+                if (f) {
+                    if (sizes[i] > 0) ok = fwrite(data[i], 1, (size_t)sizes[i], f) == (size_t)sizes[i];
+                    ok = (fclose(f) == 0) && ok;
+                }
+            }
+            if (!ok) { int expect = -1; bad.compare_exchange_strong(expect, i); }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (bad.load() >= 0) return gpcc::fail(GPCC_ERR_ARG, "cannot write %s", paths[bad.load()] ? paths[bad.load()] : "(null path)");
+    return GPCC_OK;
 }

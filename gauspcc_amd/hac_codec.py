@@ -29,7 +29,7 @@ import time
 import torch
 
 from . import _lib, runtime
-from .encodings_cuda import decoder, decoder_gaussian_slices, encoder, encoder_gaussian_slices
+from .encodings_cuda import decoder, decoder_gaussian_slices, deferred_writes, encoder, encoder_gaussian_slices
 from .pcc_utils import calculate_morton_order, compress_point_cloud, decompress_point_cloud
 
 bit2MB_scale = 8 * 1024 * 1024     # HAC/scene/gaussian_model.py:30
@@ -130,21 +130,22 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
     bounds = [min(s * MAX_BATCH_SIZE, N) for s in range(steps + 1)]
 
     torch.cuda.synchronize(); t0 = time.time()
-    Q = c["Q_feat"].reshape(-1)
-    feat = ste_multistep(_feat.reshape(-1), Q, feat_mean)
-    bit_feat_list = encoder_gaussian_slices(feat, c["mean"].reshape(-1), c["scale"].reshape(-1), Q, [b * self.feat_dim for b in bounds], names('feat'))
+    with deferred_writes():      # the 3 x 334 slice files are written while the next attribute is coded; all on disk when the block ends
+        Q = c["Q_feat"].reshape(-1)
+        feat = ste_multistep(_feat.reshape(-1), Q, feat_mean)
+        bit_feat_list = encoder_gaussian_slices(feat, c["mean"].reshape(-1), c["scale"].reshape(-1), Q, [b * self.feat_dim for b in bounds], names('feat'))
 
-    Q = c["Q_scaling"].reshape(-1)
-    scaling = ste_multistep(_scaling.reshape(-1), Q, scaling_mean)
-    bit_scaling_list = encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds], names('scaling'))
+        Q = c["Q_scaling"].reshape(-1)
+        scaling = ste_multistep(_scaling.reshape(-1), Q, scaling_mean)
+        bit_scaling_list = encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds], names('scaling'))
 
-    mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
-    Q = c["Q_offsets"].reshape(-1)
-    offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
-    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()           # masked elements up to each anchor
-    off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
-    bit_offsets_list = encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask],
-                                               off_bounds, names('offsets'))
+        mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
+        Q = c["Q_offsets"].reshape(-1)
+        offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
+        kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()           # masked elements up to each anchor
+        off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+        bit_offsets_list = encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask],
+                                                   off_bounds, names('offsets'))
     torch.cuda.synchronize(); t_codec += time.time() - t0
 
     bit_anchor = bits_xyz

@@ -29,7 +29,7 @@ import time
 
 import torch
 
-from .encodings_cuda import (decoder, decoder_gaussian_mixed_slices, decoder_gaussian_slices, encoder, encoder_gaussian_mixed_slices,
+from .encodings_cuda import (decoder, decoder_gaussian_mixed_slices, decoder_gaussian_slices, deferred_writes, encoder, encoder_gaussian_mixed_slices,
                              encoder_gaussian_slices)
 from .hac_codec import _install_hash, bit2MB_scale, default_ckpt_path, grid_mlp, ste_multistep
 from .pcc_utils import calculate_morton_order, compress_point_cloud, decompress_point_cloud
@@ -142,27 +142,28 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
     masks_b_name = os.path.join(pre_path_name, 'masks.b')
 
     torch.cuda.synchronize(); t0 = time.time()
-    # feat: quantised once (:1298-1299), then group by group under the mixture whose second component the channel-context MLP predicts
-    feat = ste_multistep(_feat, c["Q_feat"], self._anchor_feat.mean())
-    bit_feat = 0
-    for cc in range(N_GROUPS):
-        means, scales, probs, q = _group_mixture(self, c, feat, cc)
-        x = feat[:, cc * GROUP:cc * GROUP + GROUP].contiguous().view(-1)
-        names = [fn.replace('.b', f'_{cc}.b') for fn in _names(pre_path_name, 'feat', steps)]
-        bit_feat += sum(encoder_gaussian_mixed_slices(x, means, scales, probs, q, [b * GROUP for b in bounds], names, chunk_size=50_0000))
+    with deferred_writes():      # the 7 x 334 slice files are written while the next attribute is coded; all on disk when the block ends
+        # feat: quantised once (:1298-1299), then group by group under the mixture whose second component the channel-context MLP predicts
+        feat = ste_multistep(_feat, c["Q_feat"], self._anchor_feat.mean())
+        bit_feat = 0
+        for cc in range(N_GROUPS):
+            means, scales, probs, q = _group_mixture(self, c, feat, cc)
+            x = feat[:, cc * GROUP:cc * GROUP + GROUP].contiguous().view(-1)
+            names = [fn.replace('.b', f'_{cc}.b') for fn in _names(pre_path_name, 'feat', steps)]
+            bit_feat += sum(encoder_gaussian_mixed_slices(x, means, scales, probs, q, [b * GROUP for b in bounds], names, chunk_size=50_0000))
 
-    Q = c["Q_scaling"].reshape(-1)
-    scaling = ste_multistep(_scaling.reshape(-1), Q, self.get_scaling.mean())
-    bit_scaling = sum(encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds],
-                                              _names(pre_path_name, 'scaling', steps), chunk_size=10_0000))
+        Q = c["Q_scaling"].reshape(-1)
+        scaling = ste_multistep(_scaling.reshape(-1), Q, self.get_scaling.mean())
+        bit_scaling = sum(encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds],
+                                                  _names(pre_path_name, 'scaling', steps), chunk_size=10_0000))
 
-    mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
-    Q = c["Q_offsets"].reshape(-1)
-    offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, self._offset.mean())
-    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
-    off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
-    bit_offsets = sum(encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask], off_bounds,
-                                              _names(pre_path_name, 'offsets', steps), chunk_size=10_0000))
+        mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
+        Q = c["Q_offsets"].reshape(-1)
+        offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, self._offset.mean())
+        kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
+        off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+        bit_offsets = sum(encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask], off_bounds,
+                                                  _names(pre_path_name, 'offsets', steps), chunk_size=10_0000))
     torch.cuda.synchronize(); t_codec += time.time() - t0
 
     bit_anchor = bits_xyz

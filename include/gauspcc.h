@@ -178,6 +178,12 @@ GPCC_API long long gpcc_debug_capture_get(gpcc_ctx *ctx, int tag, void *host, lo
 GPCC_API int gpcc_debug_exclusive_scan(gpcc_ctx *ctx, const uint32_t *in_dev, uint32_t *out_dev, const uint32_t *in2_dev, uint32_t *out2_dev, int64_t n,
                                        uint32_t *total_dev, void *stream);
 
+/* Write n host buffers to n files on `threads` native threads (<= 0: 8).  The attribute loops of HAC / HAC++ produce one `.b` file per
+ * 3 000-anchor slice and attribute (HAC/scene/gaussian_model.py:1176-1213: 1 002 files per million anchors; HAC++: 2 338) -- in Python that is
+ * ~55 us of interpreter time per file under the GIL; here it is open / write / close.  Returns GPCC_OK or GPCC_ERR_ARG with the first
+ * path that failed in gpcc_last_error().  No context, no GPU call. */
+GPCC_API int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads);
+
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */
 GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);

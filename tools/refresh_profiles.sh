@@ -21,7 +21,7 @@ python3 tools/make_pmc_json.py "$OUT/${R}_pmc_conv_fetch_write.txt" "$OUT/${R}_p
 cp "$OUT/${R}_pmc_conv.json" profiles/${R}_pmc_conv.json
 # 2. the bench line (default flags) and the same command under the kernel tracer
 timeout 600 python3 bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py $QUIET > "$OUT/bench_traced.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py --steps 5 --warmup 1 $QUIET > "$OUT/bench_traced.log" 2>&1
 cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/${R}_kernel_stats.csv"
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"

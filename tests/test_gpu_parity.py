@@ -557,7 +557,7 @@ def test_roundtrip_sizes_back_to_back(gh, dev_model_k5):
         assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts)), (i, n)
 
 
-def test_cli_compress_decompress_roundtrip(gh, tmp_path):
+def test_cli_compress_decompress_roundtrip(gh, tmp_path, capsys):
     """python -m gauspcc_amd.cli.compress / .decompress over a folder: .bin per file, CSV with an avg row,
     PLYs holding exactly the quantised input geometry (reference CLIs: compress_ue_4stage_conv.py, decompress_ue_4stage_conv.py)."""
     import pandas as pd
@@ -577,6 +577,11 @@ def test_cli_compress_decompress_roundtrip(gh, tmp_path):
                           "--resultdir", str(res), "--prefix", "t", "--chunk_log2", "0"] + common) == 0
     df = pd.read_csv(res / "t_data2.csv")
     assert df["filedir"].tolist() == ["c0.ply", "c1.ply", "avg"]
+    # the reference's summary line (compress_ue_4stage_conv.py:148-170); "Max GPU memory" counts the codec's own workspace
+    # (gpcc_ctx_bytes: the arena is not torch's) as well as torch's allocator
+    import re
+    m = re.search(r"Total: 2 \| Average bitrate:[0-9.]+ \| Encoding time:[0-9.]+s \| Max GPU memory:([0-9.]+)MB", capsys.readouterr().out)
+    assert m and float(m.group(1)) > 32.0, "summary line / workspace not counted"
     for i, name in enumerate(clouds):
         size = os.path.getsize(out / (name + ".bin")) * 8
         assert df["file_size_bits"][i] == size and df["num_points"][i] == len(clouds[name])

@@ -75,3 +75,24 @@ def test_scalar_q_and_binary_coder(orc, tmp_path):
     # the stream costs what the model says these symbols cost (16-bit counts: a fraction of a per cent on top)
     ideal = float(-torch.log2(torch.where(xb > 0, p, 1 - p)).sum())
     assert ideal <= bits <= ideal * 1.01 + 64
+
+
+def test_degenerate_ranges_and_empty_masks(orc, tmp_path):
+    """All symbols equal (the table has two entries + the closing one), a single element, and a mask of one value only."""
+    from gauspcc_amd import torchac_encodings as te
+
+    n = 500
+    mean = torch.zeros(n); scale = torch.full((n,), 0.3); Q = torch.full((n,), 0.1)
+    x = torch.full((n,), 0.7)
+    f = str(tmp_path / "c.b")
+    bits, lo, hi = te.encoder_gaussian(x, mean, scale, Q, file_name=f)
+    assert lo == hi == 7.0
+    assert torch.equal(te.decoder_gaussian(mean, scale, Q, file_name=f, min_value=lo, max_value=hi), torch.round(x / Q) * Q)
+    f1 = str(tmp_path / "one.b")
+    bits, lo, hi = te.encoder_gaussian(x[:1], mean[:1], scale[:1], 0.1, file_name=f1)
+    assert torch.equal(te.decoder_gaussian(mean[:1], scale[:1], 0.1, file_name=f1, min_value=lo, max_value=hi), torch.round(x[:1] / 0.1) * 0.1)
+    p = torch.full((300,), 0.9)
+    xb = torch.ones(300)
+    fb = str(tmp_path / "m.b")
+    bits = te.encoder(xb, p, fb)
+    assert bits <= 8 * 16 and torch.equal(te.decoder(p, fb), xb)       # 300 x 0.15 bits

@@ -4,6 +4,9 @@
 #   a7:CONV_ASM_EXP=7          ablation: no LDS sums, no weight loads, no gathers (results are WRONG on purpose)
 #   rb128:CONV_ASM_ROWB=128    LDS row pitch of 128 bytes (the bank-conflicted layout of rounds 1-2)
 #   timing::-DCONV_TIMING      shader-clock stamps per phase
+#   noepi::-DCONV_NO_EPILOGUE  ablation: no copy-out (results are WRONG on purpose)
+# (the other objects come from the regular build: run `make -C gauspcc_amd/csrc` first; pair-loop ablations: CONV_ASM_EXP2=.. tools/gen_conv_loop2.py, then
+#  rebuild network.o by hand and regenerate the include)
 # Time them with  GAUSPCC_LIB=gauspcc_amd/variants/libgauspcc_<name>.so python tools/enc_only.py
 # Usage: tools/build_variants.sh spec [spec ...]
 set -e
@@ -23,6 +26,6 @@ for spec in "$@"; do
 done
 wait
 for name in "${names[@]}"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_$name.so primitives.o octree.o ../variants/tiles_$name.o ../variants/network_$name.o rangecoder.o codec.o api.o attributes.o rasterizer.o neural_gaussians.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libgauspcc_$name.so primitives.o octree.o ../variants/tiles_$name.o ../variants/network_$name.o rangecoder.o hostcoder.o codec.o fused.o api.o attributes.o rasterizer.o neural_gaussians.o
 done
 ls -la ../variants/*.so

@@ -43,7 +43,7 @@ class Stage(C.Structure):
 
 EXPORTS = [
     "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_ctx_bytes", "gpcc_ctx_set_container_version", "gpcc_raster_order", "gpcc_voxelise",
-    "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_sort_zyx",
+    "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_encode_batch", "gpcc_decode_batch", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get", "gpcc_debug_exclusive_scan",
     "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_host_encode_f32", "gsac_host_decode_f32", "gpcc_write_files", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gsac_encode_gaussian_mixed_slices", "gsac_decode_gaussian_mixed_slices", "gshac_mlp2", "gshac_mlp2_act", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
@@ -78,6 +78,8 @@ def lib():
     L.gpcc_model_destroy.restype = None
     L.gpcc_encode.argtypes = [vp, vp, vp, i64, i32, u16, C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats), vp]
     L.gpcc_decode.argtypes = [vp, vp, vp, i64, C.POINTER(vp), C.POINTER(i64), C.POINTER(u16), C.POINTER(Stats), vp]
+    L.gpcc_encode_batch.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(i64), i32, i32, C.POINTER(u16), C.POINTER(vp), C.POINTER(i64), C.POINTER(Stats), C.POINTER(i32), vp]
+    L.gpcc_decode_batch.argtypes = [vp, vp, C.POINTER(vp), C.POINTER(i64), i32, C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(u16), C.POINTER(Stats), C.POINTER(i32), vp]
     L.gpcc_decode_to.argtypes = [vp, vp, vp, i64, vp, i64, C.POINTER(i64), C.POINTER(u16), C.POINTER(Stats), vp]
     L.gpcc_sort_zyx.argtypes = [vp, vp, i64, vp, vp]
     L.gpcc_build_octree.argtypes = [vp, vp, i64, C.POINTER(i32), C.POINTER(i64), vp, vp, i64, vp]

@@ -48,6 +48,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
+    if (c->hbatch.p) (void)hipHostFree(c->hbatch.p);
     delete c;
 }
 
@@ -69,7 +70,7 @@ extern "C" int gpcc_ctx_bytes(const gpcc_ctx *c, int64_t *device_bytes, int64_t 
     size_t d = c->arena.cap + c->conv_products_cap * sizeof(float) + (c->dbg_dev ? 8 * (size_t)4096 : 0);
     for (const auto &e : c->dbg_caps) d += e.cap;
     if (device_bytes) *device_bytes = (int64_t)d;
-    if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap);
+    if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap + c->hbatch.cap);
     return GPCC_OK;
 }
 

@@ -175,7 +175,7 @@ struct HeadArgs {
     uint32_t *lohi; uint16_t *cdf; float *prob; int mode;
     int chunk_log2; uint32_t nch;
     // mode 0 over several concatenated levels: per-row slot of stage 0 and per-row stride between stages
-    // (then m2r / chunk_log2 / nch are unused)
+    // (then m2r / chunk_log2 / nch are unused); mode 1 with pos: the row slot of every node (a batch's merged level)
     const uint32_t *pos; const uint32_t *slots;
     // mode 0, optional: 16 accumulators of sum clamp(-log2(p_gt + 1e-10), 0, 50) (network_ue_4stage_conv.py:176-179)
     double *bits;

@@ -82,7 +82,8 @@ __device__ __forceinline__ void head_tail(const HeadArgs &a, int64_t i, const fl
         }
     } else if (MODE == 1) {
         constexpr int RS = M == 2 ? 1 : M == 4 ? 4 : 16;
-        uint16_t *dst = a.cdf + (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch) * RS;
+        // (a.pos: a merged level of several scenes -- forest.hpp -- brings every node's row slot; else the one stream's interleave)
+        uint16_t *dst = a.cdf + (a.pos ? (size_t)a.pos[i] : (size_t)rc_interleaved(a.m2r[i], a.chunk_log2, a.nch)) * RS;
         if (M == 2) dst[0] = (uint16_t)v[1];
         else if (M == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(v[1] | (v[2] << 16), v[3]);
         else {

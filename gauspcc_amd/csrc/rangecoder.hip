@@ -244,6 +244,69 @@ __global__ __launch_bounds__(256) void k_rc_layout(const uint32_t *__restrict__ 
     for (int l = threadIdx.x; l < nlanes; l += 256) gap[l] = pre[lane_stream[l]];
 }
 
+// The same for any number of streams (a batch of scenes: codec_batch.hip), as three launches: per-stream sizes (a wave per
+// stream), a one-workgroup scan, the gaps.  extra[s] (nullable): container bytes in front of stream s that belong to no stream
+// (the header of the scene the stream opens).
+__global__ __launch_bounds__(256) void k_rc_stream_sizes(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ stream_first, int nstreams, int dual,
+                                                         const uint32_t *__restrict__ extra, uint32_t *__restrict__ ssize)
+{
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= nstreams) return;
+    const uint32_t l0 = stream_first[s], l1 = stream_first[s + 1];
+    uint32_t t = 0;
+    if (dual) {
+        uint32_t bits[RC_TAB_KMAX + 1];
+#pragma unroll
+        for (int k = 0; k <= RC_TAB_KMAX; ++k) bits[k] = 0u;
+        auto chunk_bytes = [&](uint32_t l) { return cnt[l] + (l + 1u < l1 ? cnt[l + 1u] : 0u); };
+        for (uint32_t l = l0 + 2u + 2u * (uint32_t)lane; l < l1; l += 128u) {
+            const uint32_t z = rc_zigzag(chunk_bytes(l), chunk_bytes(l - 2u));
+#pragma unroll
+            for (int k = 0; k <= RC_TAB_KMAX; ++k) bits[k] += rc_tab_cost(z, k);
+        }
+        uint64_t tot[RC_TAB_KMAX + 1];
+#pragma unroll
+        for (int k = 0; k <= RC_TAB_KMAX; ++k) {
+            uint32_t v = bits[k];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+            tot[k] = v;
+        }
+        t = l1 > l0 ? rc_tab_bytes(chunk_bytes(l0), (l1 - l0 + 1u) / 2u, tot, nullptr) : 0u;
+    } else t = 2u * (l1 - l0);
+    if (lane == 0) ssize[s] = 4u + t + (extra ? extra[s] : 0u);
+}
+
+// inclusive scan of the stream sizes in place (one workgroup, tiles of 256 with a carry); *gap_total = the sum
+__global__ __launch_bounds__(256) void k_rc_stream_scan(uint32_t *__restrict__ ssize, int nstreams, uint32_t *__restrict__ gap_total)
+{
+    __shared__ uint32_t wsum[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (int s0 = 0; s0 < nstreams; s0 += 256) {
+        const int s = s0 + (int)threadIdx.x;
+        const uint32_t v = s < nstreams ? ssize[s] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += u; }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        const uint32_t w0 = wsum[0], w1 = wsum[1], w2 = wsum[2], w3 = wsum[3];
+        const uint32_t base = carry + (wave == 0 ? 0u : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2);
+        if (s < nstreams) ssize[s] = base + inc;
+        carry += w0 + w1 + w2 + w3;
+    }
+    if (threadIdx.x == 0) *gap_total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_rc_lane_gaps(const uint32_t *__restrict__ spre, const uint32_t *__restrict__ lane_stream, int nlanes, uint32_t *__restrict__ gap)
+{
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l < nlanes) gap[l] = spre[lane_stream[l]];
+}
+
 // ------------------------------------------------------------------ decode
 // Bit window over a chunk's bytes, addressed by the absolute bit position `bp` of the next unread bit.  The
 // eight bytes around bp are fetched as soon as bp is known (end of a symbol) and consumed at the end of the
@@ -499,6 +562,18 @@ int rc_layout_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream
     if (nstreams > 4 * MAXLV) return fail(GPCC_ERR_ARG, "internal: %d streams", nstreams);
     k_rc_layout<<<1, 256, 0, st>>>(cnt, stream_first, nstreams, lane_stream, nlanes, dual ? 1 : 0, gap, gap_total);
     LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+int rc_layout_many_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream_first, int nstreams, const uint32_t *lane_stream, int nlanes, bool dual, const uint32_t *extra,
+                          uint32_t *ssize, uint32_t *gap, uint32_t *gap_total)
+{
+    if (nstreams <= 0) return GPCC_OK;
+    k_rc_stream_sizes<<<(unsigned)cdiv(nstreams, 4), 256, 0, st>>>(cnt, stream_first, nstreams, dual ? 1 : 0, extra, ssize);
+    LAUNCH_CHECK();
+    k_rc_stream_scan<<<1, 256, 0, st>>>(ssize, nstreams, gap_total);
+    LAUNCH_CHECK();
+    if (nlanes > 0) { k_rc_lane_gaps<<<(unsigned)cdiv(nlanes, 256), 256, 0, st>>>(ssize, lane_stream, nlanes, gap); LAUNCH_CHECK(); }
     return GPCC_OK;
 }
 

@@ -223,6 +223,10 @@ int rc_decode_launch(hipStream_t st, const uint16_t *cdf, int lp, const uint8_t 
 // and are worked out on the device: lane_stream[l] = stream of lane l, stream_first[s] = first lane of stream s (nstreams + 1
 // entries), dual: lanes pair up into chunks.  gap[l] and *gap_total come out.
 int rc_layout_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream_first, int nstreams, const uint32_t *lane_stream, int nlanes, bool dual, uint32_t *gap, uint32_t *gap_total);
+// the same for any number of streams (a batch of scenes); extra[s] (nullable): bytes in front of stream s that belong to no stream (a scene's
+// header); ssize: nstreams words of scratch (out: the inclusive prefix sums)
+int rc_layout_many_launch(hipStream_t st, const uint32_t *cnt, const uint32_t *stream_first, int nstreams, const uint32_t *lane_stream, int nlanes, bool dual, const uint32_t *extra,
+                          uint32_t *ssize, uint32_t *gap, uint32_t *gap_total);
 // full natural-order rows (n, Lp) -> compact interleaved rows; (cdf, sym) -> interleaved packed words (lanes of 2^lane_log2
 // symbols, nlanes of them; lane_log2 = 0: one lane)
 int rc_pack_rows(hipStream_t st, const uint16_t *cdf_full, int lp, int64_t n, int lane_log2, uint32_t nlanes, uint16_t *rows);

@@ -253,3 +253,123 @@ def decompress_point_cloud(
         'point_cloud': point_cloud,
         'output_path': output_path,
     }
+
+
+# ---------------------------------------------------------------------------------------------------------------- batches
+# The reference's coordinate tensor has a batch column (coords = [b, x, y, z], pcc_utils.py:73, b pinned to 0; sort_CF orders by
+# batch last, kit/op.py:17-30) and its stand-alone CLI loops over files (compress_ue_4stage_conv.py:72-75).  A scene is a chain of
+# ~60 dependent launches per octree level whatever its size, so scenes of 10^4 .. 10^5 anchors leave most of an MI355X idle;
+# the functions below code K scenes through ONE chain of launches (csrc/forest.hpp).  Every scene's file is byte-identical to
+# what compress_point_cloud writes for it alone, and any reader of that file reads these.
+
+def _encode_batch(xyz_list, model, chunk_log2: int, posQ_list, version=None):
+    """xyz_list: (N_i, 3) int32 tensors on one device -> ([bytes, ...], [Stats, ...], batched flag)."""
+    K = len(xyz_list)
+    device = xyz_list[0].device
+    ctx = runtime.context(device)
+    _set_version(ctx, version)
+    ptrs = (C.c_void_p * K)(*[x.data_ptr() for x in xyz_list])
+    ns = (C.c_int64 * K)(*[int(x.shape[0]) for x in xyz_list])
+    pq = (C.c_uint16 * K)(*[runtime.f16_bits(q) for q in posQ_list])
+    offs = (C.c_int64 * (K + 1))()
+    stats = (_lib.Stats * K)()
+    pb, batched = C.c_void_p(), C.c_int(0)
+    _lib.check(_lib.lib().gpcc_encode_batch(ctx, model.handle, ptrs, ns, K, chunk_log2, pq, C.byref(pb), offs, stats, C.byref(batched), runtime.stream_ptr(device)))
+    blob = C.string_at(pb, offs[K])
+    return [blob[offs[i]:offs[i + 1]] for i in range(K)], list(stats), bool(batched.value)
+
+
+def _decode_batch(datas, model, device):
+    """datas: container bytes of K scenes -> ([(N_i, 3) int32 tensors], [posQ], [Stats], batched flag)."""
+    K = len(datas)
+    datas = [d if isinstance(d, bytes) else bytes(d) for d in datas]
+    ctx = runtime.context(device)
+    npts = [_header_points(d[:96]) for d in datas]
+    if any(n is None or not (0 < n < (1 << 31)) for n in npts):
+        # a container without a point count (the reference layout): one by one
+        outs, pqs, sts = [], [], []
+        for d in datas:
+            o, q, s = _decode_bytes(d, model, device)
+            outs.append(o); pqs.append(q); sts.append(s)
+        return outs, pqs, sts, False
+    outs = [torch.empty((n, 3), dtype=torch.int32, device=device) for n in npts]
+    bptr = (C.c_void_p * K)(*[C.cast(C.c_char_p(d), C.c_void_p) for d in datas])
+    bn = (C.c_int64 * K)(*[len(d) for d in datas])
+    optr = (C.c_void_p * K)(*[o.data_ptr() for o in outs])
+    caps = (C.c_int64 * K)(*npts)
+    n_out = (C.c_int64 * K)()
+    pq = (C.c_uint16 * K)()
+    stats = (_lib.Stats * K)()
+    batched = C.c_int(0)
+    _lib.check(_lib.lib().gpcc_decode_batch(ctx, model.handle, bptr, bn, K, optr, caps, n_out, pq, stats, C.byref(batched), runtime.stream_ptr(device)))
+    return [o[: n_out[i]] for i, o in enumerate(outs)], [runtime.bits_f16(pq[i]) for i in range(K)], list(stats), bool(batched.value)
+
+
+def compress_point_clouds(
+    xyz_quantized_list,       # list of quantized point clouds (numpy arrays or torch tensors)
+    ckpt_path,                # Path to pre-trained weights file
+    output_paths,             # one bin file path per cloud
+    channels=32,
+    kernel_size=5,
+    posQ=1,                   # one scale for all clouds, or a list
+    *,
+    chunk_log2=None,
+):
+    """compress_point_cloud (pcc_utils.py:24-217) over a batch: the clouds share every launch of an octree depth.  Returns one
+    dict per cloud with the reference's keys; 'enc_time' is the batch's span divided by the number of clouds, 'batch_enc_time'
+    the span itself."""
+    assert len(xyz_quantized_list) == len(output_paths) and len(output_paths) > 0
+    if chunk_log2 is None:
+        chunk_log2 = DEFAULT_CHUNK_LOG2
+    if not torch.cuda.is_available():
+        raise RuntimeError("gauspcc_amd.compress_point_clouds needs an MI355X (no CPU path)")
+    first = xyz_quantized_list[0]
+    device = first.device if (isinstance(first, torch.Tensor) and first.is_cuda) else torch.device('cuda', torch.cuda.current_device())
+    model = runtime.get_model(ckpt_path, channels, kernel_size, device)
+    xs = [(torch.tensor(x) if isinstance(x, np.ndarray) else x).to(device).int().contiguous() for x in xyz_quantized_list]
+    posQs = list(posQ) if isinstance(posQ, (list, tuple)) else [posQ] * len(xs)
+    for p in output_paths:
+        d = os.path.dirname(p)
+        if d:
+            os.makedirs(d, exist_ok=True)
+    torch.cuda.current_stream(device).synchronize()
+    t0 = time.time()
+    blobs, _, _ = _encode_batch(xs, model, chunk_log2, posQs)
+    torch.cuda.current_stream(device).synchronize()
+    span = time.time() - t0
+    out = []
+    for x, p, b in zip(xs, output_paths, blobs):
+        with open(p, 'wb') as f:
+            f.write(b)
+        bits = os.stat(p).st_size * 8
+        out.append({'bpp': bits / x.shape[0], 'enc_time': span / len(xs), 'batch_enc_time': span, 'file_size_bits': bits, 'num_points': x.shape[0], 'output_path': p})
+    return out
+
+
+def decompress_point_clouds(bin_file_paths, ckpt_path, output_paths=None, channels=32, kernel_size=5, is_data_pre_quantized=True):
+    """decompress_point_cloud (pcc_utils.py:230-400) over a batch of files; one dict per file with the reference's keys."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("gauspcc_amd.decompress_point_clouds needs an MI355X (no CPU path)")
+    device = torch.device('cuda', torch.cuda.current_device())
+    model = runtime.get_model(ckpt_path, channels, kernel_size, device)
+    datas = []
+    for p in bin_file_paths:
+        with open(p, 'rb') as f:
+            datas.append(f.read())
+    torch.cuda.current_stream(device).synchronize()
+    t0 = time.time()
+    with torch.no_grad():
+        scans, posQs, _, _ = _decode_batch(datas, model, device)
+        clouds = [s * q.item() if is_data_pre_quantized else (s * q.item() - 131072) * 0.001 for s, q in zip(scans, posQs)]   # :378-381
+    torch.cuda.current_stream(device).synchronize()
+    span = time.time() - t0
+    out = []
+    for i, pc in enumerate(clouds):
+        op = output_paths[i] if output_paths else None
+        if op:
+            d = os.path.dirname(op)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            save_ply_ascii_geo(pc.cpu().numpy(), op)
+        out.append({'dec_time': span / len(clouds), 'batch_dec_time': span, 'num_points': pc.shape[0], 'point_cloud': pc, 'output_path': op})
+    return out

@@ -130,6 +130,28 @@ GPCC_API int gpcc_decode_to(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *b
                 int32_t *xyz_dev, int64_t capacity_points, int64_t *n_out, uint16_t *posq_f16_out,
                 gpcc_stats *stats, void *stream);
 
+/* ---- batched a12 / a13: K scenes through ONE chain of launches
+ * Reference: the codec's coordinate tensor has a batch column -- coords = [b, x, y, z], src/gs_compress/HAC/utils/pcc_utils.py:73
+ * (b pinned to 0), sort_CF orders by batch last (src/ai_pcc/GausPcgc/kit/op.py:17-30) -- and the stand-alone CLI loops over files
+ * (src/ai_pcc/GausPcgc/compress_ue_4stage_conv.py:72-75).  Every scene gets its own container, byte-identical to what gpcc_encode
+ * writes for it alone; the scenes share every convolution / head / coder / scan launch of an octree depth (csrc/forest.hpp).
+ * xyz_dev / n / posq_f16: HOST arrays of nscenes device pointers, point counts and posQ bits.  On success *bytes_out points at a
+ * context-owned host buffer holding the containers one after the other, scene i at [offsets_out[i], offsets_out[i + 1])
+ * (offsets_out: nscenes + 1 entries, caller-owned).  stats (nullable): nscenes records; conv_pairs and device_ms of the whole
+ * batch are in stats[0].  *batched_out (nullable): 1 when the scenes shared one tree, 0 when they were coded one by one (the
+ * reference container layout chunk_log2 = 0, a scene whose extent reaches 2^20, more than 256 scenes, or more scenes than the
+ * 21-bit coordinate frame stacks: same bytes either way). */
+GPCC_API int gpcc_encode_batch(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *const *xyz_dev, const int64_t *n, int nscenes,
+                int chunk_log2, const uint16_t *posq_f16, const uint8_t **bytes_out, int64_t *offsets_out,
+                gpcc_stats *stats, int *batched_out, void *stream);
+/* bytes / nbytes: HOST arrays of nscenes container pointers (host memory) and sizes; xyz_dev / capacity_points: nscenes caller-owned
+ * DEVICE buffers ((capacity, 3) int32 each; a chunked container's header carries its point count, see gpcc_decode_to).  Every
+ * scene's points come out as gpcc_decode gives them for that container alone.  Containers of the reference layout or of mixed
+ * versions are decoded one by one (*batched_out = 0). */
+GPCC_API int gpcc_decode_batch(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *bytes, const int64_t *nbytes, int nscenes,
+                int32_t *const *xyz_dev, const int64_t *capacity_points, int64_t *n_out, uint16_t *posq_f16_out,
+                gpcc_stats *stats, int *batched_out, void *stream);
+
 /* Live timing of the dominant kernel (the sparse convolution): while enabled, every launch is
  * bracketed by HIP events on the stream it runs on.  conv_pair_jobs = sum over launches of
  * (output node, present neighbour) pairs x jobs in the launch; algorithmic flops = 2*C*C*conv_pair_jobs. */

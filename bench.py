@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--side-anchors", type=int, default=200_000, help="anchors of the synthetic HAC-style scene behind the `side_paths` object (SURVEY 8f: attribute "
                     "loop, Gaussian coder, mlp_grid, generate_neural_gaussians + rasteriser, torchac shim; untimed pass on rank 0 at N = 1; 0 = skip)")
     ap.add_argument("--skip-stages", action="store_true", help="do not run the extra pass that times the HBM-bound stages")
+    ap.add_argument("--skip-sizes", action="store_true", help="do not run the untimed passes behind `sizes` (one scene of 10 k / 100 k / 1 M points) and `batched` "
+                    "(K scenes through one chain of launches: gpcc_encode_batch / gpcc_decode_batch)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
     args = ap.parse_args()
 
@@ -260,6 +262,59 @@ def main():
         inflight = {"scenes": S, "value": round(S * fsteps * args.points / el / 1e6, 4), "unit": "Mpoints/s", "steps": fsteps,
                     "ms_per_scene_step": round(1e3 * el / fsteps, 3)}
 
+    # Scenes of realistic size, and batches of them (untimed passes on rank 0 at N = 1; `value` stays the one-scene 1 M figure).
+    # sizes:   one scene at a time (gpcc_encode / gpcc_decode), per size enc / dec ms, Mpoints/s and kernel launches per call.
+    # batched: K scenes through ONE chain of launches (gpcc_encode_batch / gpcc_decode_batch, csrc/forest.hpp; BASELINE configs[3] is a
+    #          batched encode): Mpoints/s over all K scenes, launches per call, every scene's bytes compared with its solo encode.
+    sizes, batched = None, None
+    if rank == 0 and world == 1 and not args.skip_sizes:
+        from gauspcc_amd.pcc_utils import _decode_batch, _encode_batch
+
+        def timed(fn, reps):
+            fn()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t0) / reps
+
+        def launches(fn):
+            L.gpcc_debug_launches(1)
+            fn()
+            return int(L.gpcc_debug_launches(1))
+
+        sizes = []
+        solo_bytes = {}
+        for n_s in (10_000, 100_000, 1_000_000):
+            xs_s = x if n_s == args.points else torch.tensor(synthetic_cloud(n_s, seed=scene_seed(1234, 200)), device=device)
+            reps = 20 if n_s < 1_000_000 else 5
+            blob = bytes(_encode_view(xs_s, model, args.chunk_log2, 1)[0])
+            solo_bytes[n_s] = len(blob)
+            te_s = timed(lambda: (_encode_view(xs_s, model, args.chunk_log2, 1), torch.cuda.synchronize(device)), reps)
+            td_s = timed(lambda: (_decode_bytes(blob, model, device), torch.cuda.synchronize(device)), reps)
+            sizes.append({"points": n_s, "enc_ms": round(te_s * 1e3, 3), "dec_ms": round(td_s * 1e3, 3), "value": round(n_s / (te_s + td_s) / 1e6, 4), "unit": "Mpoints/s",
+                          "kernels_per_encode": launches(lambda: _encode_view(xs_s, model, args.chunk_log2, 1)),
+                          "kernels_per_decode": launches(lambda: _decode_bytes(blob, model, device))})
+        batched = []
+        for K_b, n_b in ((8, 100_000), (32, 10_000), (2, 1_000_000)):
+            xs_b = [torch.tensor(synthetic_cloud(n_b, seed=scene_seed(1234, 300 + i)), device=device) for i in range(K_b)]
+            reps = 10 if K_b * n_b < 2_000_000 else 4
+            views, _, was_b = _encode_batch(xs_b, model, args.chunk_log2, [1] * K_b, view=True)
+            blobs_b = [bytes(v) for v in views]
+            same = all(bytes(_encode_view(xi, model, args.chunk_log2, 1)[0]) == bi for xi, bi in zip(xs_b, blobs_b))
+            te_b = timed(lambda: (_encode_batch(xs_b, model, args.chunk_log2, [1] * K_b, view=True), torch.cuda.synchronize(device)), reps)
+            td_b = timed(lambda: (_decode_batch(blobs_b, model, device), torch.cuda.synchronize(device)), reps)
+            outs_b, _, _, was_db = _decode_batch(blobs_b, model, device)
+            rt = all(torch.equal(o, _decode_bytes(bi, model, device)[0]) for o, bi in zip(outs_b, blobs_b))
+            batched.append({"scenes": K_b, "points_per_scene": n_b, "enc_ms": round(te_b * 1e3, 3), "dec_ms": round(td_b * 1e3, 3),
+                            "value": round(K_b * n_b / (te_b + td_b) / 1e6, 4), "unit": "Mpoints/s",
+                            "kernels_per_encode": launches(lambda: _encode_batch(xs_b, model, args.chunk_log2, [1] * K_b, view=True)),
+                            "kernels_per_decode": launches(lambda: _decode_batch(blobs_b, model, device)),
+                            "one_tree": bool(was_b and was_db), "bytes_identical_to_solo": bool(same), "decode_identical_to_solo": bool(rt)})
+            del xs_b
+        data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
+
     # correctness of what was just timed: decoded geometry == input geometry (as sets; bit-identical)
     d = dec.cpu().numpy()
     ok = d.shape == pts.shape and np.array_equal(d[np.lexsort((d[:, 0], d[:, 1], d[:, 2]))], pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))])
@@ -334,6 +389,8 @@ def main():
             "chunk_overhead_frac": None if bytes_v0 is None else round((len(data) - bytes_v0) / bytes_v0, 5),
             "chunk_overhead_frac_at_4bpp": None if bytes_v0 is None else round((len(data) - bytes_v0) / (4.0 * args.points / 8), 5),
             "scenes_in_flight": inflight,
+            "sizes": sizes,
+            "batched": batched,
             "coded_nodes": int(allstats[0, 3]),
             "roundtrip_bit_identical": True,
             "roofline": {

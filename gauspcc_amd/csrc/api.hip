@@ -12,6 +12,7 @@ using namespace gpcc;
 
 namespace gpcc {
 thread_local char g_err[512] = "";
+thread_local long long g_launches = 0;
 }
 
 extern "C" const char *gpcc_last_error(void) { return gpcc::g_err; }
@@ -54,6 +55,15 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
 
 // Version gpcc_encode (and the stage-level gpcc_rc_encode / gpcc_rc_decode) use for chunked containers: 4 (default: the
 // carry-propagating coder in the lanes) or 3 (torchac's coder in the lanes: what round 3 wrote).  Readers take 0-4.
+// kernel launches enqueued by the calling thread since the last reset (every launch site of the library passes LAUNCH_CHECK);
+// bench.py's `kernels per decode` and the batch's launch-count bar read it
+extern "C" long long gpcc_debug_launches(int reset)
+{
+    const long long v = gpcc::g_launches;
+    if (reset) gpcc::g_launches = 0;
+    return v;
+}
+
 extern "C" int gpcc_ctx_set_container_version(gpcc_ctx *c, int version)
 {
     if (!c) return fail(GPCC_ERR_ARG, "null argument");

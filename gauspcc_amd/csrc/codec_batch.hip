@@ -30,6 +30,8 @@ namespace {
 
 // internal: code the scenes one by one instead (not an error)
 constexpr int BATCH_SOLO = -2001;
+// internal: a persistent small-level launch timed out (fused.hip) -- decode again on the launch-per-layer path (ctx->fused_off is set)
+constexpr int BATCH_RETRY_UNFUSED = -2002;
 
 struct FPosArgs {
     int L;
@@ -671,6 +673,12 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         GP_TRY(tiles_build(ctx, st, &tl, 1, m->k, R, conv_pick_height(bn, R), &pool, pairs_dev));
         GP_TRY(tiles_view(ctx, st, pool, 0, 1, zero_base, &tilesP));
     }
+    // small levels (fused.hpp): a merged level of at most FUSE_MAX_NODES nodes gets a pair plan, its chain is one persistent launch
+    const bool fuse_ctx = fused_enabled() && !ctx->fused_off;
+    const int fmode = fused_mode();
+    PairPlan planP;
+    int64_t planP_np = 0;
+    bool any_fused = false;
     HIP_TRY(hipEventRecord(ctx->ev_main, st));
     for (int g = 0; g + 1 < L; ++g) {
         const size_t top_mk = ctx->arena.top_mark();
@@ -680,8 +688,18 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         // ---- st: parent trunk (only the rows that have children need it: a prefix -- but a block of the tile list may straddle
         // the boundary, so the trunk runs on the whole level; the rows of finished scenes are a level's tail and cost their share)
         TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
-        GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np));
+        float *Pp = nullptr;
+        if (planP.valid()) { TAKE_TOP(pp, float, planP.pcap * 32); Pp = pp; }
+        if (planP.valid() && fmode == 1) {
+            ConvRec rec = {0, 0, g, 1, 0, 0, (long long)np, 0, 5, 1};
+            if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
+            GP_TRY(fused_parent_trunk(ctx, st, m, planP, planP_np, cur.occ, pF, pA, pB, Pp));
+            if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+            any_fused = true;
+        } else {
+            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
+            GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np, planP.valid() ? &planP : nullptr, Pp));
+        }
         // ---- side: the child level's structure
         HIP_TRY(hipStreamWaitEvent(sd, ctx->ev_main, 0));
         Level &chi = T.lv[g + 1];
@@ -697,7 +715,12 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }
         ConvTiles tilesC;
-        {
+        PairPlan planC;
+        const bool child_plan = fuse_ctx && fused_level_ok(nc, m->k) && fused_windows_fit(nc, cur.n, nch_tot[g + 1], win_bytes[g + 1]);
+        if (child_plan) {
+            StageTimer tm(ctx, sd, ST_TILES, 0.0);
+            GP_TRY(pairplan_build(ctx, sd, &cur, cellP, &chi, cellC, m->k, &planC, pairs_dev + g + 1));
+        } else {
             const TileLevel tl = {&chi, &cur, cellP, cellC};
             const int R = conv_pick_rows(nc, m->k);
             TilePool pool;
@@ -717,21 +740,42 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         const RcChunk *dchunks = dchunks_all + desc_at[g + 1];
         // ---- st: child trunk and the four stages
         TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
+        float *Pc = nullptr;
+        if (child_plan) { TAKE_TOP(pc, float, planC.pcap * 32); Pc = pc; }
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, symlen[g + 1]); sym[s] = sy; }
+        if (child_plan && fmode == 1) {
+            // the level's whole chain in one persistent launch (fused.hip)
+            if (g == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
+            FusedChild fa = {};
+            fa.pA = pA; fa.np = np; fa.parent = chi.parent; fa.rkey = chi.rkey; fa.m2r = chi.m2r; fa.bytes = dbytes; fa.chunks = dchunks; fa.nlanes = (uint32_t)nch; fa.llog = 4;
+            fa.cpos = cpos; fa.spos = spos;
+            for (int s = 0; s < 4; ++s) { fa.win_bytes[s] = win_bytes[g + 1][s]; fa.sym[s] = sym[s]; }
+            fa.cX = cX; fa.cA = cA; fa.cB = cB; fa.cU = cU; fa.P = Pc; fa.cdf = cdf; fa.occ = chi.occ; fa.coder = rc_coder_of_version(version);
+            ConvRec rec = {0, 0, g + 1, 1, 0, 0, (long long)nc, 0, 13, 1};
+            if (ctx->prof.on) GP_TRY(prof_event(ctx, st, &rec.e0));
+            GP_TRY(fused_child_level(ctx, st, m, planC, fa));
+            if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
+            any_fused = true;
+        } else {
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
-        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc));
+        GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc, child_plan ? &planC : nullptr, Pc));
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
             if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, spos, s, nc, cU)); xin = cU; }
             ConvBatch cb = {};
+            if (child_plan) {
+                GP_TRY(plan_conv(st, planC, ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX}, Pc, 1));
+                GP_TRY(plan_conv(st, planC, ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB}, Pc, 0));
+            } else {
             GP_TRY(conv_chain_begin(ctx, st));
             cb.job[0] = ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 1));
             cb.job[0] = ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB};
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
             GP_TRY(conv_chain_end(ctx, st));
+            }
             HeadArgs ha = {};
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
@@ -745,9 +789,10 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             }
         }
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, spos, nc, chi.occ)); }
+        }
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
         ctx->arena.top_rewind(top_mk);
-        cellP = cellC; tilesP = tilesC;
+        cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan(); planP_np = np;
         ht.mark("bdec level queued", g + 1, nc);
     }
     // ---- leaves: every level hands out the points of the scenes that end there
@@ -775,8 +820,17 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     HIP_TRY(hipMemcpyAsync(h_lvl, dlevel_tot, 4 * (size_t)MAXLV, hipMemcpyDeviceToHost, st));
     unsigned long long hpairs[MAXLV];
     HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
+    uint32_t *h_tmo = hcnt + K + MAXLV;
+    *h_tmo = 0;
+    if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(h_tmo, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     ht.mark("bdec leaves done (sync)");
+    if (*h_tmo) {
+        // a persistent launch gave up waiting for its workgroups (fused.hip: bounded spins): nothing it produced is trusted
+        ctx->fused_off = true;
+        GP_TRY(fused_reset(ctx, st));
+        return BATCH_RETRY_UNFUSED;
+    }
     for (int g = 0; g + 1 < L; ++g)
         if (h_lvl[g] != (uint32_t)lvl_n[g + 1]) return fail(GPCC_ERR_FORMAT, "level %d: the headers say %lld nodes, the occupancy expands to %u", g + 1, (long long)lvl_n[g + 1], h_lvl[g]);
     if (h_lvl[MAXLV - 1]) return fail(GPCC_ERR_FORMAT, "a scene's occupancy expands to a node count its header does not state");
@@ -896,9 +950,20 @@ extern "C" int gpcc_decode_batch(gpcc_ctx *ctx, const gpcc_model *m, const uint8
             int64_t nmax = 0;
             for (int d = 0; d < MAXLV; ++d) nmax = std::max(nmax, nmax_sum[d]);
             size_t want = arena_scaled_b((size_t)nmax * 2700 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)total_bytes + (size_t)nscenes * 65536 + ((size_t)48 << 20));
+            if (fused_enabled()) {   // small levels (fused.hpp): the product buffer n K + 1 rows, the plan and its build scratch
+                int64_t nf = 0;
+                for (int d = 0; d < MAXLV; ++d) if (nmax_sum[d] > 0 && fused_level_ok(nmax_sum[d], m->k)) nf = std::max(nf, nmax_sum[d]);
+                want += (size_t)nf * (size_t)m->K * (128 + 10 + 9) + ((size_t)4 << 20);
+            }
             for (int attempt = 0; attempt < 6; ++attempt) {
                 GP_TRY(ctx->arena.reserve(want));
                 rc = decode_batch_body(ctx, m, bytes, nbytes, nscenes, xyz_dev, capacity_points, n_out, posq_f16_out, stats, st);
+                if (rc == BATCH_RETRY_UNFUSED) {
+                    static const bool loud = getenv("GAUSPCC_FUSED_QUIET") == nullptr;
+                    if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; this context decodes on the launch-per-layer path from now on\n", ctx->device);
+                    attempt -= 1;
+                    continue;
+                }
                 if (rc != GPCC_ERR_NOMEM) break;
                 HIP_TRY(hipStreamSynchronize(st));
                 want *= 2;

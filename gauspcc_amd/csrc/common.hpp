@@ -17,6 +17,7 @@
 namespace gpcc {
 
 extern thread_local char g_err[512];
+extern thread_local long long g_launches;   // kernel launch sites passed by this thread (LAUNCH_CHECK): gpcc_debug_launches
 
 inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 inline int fail(int code, const char *fmt, ...)
@@ -47,6 +48,7 @@ inline bool debug_sync_on() { static const bool on = [] { const char *e = getenv
 inline hipError_t launch_check(const char *file, int line)
 {
     hipError_t e = hipGetLastError();
+    ++g_launches;
     if (e == hipSuccess && debug_sync_on()) { fprintf(stderr, "[launch] %s:%d\n", file, line); fflush(stderr); e = hipDeviceSynchronize(); }
     return e;
 }

@@ -18,8 +18,10 @@ int fused_mode()
     return m;
 }
 bool fused_enabled() { return fused_mode() != 0; }
+int fused_device_cap();   // below: workgroups of a persistent launch the current device holds at once
 bool fused_level_ok(int64_t n, int k)
 {
+    if (fused_device_cap() < 16) return false;   // a partitioned / masked device too small for a persistent grid: the launch-per-layer path
     static const int64_t nmax = std::min<int64_t>(env_ll("GAUSPCC_FUSED_MAX", FUSE_MAX_NODES), FUSE_MAX_NODES);
     const int64_t K = (int64_t)k * k * k;
     return fused_enabled() && n >= 1 && n <= nmax && (n * K + 1) * 128 <= ((int64_t)768 << 20);
@@ -381,16 +383,20 @@ __device__ __forceinline__ bool bar_begin(BarCtx &bc, FusedBar *b, FusedBar *b_n
     }
     if (threadIdx.x == 0) {
         bool ok = ld_rlx(tmo) == 0u;
+        // the members add must be visible to whoever sees the census complete (the two words live on different cache lines, possibly
+        // different L2 channels, and nothing orders relaxed adds of one workgroup): the census add is a RELEASE, the reader acquires
         add_rlx(&b->members[bc.xcc * 32], 1u);
-        add_rlx(&b->census[0], 1u);
+        __hip_atomic_fetch_add(&b->census[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         ok = ok && poll_ge(&b->census[0], gridDim.x, tmo);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (ok && blockIdx.x == 0) {
             uint32_t nx = 0;
             for (uint32_t x = 0; x < 8u; ++x) nx += ld_rlx(&b->members[x * 32]) ? 1u : 0u;
             st_rlx(&b->nxcc[0], nx);
         }
-        add_rlx(&b->census[1], 1u);
+        __hip_atomic_fetch_add(&b->census[1], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // (workgroup 0: nxcc before its second census add)
         ok = ok && poll_ge(&b->census[1], gridDim.x, tmo);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         ok_s = ok ? 1u : 0u;
     }
     __syncthreads();
@@ -445,6 +451,7 @@ struct FusedK {
     float *P;
     // CHILD: parent features, structure, buffers x / a / b / u, the container; PARENT: occupancy in, buffers x (= F) / a / b
     const float *pA; const uint32_t *parent; const uint64_t *rkey; const uint32_t *m2r;
+    const uint32_t *m2s, *cpos;      // symbol slot of every node (one scene: its raster rank = m2r) and, for a batch's merged level, its CDF row slot
     float *x, *a, *b, *u;
     const float *w[13];              // CHILD: conv[5 .. 17]; PARENT: conv[0 .. 4] -- transposed fragments (conv + K * 1024)
     const float *temb, *semb[3], *hfrag[4], *prior_emb;
@@ -481,7 +488,7 @@ __device__ __forceinline__ void head_rows(const FusedK &k, const WgMap &m, int s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     HeadArgs ha = {};
-    ha.x = k.b; ha.n = k.pl.n; ha.stage_m = M; ha.frag = k.hfrag[stage]; ha.m2r = k.m2r; ha.cdf = k.cdf; ha.mode = 1; ha.chunk_log2 = k.llog; ha.nch = k.nlanes; ha.stage = stage;
+    ha.x = k.b; ha.n = k.pl.n; ha.stage_m = M; ha.frag = k.hfrag[stage]; ha.m2r = k.m2r; ha.cdf = k.cdf; ha.mode = 1; ha.chunk_log2 = k.llog; ha.nch = k.nlanes; ha.stage = stage; ha.pos = k.cpos;
     if (m.wave < FUSE_HEAD_WAVES)
         for (int r = m.row0 + 64 * m.wave; r < m.row1; r += 64 * FUSE_HEAD_WAVES)
             head_wave<M, 1>(ha, r, m.row1, m.lane, lds + m.wave * HEAD_LDS_FLOATS, 0u);
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
         if (s) {
             const float4 *X = reinterpret_cast<const float4 *>(k.a), *emb = reinterpret_cast<const float4 *>(k.semb[s - 1]);
             for (int64_t t = m.gtid; t < n8; t += m.NT) {
-                const uint32_t r = k.m2r[t >> 3];
+                const uint32_t r = k.m2s[t >> 3];
                 uint32_t prev = k.sym[0][r];
                 if (s >= 2) prev = prev * 2 + k.sym[1][r];
                 if (s >= 3) prev = prev * 4 + k.sym[2][r];
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
     }
     // occupancy byte from the four symbol arrays (raster order) -> Morton order (pcc_utils.py:369)
     for (int64_t i = m.gtid; i < n; i += m.NT) {
-        const uint32_t r = k.m2r[i];
+        const uint32_t r = k.m2s[i];
         k.occ[i] = (uint8_t)(k.sym[0][r] * 128 + k.sym[1][r] * 64 + k.sym[2][r] * 16 + k.sym[3][r]);
     }
 #ifdef FUSED_TIMING
@@ -601,7 +608,10 @@ int fused_grid(int64_t n, int64_t np)
     const bool dense = np > 0 && n > 3 * np;
     const int64_t tiles = dense ? 5 * n : n / 2 + 64;
     const int64_t g = cdiv(tiles, 2 * (FUSE_THREADS / 64));   // two tiles per wave
-    return (int)std::min<int64_t>(256, std::max<int64_t>(16, (g + 15) / 16 * 16));
+    // never more workgroups than the device holds at once (the grid barrier needs them all resident): 256 CUs x one workgroup on a
+    // whole MI355X, fewer on a partitioned (CPX / DPX) part
+    const int64_t cap = std::max<int64_t>(16, std::min<int64_t>(256, fused_device_cap() / 16 * 16));
+    return (int)std::min<int64_t>(cap, std::max<int64_t>(16, (g + 15) / 16 * 16));
 }
 
 // Two persistent launches whose workgroups spin on grid barriers must not share the device: each may hold CUs the other's missing
@@ -654,6 +664,25 @@ int fused_state(gpcc_ctx *ctx, hipStream_t st, FusedBar **cur, FusedBar **next, 
 
 }  // namespace
 
+int fused_device_cap()
+{
+    static std::mutex mu;
+    static int cap[64];
+    static bool have[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (!have[dev & 63]) {
+        hipDeviceProp_t p;
+        int occ = 0;
+        if (hipGetDeviceProperties(&p, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_level_fused<FUSED_CHILD, RC_CODER_CARRY>, FUSE_THREADS, FUSE_LDS_BYTES) != hipSuccess) return 0;
+        cap[dev & 63] = std::max(0, occ * p.multiProcessorCount - 2);   // two CUs of slack for whatever else runs
+        have[dev & 63] = true;
+    }
+    return cap[dev & 63];
+}
+
 void fused_ctx_release(gpcc_ctx *ctx)
 {
     if (!ctx->fused_state) return;
@@ -679,6 +708,7 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
     k.desert = fused_test_desert();
     k.P = a.P;
     k.pA = a.pA; k.parent = a.parent; k.rkey = a.rkey; k.m2r = a.m2r;
+    k.m2s = a.spos ? a.spos : a.m2r; k.cpos = a.cpos;
     k.x = a.cX; k.a = a.cA; k.b = a.cB; k.u = a.cU;
     for (int i = 0; i < 13; ++i) k.w[i] = m->conv[5 + i] + (size_t)m->K * 1024;
     k.temb = m->temb;
@@ -698,6 +728,7 @@ int fused_child_level(gpcc_ctx *ctx, hipStream_t st, const gpcc_model *m, const 
 bool fused_windows_fit(int64_t n, int64_t np, uint32_t nlanes, const uint32_t win_bytes[4])
 {
     const uint32_t G = (uint32_t)fused_grid(n, np), LPW = (nlanes + G - 1u) / G;
+    if (LPW > 64u) return false;   // (a wave decodes its workgroup's lanes of the 3- / 5-entry streams: one lane each)
     for (int s = 0; s < 4; ++s) {
         const uint64_t rdw = rc_window_dwords(win_bytes[s]);
         const uint64_t lanes = s == 3 ? (uint64_t)((LPW + 3u) / 4u) * 4u : LPW;

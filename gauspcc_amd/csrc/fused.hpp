@@ -77,6 +77,9 @@ struct FusedChild {
     const uint8_t *bytes;            // the uploaded container
     const RcChunk *chunks;           // [4][nlanes] lane descriptors of the level's four streams
     uint32_t nlanes; int llog;       // lanes per stream, log2 symbols per lane
+    // a batch's merged level (forest.hpp): the lanes of all scenes (nlanes = their total, chunks carry their own geometry), and per node
+    // its CDF row slot and its symbol slot (nullptr: one scene -- both follow from m2r, nlanes and llog)
+    const uint32_t *cpos = nullptr, *spos = nullptr;
     uint32_t win_bytes[4];           // longest byte window of a lane, per stage
     int coder;                       // the lanes' coder (rangecoder_dev.hpp: RC_CODER_*: container version 4 / versions 1-3)
     // work buffers (n, 32) and outputs

@@ -262,8 +262,9 @@ def decompress_point_cloud(
 # the functions below code K scenes through ONE chain of launches (csrc/forest.hpp).  Every scene's file is byte-identical to
 # what compress_point_cloud writes for it alone, and any reader of that file reads these.
 
-def _encode_batch(xyz_list, model, chunk_log2: int, posQ_list, version=None):
-    """xyz_list: (N_i, 3) int32 tensors on one device -> ([bytes, ...], [Stats, ...], batched flag)."""
+def _encode_batch(xyz_list, model, chunk_log2: int, posQ_list, version=None, view=False):
+    """xyz_list: (N_i, 3) int32 tensors on one device -> ([bytes, ...], [Stats, ...], batched flag).  view=True: ctypes byte
+    arrays over the context's pinned output buffer instead of owned bytes (valid until the context's next encode of any kind)."""
     K = len(xyz_list)
     device = xyz_list[0].device
     ctx = runtime.context(device)
@@ -275,6 +276,8 @@ def _encode_batch(xyz_list, model, chunk_log2: int, posQ_list, version=None):
     stats = (_lib.Stats * K)()
     pb, batched = C.c_void_p(), C.c_int(0)
     _lib.check(_lib.lib().gpcc_encode_batch(ctx, model.handle, ptrs, ns, K, chunk_log2, pq, C.byref(pb), offs, stats, C.byref(batched), runtime.stream_ptr(device)))
+    if view:
+        return [(C.c_ubyte * (offs[i + 1] - offs[i])).from_address(pb.value + offs[i]) for i in range(K)], list(stats), bool(batched.value)
     blob = C.string_at(pb, offs[K])
     return [blob[offs[i]:offs[i + 1]] for i in range(K)], list(stats), bool(batched.value)
 
@@ -282,9 +285,9 @@ def _encode_batch(xyz_list, model, chunk_log2: int, posQ_list, version=None):
 def _decode_batch(datas, model, device):
     """datas: container bytes of K scenes -> ([(N_i, 3) int32 tensors], [posQ], [Stats], batched flag)."""
     K = len(datas)
-    datas = [d if isinstance(d, bytes) else bytes(d) for d in datas]
+    datas = [d if isinstance(d, (bytes, C.Array)) else bytes(d) for d in datas]
     ctx = runtime.context(device)
-    npts = [_header_points(d[:96]) for d in datas]
+    npts = [_header_points(bytes(d[:96])) for d in datas]
     if any(n is None or not (0 < n < (1 << 31)) for n in npts):
         # a container without a point count (the reference layout): one by one
         outs, pqs, sts = [], [], []
@@ -293,7 +296,7 @@ def _decode_batch(datas, model, device):
             outs.append(o); pqs.append(q); sts.append(s)
         return outs, pqs, sts, False
     outs = [torch.empty((n, 3), dtype=torch.int32, device=device) for n in npts]
-    bptr = (C.c_void_p * K)(*[C.cast(C.c_char_p(d), C.c_void_p) for d in datas])
+    bptr = (C.c_void_p * K)(*[C.c_void_p(C.addressof(d)) if isinstance(d, C.Array) else C.cast(C.c_char_p(d), C.c_void_p) for d in datas])
     bn = (C.c_int64 * K)(*[len(d) for d in datas])
     optr = (C.c_void_p * K)(*[o.data_ptr() for o in outs])
     caps = (C.c_int64 * K)(*npts)

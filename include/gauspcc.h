@@ -51,6 +51,10 @@ GPCC_API int gpcc_ctx_set_container_version(gpcc_ctx *ctx, int version);
  * workspace itself, so its CLIs add this figure.  Either pointer may be null. */
 GPCC_API int gpcc_ctx_bytes(const gpcc_ctx *ctx, int64_t *device_bytes, int64_t *pinned_bytes);
 
+/* developer counter: kernel launches the calling thread has enqueued through this library since the last reset (reset != 0
+ * zeroes it); memcpy / memset nodes are not counted.  bench.py reports kernels per decode with it. */
+GPCC_API long long gpcc_debug_launches(int reset);
+
 /* ---- a2  calculate_morton_order            src/gs_compress/HAC/utils/pcc_utils.py:12-22
  * perm_out[N] (int64, device): argsort of x + y*M + z*M^2 after the per-axis min shift
  * (M = max over all axes + 1), i.e. the (z,y,x) raster order; stable for equal keys. */

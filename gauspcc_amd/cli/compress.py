@@ -34,6 +34,8 @@ def build_parser():
     p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context: one file's host work and idle device time overlap another's kernels)")
     p.add_argument("--chunk_log2", type=int, default=None, help="extension: 0 = reference container, 6..14 = chunked container (default: pcc_utils.DEFAULT_CHUNK_LOG2)")
     p.add_argument("--gpus", type=int, default=1, help="extension: shard the files over this many GPUs of the node, one process per GPU (file i -> rank i mod N)")
+    p.add_argument("--batch", type=int, default=1, help="extension: code this many files of a rank's share through ONE chain of launches (pcc_utils.compress_point_clouds; "
+                   "small clouds leave most of the GPU idle one at a time).  Same .bin files; a file's enc_time is its batch's span divided by the batch size")
     p.add_argument("--selftest-stub", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the sharding / collation path without a GPU
     return p
 
@@ -137,7 +139,25 @@ def main(argv=None):
             io.note_workspace(device)
         return {"filedir": name, "bpp": r["file_size_bits"] / n_in, "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": n_in}
 
-    if args.jobs <= 1:
+    def group(items):
+        """--batch K: K files through one chain of launches (the reference's batch column, pcc_utils.py:73); same rows as `one`."""
+        if args.selftest_stub or len(items) == 1:
+            return [one(it) for it in items]
+        names = [os.path.split(p)[-1] for p, _ in items]
+        xyzs = [quantise(pts, args.is_data_pre_quantized, args.posQ, device) for _, pts in items]
+        res = pcc_utils.compress_point_clouds(xyzs, args.ckpt, [os.path.join(args.output_folder, nm + ".bin") for nm in names], channels=args.channels,
+                                              kernel_size=args.kernel_size, posQ=args.posQ, chunk_log2=args.chunk_log2)
+        io.note_workspace(device)
+        return [{"filedir": nm, "bpp": r["file_size_bits"] / len(pts), "enc_time": r["enc_time"], "file_size_bits": r["file_size_bits"], "num_points": len(pts)}
+                for nm, (_, pts), r in zip(names, items, res)]
+
+    if args.batch > 1:
+        items = list(zip(my_files, xyz_ls))
+        for g0 in range(0, len(items), args.batch):
+            rows.extend(group(items[g0:g0 + args.batch]))
+            if world == 1:
+                write_results_csv(rows, csvfile, with_avg=False)
+    elif args.jobs <= 1:
         for item in zip(my_files, xyz_ls):
             rows.append(one(item))
             if world == 1:
@@ -167,7 +187,8 @@ def main(argv=None):
         mem = (torch.cuda.max_memory_allocated() + io.workspace_peak()) / 1024 / 1024 if device.type == "cuda" else 0.0
         print("Total: {total_n:d} | Average bitrate:{bpp:.3f} | Encoding time:{enc_time:.3f}s | Max GPU memory:{memory:.2f}MB".format(
             total_n=len(rows), bpp=np.mean([r["bpp"] for r in rows]), enc_time=np.mean([r["enc_time"] for r in rows]), memory=mem)
-            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight" + (" per rank" if world > 1 else "") + " (times under contention)" if args.jobs > 1 else ""))
+            + (f" | {world} ranks" if world > 1 else "") + (f" | {args.jobs} files in flight" + (" per rank" if world > 1 else "") + " (times under contention)" if args.jobs > 1 and args.batch <= 1 else "")
+            + (f" | batches of {args.batch} (a file's time = its batch's span / the batch size)" if args.batch > 1 else ""))
         print("Results saved to ", csvfile)
     if world > 1:
         import torch.distributed as td

@@ -23,6 +23,7 @@ def build_parser():
     p.add_argument("--ckpt", help="Checkpoint loading path ('synthetic[:seed]' = seeded random weights)", default="./model/KITTIDetection/ckpt_ue_4stage_conv.pt")
     p.add_argument("--jobs", type=int, default=1, help="extension: files in flight on the GPU (host threads with their own stream and context)")
     p.add_argument("--gpus", type=int, default=1, help="extension: shard the files over this many GPUs of the node, one process per GPU (file i -> rank i mod N)")
+    p.add_argument("--batch", type=int, default=1, help="extension: decode this many files of a rank's share through ONE chain of launches (pcc_utils.decompress_point_clouds)")
     p.add_argument("--selftest-stub", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the sharding / collation path without a GPU
     return p
 
@@ -75,7 +76,20 @@ def main(argv=None):
         print(f"Points after decompression: {r['num_points']}")
         return r["dec_time"]
 
-    dec_time_ls = io.run_jobs(one, files, args.jobs)
+    if args.batch > 1 and not args.selftest_stub:
+        from .. import pcc_utils
+
+        dec_time_ls = []
+        for g0 in range(0, len(files), args.batch):
+            grp = files[g0:g0 + args.batch]
+            res = pcc_utils.decompress_point_clouds(grp, args.ckpt, [os.path.join(args.output_folder, os.path.split(p)[-1] + ".ply") for p in grp], channels=args.channels,
+                                                    kernel_size=args.kernel_size, is_data_pre_quantized=args.is_data_pre_quantized)
+            io.note_workspace(device)
+            for r in res:
+                print(f"Points after decompression: {r['num_points']}")
+                dec_time_ls.append(r["dec_time"])
+    else:
+        dec_time_ls = io.run_jobs(one, files, args.jobs)
     if world > 1:
         allst = gdist.collate_stats([gdist.SceneStats(dec_s=t) for t in dec_time_ls], device)
         dec_time_ls = [s.dec_s for s in allst]

@@ -15,6 +15,7 @@
 
 #include <functional>
 #include "codec_shared.hpp"
+#include "container.hpp"
 #include "rangecoder_dev.hpp"
 
 using namespace gpcc;
@@ -380,47 +381,18 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     ctx->arena.reset();
     HostTrace ht;
 
-    int64_t pos = 0;
-    int chunk_log2 = 0, L = -1, version = 0;
+    // header and stream directory (container.hpp: plain C++, the part of a decode that the sanitizer build fuzzes)
+    ContainerHdr hdr;
+    GP_TRY(container_parse(in, nbytes, &hdr));
+    const bool v1 = hdr.chunked;
+    const int chunk_log2 = hdr.chunk_log2, version = hdr.version;
+    const int L = hdr.L;
     int64_t lvl_n[MAXLV] = {0};
-    int64_t npts_hdr = -1;
-#define NEED(b) do { if (pos + (int64_t)(b) > nbytes) return fail(GPCC_ERR_FORMAT, "truncated bitstream (need %lld bytes at %lld of %lld)", (long long)(b), (long long)pos, (long long)nbytes); } while (0)
-    NEED(2);
-    const bool v1 = in[0] == 0xFF && in[1] == 0xFF;
-    if (v1) {
-        NEED(8);
-        version = in[2];
-        if (version < 1 || version > 4) return fail(GPCC_ERR_FORMAT, "unknown container version %d", version);
-        chunk_log2 = in[3];
-        if (chunk_log2 < 6 || chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "bad chunk_log2 %d", chunk_log2);
-        *posq_out = (uint16_t)(in[4] | in[5] << 8);
-        L = in[6]; pos = 8;
-        if (L < 1 || L > 21) return fail(GPCC_ERR_FORMAT, "bad level count %d", L);
-        NEED(4 * L + 4);
-        for (int d = 0; d < L; ++d) { lvl_n[d] = get32(in + pos); pos += 4; }
-        npts_hdr = get32(in + pos); pos += 4;
-        if (npts_hdr < 1 || npts_hdr > 8 * lvl_n[L - 1]) return fail(GPCC_ERR_FORMAT, "header: %lld points under %lld finest nodes", (long long)npts_hdr, (long long)lvl_n[L - 1]);
-    } else {
-        *posq_out = (uint16_t)(in[0] | in[1] << 8); pos = 2;
-    }
-    NEED(4);
-    const int64_t bn = (int32_t)get32(in + pos); pos += 4;
-    if (bn <= 0 || bn >= 64) return fail(GPCC_ERR_FORMAT, "bad base length %lld", (long long)bn);
-    NEED(13 * bn + 2);
-    const uint8_t *bxyz = in + pos; pos += 12 * bn;
-    const uint8_t *bocc = in + pos; pos += bn;
-    const int nstreams = in[pos] | in[pos + 1] << 8; pos += 2;
-    if (nstreams % 4) return fail(GPCC_ERR_FORMAT, "stream count %d is not a multiple of 4", nstreams);
-    if (v1) { if (nstreams != 4 * (L - 1) || lvl_n[0] != bn) return fail(GPCC_ERR_FORMAT, "header/stream count mismatch"); }
-    else { L = nstreams / 4 + 1; if (L > 21) return fail(GPCC_ERR_FORMAT, "too many levels"); lvl_n[0] = bn; }
-    std::vector<int64_t> s_off(nstreams), s_len(nstreams);
-    for (int si = 0; si < nstreams; ++si) {
-        NEED(4);
-        const int64_t len = get32(in + pos); pos += 4;
-        NEED(len);
-        s_off[si] = pos; s_len[si] = len; pos += len;
-    }
-#undef NEED
+    for (int d = 0; d < MAXLV; ++d) lvl_n[d] = hdr.lvl_n[d];
+    const int64_t npts_hdr = hdr.npts, bn = hdr.bn;
+    const uint8_t *bxyz = hdr.bxyz, *bocc = hdr.bocc;
+    const std::vector<int64_t> &s_len = hdr.s_len;
+    *posq_out = hdr.posq;
     // ---- base level -> Morton order on the host (< 64 nodes)
     // internal frame (octree.hpp: Tree::bias): 2^20 when the whole cloud lies inside (-2^20, 2^20), else the base level's own
     // minimum per axis -- in leaf units a multiple of 2^L, which is all the tree needs
@@ -485,11 +457,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         RcChunk *lanes = hdesc + desc_used;
         *at = desc_used;
         desc_used += (size_t)4 * pl.nlanes;
-        for (int s = 0; s < 4; ++s) {
-            const int si = 4 * g + s;
-            const char *err = rc_parse_table(in + s_off[si], s_off[si], s_len[si], pl, nc, version, lanes + (size_t)s * pl.nlanes, &win_bytes[g][s]);
-            if (err) return fail(GPCC_ERR_FORMAT, "stream %d: %s", si, err);
-        }
+        GP_TRY(container_level_tables(in, hdr, g, nc, lanes, win_bytes[g]));
         return GPCC_OK;
     };
     // chunked containers know every level's size from the header: all tables go up once, behind the container.  Parsing
@@ -809,20 +777,12 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
     const auto t0 = std::chrono::steady_clock::now();
     // v1 headers carry the node counts; otherwise start from a size-based guess and grow on demand
     size_t want = arena_estimate(std::max<int64_t>(nbytes, 1 << 16), m->K);
-    if (nbytes >= 8 && bytes[0] == 0xFF && bytes[1] == 0xFF && bytes[6] >= 1 && bytes[6] <= 21 && nbytes >= 12 + 4 * (int64_t)bytes[6]) {
+    // the cheap consistency checks BEFORE the header sizes the workspace (container.hpp: container_precheck)
+    int64_t nodes = 0, nmax = 0, npts = 0;
+    const int pre = container_precheck(bytes, nbytes, &nodes, &nmax, &npts);
+    if (pre < 0) return pre;
+    if (pre > 0) {
         const int L = bytes[6];
-        int64_t nodes = 0, nmax = 0, prev = 0;
-        for (int d = 0; d < L; ++d) {
-            const int64_t v = get32(bytes + 8 + 4 * d);
-            // the cheap consistency checks BEFORE the header sizes the workspace: a base level below 64 nodes, at most 8
-            // children per node, and no more symbols than the file can carry (a lane of up to 2^14 symbols costs a table
-            // byte and a payload byte at least) -- a corrupt header of a few hundred bytes must not reserve gigabytes
-            if (v <= 0 || (d == 0 ? v >= 64 : v > 8 * prev)) return fail(GPCC_ERR_FORMAT, "bad node count at level %d", d);
-            nodes += v; nmax = std::max(nmax, v); prev = v;
-        }
-        const int64_t npts = get32(bytes + 8 + 4 * L);
-        if (npts < 1 || npts > 8 * prev) return fail(GPCC_ERR_FORMAT, "header: %lld points under %lld finest nodes", (long long)npts, (long long)prev);
-        if (nodes > (nbytes << 13)) return fail(GPCC_ERR_FORMAT, "header: %lld nodes cannot come from %lld bytes", (long long)nodes, (long long)nbytes);
         want = (size_t)nmax * 2600 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)nbytes + ((size_t)48 << 20);
         if (fused_enabled()) {   // small levels (fused.hpp): the product buffer n K + 1 rows, the plan and its build scratch
             int64_t nf = 0;

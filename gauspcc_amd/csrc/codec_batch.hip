@@ -15,6 +15,7 @@
 #include <functional>
 
 #include "codec_shared.hpp"
+#include "container.hpp"
 #include "forest.hpp"
 #include "rangecoder_dev.hpp"
 
@@ -376,56 +377,15 @@ int encode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *const *
 }
 
 // ---------------------------------------------------------------------------------------------------------------- decode
-struct Hdr {
-    int version = 0, chunk_log2 = 0, L = 0;
-    uint16_t posq = 0;
-    int64_t lvl_n[MAXLV] = {0};
-    int64_t npts = 0, bn = 0;
-    const uint8_t *bxyz = nullptr, *bocc = nullptr;
-    int nstreams = 0;
-    std::vector<int64_t> s_off, s_len;
-};
-
-// header of a chunked container (codec.hip: decode_body, the same checks and messages); BATCH_SOLO for the reference layout
-int parse_chunked(const uint8_t *in, int64_t nbytes, int scene, Hdr *h)
+// header of a chunked container (container.hpp: the parser gpcc_decode runs); BATCH_SOLO for the reference layout
+int parse_chunked(const uint8_t *in, int64_t nbytes, int scene, ContainerHdr *h)
 {
-    int64_t pos = 0;
-#define NEED(b) do { if (pos + (int64_t)(b) > nbytes) return fail(GPCC_ERR_FORMAT, "scene %d: truncated bitstream (need %lld bytes at %lld of %lld)", scene, (long long)(b), (long long)pos, (long long)nbytes); } while (0)
-    NEED(2);
-    if (!(in[0] == 0xFF && in[1] == 0xFF)) return BATCH_SOLO;
-    NEED(8);
-    h->version = in[2];
-    if (h->version < 1 || h->version > 4) return fail(GPCC_ERR_FORMAT, "scene %d: unknown container version %d", scene, h->version);
-    h->chunk_log2 = in[3];
-    if (h->chunk_log2 < 6 || h->chunk_log2 > 14) return fail(GPCC_ERR_FORMAT, "scene %d: bad chunk_log2 %d", scene, h->chunk_log2);
-    h->posq = (uint16_t)(in[4] | in[5] << 8);
-    h->L = in[6]; pos = 8;
-    if (h->L < 1 || h->L > 21) return fail(GPCC_ERR_FORMAT, "scene %d: bad level count %d", scene, h->L);
-    NEED(4 * h->L + 4);
-    for (int d = 0; d < h->L; ++d) { h->lvl_n[d] = get32(in + pos); pos += 4; }
-    h->npts = get32(in + pos); pos += 4;
-    if (h->npts < 1 || h->npts > 8 * h->lvl_n[h->L - 1]) return fail(GPCC_ERR_FORMAT, "scene %d: header: %lld points under %lld finest nodes", scene, (long long)h->npts, (long long)h->lvl_n[h->L - 1]);
-    NEED(4);
-    h->bn = (int32_t)get32(in + pos); pos += 4;
-    if (h->bn <= 0 || h->bn >= 64) return fail(GPCC_ERR_FORMAT, "scene %d: bad base length %lld", scene, (long long)h->bn);
-    NEED(13 * h->bn + 2);
-    h->bxyz = in + pos; pos += 12 * h->bn;
-    h->bocc = in + pos; pos += h->bn;
-    h->nstreams = in[pos] | in[pos + 1] << 8; pos += 2;
-    if (h->nstreams != 4 * (h->L - 1) || h->lvl_n[0] != h->bn) return fail(GPCC_ERR_FORMAT, "scene %d: header/stream count mismatch", scene);
-    for (int g = 0; g + 1 < h->L; ++g)
-        if (h->lvl_n[g + 1] <= 0 || h->lvl_n[g + 1] > 8 * h->lvl_n[g]) return fail(GPCC_ERR_FORMAT, "scene %d: bad node count at level %d", scene, g + 1);
+    const int rc = container_parse(in, nbytes, h);
+    if (rc != GPCC_OK) { char msg[400]; snprintf(msg, sizeof msg, "%s", g_err); return fail(rc, "scene %d: %s", scene, msg); }
+    if (!h->chunked) return BATCH_SOLO;
     int64_t nodes = 0;
     for (int d = 0; d < h->L; ++d) nodes += h->lvl_n[d];
     if (nodes > (nbytes << 13)) return fail(GPCC_ERR_FORMAT, "scene %d: header: %lld nodes cannot come from %lld bytes", scene, (long long)nodes, (long long)nbytes);
-    h->s_off.resize((size_t)h->nstreams); h->s_len.resize((size_t)h->nstreams);
-    for (int si = 0; si < h->nstreams; ++si) {
-        NEED(4);
-        const int64_t len = get32(in + pos); pos += 4;
-        NEED(len);
-        h->s_off[(size_t)si] = pos; h->s_len[(size_t)si] = len; pos += len;
-    }
-#undef NEED
     return GPCC_OK;
 }
 
@@ -435,7 +395,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     ctx->arena.reset();
     HostTrace ht;
     // ---- headers, internal order (deepest scenes first)
-    std::vector<Hdr> H((size_t)K);
+    std::vector<ContainerHdr> H((size_t)K);
     int64_t blob = 0;
     for (int u = 0; u < K; ++u) {
         GP_TRY(parse_chunked(in[u], nbytes[u], u, &H[(size_t)u]));
@@ -464,7 +424,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     int64_t zcur = 0, xymax = 0;
     for (int qi = 0; qi < K; ++qi) {
         const int u = order[(size_t)qi];
-        const Hdr &h = H[(size_t)u];
+        const ContainerHdr &h = H[(size_t)u];
         ForestScene &sc = F.sc[(size_t)qi];
         sc.user = u; sc.L = h.L; sc.npts = h.npts;
         for (int d = 0; d < h.L; ++d) sc.n[d] = h.lvl_n[d];
@@ -587,7 +547,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             desc_at[d] = at;
             for (int qi = 0; qi < F.Kd[d]; ++qi) {
                 const int u = order[(size_t)qi];
-                const Hdr &h = H[(size_t)u];
+                const ContainerHdr &h = H[(size_t)u];
                 const int64_t nc = F.sc[(size_t)qi].n[d];
                 const RcPlan pl = rc_plan(nc, h.chunk_log2, version);
                 const ForestSeg &sg = seg[d][(size_t)qi];
@@ -838,7 +798,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         if ((int64_t)h_leaf[qi] != F.sc[(size_t)qi].npts) return fail(GPCC_ERR_FORMAT, "scene %d: decoded %u points, header says %lld", F.sc[(size_t)qi].user, h_leaf[qi], (long long)F.sc[(size_t)qi].npts);
     if (ctx->prof.on) GP_TRY(prof_collect(ctx, hpairs, L));
     for (int u = 0; u < K; ++u) {
-        const Hdr &h = H[(size_t)u];
+        const ContainerHdr &h = H[(size_t)u];
         n_out[u] = h.npts; posq_out[u] = h.posq;
         if (stats) {
             gpcc_stats *s = &stats[u];

@@ -14,32 +14,15 @@
 
 #include "../../include/gauspcc.h"
 
+#include "errors.hpp"
+
 namespace gpcc {
-
-extern thread_local char g_err[512];
-extern thread_local long long g_launches;   // kernel launch sites passed by this thread (LAUNCH_CHECK): gpcc_debug_launches
-
-inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
-inline int fail(int code, const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
         hipError_t e_ = (expr);                                                                        \
         if (e_ != hipSuccess)                                                                          \
             return gpcc::fail(GPCC_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
-    } while (0)
-
-#define GP_TRY(expr)                 \
-    do {                             \
-        int s_ = (expr);             \
-        if (s_ != GPCC_OK) return s_; \
     } while (0)
 
 // GAUSPCC_DEBUG_SYNC=1 (developer): every launch site prints itself and waits for the device -- the last line on stderr
@@ -56,7 +39,6 @@ inline hipError_t launch_check(const char *file, int line)
 
 constexpr int CB = 1 << 20;        // coordinate bias at level 0
 constexpr int CLIM = CB - 8;       // |coordinate| limit
-constexpr int MAXLV = 24;
 constexpr int NSTAGE = 4;
 constexpr int CH = 32;             // channels the MFMA kernels are specialised for
 

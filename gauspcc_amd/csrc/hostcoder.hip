@@ -22,7 +22,7 @@
 #include <vector>
 
 #include "../../include/gauspcc.h"
-#include "common.hpp"
+#include "errors.hpp"
 
 namespace {
 

@@ -193,3 +193,32 @@ def test_plugin_api_batch_roundtrip(gh, tmp_path):
         assert np.array_equal(got[np.lexsort((got[:, 0], got[:, 1], got[:, 2]))], c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))])
     one = pcc_utils.decompress_point_cloud(paths[0], ckpt, kernel_size=3)
     assert torch.equal(one['point_cloud'], dec[0]['point_cloud'])
+
+
+def test_cli_batch_gives_the_same_files(gh, tmp_path):
+    """--batch 3 (extension: three files through one chain of launches) writes byte-identical .bin files, the same CSV rows in the
+    same order, and PLYs with the same points as the one-at-a-time run (reference file loop: compress_ue_4stage_conv.py:72-75)."""
+    import pandas as pd
+    from gauspcc_amd.cli import compress, decompress, io
+    from gauspcc_amd.pcc_utils import save_ply_ascii_geo
+
+    src = tmp_path / "src"
+    src.mkdir()
+    for i, n in enumerate((20000, 3000, 12000, 7000, 16000)):
+        save_ply_ascii_geo(_cloud(n, seed=70 + i).astype(np.float32), str(src / f"c{i}.ply"))
+    common = ["--channels", "32", "--kernel_size", "3", "--ckpt", "synthetic:3"]
+    tabs, recs = [], []
+    for batch in (1, 3):
+        out, rec, res = (tmp_path / f"{n}{batch}" for n in ("bin", "rec", "res"))
+        assert compress.main(["--input_glob", str(src), "--output_folder", str(out), "--is_data_pre_quantized", "1", "--posQ", "1",
+                              "--resultdir", str(res), "--prefix", "t", "--batch", str(batch)] + common) == 0
+        assert decompress.main(["--input_glob", str(out / "*.bin"), "--output_folder", str(rec), "--is_data_pre_quantized", "1", "--batch", str(batch)] + common) == 0
+        tabs.append(pd.read_csv(res / "t_data5.csv"))
+        recs.append((out, rec))
+    assert tabs[0]["filedir"].tolist() == tabs[1]["filedir"].tolist() == [f"c{i}.ply" for i in range(5)] + ["avg"]
+    assert tabs[0]["file_size_bits"].tolist() == tabs[1]["file_size_bits"].tolist()
+    for i in range(5):
+        a, b = (open(o / f"c{i}.ply.bin", "rb").read() for o, _ in recs)
+        assert a == b
+        pa, pb = (io.read_points(str(r / f"c{i}.ply.bin.ply")) for _, r in recs)
+        assert np.array_equal(pa, pb)

@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--chunk-log2", type=int, default=11)
     ap.add_argument("--scenes-per-gpu", type=int, default=1, help="independent scenes each rank codes per step, one after the other (weak scaling: scene i of the "
                     "batch -> rank i mod N, gauspcc_amd.dist.scenes_for_rank; BASELINE configs[3] is --gpus 8 with one or more scenes per GPU)")
+    ap.add_argument("--solo-scenes", action="store_true", help="with --scenes-per-gpu K > 1: code a rank's K scenes one after the other (gpcc_encode / gpcc_decode) instead of "
+                    "through one chain of launches (gpcc_encode_batch / gpcc_decode_batch, the default: BASELINE configs[3] is a BATCHED encode)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = the fastest of 8 / 16 / 32 / 64 / 128 / all cores on a short calibration run; a positive value pins the count, capped by the cores this process may use)")
     ap.add_argument("--measure-traffic", action="store_true", help="(informative) leave roofline.traffic null instead of quoting profiles/: run tools/pmc_traffic.sh for a fresh figure")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
@@ -112,7 +114,7 @@ def main():
 
     from gauspcc_amd import _lib, runtime
     from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed, scenes_for_rank
-    from gauspcc_amd.pcc_utils import _decode_bytes, _encode_view
+    from gauspcc_amd.pcc_utils import _decode_batch, _decode_bytes, _encode_batch, _encode_view
     from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
 
     k = args.kernel_size
@@ -134,8 +136,22 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    batch_mode = K > 1 and not args.solo_scenes and args.chunk_log2 != 0
+
     def step():
         te = td = 0.0
+        if batch_mode:
+            # the rank's K scenes through ONE chain of launches; `data` / `dec` of the step are scene 0's (checked after the timed region)
+            t0 = time.perf_counter()
+            views, sts, _ = _encode_batch(xs_batch, model, args.chunk_log2, [1] * K, view=True)
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            decs, _, _, _ = _decode_batch(views, model, device)
+            torch.cuda.synchronize(device)
+            t2 = time.perf_counter()
+            st0 = sts[0]
+            st0.coded_nodes = sum(s_.coded_nodes for s_ in sts)
+            return views[0], st0, decs[0], t1 - t0, t2 - t1
         for xi in reversed(xs_batch):   # scene 0 last: `data` / `dec` of the step are its (checked after the timed region)
             t0 = time.perf_counter()
             data, st = _encode_view(xi, model, args.chunk_log2, 1)   # the bitstream stays in the library's pinned host buffer
@@ -369,6 +385,7 @@ def main():
                 "workload": "GausPcgc encode+decode of one synthetic anchor cloud per GPU (BASELINE configs[1])",
                 "points_per_scene": args.points,
                 "scenes_per_gpu": K,
+                "scenes_share_launches": bool(batch_mode),   # K > 1: gpcc_encode_batch / gpcc_decode_batch (csrc/forest.hpp)
                 "channels": 32,
                 "kernel_size": k,
                 "container": f"v{data[2]} (per-level chunks of two coder lanes, chunk_log2<={args.chunk_log2}" + ("; carry-propagating range coder in the lanes)" if data[2] >= 4 else ")") if args.chunk_log2 else "v0 (reference layout)",
@@ -392,6 +409,7 @@ def main():
             "sizes": sizes,
             "batched": batched,
             "coded_nodes": int(allstats[0, 3]),
+            "ranks": [{"bytes": int(r_[0]), "coded_nodes": int(r_[3]), "enc_ms": round(float(r_[1]) * 1e3, 3), "dec_ms": round(float(r_[2]) * 1e3, 3)} for r_ in allstats],
             "roundtrip_bit_identical": True,
             "roofline": {
                 "kernel": "k_sparse_conv",

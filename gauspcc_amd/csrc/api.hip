@@ -78,6 +78,8 @@ extern "C" int gpcc_ctx_bytes(const gpcc_ctx *c, int64_t *device_bytes, int64_t 
 {
     if (!c) return fail(GPCC_ERR_ARG, "null argument");
     size_t d = c->arena.cap + c->conv_products_cap * sizeof(float) + (c->dbg_dev ? 8 * (size_t)4096 : 0);
+    d += c->scan_states.size() * (8 * (size_t)65536 + 256);      // single-pass scan states (primitives.hip: scan_state; at most 8)
+    if (c->fused_state) d += 2 * 3456 + 128;                     // grid-barrier blocks of the persistent launches (fused.hip)
     for (const auto &e : c->dbg_caps) d += e.cap;
     if (device_bytes) *device_bytes = (int64_t)d;
     if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap + c->hbatch.cap);

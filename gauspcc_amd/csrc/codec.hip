@@ -791,6 +791,7 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
         }
     }
     want = arena_scaled(want);
+    ctx->fused_note_decode();   // (re-arms the persistent small-level path some decodes after a timeout)
     int rc = GPCC_OK;
     const int32_t *xyz = nullptr;
     for (int attempt = 0; attempt < 6; ++attempt) {
@@ -798,7 +799,7 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
         rc = decode_body(ctx, m, bytes, nbytes, &xyz, n_out, posq_f16_out, stats, st, out_user, out_cap);
         if (rc == DEC_RETRY_UNFUSED) {
             static const bool loud = getenv("GAUSPCC_FUSED_QUIET") == nullptr;
-            if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; this context decodes on the launch-per-layer path from now on\n", ctx->device);
+            if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; the launch-per-layer path serves this context's next %d decodes\n", ctx->device, ctx->fused_rearm_after);
             attempt -= 1;
             continue;
         }

@@ -907,6 +907,7 @@ extern "C" int gpcc_decode_batch(gpcc_ctx *ctx, const gpcc_model *m, const uint8
             nodes += mine; npts += np;
         }
         if (ok) {
+            ctx->fused_note_decode();
             int64_t nmax = 0;
             for (int d = 0; d < MAXLV; ++d) nmax = std::max(nmax, nmax_sum[d]);
             size_t want = arena_scaled_b((size_t)nmax * 2700 + (size_t)nodes * (size_t)(4 * 125 + m->K * 81 / 16 + 96) + (size_t)npts * 32 + (size_t)total_bytes + (size_t)nscenes * 65536 + ((size_t)48 << 20));
@@ -920,7 +921,7 @@ extern "C" int gpcc_decode_batch(gpcc_ctx *ctx, const gpcc_model *m, const uint8
                 rc = decode_batch_body(ctx, m, bytes, nbytes, nscenes, xyz_dev, capacity_points, n_out, posq_f16_out, stats, st);
                 if (rc == BATCH_RETRY_UNFUSED) {
                     static const bool loud = getenv("GAUSPCC_FUSED_QUIET") == nullptr;
-                    if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; this context decodes on the launch-per-layer path from now on\n", ctx->device);
+                    if (loud) fprintf(stderr, "[gauspcc] a persistent small-level launch timed out on device %d; the launch-per-layer path serves this context's next %d decodes\n", ctx->device, ctx->fused_rearm_after);
                     attempt -= 1;
                     continue;
                 }

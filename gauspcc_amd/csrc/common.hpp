@@ -202,6 +202,14 @@ struct gpcc_ctx {
     void *fused_state = nullptr;
     int fused_flip = 0;
     bool fused_off = false;
+    // a timeout may have been transient (another process's long kernel held the CUs): the persistent path is tried again after
+    // fused_rearm_after decodes on the launch-per-layer path, and the wait doubles with every further timeout (32, 64, ... 4096)
+    int fused_off_decodes = 0, fused_rearm_after = 32;
+    void fused_note_decode()
+    {
+        if (!fused_off) return;
+        if (++fused_off_decodes >= fused_rearm_after) { fused_off = false; fused_off_decodes = 0; fused_rearm_after = fused_rearm_after < 4096 ? 2 * fused_rearm_after : 4096; }
+    }
     hipEvent_t fused_ev = nullptr;   // recorded behind every persistent launch of this context while other contexts use the device (fused.hip: FusedGate)
     // developer trace (gpcc_debug_trace_*): checksums of intermediate buffers of a decode, one (tag, sum) per mark, computed
     // on the stream that produced the buffer -- to find the first stage whose output differs between two runs

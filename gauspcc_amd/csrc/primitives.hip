@@ -288,6 +288,16 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
 {
     for (auto &ss : ctx->scan_states)
         if (ss.st == st) { *out = &ss; return GPCC_OK; }
+    // A caller that cycles through raw stream handles must not grow this for ever (a context's own calls use its three streams and
+    // the caller's): beyond SCAN_STATES_MAX the oldest state is retired -- its stream is drained first, so no scan of it is in flight.
+    constexpr size_t SCAN_STATES_MAX = 8;
+    if (ctx->scan_states.size() >= SCAN_STATES_MAX) {
+        gpcc_ctx::ScanState old = ctx->scan_states.front();
+        (void)hipStreamSynchronize(old.st);   // (a destroyed stream reports an error here: nothing of it is in flight either)
+        (void)hipGetLastError();
+        if (old.status) (void)hipFree(old.status);
+        ctx->scan_states.erase(ctx->scan_states.begin());
+    }
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
     void *p = nullptr;
     HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + 256));

@@ -105,9 +105,16 @@ def _names(pre_path_name, stem, steps):
     return [os.path.join(pre_path_name, f'{stem}.b').replace('.b', f'_{s}.b') for s in range(steps)]
 
 
+def get_time():
+    """(:43-46) a device-wide sync, then the wall clock: the spans of the `Encoded time in s:` / `Decoded time in s:` lines."""
+    torch.cuda.synchronize()
+    return time.time()
+
+
 @torch.no_grad()
 def conduct_encoding(self, pre_path_name, ckpt_path=None):
     t_codec = 0
+    t_total_0 = get_time()
     torch.cuda.synchronize(); t1 = time.time()
     print('Start encoding ...')
     mask_anchor = self.get_mask_anchor.to(torch.bool)[:, 0]  # N
@@ -118,12 +125,14 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
     _mask = self.get_mask[mask_anchor]           # N, K, 1
     N = _anchor.shape[0]
 
+    t_anchor_0 = get_time()     # (:1234-1248) `anchor` = the order + compress_point_cloud: the in-pipeline timing of the geometry codec
     _anchor_int = torch.round(_anchor / self.voxel_size)
     sorted_indices = calculate_morton_order(_anchor_int)
     _anchor_int = _anchor_int[sorted_indices]
     npz_path = os.path.join(pre_path_name, 'xyz_pcc.bin')
     out = compress_point_cloud(_anchor_int, ckpt_path or default_ckpt_path(), npz_path)
     bits_xyz = out['file_size_bits']
+    t_anchor = get_time() - t_anchor_0
 
     _anchor = _anchor_int * self.voxel_size
     _feat = _feat[sorted_indices]
@@ -144,6 +153,7 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
     torch.cuda.synchronize(); t0 = time.time()
     with deferred_writes():      # the 7 x 334 slice files are written while the next attribute is coded; all on disk when the block ends
         # feat: quantised once (:1298-1299), then group by group under the mixture whose second component the channel-context MLP predicts
+        t_feature_0 = get_time()
         feat = ste_multistep(_feat, c["Q_feat"], self._anchor_feat.mean())
         bit_feat = 0
         for cc in range(N_GROUPS):
@@ -151,12 +161,16 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
             x = feat[:, cc * GROUP:cc * GROUP + GROUP].contiguous().view(-1)
             names = [fn.replace('.b', f'_{cc}.b') for fn in _names(pre_path_name, 'feat', steps)]
             bit_feat += sum(encoder_gaussian_mixed_slices(x, means, scales, probs, q, [b * GROUP for b in bounds], names, chunk_size=50_0000))
+        t_feature = get_time() - t_feature_0
 
+        t_scaling_0 = get_time()
         Q = c["Q_scaling"].reshape(-1)
         scaling = ste_multistep(_scaling.reshape(-1), Q, self.get_scaling.mean())
         bit_scaling = sum(encoder_gaussian_slices(scaling, c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), Q, [b * 6 for b in bounds],
                                                   _names(pre_path_name, 'scaling', steps), chunk_size=10_0000))
+        t_scaling = get_time() - t_scaling_0
 
+        t_offset_0 = get_time()
         mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
         Q = c["Q_offsets"].reshape(-1)
         offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, self._offset.mean())
@@ -164,15 +178,21 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
         off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
         bit_offsets = sum(encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask], off_bounds,
                                                   _names(pre_path_name, 'offsets', steps), chunk_size=10_0000))
+        t_offset = get_time() - t_offset_0
     torch.cuda.synchronize(); t_codec += time.time() - t0
 
     bit_anchor = bits_xyz
+    t_hash_0 = get_time()
     hash_embeddings = self.get_encoding_params()  # {-1, 1}
     if self.ste_binary:
         bit_hash = encoder(((hash_embeddings.view(-1) + 1) / 2), file_name=hash_b_name)
     else:
         bit_hash = hash_embeddings.numel() * 32
+    t_hash = get_time() - t_hash_0
+    t_mask_0 = get_time()
     bit_masks = encoder(_mask, file_name=masks_b_name)
+    t_mask = get_time() - t_mask_0
+    t_total = get_time() - t_total_0
 
     torch.cuda.synchronize(); t2 = time.time()
     print('encoding time:', t2 - t1)
@@ -189,11 +209,23 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
                f"MLPs {round(mlp_bits/bit2MB_scale, 4)}, " \
                f"Total {round((bit_anchor + bit_feat + bit_scaling + bit_offsets + bit_hash + bit_masks + mlp_bits)/bit2MB_scale + 32*3*2/bit2MB_scale, 4)}, " \
                f"EncTime {round(t2 - t1, 4)}"
-    return log_info
+    # (:1384-1392) per-component spans, the same seven fields.  The reference codes slice by slice, so its feat / scaling / offsets spans
+    # are sums over the slices; here an attribute's slices are one call each, and the slice files of an attribute are still being written
+    # (deferred_writes) while the next attribute's span runs -- the spans add up to less than `Total`, which covers the flush as well.
+    log_info_time = f"\nEncoded time in s: " \
+               f"anchor {round(t_anchor, 4)}, " \
+               f"feat {round(t_feature, 4)}, " \
+               f"scaling {round(t_scaling, 4)}, " \
+               f"offsets {round(t_offset, 4)}, " \
+               f"hash {round(t_hash, 4)}, " \
+               f"masks {round(t_mask, 4)}, " \
+               f"Total {round(t_total, 4)}"
+    return log_info + log_info_time
 
 
 @torch.no_grad()
 def conduct_decoding(self, pre_path_name, ckpt_path=None):
+    t_total_0 = get_time()
     torch.cuda.synchronize(); t1 = time.time()
     print('Start decoding ...')
     self.x_bound_min = torch.load(os.path.join(pre_path_name, 'x_bound_min.pkl'))
@@ -203,34 +235,45 @@ def conduct_decoding(self, pre_path_name, ckpt_path=None):
     hash_b_name = os.path.join(pre_path_name, 'hash.b')
     masks_b_name = os.path.join(pre_path_name, 'masks.b')
 
+    t_anchor_0 = get_time()     # (:1422-1438) decompress_point_cloud + the order
     npz_path = os.path.join(pre_path_name, 'xyz_pcc.bin')
     anchor_decoded = decompress_point_cloud(npz_path, ckpt_path or default_ckpt_path())
     _anchor_int_dec = anchor_decoded['point_cloud'].to(dev)
     sorted_indices = calculate_morton_order(_anchor_int_dec)
     _anchor_int_dec = _anchor_int_dec[sorted_indices]
     anchor_decoded = _anchor_int_dec * self.voxel_size
+    t_anchor = get_time() - t_anchor_0
     N = anchor_decoded.shape[0]
     steps = (N // MAX_BATCH_SIZE) if (N % MAX_BATCH_SIZE) == 0 else (N // MAX_BATCH_SIZE + 1)
 
+    t_mask_0 = get_time()
     masks_decoded = decoder(N * n_off, masks_b_name, device=dev).to(torch.float32).view(-1, n_off, 1)   # {0, 1}
+    t_mask = get_time() - t_mask_0
+    t_hash_0 = get_time()
     if self.ste_binary:
         N_hash = torch.zeros_like(self.get_encoding_params()).numel()
         hash_embeddings = decoder(N_hash, hash_b_name, device=dev)  # {0, 1}
         hash_embeddings = (hash_embeddings * 2 - 1).to(torch.float32).view(-1, self.n_features_per_level)
         _install_hash(self, hash_embeddings)      # the context below must run on the decoded tables (bit-identical for {-1, 1})
+    t_hash = get_time() - t_hash_0
 
     c = _context(self, anchor_decoded)
     bounds = [min(s * MAX_BATCH_SIZE, N) for s in range(steps + 1)]
     # feat: the autoregressive chain over the five channel groups (:1484-1504) -- group cc of every anchor at once
+    t_feature_0 = get_time()
     feat_decoded = torch.zeros(size=[N, self.feat_dim], device=dev, dtype=torch.float32)
     for cc in range(N_GROUPS):
         means, scales, probs, q = _group_mixture(self, c, feat_decoded, cc)
         names = [fn.replace('.b', f'_{cc}.b') for fn in _names(pre_path_name, 'feat', steps)]
         dec = decoder_gaussian_mixed_slices(means, scales, probs, q, [b * GROUP for b in bounds], names)
         feat_decoded[:, cc * GROUP:cc * GROUP + GROUP] = dec.view(N, GROUP)
+    t_feature = get_time() - t_feature_0
 
+    t_scaling_0 = get_time()
     scaling_decoded = decoder_gaussian_slices(c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), c["Q_scaling"].reshape(-1),
                                               [b * 6 for b in bounds], _names(pre_path_name, 'scaling', steps)).view(N, 6)
+    t_scaling = get_time() - t_scaling_0
+    t_offset_0 = get_time()
     mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
     kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
     off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
@@ -239,6 +282,8 @@ def conduct_decoding(self, pre_path_name, ckpt_path=None):
     offsets_decoded[mask] = decoder_gaussian_slices(mo[mask], c["scale_offsets"].reshape(-1)[mask], c["Q_offsets"].reshape(-1)[mask], off_bounds,
                                                     _names(pre_path_name, 'offsets', steps))
     offsets_decoded = offsets_decoded.view(N, n_off, 3)
+    t_offset = get_time() - t_offset_0
+    t_total = get_time() - t_total_0
 
     torch.cuda.synchronize(); t2 = time.time()
     print('decoding time:', t2 - t1)
@@ -254,4 +299,13 @@ def conduct_decoding(self, pre_path_name, ckpt_path=None):
     self._scaling = nn.Parameter(scaling_decoded)
     self._mask = nn.Parameter(_mask)
     print('Parameters are successfully replaced by decoded ones!')
-    return f"\nDecTime {round(t2 - t1, 4)}"
+    log_info = f"\nDecTime {round(t2 - t1, 4)}"
+    log_info_time = f"\nDecoded time in s: " \
+                    f"anchor {round(t_anchor, 4)}, " \
+                    f"feat {round(t_feature, 4)}, " \
+                    f"scaling {round(t_scaling, 4)}, " \
+                    f"offsets {round(t_offset, 4)}, " \
+                    f"hash {round(t_hash, 4)}, " \
+                    f"masks {round(t_mask, 4)}, " \
+                    f"Total {round(t_total, 4)}"
+    return log_info + log_info_time

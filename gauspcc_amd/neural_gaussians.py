@@ -1,5 +1,9 @@
-"""generate_neural_gaussians of HAC (src/gs_compress/HAC/gaussian_renderer/__init__.py:25-172; the same function in
-HAC-plus / TC-GS / CAT-3DGS) for RD evaluation -- SURVEY.md §8(f) row 2: anchors -> the Gaussians the rasteriser draws.
+"""generate_neural_gaussians of HAC (src/gs_compress/HAC/gaussian_renderer/__init__.py:25-172) and of HAC++
+(src/gs_compress/HAC-plus/gaussian_renderer/__init__.py:25-205) for RD evaluation -- SURVEY.md §8(f) row 2: anchors -> the
+Gaussians the rasteriser draws.  The two differ in two places, both handled here: an un-decoded HAC++ model's mlp_grid has the extra
+`prob` head (a TEN-way split, :121-123, against HAC's nine, :103-105), and HAC++ applies the binary offset masks AFTER the opacity
+test (:188-205) where HAC multiplies them into the opacity before it (:136-137) -- the same set of Gaussians with the same values
+(the masks are {0, 1}), which is what gsnn_generate computes.
 
     from gauspcc_amd.neural_gaussians import generate_neural_gaussians
     xyz, color, opacity, scaling, rot, time_sub = generate_neural_gaussians(viewpoint_camera, pc, visible_mask)
@@ -16,7 +20,21 @@ import time
 import torch
 
 from . import _lib, runtime
-from .hac_codec import _context, ste_multistep
+from .hac_codec import Q_FEAT, Q_OFFSETS, Q_SCALING, grid_mlp, ste_multistep
+
+
+def quant_steps(pc, anchor):
+    """Step sizes of the three attributes from the context model, for an un-decoded model (HAC :103-111, HAC++ :121-132): the last three
+    columns of mlp_grid's output whatever heads sit in front of them -- nine-way split (HAC: mean, scale, 2 x scaling, 2 x offsets) or
+    ten-way (HAC++: + prob).  Returns (Q_feat (N, F), Q_scaling (N, 6), Q_offsets (N, 3 K)); HAC++ views the last as (N, K, 3), the same values."""
+    F, K = pc.feat_dim, pc.n_offsets
+    out = grid_mlp(pc, pc.calc_interp_feat(anchor))
+    nine, ten = 2 * F + 12 + 6 * K + 3, 3 * F + 12 + 6 * K + 3
+    if out.shape[1] not in (nine, ten):
+        raise ValueError(f"mlp_grid returns {out.shape[1]} columns; HAC has {nine} (feat_dim {F}, {K} offsets), HAC++ {ten}")
+    qa_f, qa_s, qa_o = out[:, -3:-2], out[:, -2:-1], out[:, -1:]
+    return ((Q_FEAT * (1 + torch.tanh(qa_f.contiguous()))).repeat(1, F), (Q_SCALING * (1 + torch.tanh(qa_s.contiguous()))).repeat(1, 6),
+            (Q_OFFSETS * (1 + torch.tanh(qa_o.contiguous()))).repeat(1, 3 * K))
 
 
 def _linears(seq):
@@ -40,10 +58,10 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     binary_grid_masks = pc.get_mask[visible_mask]
     if not pc.decoded_version:      # quantise as the encoder would (:103-114)
         torch.cuda.synchronize(); t1 = time.time()
-        c = _context(pc, anchor)
-        feat = ste_multistep(feat, c["Q_feat"], pc._anchor_feat.mean())
-        grid_scaling = ste_multistep(grid_scaling, c["Q_scaling"], pc.get_scaling.mean())
-        grid_offsets = ste_multistep(grid_offsets.reshape(anchor.shape[0], -1), c["Q_offsets"], pc._offset.mean()).view_as(grid_offsets)
+        q_feat, q_scaling, q_offsets = quant_steps(pc, anchor)
+        feat = ste_multistep(feat, q_feat, pc._anchor_feat.mean())
+        grid_scaling = ste_multistep(grid_scaling, q_scaling, pc.get_scaling.mean())
+        grid_offsets = ste_multistep(grid_offsets.reshape(anchor.shape[0], -1), q_offsets, pc._offset.mean()).view_as(grid_offsets)
         torch.cuda.synchronize(); time_sub = time.time() - t1
     n, K, F = anchor.shape[0], pc.n_offsets, pc.feat_dim
     dev = anchor.device

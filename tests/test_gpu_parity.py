@@ -398,6 +398,19 @@ def test_codec_bitstream_identical_to_oracle_150k(gh, orc, dev_model_k5, synth_m
     assert np.array_equal(dec, orc.decode(synth_model_k5, ref)[0])
 
 
+@pytest.mark.parametrize("n,seed", [(30_000, 21), (500_000, 22)])
+def test_codec_bitstream_identical_to_oracle_class_boundaries(gh, orc, n, seed, dev_model_k5, synth_model_k5):
+    """Clouds either side of the conv class boundaries (network.hip: conv_pick_rows / conv_pick_height switch kernels and block heights at
+    16 k / 24 k / 96 k / 192 k nodes per level): 30 k points put the finest levels between the cooperative and the 255-row classes, 500 k points
+    above the last boundary.  With 10 k, 150 k and 1 M (above / below) every class has an oracle-checked cloud on each side."""
+    pts = _cloud(n, seed=seed)
+    data, st = gh.encode(dev_model_k5, pts, 11)
+    ref = orc.encode(synth_model_k5, pts, chunk_log2=11)
+    assert data == ref
+    dec, _, _ = gh.decode(dev_model_k5, data)
+    assert np.array_equal(dec, orc.decode(synth_model_k5, ref, cap_pts=n)[0])
+
+
 def test_codec_bitstream_identical_to_oracle_1m(gh, orc, dev_model_k5, synth_model_k5):
     """BASELINE configs[1] at its full size -- the cloud bench.py times: 1 M points, k = 5, C = 32, container v4 with chunk_log2 = 11 (bench.py's default).  The device
     writes the oracle's bytes and decodes to the oracle's points in the oracle's order (the oracle needs ~15 s of the box's

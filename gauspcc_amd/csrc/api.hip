@@ -241,19 +241,21 @@ extern "C" int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst, const void *src, int64_
 extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, const float *const *t, gpcc_model **out)
 {
     if (!ctx || !t || !out) return fail(GPCC_ERR_ARG, "null argument");
-    if (channels != CH) return fail(GPCC_ERR_ARG, "the gfx950 kernels are specialised for channels = 32 (got %d)", channels);
+    if (channels != 16 && channels != CH && channels != 64) return fail(GPCC_ERR_ARG, "channels must be 16, 32 or 64 (got %d)", channels);
     if (kernel_size != 3 && kernel_size != 5 && kernel_size != 7) return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
     for (int i = 0; i < GPCC_T_COUNT; ++i) if (!t[i]) return fail(GPCC_ERR_ARG, "tensor %d is null", i);
     HIP_TRY(hipSetDevice(ctx->device));
-    const int C = CH, K = kernel_size * kernel_size * kernel_size;
+    const int C = channels, K = kernel_size * kernel_size * kernel_size;
+    const bool fast = C == CH;   // 32: MFMA fragments and the physical channel order; 16 / 64: upstream layouts (network_any.hip)
     std::vector<float> h;
     std::vector<size_t> off;
-    auto push_rows_phys = [&](const float *src, int rows) {  // (rows, C) logical -> physical channel order
+    auto push_rows_phys = [&](const float *src, int rows) {  // (rows, C) logical -> physical channel order (32 channels only)
         off.push_back(h.size());
         size_t b = h.size();
         h.resize(b + (size_t)rows * C);
         for (int r = 0; r < rows; ++r)
-            for (int c = 0; c < C; ++c) h[b + (size_t)r * C + phys_of(c)] = src[(size_t)r * C + c];
+            for (int c = 0; c < C; ++c) h[b + (size_t)r * C + (fast ? phys_of(c) : c)] = src[(size_t)r * C + c];
+        while (h.size() % 64) h.push_back(0.0f);
     };
     auto push_raw = [&](const float *src, size_t count) {
         off.push_back(h.size());
@@ -262,6 +264,7 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     };
     push_rows_phys(t[GPCC_T_PRIOR_EMB], 256);
     for (int ci = 0; ci < 18; ++ci) {  // (K, C, C) -> MFMA B fragments per offset
+        if (!fast) { push_raw(t[GPCC_T_CONV0 + ci], (size_t)K * C * C); continue; }
         off.push_back(h.size());
         size_t b = h.size();
         h.resize(b + 3 * (size_t)K * C * C);
@@ -274,7 +277,7 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB1 + s], (size_t)C);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW2 + s], (size_t)STAGE_M[s] * C);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HB2 + s], (size_t)STAGE_M[s]);
-    for (int s = 0; s < 4; ++s) {   // MFMA fragments of the heads: B[k][c] = W[c][k] through the conv fragment layout
+    for (int s = 0; s < 4 && fast; ++s) {   // MFMA fragments of the heads: B[k][c] = W[c][k] through the conv fragment layout
         off.push_back(h.size());
         const size_t b = h.size();
         h.resize(b + HEAD_FRAG_FLOATS, 0.0f);
@@ -303,7 +306,7 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
     for (int s = 0; s < 4; ++s) m->hb1[s] = m->slab + off[i++];
     for (int s = 0; s < 4; ++s) m->hw2[s] = m->slab + off[i++];
     for (int s = 0; s < 4; ++s) m->hb2[s] = m->slab + off[i++];
-    for (int s = 0; s < 4; ++s) m->hfrag[s] = m->slab + off[i++];
+    for (int s = 0; s < 4; ++s) m->hfrag[s] = fast ? m->slab + off[i++] : nullptr;
     for (int s = 0; s < 3; ++s) m->semb[s] = m->slab + off[i++];
     *out = m;
     return GPCC_OK;
@@ -491,6 +494,15 @@ __global__ __launch_bounds__(TB) void k_rows_out(const float *__restrict__ in, c
     const int64_t i = t >> 5; const int c = (int)(t & 31);
     out[(int64_t)m2r[i] * 32 + c] = in[i * 32 + phys_of(c)];
 }
+// the same for any channel count, logical order on both sides (network_any.hip); dir 0: raster -> Morton, 1: Morton -> raster
+__global__ __launch_bounds__(TB) void k_rows_any(const float *__restrict__ in, const uint32_t *__restrict__ m2r, int64_t n, int C, int dir, float *__restrict__ out)
+{
+    int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= n * C) return;
+    const int64_t i = t / C; const int c = (int)(t % C);
+    if (dir == 0) out[i * C + c] = in[(int64_t)m2r[i] * C + c];
+    else out[(int64_t)m2r[i] * C + c] = in[i * C + c];
+}
 
 }  // namespace
 
@@ -551,12 +563,14 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
                            const float *w_host, const float *res_dev, int relu, float *out_dev, int64_t *pairs_out, void *stream)
 {
     if (!ctx || !xyz_sorted || !in_dev || !w_host || !out_dev) return fail(GPCC_ERR_ARG, "null argument");
-    if (channels != CH) return fail(GPCC_ERR_ARG, "channels must be 32");
+    if (channels != 16 && channels != CH && channels != 64) return fail(GPCC_ERR_ARG, "channels must be 16, 32 or 64");
     if (kernel_size != 3 && kernel_size != 5 && kernel_size != 7) return fail(GPCC_ERR_ARG, "kernel_size must be 3, 5 or 7");
+    if (channels != CH && (relu & 2)) return fail(GPCC_ERR_ARG, "the pair-plan convolution is the 32-channel path");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int K = kernel_size * kernel_size * kernel_size;
-    size_t want = (size_t)n * (size_t)(4 * 125 * 2 + K * 81 / 16 + 1300) + ((size_t)32 << 20);
+    const int C = channels;
+    size_t want = (size_t)n * (size_t)(4 * 125 * 2 + K * 81 / 16 + 1300 + 12 * C) + (size_t)K * C * C * 4 + ((size_t)32 << 20);
     for (int attempt = 0;; ++attempt) {
         GP_TRY(ctx->arena.reserve(want));
         ctx->arena.reset();
@@ -589,18 +603,26 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             ConvTiles tiles;
             const int64_t zero_base[1] = {0};
             GP_TRY(tiles_view(ctx, st, pool, T.L - 1, T.L, zero_base, &tiles));
-            // weights -> B-fragment order
-            std::vector<float> wf((size_t)K * 3072);
-            conv_weight_fragments(w_host, K, wf.data());
-            conv_weight_fragments_t(w_host, K, wf.data() + (size_t)K * 1024);
-            conv_weight_fragments_q(w_host, K, wf.data() + (size_t)K * 2048);
-            TAKE(dw, float, (size_t)K * 3072); TAKE(xin, float, n * 32); TAKE(xres, float, n * 32); TAKE(xout, float, n * 32);
+            // weights -> B-fragment order (32 channels); other widths keep the upstream (K, C, C) layout (network_any.hip)
+            std::vector<float> wf(C == CH ? (size_t)K * 3072 : (size_t)K * C * C);
+            if (C == CH) {
+                conv_weight_fragments(w_host, K, wf.data());
+                conv_weight_fragments_t(w_host, K, wf.data() + (size_t)K * 1024);
+                conv_weight_fragments_q(w_host, K, wf.data() + (size_t)K * 2048);
+            } else std::copy(w_host, w_host + (size_t)K * C * C, wf.begin());
+            TAKE(dw, float, wf.size()); TAKE(xin, float, n * C); TAKE(xres, float, n * C); TAKE(xout, float, n * C);
             HIP_TRY(hipMemcpyAsync(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
-            k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(in_dev, fin->m2r, n, xin);
-            if (res_dev) k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(res_dev, fin->m2r, n, xres);
+            if (C == CH) {
+                k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(in_dev, fin->m2r, n, xin);
+                if (res_dev) k_rows_in<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(res_dev, fin->m2r, n, xres);
+            } else {
+                k_rows_any<<<(unsigned)cdiv(n * C, TB), TB, 0, st>>>(in_dev, fin->m2r, n, C, 0, xin);
+                if (res_dev) k_rows_any<<<(unsigned)cdiv(n * C, TB), TB, 0, st>>>(res_dev, fin->m2r, n, C, 0, xres);
+            }
             LAUNCH_CHECK();
             ConvBatch cb = {};
+            cb.C = C;
             cb.job[0] = ConvJob{xin, dw, res_dev ? xres : nullptr, xout};
             if (relu & 2) {
                 // test knob: the pair-plan form of the decoder's small levels (fused.hpp) -- products + ordered sums on a level-wide plan
@@ -611,7 +633,8 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
                 GP_TRY(plan_conv(st, plan, cb.job[0], P, relu & 1));
             } else
             GP_TRY(sparse_conv(nullptr, -1, st, cb, 1, tiles, n, relu & 1));
-            k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
+            if (C == CH) k_rows_out<<<(unsigned)cdiv(n * 32, TB), TB, 0, st>>>(xout, fin->m2r, n, out_dev);
+            else k_rows_any<<<(unsigned)cdiv(n * C, TB), TB, 0, st>>>(xout, fin->m2r, n, C, 1, out_dev);
             LAUNCH_CHECK();
             unsigned long long hpairs = 0;
             HIP_TRY(hipMemcpyAsync(&hpairs, pairs + (T.L - 1), 8, hipMemcpyDeviceToHost, st));
@@ -628,18 +651,21 @@ extern "C" int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int c
                              const float *w2, const float *b2, float *prob_dev, uint16_t *cdf_dev, void *stream)
 {
     if (!ctx || !x_dev || !w1 || !b1 || !w2 || !b2) return fail(GPCC_ERR_ARG, "null argument");
-    if (channels != CH) return fail(GPCC_ERR_ARG, "channels must be 32");
+    if (channels != 16 && channels != CH && channels != 64) return fail(GPCC_ERR_ARG, "channels must be 16, 32 or 64");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     GP_TRY(ctx->arena.reserve((size_t)1 << 20));
     ctx->arena.reset();
-    TAKE(dw, float, 32 * 32 + 32 + 16 * 32 + 16 + 64);
-    HIP_TRY(hipMemcpyAsync(dw, w1, 4 * 1024, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dw + 1024, b1, 4 * 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dw + 1056, w2, 4 * (size_t)m * 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dw + 1056 + 512, b2, 4 * (size_t)m, hipMemcpyHostToDevice, st));
+    const int C = channels;
+    const size_t o_b1 = (size_t)C * C, o_w2 = o_b1 + C, o_b2 = o_w2 + 16 * (size_t)C;
+    TAKE(dw, float, o_b2 + 16 + 64);
+    HIP_TRY(hipMemcpyAsync(dw, w1, 4 * (size_t)C * C, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + o_b1, b1, 4 * (size_t)C, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + o_w2, w2, 4 * (size_t)m * C, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dw + o_b2, b2, 4 * (size_t)m, hipMemcpyHostToDevice, st));
     HeadArgs ha = {};
-    ha.x = x_dev; ha.n = n; ha.stage_m = m; ha.w1 = dw; ha.b1 = dw + 1024; ha.w2 = dw + 1056; ha.b2 = dw + 1056 + 512;
+    ha.C = C;
+    ha.x = x_dev; ha.n = n; ha.stage_m = m; ha.w1 = dw; ha.b1 = dw + o_b1; ha.w2 = dw + o_w2; ha.b2 = dw + o_b2;
     ha.prob = prob_dev; ha.cdf = cdf_dev; ha.mode = 2;
     GP_TRY(head_cdf(st, ha));
     HIP_TRY(hipStreamSynchronize(st));

@@ -153,28 +153,28 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
             tm.add_bytes(pool.alg_bytes);
         }
         ht.mark("enc tiles built");
-        TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF)); }
+        TAKE(pF, float, nP * m->C); TAKE(pA, float, nP * m->C); TAKE(pB, float, nP * m->C);
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF, m->C)); }
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));           // -> pA
         GP_TRY(queue_ranks());   // the device now has milliseconds of convolutions queued: the host time of these launches is free
-        TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX)); }
+        TAKE(cX, float, nC * m->C); TAKE(cA, float, nC * m->C); TAKE(cB, float, nC * m->C);
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX, m->C)); }
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));           // -> cA  (X of pcc_utils.py:109)
         // stages: cX, cB are free now; inputs u[s], mid v[s], outputs y[s]
-        TAKE(u1, float, nC * 32); TAKE(u2, float, nC * 32); TAKE(u3, float, nC * 32);
-        TAKE(v1, float, nC * 32); TAKE(v2, float, nC * 32);
+        TAKE(u1, float, nC * m->C); TAKE(u2, float, nC * m->C); TAKE(u3, float, nC * m->C);
+        TAKE(v1, float, nC * m->C); TAKE(v2, float, nC * m->C);
         float *u[4] = {cA, u1, u2, u3};
         float *v[4] = {cX, cB, v1, v2};
         {
             const float *const embs[3] = {m->semb[0], m->semb[1], m->semb[2]};
             float *const outs[3] = {u1, u2, u3};
             StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 1 + 3 * 128));
-            GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs));
+            GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs, m->C));
         }
-        ConvBatch cb = {};
+        ConvBatch cb = {}; cb.C = m->C;
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 1));
-        TAKE(y0, float, nC * 32);
+        TAKE(y0, float, nC * m->C);
         float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
@@ -185,7 +185,7 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
         ctx->arena.release_top_low();                       // what is enqueued on st from here on runs behind the rank pass: its temporaries are free
         StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
-            HeadArgs ha = {};
+            HeadArgs ha = {}; ha.C = m->C;
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
@@ -515,7 +515,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     int64_t coded = 0;
     // Small levels (fused.hpp): a chunked container's levels of at most FUSE_MAX_NODES nodes get a pair plan instead of a tile list,
     // their chain runs as one persistent launch (plus one for the finished level's prior trunk).  planP: the plan of `cur`.
-    const bool fuse_ctx = fused_enabled() && !ctx->fused_off && v1 && version >= 1;
+    const bool fuse_ctx = fused_enabled() && !ctx->fused_off && v1 && version >= 1 && m->C == 32;   // (the persistent kernels are the 32-channel MFMA path)
     const int fmode = fused_mode();
     PairPlan planP;
     int64_t planP_np = 0;          // nodes of the level above planP's (the grid policy's density hint)
@@ -531,7 +531,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         const size_t top_mk = ctx->arena.top_mark();
         const int64_t np = cur.n;
         // ---- st: parent trunk
-        TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
+        TAKE_TOP(pF, float, np * m->C); TAKE_TOP(pA, float, np * m->C); TAKE_TOP(pB, float, np * m->C);
         float *Pp = nullptr;
         if (planP.valid()) { TAKE_TOP(pp, float, planP.pcap * 32); Pp = pp; }
         if (planP.valid() && fmode == 1) {
@@ -543,7 +543,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
-            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
+            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF, m->C)); }
             GP_TRY(dbg_mark(ctx, st, g * 100 + 1, pF, (size_t)np * 128));
             GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np, planP.valid() ? &planP : nullptr, Pp));
         }
@@ -608,7 +608,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             dchunks = dch;
         }
         // ---- st: child trunk and the four stages
-        TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
+        TAKE_TOP(cX, float, nc * m->C); TAKE_TOP(cA, float, nc * m->C); TAKE_TOP(cB, float, nc * m->C); TAKE_TOP(cU, float, nc * m->C);
         float *Pc = nullptr;
         if (child_plan) { TAKE_TOP(pc, float, planC.pcap * 32); Pc = pc; }
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);  // interleaved rows + the decoder's look-ahead
@@ -628,14 +628,14 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX, m->C)); }
         GP_TRY(dbg_mark(ctx, st, g * 100 + 8, cX, (size_t)nc * 128));
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc, child_plan ? &planC : nullptr, Pc));  // -> cA
         GP_TRY(dbg_mark(ctx, st, g * 100 + 9, cA, (size_t)nc * 128));
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
-            if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU)); xin = cU; }
-            ConvBatch cb = {};
+            if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, chi.m2r, s, nc, cU, m->C)); xin = cU; }
+            ConvBatch cb = {}; cb.C = m->C;
             if (child_plan) {
                 GP_TRY(plan_conv(st, planC, ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX}, Pc, 1));
                 GP_TRY(plan_conv(st, planC, ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB}, Pc, 0));
@@ -649,7 +649,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             }
             GP_TRY(dbg_mark(ctx, st, g * 100 + 10 + 5 * s, xin, (size_t)nc * 128)); GP_TRY(dbg_mark(ctx, st, g * 100 + 11 + 5 * s, cX, (size_t)nc * 128));
             GP_TRY(dbg_mark(ctx, st, g * 100 + 12 + 5 * s, cB, (size_t)nc * 128));
-            HeadArgs ha = {};
+            HeadArgs ha = {}; ha.C = m->C;
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.chunk_log2 = clog; ha.nch = (uint32_t)nch;

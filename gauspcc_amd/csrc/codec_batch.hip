@@ -180,27 +180,27 @@ int encode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *const *
             tm.add_bytes(pool.alg_bytes);
         }
         ht.mark("benc tiles built");
-        TAKE(pF, float, nP * 32); TAKE(pA, float, nP * 32); TAKE(pB, float, nP * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF)); }
+        TAKE(pF, float, nP * m->C); TAKE(pA, float, nP * m->C); TAKE(pB, float, nP * m->C);
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nP * 129); GP_TRY(embed_occ(st, m->prior_emb, occP, nP, pF, m->C)); }
         GP_TRY(run_trunk(ctx, 0, st, m, 0, Trunk{pF, pA, pB}, tilesP, nP));
         GP_TRY(queue_ranks());
-        TAKE(cX, float, nC * 32); TAKE(cA, float, nC * 32); TAKE(cB, float, nC * 32);
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX)); }
+        TAKE(cX, float, nC * m->C); TAKE(cA, float, nC * m->C); TAKE(cB, float, nC * m->C);
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 12 + 128)); GP_TRY(child_features(st, pA, parentC, rkeyC, m->temb, nC, cX, m->C)); }
         GP_TRY(run_trunk(ctx, 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nC));
-        TAKE(u1, float, nC * 32); TAKE(u2, float, nC * 32); TAKE(u3, float, nC * 32);
-        TAKE(v1, float, nC * 32); TAKE(v2, float, nC * 32);
+        TAKE(u1, float, nC * m->C); TAKE(u2, float, nC * m->C); TAKE(u3, float, nC * m->C);
+        TAKE(v1, float, nC * m->C); TAKE(v2, float, nC * m->C);
         float *u[4] = {cA, u1, u2, u3};
         float *v[4] = {cX, cB, v1, v2};
         {
             const float *const embs[3] = {m->semb[0], m->semb[1], m->semb[2]};
             float *const outs[3] = {u1, u2, u3};
             StageTimer tm(ctx, st, ST_ELEM, (double)nC * (128 + 1 + 3 * 128));
-            GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs));
+            GP_TRY(stage_inputs_gt(st, cA, embs, occC, nC, outs, m->C));
         }
-        ConvBatch cb = {};
+        ConvBatch cb = {}; cb.C = m->C;
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{u[s], m->conv[10 + 2 * s], nullptr, v[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 1));
-        TAKE(y0, float, nC * 32);
+        TAKE(y0, float, nC * m->C);
         float *y[4] = {y0, u1, u2, u3};
         for (int s = 0; s < 4; ++s) cb.job[s] = ConvJob{v[s], m->conv[10 + 2 * s + 1], nullptr, y[s]};
         GP_TRY(sparse_conv(ctx, 1, st, cb, 4, tilesC, nC, 0));
@@ -208,7 +208,7 @@ int encode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *const *
         ctx->arena.release_top_low();
         StageTimer tm_heads(ctx, st, ST_HEADS, (double)nC * 4 * (128 + 1 + 8 + 4));
         for (int s = 0; s < 4; ++s) {
-            HeadArgs ha = {};
+            HeadArgs ha = {}; ha.C = m->C;
             ha.x = y[s]; ha.n = nC; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.occ = occC; ha.stage = s; ha.lohi = lohi; ha.mode = 0; ha.pos = posC; ha.slots = slotsC;
@@ -634,7 +634,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         GP_TRY(tiles_view(ctx, st, pool, 0, 1, zero_base, &tilesP));
     }
     // small levels (fused.hpp): a merged level of at most FUSE_MAX_NODES nodes gets a pair plan, its chain is one persistent launch
-    const bool fuse_ctx = fused_enabled() && !ctx->fused_off;
+    const bool fuse_ctx = fused_enabled() && !ctx->fused_off && m->C == 32;
     const int fmode = fused_mode();
     PairPlan planP;
     int64_t planP_np = 0;
@@ -647,7 +647,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         const int64_t np_in = F.inner(g);   // rows with children in level g + 1: the scenes that go on
         // ---- st: parent trunk (only the rows that have children need it: a prefix -- but a block of the tile list may straddle
         // the boundary, so the trunk runs on the whole level; the rows of finished scenes are a level's tail and cost their share)
-        TAKE_TOP(pF, float, np * 32); TAKE_TOP(pA, float, np * 32); TAKE_TOP(pB, float, np * 32);
+        TAKE_TOP(pF, float, np * m->C); TAKE_TOP(pA, float, np * m->C); TAKE_TOP(pB, float, np * m->C);
         float *Pp = nullptr;
         if (planP.valid()) { TAKE_TOP(pp, float, planP.pcap * 32); Pp = pp; }
         if (planP.valid() && fmode == 1) {
@@ -657,7 +657,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
-            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF)); }
+            { StageTimer tm(ctx, st, ST_ELEM, (double)np * 129); GP_TRY(embed_occ(st, m->prior_emb, cur.occ, np, pF, m->C)); }
             GP_TRY(run_trunk(ctx, g, st, m, 0, Trunk{pF, pA, pB}, tilesP, np, planP.valid() ? &planP : nullptr, Pp));
         }
         // ---- side: the child level's structure
@@ -699,7 +699,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         const int nch = (int)nch_tot[g + 1];
         const RcChunk *dchunks = dchunks_all + desc_at[g + 1];
         // ---- st: child trunk and the four stages
-        TAKE_TOP(cX, float, nc * 32); TAKE_TOP(cA, float, nc * 32); TAKE_TOP(cB, float, nc * 32); TAKE_TOP(cU, float, nc * 32);
+        TAKE_TOP(cX, float, nc * m->C); TAKE_TOP(cA, float, nc * m->C); TAKE_TOP(cB, float, nc * m->C); TAKE_TOP(cU, float, nc * m->C);
         float *Pc = nullptr;
         if (child_plan) { TAKE_TOP(pc, float, planC.pcap * 32); Pc = pc; }
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);
@@ -719,12 +719,12 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             if (ctx->prof.on) { GP_TRY(prof_event(ctx, st, &rec.e1)); ctx->prof.recs.push_back(rec); }
             any_fused = true;
         } else {
-        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX)); }
+        { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 12 + 128)); GP_TRY(child_features(st, pA, chi.parent, chi.rkey, m->temb, nc, cX, m->C)); }
         GP_TRY(run_trunk(ctx, g + 1, st, m, 5, Trunk{cX, cA, cB}, tilesC, nc, child_plan ? &planC : nullptr, Pc));
         for (int s = 0; s < 4; ++s) {
             const float *xin = cA;
-            if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, spos, s, nc, cU)); xin = cU; }
-            ConvBatch cb = {};
+            if (s) { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (128 + 4 + s + 128)); GP_TRY(stage_input_dec(st, cA, m->semb[s - 1], sym, spos, s, nc, cU, m->C)); xin = cU; }
+            ConvBatch cb = {}; cb.C = m->C;
             if (child_plan) {
                 GP_TRY(plan_conv(st, planC, ConvJob{xin, m->conv[10 + 2 * s], nullptr, cX}, Pc, 1));
                 GP_TRY(plan_conv(st, planC, ConvJob{cX, m->conv[10 + 2 * s + 1], nullptr, cB}, Pc, 0));
@@ -736,7 +736,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             GP_TRY(sparse_conv(ctx, g + 1, st, cb, 1, tilesC, nc, 0));
             GP_TRY(conv_chain_end(ctx, st));
             }
-            HeadArgs ha = {};
+            HeadArgs ha = {}; ha.C = m->C;
             ha.x = cB; ha.n = nc; ha.stage_m = STAGE_M[s];
             ha.w1 = m->hw1[s]; ha.b1 = m->hb1[s]; ha.w2 = m->hw2[s]; ha.b2 = m->hb2[s]; ha.frag = m->hfrag[s];
             ha.m2r = chi.m2r; ha.cdf = cdf; ha.mode = 1; ha.pos = cpos;

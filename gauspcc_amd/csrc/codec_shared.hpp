@@ -14,7 +14,7 @@ struct Trunk { float *x, *a, *b; };
 static inline int run_trunk(gpcc_ctx *ctx, int level, hipStream_t st, const gpcc_model *m, int conv0, const Trunk &t, const ConvTiles &tiles, int64_t n, const PairPlan *plan = nullptr,
               float *P = nullptr)
 {
-    ConvBatch cb = {};
+    ConvBatch cb = {}; cb.C = m->C;
     auto one = [&](const float *in, int ci, const float *res, float *out) {
         cb.job[0] = ConvJob{in, m->conv[ci], res, out};
         if (plan) return plan_conv(st, *plan, cb.job[0], P, 1);

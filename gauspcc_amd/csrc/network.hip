@@ -870,6 +870,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
 {
     if (n <= 0) return GPCC_OK;
     if (n >= (int64_t)1 << 31) return fail(GPCC_ERR_ARG, "level too large");
+    if (jobs.C != 0 && jobs.C != 32) return any_sparse_conv(st, jobs, njobs, T, n, relu, jobs.C);   // (not timed as k_sparse_conv: another kernel family)
     const bool chained = ctx && ctx->prof.on && ctx->prof.chain_open;
     const bool prof = ctx && ctx->prof.on && !chained;
     ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk, 1};
@@ -1110,8 +1111,9 @@ __global__ __launch_bounds__(TB) void k_embed_occ(const float4 *__restrict__ emb
     if (i >= n) return;
     out[t] = emb[(size_t)occ[i] * 8 + (t & 7)];
 }
-int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out)
+int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out, int C)
 {
+    if (C != 32) return any_embed_occ(st, emb, occ, n, out, C);
     k_embed_occ<<<nblk(n * 8), TB, 0, st>>>((const float4 *)emb, occ, n, (float4 *)out);
     LAUNCH_CHECK();
     return GPCC_OK;
@@ -1130,8 +1132,9 @@ __global__ __launch_bounds__(TB) void k_child_features(const float4 *__restrict_
     const int q = (int)((rk_x(k) & 1) | ((rk_y(k) & 1) << 1) | ((rk_z(k) & 1) << 2));
     out[t] = add4(F[(size_t)parent[i] * 8 + g], temb[q * 8 + g]);
 }
-int child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out)
+int child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out, int C)
 {
+    if (C != 32) return any_child_features(st, F, parent, rkey_c, temb, n, out, C);
     k_child_features<<<nblk(n * 8), TB, 0, st>>>((const float4 *)F, parent, rkey_c, (const float4 *)temb, n, (float4 *)out);
     LAUNCH_CHECK();
     return GPCC_OK;
@@ -1151,8 +1154,9 @@ __global__ __launch_bounds__(TB) void k_stage_inputs_gt(const float4 *__restrict
     o2[t] = add4(x, e2[((o >> 6) & 3u) * 8 + c]);
     o3[t] = add4(x, e3[((o >> 4) & 15u) * 8 + c]);
 }
-int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3])
+int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3], int C)
 {
+    if (C != 32) return any_stage_inputs_gt(st, X, emb, occ, n, out, C);
     k_stage_inputs_gt<<<nblk(n * 8), TB, 0, st>>>((const float4 *)X, (const float4 *)emb[0], (const float4 *)emb[1], (const float4 *)emb[2], occ, n,
                                                   (float4 *)out[0], (float4 *)out[1], (float4 *)out[2]);
     LAUNCH_CHECK();
@@ -1173,8 +1177,9 @@ __global__ __launch_bounds__(TB) void k_stage_input_dec(const float4 *__restrict
     if (stage >= 3) prev = prev * 4 + sp.s[2][r];
     out[t] = add4(X[t], emb[prev * 8 + (t & 7)]);
 }
-int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out)
+int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out, int C)
 {
+    if (C != 32) return any_stage_input_dec(st, X, emb, sym_r, m2r, stage, n, out, C);
     SymPtrs sp = {{sym_r[0], sym_r[1], sym_r[2], nullptr}};
     k_stage_input_dec<<<nblk(n * 8), TB, 0, st>>>((const float4 *)X, (const float4 *)emb, sp, m2r, stage, n, (float4 *)out);
     LAUNCH_CHECK();
@@ -1292,6 +1297,7 @@ static int head_launch(hipStream_t st, const HeadArgs &a)
 int head_cdf(hipStream_t st, const HeadArgs &a)
 {
     if (a.n <= 0) return GPCC_OK;
+    if (a.C != 0 && a.C != 32) return any_head_cdf(st, a, a.C);
     if (a.mode == 0) return head_launch<0>(st, a);
     if (a.mode == 1) return head_launch<1>(st, a);
     return head_launch<2>(st, a);

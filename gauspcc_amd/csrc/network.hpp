@@ -84,7 +84,7 @@ struct ConvJob {
     const float *res;  // nullable, physical
     float *out;        // physical
 };
-struct ConvBatch { ConvJob job[4]; };
+struct ConvBatch { ConvJob job[4]; int C = 0; };   // C: channels (0 = 32, the MFMA kernels; 16 / 64: network_any.hip, weights (K, C, C) and rows in logical order)
 
 // Compacted work list of a SET of levels (one level in the decoder; all parent levels / all coded levels in the encoder,
 // which batches them into one launch per layer): every wave owns a block of up to H consecutive (Morton-ordered) rows of ONE
@@ -154,13 +154,13 @@ int conv_chain_end(gpcc_ctx *ctx, hipStream_t st);
 int prof_collect(gpcc_ctx *ctx, const unsigned long long *pairs_per_level, int nlevels);
 
 // F[i] = Emb256[occ[i]]                                    (pcc_utils.py:99)
-int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out);
+int embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out, int C = 32);
 // X[i] = F[parent[i]] + Emb8[octant(i)]                    (kit/nn.py:77-98,108-117)
-int child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out);
+int child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out, int C = 32);
 // stage input X + Emb_s[prev bits]; prev from ground-truth occupancy (encode) ...
-int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3]);   // stages 1..3 in one pass
+int stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3], int C = 32);   // stages 1..3 in one pass
 // ... or from the symbols decoded so far (raster order, looked up through m2r)
-int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out);
+int stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out, int C = 32);
 
 // Heads.  mode 0: encode -> lohi[pos] = c_low | (c_high-1) << 16 for the ground-truth symbol of `stage`
 //         mode 1: decode -> compact cdf row (interior values only, rc_row_stride u16) at row pos
@@ -179,11 +179,20 @@ struct HeadArgs {
     const uint32_t *pos; const uint32_t *slots;
     // mode 0, optional: 16 accumulators of sum clamp(-log2(p_gt + 1e-10), 0, 50) (network_ue_4stage_conv.py:176-179)
     double *bits;
+    int C;   // channels (0 = 32); other widths: x in logical order, w1 .. b2 used (network_any.hip)
 };
 int head_cdf(hipStream_t st, const HeadArgs &a);
 
 // occupancy byte from the four decoded symbol arrays (raster order) -> Morton order (pcc_utils.py:369)
 int assemble_occ(hipStream_t st, const uint8_t *const sym_r[4], const uint32_t *m2r, int64_t n, uint8_t *occ);
+
+// channel counts other than 32 (network_any.hip): the same arithmetic as plain kernels in logical channel order
+int any_embed_occ(hipStream_t st, const float *emb, const uint8_t *occ, int64_t n, float *out, int C);
+int any_child_features(hipStream_t st, const float *F, const uint32_t *parent, const uint64_t *rkey_c, const float *temb, int64_t n, float *out, int C);
+int any_stage_inputs_gt(hipStream_t st, const float *X, const float *const emb[3], const uint8_t *occ, int64_t n, float *const out[3], int C);
+int any_stage_input_dec(hipStream_t st, const float *X, const float *emb, const uint8_t *const sym_r[3], const uint32_t *m2r, int stage, int64_t n, float *out, int C);
+int any_sparse_conv(hipStream_t st, const ConvBatch &jobs, int njobs, const ConvTiles &T, int64_t n, int relu, int C);
+int any_head_cdf(hipStream_t st, const HeadArgs &a, int C);
 
 // logical <-> physical row conversion (test entry points)
 int rows_permute(hipStream_t st, const float *in, float *out, int64_t n, int to_physical);

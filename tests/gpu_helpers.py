@@ -43,7 +43,7 @@ def conv3d(xyz_sorted: np.ndarray, feats: np.ndarray, w: np.ndarray, k: int, res
     out = torch.empty_like(f)
     w = np.ascontiguousarray(w, dtype=np.float32)
     pairs = C.c_int64()
-    _lib.check(_lib.lib().gpcc_conv3d(runtime.context(dev()), x.data_ptr(), x.shape[0], 32, k, f.data_ptr(), w.ctypes.data,
+    _lib.check(_lib.lib().gpcc_conv3d(runtime.context(dev()), x.data_ptr(), x.shape[0], f.shape[1], k, f.data_ptr(), w.ctypes.data,
                                       None if r is None else r.data_ptr(), int(relu) | (2 if plan else 0), out.data_ptr(), C.byref(pairs), _st()))
     return out.cpu().numpy(), pairs.value
 
@@ -54,7 +54,7 @@ def head_cdf(x: np.ndarray, w1, b1, w2, b2):
     prob = torch.empty((xt.shape[0], m), dtype=torch.float32, device=dev())
     cdf = torch.empty((xt.shape[0], m + 1), dtype=torch.int16, device=dev())
     a = [np.ascontiguousarray(t, dtype=np.float32) for t in (w1, b1, w2, b2)]
-    _lib.check(_lib.lib().gpcc_head_cdf(runtime.context(dev()), xt.data_ptr(), xt.shape[0], 32, m, a[0].ctypes.data, a[1].ctypes.data,
+    _lib.check(_lib.lib().gpcc_head_cdf(runtime.context(dev()), xt.data_ptr(), xt.shape[0], xt.shape[1], m, a[0].ctypes.data, a[1].ctypes.data,
                                         a[2].ctypes.data, a[3].ctypes.data, prob.data_ptr(), cdf.data_ptr(), _st()))
     return prob.cpu().numpy(), cdf.cpu().numpy().view(np.uint16)
 

@@ -617,7 +617,7 @@ extern "C" int gshac_mlp2_act(gpcc_ctx *ctx, const float *x, const float *w1, co
     HIP_TRY(hipSetDevice(ctx->device));
     const float sl = act == 1 ? slope : 0.0f;
     hipStream_t st = (hipStream_t)stream;
-    static const bool use_mfma = [] { const char *e = getenv("GAUSPCC_MLP2_MFMA"); return !e || atoi(e) != 0; }();
+    static const bool use_mfma = dev_env_int("GAUSPCC_MLP2_MFMA", 1) != 0;
     if (use_mfma) {
         // the smallest class that holds the layer (HAC's mlp_grid in its exact class)
         if (din == 96 && dh == 100 && dout == 175) return mlp2_mfma_launch<96, 100, 175>(ctx, x, w1, b1, w2, b2, n, din, dh, dout, sl, y, st);

@@ -97,6 +97,22 @@ struct Arena {
 // PER DEVICE (hipFuncSetAttribute is a per-device setting) runs under a mutex with a bit per device.
 inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 inline long long env_ll(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+// Knobs that change WHICH kernel runs (block classes, parked loops, fused / unfused paths ...) are developer switches: honoured only
+// with GAUSPCC_DEV=1 in the environment, so that a stray variable in a user's shell cannot silently change the kernel mix.  One
+// line on stderr says so when such a variable is set without it.  (The tests of the variants set GAUSPCC_DEV=1.)
+inline bool dev_mode() { static const bool on = env_int("GAUSPCC_DEV", 0) != 0; return on; }
+inline long long dev_env_ll(const char *name, long long dflt)
+{
+    const char *e = getenv(name);
+    if (!e) return dflt;
+    if (dev_mode()) return atoll(e);
+    static std::mutex m;
+    static bool told = false;
+    std::lock_guard<std::mutex> g(m);
+    if (!told) { told = true; fprintf(stderr, "[gauspcc] %s is a developer knob and is ignored without GAUSPCC_DEV=1 (as are the other kernel-selection knobs)\n", name); }
+    return dflt;
+}
+inline int dev_env_int(const char *name, int dflt) { return (int)dev_env_ll(name, dflt); }
 struct PerDeviceOnce {
     std::mutex m;
     uint64_t done = 0;

@@ -14,7 +14,7 @@ namespace gpcc {
 // ------------------------------------------------------------------ policy
 int fused_mode()
 {
-    static const int m = [] { const int v = env_int("GAUSPCC_FUSED", 1); return v < 0 || v > 2 ? 1 : v; }();
+    static const int m = [] { const int v = dev_env_int("GAUSPCC_FUSED", 1); return v < 0 || v > 2 ? 1 : v; }();
     return m;
 }
 bool fused_enabled() { return fused_mode() != 0; }
@@ -22,7 +22,7 @@ int fused_device_cap();   // below: workgroups of a persistent launch the curren
 bool fused_level_ok(int64_t n, int k)
 {
     if (fused_device_cap() < 16) return false;   // a partitioned / masked device too small for a persistent grid: the launch-per-layer path
-    static const int64_t nmax = std::min<int64_t>(env_ll("GAUSPCC_FUSED_MAX", FUSE_MAX_NODES), FUSE_MAX_NODES);
+    static const int64_t nmax = std::min<int64_t>(dev_env_ll("GAUSPCC_FUSED_MAX", FUSE_MAX_NODES), FUSE_MAX_NODES);
     const int64_t K = (int64_t)k * k * k;
     return fused_enabled() && n >= 1 && n <= nmax && (n * K + 1) * 128 <= ((int64_t)768 << 20);
 }
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(FUSE_THREADS) void k_level_fused(FusedK k)
 // 40-77 neighbours per node) ~4 n.  The host knows the density only through the growth of the level (children per parent node).
 int fused_grid(int64_t n, int64_t np)
 {
-    static const int forced = env_int("GAUSPCC_FUSED_GRID", 0);
+    static const int forced = dev_env_int("GAUSPCC_FUSED_GRID", 0);
     if (forced >= 1 && forced <= 256) return forced;
     const bool dense = np > 0 && n > 3 * np;
     const int64_t tiles = dense ? 5 * n : n / 2 + 64;

@@ -28,10 +28,15 @@
 #endif
 #include CONV_LOOP_INC
 #include "conv_loop2_gfx950.inc"               // generated: tools/gen_conv_loop2.py (the pair-step loop of paired tile lists)
+// Two loops that were built, proven bit-exact, measured slower everywhere and parked (the 32x32x2 pair step -7 %,
+// half-channel waves -6 .. -35 %): they compile only with -DGAUSPCC_PARKED_VARIANTS (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
+// -> gauspcc_amd/variants/libgauspcc_parked.so, where their parity tests run them), not into the product library.
+#ifdef GAUSPCC_PARKED_VARIANTS
 #include "conv_loop3_gfx950.inc"               // generated: tools/gen_conv_loop3.py (the same step on v_mfma_f32_32x32x2_f32)
 #include "conv_looph_gfx950.inc"               // generated: CONV_ASM_HALF=1 tools/gen_conv_loop.py (the one-tile loop on 16 of the 32 output channels)
-static_assert(CONV_LOOP2_ROW_BYTES == CONV_LDS_ROW_BYTES, "both asm loops address the running sums at one LDS row pitch");
 static_assert(CONV_LOOP3_ROW_BYTES == CONV_LDS_ROW_BYTES, "all asm loops address the running sums at one LDS row pitch");
+#endif
+static_assert(CONV_LOOP2_ROW_BYTES == CONV_LDS_ROW_BYTES, "both asm loops address the running sums at one LDS row pitch");
 
 namespace gpcc {
 
@@ -56,14 +61,14 @@ __host__ __device__ constexpr int conv_lds_wave_floats(int R) { return (R + 1) *
 static int conv_rows_forced()
 {
     static const int forced = [] {
-        const int f = env_int("GAUSPCC_CONV_R", 0);
+        const int f = dev_env_int("GAUSPCC_CONV_R", 0);
         return (f != 0 && f != 16 && f != 32 && f != 64 && f != 96 && f != 128 && f != 255) ? 0 : f;
     }();
     return forced;
 }
 static int64_t conv_tall_min()
 {
-    static const int64_t tall_min = env_ll("GAUSPCC_CONV_TALL_MIN", 64 * 256 + 1);   // 245 64-row workgroups: 22.2 us against 23.1 for 977 16-row waves at 15.6 k nodes
+    static const int64_t tall_min = dev_env_ll("GAUSPCC_CONV_TALL_MIN", 64 * 256 + 1);   // 245 64-row workgroups: 22.2 us against 23.1 for 977 16-row waves at 15.6 k nodes
     return tall_min;
 }
 
@@ -74,13 +79,13 @@ static int64_t conv_tall_min()
 // height only grows when the rounds of workgroups shrink.  (k = 7: the headers of a 64-row block do not fit the LDS; 16.)
 int conv_coop_rows(int64_t n, int k)
 {
-    static const int tall = env_int("GAUSPCC_COOP_TALL", 1);
+    static const int tall = dev_env_int("GAUSPCC_COOP_TALL", 1);
     if (!tall || k > 5) return 16;
     return n <= 16 * 256 ? 16 : n <= 32 * 256 ? 32 : 64;
 }
 bool conv_is_coop(int64_t n, int R)
 {
-    static const int use_coop = env_int("GAUSPCC_CONV_COOP", 1) != 0;
+    static const int use_coop = dev_env_int("GAUSPCC_CONV_COOP", 1) != 0;
     if (!use_coop) return false;
     if (R == 16) return true;
     return (R == 32 || R == 64) && !conv_rows_forced() && n < conv_tall_min() && n <= 64 * 256;
@@ -89,8 +94,12 @@ bool conv_is_coop(int64_t n, int R)
 // GAUSPCC_CONV_QUAD: the paired blocks of the 255-row class run the 32x32x2 pair step (1) or the 16x16x4 one (0)
 bool conv_quad()
 {
-    static const bool q = env_int("GAUSPCC_CONV_QUAD", 0) != 0;
+#ifdef GAUSPCC_PARKED_VARIANTS
+    static const bool q = dev_env_int("GAUSPCC_CONV_QUAD", 0) != 0;
     return q;
+#else
+    return false;
+#endif
 }
 
 int conv_pick_rows(int64_t n, int k)
@@ -114,18 +123,23 @@ int conv_pick_rows(int64_t n, int k)
 // Half-channel waves (k_sparse_conv_half): single levels of the 255-row class below GAUSPCC_CONV_HALF_MAX nodes, when GAUSPCC_CONV_HALF is on
 bool conv_half_level(int64_t n, int R)
 {
-    static const int on = env_int("GAUSPCC_CONV_HALF", 0);
-    static const int64_t maxn = env_int("GAUSPCC_CONV_HALF_MAX", 300000);
+#ifdef GAUSPCC_PARKED_VARIANTS
+    static const int on = dev_env_int("GAUSPCC_CONV_HALF", 0);
+    static const int64_t maxn = dev_env_int("GAUSPCC_CONV_HALF_MAX", 300000);
     return on != 0 && R == CONV_R_MAX && n < maxn && !conv_is_coop(n, R);
+#else
+    (void)n; (void)R;
+    return false;
+#endif
 }
 
 int conv_pick_height(int64_t n, int R)
 {
-    static const int balance = env_int("GAUSPCC_CONV_BALANCE", 2);
+    static const int balance = dev_env_int("GAUSPCC_CONV_BALANCE", 2);
     if (!balance || R <= 16 || conv_is_coop(n, R)) return R;
     if (conv_half_level(n, R)) {
         // two waves per block: GAUSPCC_CONV_HALF_BLOCKS blocks (1 024: two waves per SIMD; 512: one, on blocks twice as tall) in one round
-        static const int64_t hb = std::max(64, env_int("GAUSPCC_CONV_HALF_BLOCKS", 1024));
+        static const int64_t hb = std::max(64, dev_env_int("GAUSPCC_CONV_HALF_BLOCKS", 1024));
         const int64_t k = cdiv(n, hb * R);
         return (int)std::min<int64_t>(R, std::max<int64_t>(cdiv(n, hb * k), 16));
     }
@@ -321,13 +335,16 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
                 atomicAdd(&g_conv_timing[14], (unsigned long long)sw2); atomicAdd(&g_conv_timing[15], (unsigned long long)sw3);
             }
 #else
+#ifdef GAUSPCC_PARKED_VARIANTS
             if (PAIR == 2 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
                 asm volatile(CONV_LOOP3_ASM
                              : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
                              : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 2048), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
                                [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
                              : CONV_LOOP3_CLOBBERS);
-            else if (PAIR == 1 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
+            else
+#endif
+            if (PAIR == 1 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
                 asm volatile(CONV_LOOP2_ASM
                              : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
                              : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
@@ -479,6 +496,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     }
 }
 
+#ifdef GAUSPCC_PARKED_VARIANTS
 // HALF-CHANNEL waves (round 4; levels whose blocks do not fill the chip's 1 024 wave slots -- a decoder's levels of 16 k .. ~300 k nodes).
 // A block is given to TWO waves: wave h computes output channels 16 h .. 16 h + 15 of every tile -- 8 of the 16 MFMAs, half a weight
 // fragment, one 16-byte piece of running sums per lane at a 64-byte LDS pitch -- from the same tile list and the same gathered rows.
@@ -576,6 +594,8 @@ __global__ __launch_bounds__(128 * SC_WAVES, 1) void k_sparse_conv_half(ConvBatc
         }
     }
 }
+#endif   // GAUSPCC_PARKED_VARIANTS
+
 
 // Small levels (16-row blocks: every (block, offset) pair is exactly one tile, a block's list is a serial chain of up to
 // 125 tiles, and the whole level is a few hundred blocks): latency, not throughput.  One 16-wave workgroup per block
@@ -876,8 +896,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk, 1};
     if (chained) { ConvRec &c = ctx->prof.chain; c.level = level; c.njobs = njobs; c.R = T.R; c.H = T.H; c.n = (long long)n; c.nblk = (long long)T.nblk; c.launches += 1; }
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
-    static const int dist = [] { const int d = env_int("GAUSPCC_CONV_DIST", 1); return d < 1 || d > 3 ? 1 : d; }();
-    static const int use_asm = env_int("GAUSPCC_CONV_ASM", 1) != 0;
+    static const int dist = [] { const int d = dev_env_int("GAUSPCC_CONV_DIST", 1); return d < 1 || d > 3 ? 1 : d; }();
+    static const int use_asm = dev_env_int("GAUSPCC_CONV_ASM", 1) != 0;
     static PerDeviceOnce lds_attr;
     int cur_dev = 0;
     HIP_TRY(hipGetDevice(&cur_dev));
@@ -886,9 +906,11 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
+#ifdef GAUSPCC_PARKED_VARIANTS
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_half<255>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SC_WAVES * conv_lds_wave_floats_half(255) * 4));
+#endif
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -897,7 +919,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(125, 64)));
         return GPCC_OK;
     }));
-    static const int use_split = env_int("GAUSPCC_CONV_SPLIT", 1) != 0;
+    static const int use_split = dev_env_int("GAUSPCC_CONV_SPLIT", 1) != 0;
     const bool use_coop = conv_is_coop(n, T.R) && T.H == T.R;
     // 16-row blocks.  Up to 64 blocks (a level of at most 1 k nodes): products over the whole chip + ordered sums, two
     // launches -- measured 11.7 / 15.2 us against 18.8 / 26.2 for the one-workgroup-per-block kernel at 4 / 32 blocks.
@@ -905,7 +927,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     // (A second cooperative kernel -- 8 waves, two workgroups per CU, transposed products parked with 16-byte swizzled
     // stores, operands one tile ahead -- was built and measured in round 3: 25.1 / 34.3 / 24.7 us at 160 / 263 / 315 blocks
     // against 25.8 / 36.5 / 22.5: a block's ~100 tiles move ~750 KB through one CU's L1 whatever the schedule.  Dropped.)
-    static const int split_max = env_int("GAUSPCC_CONV_SPLIT_MAX", 64);
+    static const int split_max = dev_env_int("GAUSPCC_CONV_SPLIT_MAX", 64);
     const size_t prod_floats = ((size_t)T.nblk * (size_t)T.K + CONV_HDR_PAD) * 512;
     if (T.R == 16 && use_coop && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
         if (ctx->conv_products_cap < prod_floats) {
@@ -978,10 +1000,13 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
     case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
     case 255:
+#ifdef GAUSPCC_PARKED_VARIANTS
         if (asm_ok && !T.paired && T.nlv == 1 && conv_half_level(n, T.R))
             k_sparse_conv_half<255><<<grid, 128 * SC_WAVES, (size_t)2 * SC_WAVES * conv_lds_wave_floats_half(255) * 4, st>>>(jobs, T, (int)n, relu, njobs);
         else if (asm_ok && T.paired && conv_quad()) k_sparse_conv<255, 1, true, 2><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
-        else if (asm_ok && T.paired) k_sparse_conv<255, 1, true, 1><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
+        else
+#endif
+        if (asm_ok && T.paired) k_sparse_conv<255, 1, true, 1><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
         else if (asm_ok) CONV_LAUNCH(255, 1, true);
         else CONV_LAUNCH(255, 1, false);
         break;

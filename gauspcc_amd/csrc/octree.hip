@@ -420,13 +420,13 @@ int level_ranks_from_parent(gpcc_ctx *ctx, hipStream_t st, const Level *par, Lev
 constexpr int64_t RANK_SORT_MAX = 1024;
 static bool no_fuse()   // cross-check knob: the one-launch-per-step path for every level
 {
-    static const bool v = env_int("GAUSPCC_SMALL_FUSE", 1) == 0;
+    static const bool v = dev_env_int("GAUSPCC_SMALL_FUSE", 1) == 0;
     return v;
 }
 
 int rank_level(gpcc_ctx *ctx, hipStream_t st, const Level *par, Level *chi, int hb_level)
 {
-    static const bool force_sort = env_int("GAUSPCC_RANK_SORT", 0) != 0;   // cross-check knob
+    static const bool force_sort = dev_env_int("GAUSPCC_RANK_SORT", 0) != 0;   // cross-check knob
     if (!par || force_sort) return level_raster_rank(ctx, st, chi, hb_level);
     if (small_level_fits(par, chi) && !no_fuse()) return small_level(ctx, st, const_cast<Level *>(par), chi, false, nullptr);
     if (chi->n <= RANK_SORT_MAX) return level_raster_rank(ctx, st, chi, hb_level);

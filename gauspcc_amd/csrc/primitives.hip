@@ -315,7 +315,7 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
 // the one-wave kernels move 16-byte words (GAUSPCC_SCAN_WAVE=0: the 256-thread kernels with their LDS words, kept as the cross-check)
 static bool scan_wave_ok(const uint32_t *in, const uint32_t *out)
 {
-    static const bool on = env_int("GAUSPCC_SCAN_WAVE", 1) != 0;
+    static const bool on = dev_env_int("GAUSPCC_SCAN_WAVE", 1) != 0;
     return on && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
 }
 
@@ -344,7 +344,7 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
         LAUNCH_CHECK();
         return GPCC_OK;
     }
-    static const bool lookback = env_int("GAUSPCC_SCAN_LOOKBACK", 1) != 0;   // (0: the three-launch scan of rounds 1-3, kept as the cross-check)
+    static const bool lookback = dev_env_int("GAUSPCC_SCAN_LOOKBACK", 1) != 0;   // (0: the three-launch scan of rounds 1-3, kept as the cross-check)
     const int64_t tiles = cdiv(n, LB_TILE);
     if (lookback && ctx && tiles <= LB_MAX_TILES && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
         gpcc_ctx::ScanState *ss = nullptr;

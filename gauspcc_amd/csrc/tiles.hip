@@ -511,8 +511,8 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     TAKE(first, uint32_t, nblk + 1);
     pool->first = first;
     LevelTilesArgs a = {};
-    static const bool pair_on = [] { const char *e = getenv("GAUSPCC_CONV_PAIR"); return !e || atoi(e) != 0; }();
-    static const int pair_min = env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
+    static const bool pair_on = dev_env_int("GAUSPCC_CONV_PAIR", 1) != 0;
+    static const int pair_min = dev_env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
     pool->paired = (H > 64 && R == CONV_R_MAX && pair_on && !(nlv == 1 && conv_half_level(lv[0].lv->n, R))) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block); half-channel levels run the one-tile loop
     pool->pflag = nullptr;
     if (pool->paired) {
@@ -571,7 +571,7 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
         // never waits for the count pass (GAUSPCC_TILES_BOUND=1).  Measured in round 4 (S1M, 10 steps, same box): dec_ms 26.93 with the
         // bound, 26.95 with the five syncs -- they fall on the second stream while the first runs a parent trunk, and the host is ahead
         // either way.  Off by default: the exact size keeps the workspace smaller.
-        static const bool by_bound = env_int("GAUSPCC_TILES_BOUND", 0) != 0;
+        static const bool by_bound = dev_env_int("GAUSPCC_TILES_BOUND", 0) != 0;
         int64_t tpr = cdiv(H, 16);
         if (pool->paired) tpr = (tpr + 1) & ~(int64_t)1;
         const int64_t bound = nblk * K * tpr;

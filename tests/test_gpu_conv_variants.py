@@ -68,9 +68,18 @@ print("variant ok", pairs)
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "1"},
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_BALANCE": "1"},
 ], ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
+PARKED_LIB = os.path.join(ROOT, "gauspcc_amd", "variants", "libgauspcc_parked.so")   # tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
+
+
 def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)
     e.update(env)
+    e["GAUSPCC_DEV"] = "1"               # kernel-selection knobs are developer switches: ignored without it (csrc/common.hpp: dev_env_int)
+    if "GAUSPCC_CONV_QUAD" in env or "GAUSPCC_CONV_HALF" in env:
+        # the parked loops are not in the product library: their parity tests run on the variant build when it exists
+        if not os.path.exists(PARKED_LIB):
+            pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is not built (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS)")
+        e["GAUSPCC_LIB"] = PARKED_LIB
     e.setdefault("GAUSPCC_FUSED", "0")   # these variants are about the block-tile kernels: keep the decoder's small levels on them
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
@@ -89,6 +98,7 @@ def test_fused_small_levels_variant_bit_exact(env):
     the oracle's, whatever the grid of the persistent launch and wherever the hand-over to the block-tile kernels lies."""
     e = dict(os.environ)
     e.update(env)
+    e["GAUSPCC_DEV"] = "1"
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
@@ -117,6 +127,7 @@ print("digest", hashlib.sha256(data).hexdigest(), hashlib.sha256(dec.tobytes()).
     for env in ({}, {"GAUSPCC_RANK_SORT": "1"}, {"GAUSPCC_SMALL_FUSE": "0"}):
         e = dict(os.environ)
         e.update(env)
+        e["GAUSPCC_DEV"] = "1"
         r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
@@ -148,6 +159,7 @@ for n, seed in ((120000, 3), (7000, 4), (40000, 5)):
     for env in ({}, {"GAUSPCC_ARENA_SCALE": "0.3"}, {"GAUSPCC_ARENA_SCALE": "0.12"}, {"GAUSPCC_ARENA_SCALE": "0.04"}):
         e = dict(os.environ)
         e.update(env)
+        e["GAUSPCC_DEV"] = "1"
         r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])

@@ -11,7 +11,7 @@ with open(sys.argv[1]) as f:
         name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name.split("(")[0]))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "k_bbox" in r[2]]
+starts = [i for i, r in enumerate(rows) if "k_bbox" in r[2] or "k_fbbox" in r[2]]   # (k_fbbox: the first kernel of a batched encode)
 seg = rows[starts[-1]:]
 cut = max(i for i, r in enumerate(seg) if "k_rc_compact" in r[2]) + 1
 

@@ -49,6 +49,9 @@ print("variant ok", pairs)
 """
 
 
+PARKED_LIB = os.path.join(ROOT, "gauspcc_amd", "variants", "libgauspcc_parked.so")   # tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
+
+
 @pytest.mark.parametrize("env", [
     {"GAUSPCC_CONV_R": "255"},
     {"GAUSPCC_CONV_R": "128"},
@@ -68,9 +71,6 @@ print("variant ok", pairs)
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "1"},
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_BALANCE": "1"},
 ], ids=lambda e: ",".join(f"{k[8:]}={v}" for k, v in e.items()))
-PARKED_LIB = os.path.join(ROOT, "gauspcc_amd", "variants", "libgauspcc_parked.so")   # tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
-
-
 def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)
     e.update(env)

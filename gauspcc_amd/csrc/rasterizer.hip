@@ -8,9 +8,9 @@
 //   k_preprocess     one lane per Gaussian, coalesced SoA outputs (HBM-bound)
 //   scan / sort      the library's own wave-ballot radix sort on (tile << 32 | depth bits)
 //   k_tile_ranges    boundary detection on the sorted keys
-//   k_render         one 256-lane workgroup per 16x16 tile; batches of 256 Gaussians staged in LDS
-//                    (id -> xy, conic+opacity, rgb = 36 B each), every lane blends its pixel front to
-//                    back and the workgroup leaves when all 256 lanes are saturated
+//   k_render         one 128-lane workgroup per 16x16 tile, two pixels per lane; batches of 128 Gaussians staged in LDS
+//                    (id -> xy, conic+opacity, rgb = 36 B each), every lane blends its pixels front to
+//                    back and the workgroup leaves when all 256 pixels are saturated
 #include "primitives.hpp"
 
 using namespace gpcc;
@@ -134,51 +134,90 @@ __global__ __launch_bounds__(TB) void k_tile_ranges(int L, const uint64_t *__res
     if (i == L - 1) ranges[t].y = (uint32_t)L;
 }
 
-__global__ __launch_bounds__(BX * BY) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int gx,
-                                                     const float2 *__restrict__ xy, const float *__restrict__ colors, const float4 *__restrict__ conic_op,
-                                                     float bg0, float bg1, float bg2, float *__restrict__ out)
+// One 16 x 16 tile per workgroup of RT = 128 lanes (two waves); a lane blends TWO pixels, (x, y) and (x, y + 8): one fetch of a
+// Gaussian from LDS (three broadcast reads) and one pass of the loop's control feed two blends.  The blend is predicated instead of
+// three data-dependent `continue`s (no exec-mask juggling), the exponential is one v_exp_f32 on power * log2(e) -- `power` itself is the
+// reference's expression, so its sign test is the reference's --, and a wave leaves a batch as soon as all its pixels are saturated.
+// Round 4 measured the one-pixel-per-lane form at 36 % of the VALU peak (three LDS waits, a libm exponential and three branches for ~15
+// useful VALU instructions per Gaussian and pixel: profiles/r04_render_counters.txt).
+constexpr int RT = 128;
+__device__ __forceinline__ void blend_one(float power, float op, float r, float g, float b, bool &done, float &T, float &C0, float &C1, float &C2)
 {
-    __shared__ float2 s_xy[BX * BY];
-    __shared__ float4 s_co[BX * BY];
-    __shared__ float s_rgb[BX * BY * 3];
+    const float e = __builtin_amdgcn_exp2f(power * 1.44269504088896341f);
+    const float alpha = fminf(0.99f, op * e);
+    const bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+    const float tt = T * (1.0f - alpha);
+    const bool sat = ok && tt < 0.0001f;
+    done = done || sat;
+    const bool upd = ok && !sat;
+    const float w = upd ? alpha * T : 0.0f;
+    C0 += r * w; C1 += g * w; C2 += b * w;
+    T = upd ? tt : T;
+}
+
+__global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int gx,
+                                               const float2 *__restrict__ xy, const float *__restrict__ colors, const float4 *__restrict__ conic_op,
+                                               float bg0, float bg1, float bg2, float *__restrict__ out)
+{
+    __shared__ float4 s_a[RT];   // x, y, conic.x, conic.y
+    __shared__ float4 s_b[RT];   // conic.z, opacity, r, g
+    __shared__ float2 s_c[RT];   // b, skip threshold: a Gaussian contributes to a pixel only if thr <= power <= 0
     const int tile = blockIdx.y * gx + blockIdx.x;
-    const int pxi = blockIdx.x * BX + (threadIdx.x & 15), pyi = blockIdx.y * BY + (threadIdx.x >> 4);
-    const bool inside = pxi < W && pyi < H;
-    const float pxf = (float)pxi, pyf = (float)pyi;
+    const int pxi = blockIdx.x * BX + (threadIdx.x & 15), py0 = blockIdx.y * BY + (threadIdx.x >> 4), py1 = py0 + 8;
+    const bool in0 = pxi < W && py0 < H, in1 = pxi < W && py1 < H;
+    const float pxf = (float)pxi, pyf0 = (float)py0, pyf1 = (float)py1;
     const uint2 range = ranges[tile];
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    for (uint32_t b0 = range.x; b0 < range.y; b0 += BX * BY) {
-        if (__syncthreads_count(done) == BX * BY) break;
+    bool done0 = !in0, done1 = !in1;
+    float T0 = 1.0f, A0 = 0.f, A1 = 0.f, A2 = 0.f;
+    float T1 = 1.0f, B0 = 0.f, B1 = 0.f, B2 = 0.f;
+    for (uint32_t b0 = range.x; b0 < range.y; b0 += RT) {
+        if (__syncthreads_count(done0 && done1) == RT) break;
         const uint32_t k = b0 + threadIdx.x;
         if (k < range.y) {
             const uint32_t id = point_list[k];
-            s_xy[threadIdx.x] = xy[id];
-            s_co[threadIdx.x] = conic_op[id];
-            s_rgb[3 * threadIdx.x] = colors[3 * id]; s_rgb[3 * threadIdx.x + 1] = colors[3 * id + 1]; s_rgb[3 * threadIdx.x + 2] = colors[3 * id + 2];
+            const float2 p = xy[id];
+            const float4 co = conic_op[id];
+            s_a[threadIdx.x] = make_float4(p.x, p.y, co.x, co.y);
+            s_b[threadIdx.x] = make_float4(co.z, co.w, colors[3 * id], colors[3 * id + 1]);
+            // alpha = op * exp(power) >= 1 / 255  <=>  power >= -ln(255 op); a margin keeps the borderline pixels on the exact test below
+            s_c[threadIdx.x] = make_float2(colors[3 * id + 2], co.w > 0.0f ? -__logf(255.0f * co.w) - 1e-3f : __builtin_inff());
+        } else {
+            // behind the list: a Gaussian of opacity 0 (alpha 0 < 1 / 255: never blended), so that the loop below runs in pairs
+            s_a[threadIdx.x] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[threadIdx.x] = make_float4(1.f, 0.f, 0.f, 0.f); s_c[threadIdx.x] = make_float2(0.f, __builtin_inff());
         }
         __syncthreads();
-        const int cnt = (int)min((uint32_t)(BX * BY), range.y - b0);
-        for (int j = 0; !done && j < cnt; ++j) {
-            const float2 p = s_xy[j];
-            const float dx = p.x - pxf, dy = p.y - pyf;
-            const float4 co = s_co[j];
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
-            if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * expf(power));
-            if (alpha < 1.0f / 255.0f) continue;
-            const float test_T = T * (1.0f - alpha);
-            if (test_T < 0.0001f) { done = true; continue; }
-            const float wgt = alpha * T;
-            C0 += s_rgb[3 * j] * wgt; C1 += s_rgb[3 * j + 1] * wgt; C2 += s_rgb[3 * j + 2] * wgt;
-            T = test_T;
+        const int cnt = (int)min((uint32_t)RT, range.y - b0);
+        for (int j = 0; j < cnt; j += 2) {
+            if (__builtin_amdgcn_ballot_w64(!(done0 && done1)) == 0ull) break;   // the wave's 128 pixels are saturated
+            // two Gaussians per trip: their six LDS reads are in flight together
+            const float4 a = s_a[j], bq = s_b[j], a2 = s_a[j + 1], bq2 = s_b[j + 1];
+            const float2 cb = s_c[j], cb2 = s_c[j + 1];
+            const float dxa = a.x - pxf, dya0 = a.y - pyf0, dya1 = a.y - pyf1;
+            const float pa0 = -0.5f * (a.z * dxa * dxa + bq.x * dya0 * dya0) - a.w * dxa * dya0;
+            const float pa1 = -0.5f * (a.z * dxa * dxa + bq.x * dya1 * dya1) - a.w * dxa * dya1;
+            const float dxb = a2.x - pxf, dyb0 = a2.y - pyf0, dyb1 = a2.y - pyf1;
+            const float pb0 = -0.5f * (a2.z * dxb * dxb + bq2.x * dyb0 * dyb0) - a2.w * dxb * dyb0;
+            const float pb1 = -0.5f * (a2.z * dxb * dxb + bq2.x * dyb1 * dyb1) - a2.w * dxb * dyb1;
+            // a Gaussian whose footprint misses all 128 pixels of the wave (most of a tile's list at the corners of the 3-sigma boxes, and
+            // every Gaussian that only touches the tile's other half) costs the twelve instructions above and no exponential
+            if (__builtin_amdgcn_ballot_w64((!done0 && pa0 >= cb.y && !(pa0 > 0.0f)) || (!done1 && pa1 >= cb.y && !(pa1 > 0.0f))) != 0ull) {
+                blend_one(pa0, bq.y, bq.z, bq.w, cb.x, done0, T0, A0, A1, A2);
+                blend_one(pa1, bq.y, bq.z, bq.w, cb.x, done1, T1, B0, B1, B2);
+            }
+            if (__builtin_amdgcn_ballot_w64((!done0 && pb0 >= cb2.y && !(pb0 > 0.0f)) || (!done1 && pb1 >= cb2.y && !(pb1 > 0.0f))) != 0ull) {
+                blend_one(pb0, bq2.y, bq2.z, bq2.w, cb2.x, done0, T0, A0, A1, A2);
+                blend_one(pb1, bq2.y, bq2.z, bq2.w, cb2.x, done1, T1, B0, B1, B2);
+            }
         }
     }
-    if (inside) {
-        const size_t pix = (size_t)pyi * W + pxi, plane = (size_t)W * H;
-        out[pix] = C0 + T * bg0;
-        out[plane + pix] = C1 + T * bg1;
-        out[2 * plane + pix] = C2 + T * bg2;
+    const size_t plane = (size_t)W * H;
+    if (in0) {
+        const size_t pix = (size_t)py0 * W + pxi;
+        out[pix] = A0 + T0 * bg0; out[plane + pix] = A1 + T0 * bg1; out[2 * plane + pix] = A2 + T0 * bg2;
+    }
+    if (in1) {
+        const size_t pix = (size_t)py1 * W + pxi;
+        out[pix] = B0 + T1 * bg0; out[plane + pix] = B1 + T1 * bg1; out[2 * plane + pix] = B2 + T1 * bg2;
     }
 }
 
@@ -262,7 +301,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             LAUNCH_CHECK();
             vals_sorted = v0;
         }
-        k_render<<<dim3((unsigned)cam.gx, (unsigned)cam.gy), BX * BY, 0, st>>>(ranges, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
+        k_render<<<dim3((unsigned)cam.gx, (unsigned)cam.gy), RT, 0, st>>>(ranges, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
         LAUNCH_CHECK();
         HIP_TRY(hipStreamSynchronize(st));
         return GPCC_OK;

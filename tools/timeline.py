@@ -18,10 +18,17 @@ cut = max(i for i, r in enumerate(seg) if "k_rc_compact" in r[2]) + 1
 
 def report(name, seg):
     busy = sum(e - s for s, e, _ in seg)
-    span = seg[-1][1] - seg[0][0]
-    gaps = [(seg[i + 1][0] - seg[i][1], seg[i][2], seg[i + 1][2]) for i in range(len(seg) - 1)]
+    span = max(e for _, e, _ in seg) - seg[0][0]
+    # Kernels of several streams overlap: a gap is a stretch that NO kernel covers (round 5: until then a gap was the distance between
+    # consecutive kernels in start order, which reported a kernel of the second stream that starts and ends under a long convolution as
+    # a hole in front of the next convolution -- the "308 us hole before the first trunk" of round 4's encode was one of those).
+    gaps, cover_end, cover_name = [], seg[0][1], seg[0][2]
+    for s_, e_, n_ in seg[1:]:
+        gaps.append((s_ - cover_end, cover_name, n_))
+        if e_ > cover_end:
+            cover_end, cover_name = e_, n_
     idle = sum(g for g, _, _ in gaps if g > 0)
-    print(f"== {name}: {len(seg)} kernels, span {span/1e6:.2f} ms, busy {busy/1e6:.2f} ms, idle {idle/1e6:.2f} ms")
+    print(f"== {name}: {len(seg)} kernels, span {span/1e6:.2f} ms, busy (summed over streams) {busy/1e6:.2f} ms, idle (no kernel running) {idle/1e6:.2f} ms")
     hist = collections.Counter()
     for g, _, _ in gaps:
         b = "<2us" if g < 2000 else "2-5us" if g < 5000 else "5-20us" if g < 20000 else "20-100us" if g < 100000 else ">100us"

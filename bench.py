@@ -349,7 +349,7 @@ def main():
         # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
         traffic, traffic_source, pmc_extra = None, None, {}
         if not args.measure_traffic:
-            for name in ("r04_pmc_conv.json", "r03_pmc_conv.json", "r02_pmc_conv.json"):
+            for name in ("r05_pmc_conv.json", "r04_pmc_conv.json", "r03_pmc_conv.json", "r02_pmc_conv.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         pj = json.load(f)

@@ -3,11 +3,11 @@
 # (every step under its own `timeout`; PMC passes never combined with tracing)
 set -u
 OUT=$1
-R=${2:-r04}
+R=${2:-r05}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-QUIET="--skip-v0 --skip-stages --cpu-sample 0 --scenes-in-flight 0 --side-anchors 0"
+QUIET="--skip-v0 --skip-stages --skip-sizes --cpu-sample 0 --scenes-in-flight 0 --side-anchors 0"
 # 1. HBM traffic of the conv kernels: FETCH_SIZE / WRITE_SIZE in separate passes
 BENCH_ARGS="$QUIET" bash tools/pmc_traffic.sh "$OUT/pmc" > "$OUT/pmc_traffic.log" 2>&1
 cp "$OUT/pmc/summary_conv.txt" "$OUT/${R}_pmc_conv_fetch_write.txt"
@@ -28,6 +28,14 @@ python3 tools/timeline.py "$f" > "$OUT/${R}_timeline.txt"
 python3 tools/conv_by_level.py "$f" > "$OUT/${R}_conv_by_level.txt"
 python3 tools/level_breakdown.py "$f" > "$OUT/${R}_decode_levels.txt" 2>&1
 rm -rf "$OUT/t" "$OUT/pmc"
+# 2a. K scenes through one chain of launches (gpcc_encode_batch / gpcc_decode_batch): timelines of the three batch shapes of bench.py's `batched` object
+for cfg in "8 100000" "32 10000" "2 1000000"; do
+  set -- $cfg
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OUT/bt" -o tr -- python3 tools/batch_probe.py $1 $2 4 > "$OUT/batch_probe_$1x$2.log" 2>&1
+  f=$(find "$OUT/bt" -name "*kernel_trace.csv" | head -1)
+  { echo "# rocprofv3 --kernel-trace -- python3 tools/batch_probe.py $1 $2 4   (last encode + decode of the batch; tools/timeline.py)"; grep "^iter" "$OUT/batch_probe_$1x$2.log" | sed 's/^/# /'; python3 tools/timeline.py "$f"; } > "$OUT/${R}_batch_timeline_$1x$2.txt"
+  rm -rf "$OUT/bt"
+done
 # 2b. convolutions per level (per-launch HIP events inside the library)
 { echo "# tools/conv_log.py 1000000 (per-launch HIP events, GAUSPCC_CONV_LOG=1): convolutions of one encode + decode of the 1 M-point bench cloud, per level"
   echo "# 'enc level 0 / 1' = the prior set (levels 0..L-2) / the target set (levels 1..L-1), all levels in one launch; 'dec level g' = the launches on level g's nodes"

@@ -155,15 +155,27 @@ __device__ __forceinline__ void blend_one(float power, float op, float r, float 
     T = upd ? tt : T;
 }
 
-__global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, int W, int H, int gx,
+// dispatch order of the tiles: longest list first (the lists of a frame differ by two orders of magnitude; a long tile that starts last is the
+// frame's tail)
+__global__ __launch_bounds__(TB) void k_tile_order_keys(const uint2 *__restrict__ ranges, int ntiles, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
+{
+    const int t = blockIdx.x * TB + threadIdx.x;
+    if (t >= ntiles) return;
+    const uint32_t c = ranges[t].y - ranges[t].x;
+    key[t] = 0xFFFFFull - (uint64_t)min(c, 0xFFFFFu);
+    idx[t] = (uint32_t)t;
+}
+
+__global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ point_list, int W, int H, int gx,
                                                const float2 *__restrict__ xy, const float *__restrict__ colors, const float4 *__restrict__ conic_op,
                                                float bg0, float bg1, float bg2, float *__restrict__ out)
 {
     __shared__ float4 s_a[RT];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[RT];   // conic.z, opacity, r, g
     __shared__ float2 s_c[RT];   // b, skip threshold: a Gaussian contributes to a pixel only if thr <= power <= 0
-    const int tile = blockIdx.y * gx + blockIdx.x;
-    const int pxi = blockIdx.x * BX + (threadIdx.x & 15), py0 = blockIdx.y * BY + (threadIdx.x >> 4), py1 = py0 + 8;
+    const int tile = (int)tile_order[blockIdx.x];
+    const int tbx = tile % gx, tby = tile / gx;
+    const int pxi = tbx * BX + (threadIdx.x & 15), py0 = tby * BY + (threadIdx.x >> 4), py1 = py0 + 8;
     const bool in0 = pxi < W && py0 < H, in1 = pxi < W && py1 < H;
     const float pxf = (float)pxi, pyf0 = (float)py0, pyf1 = (float)py1;
     const uint2 range = ranges[tile];
@@ -301,7 +313,18 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             LAUNCH_CHECK();
             vals_sorted = v0;
         }
-        k_render<<<dim3((unsigned)cam.gx, (unsigned)cam.gy), RT, 0, st>>>(ranges, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
+        uint32_t *tile_order = nullptr;
+        {
+            uint64_t *oka = ctx->arena.take<uint64_t>(ntiles), *okb = ctx->arena.take<uint64_t>(ntiles);
+            uint32_t *ova = ctx->arena.take<uint32_t>(ntiles), *ovb = ctx->arena.take<uint32_t>(ntiles);
+            if (!oka || !okb || !ova || !ovb) { want += (size_t)ntiles * 32; continue; }
+            k_tile_order_keys<<<(unsigned)cdiv(ntiles, TB), TB, 0, st>>>(ranges, ntiles, oka, ova);
+            LAUNCH_CHECK();
+            uint64_t *k0 = oka, *k1 = okb; uint32_t *v0 = ova, *v1 = ovb;
+            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, ntiles, 20));
+            tile_order = v0;
+        }
+        k_render<<<(unsigned)ntiles, RT, 0, st>>>(ranges, tile_order, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
         LAUNCH_CHECK();
         HIP_TRY(hipStreamSynchronize(st));
         return GPCC_OK;

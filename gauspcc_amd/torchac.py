@@ -43,7 +43,10 @@ def _to_int_rows(cdf_float):
     round(cdf * (2^16 - (Lp - 1))) + arange(Lp), kept as the int16 bit pattern.  Through int32 (exact for values up to 2^16):
     a float -> int16 conversion of 32768 .. 65536 is not the same on every backend, the int32 -> int16 truncation is."""
     lp = cdf_float.shape[-1]
-    scaled = cdf_float.to(torch.float32).mul(float(2 ** PRECISION - (lp - 1))).round().to(torch.int32)
+    # in the tensor's OWN dtype, as torchac multiplies and rounds it (a float64 table rounds differently from its float32 image:
+    # ADVICE round 4); half-precision tables go through float32, the only case torch's CPU backend cannot round natively everywhere
+    own = cdf_float if cdf_float.dtype in (torch.float32, torch.float64) else cdf_float.to(torch.float32)
+    scaled = own.mul(float(2 ** PRECISION - (lp - 1))).round().to(torch.int32)
     return (scaled + torch.arange(lp, dtype=torch.int32, device=cdf_float.device)).to(torch.int16)
 
 

@@ -247,7 +247,9 @@ GPCC_API int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int cha
 
 /* torchac.encode_int16_normalized_cdf / decode_int16_normalized_cdf   pcc_utils.py:174-177,322-366
  * cdf (n,Lp) uint16 device, sym (n) uint8 device.  chunk_log2 as in gpcc_encode
- * (0 = one stream, bytes identical to torchac's).  encode: *bytes_out context-owned host buffer. */
+ * (0 = one stream, bytes identical to torchac's).  encode: *bytes_out context-owned host buffer.
+ * For chunk_log2 != 0 both calls code the lanes with the coder of the CONTEXT's container version (gpcc_ctx_set_container_version:
+ * 4 = the carry-propagating coder, the default; 3 = torchac's): a caller holding version-3 stage streams sets version 3 first. */
 GPCC_API int gpcc_rc_encode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *sym_dev, int64_t n,
                    int chunk_log2, const uint8_t **bytes_out, int64_t *nbytes_out, void *stream);
 GPCC_API int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, const uint8_t *bytes, int64_t nbytes,

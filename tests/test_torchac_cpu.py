@@ -76,8 +76,15 @@ def test_float_rows_on_the_fly_equal_torch_rounding(orc):
     assert np.array_equal(rows_torch, orc.cdf_to_int16(cdf))
     b_fly = torchac.encode_float_cdf(t32, torch.tensor(sym))       # float32 on the host: on the fly
     b_rows = torchac.encode_int16_normalized_cdf(torch.tensor(rows_torch), torch.tensor(sym))
-    b_f64 = torchac.encode_float_cdf(t32.double(), torch.tensor(sym))   # any other dtype: torch ops first
-    assert b_fly == b_rows == b_f64
+    assert b_fly == b_rows
+    # a float64 table is multiplied and rounded in float64, as torchac does with the tensor it is given (its _convert_to_int_and_normalize has no
+    # cast): the fp32 ties above are not ties in fp64, so the rows -- and the bytes -- are those of the float64 arithmetic
+    t64 = t32.double()
+    rows64 = ((t64 * scale).round().to(torch.int32) + torch.arange(lp, dtype=torch.int32)).to(torch.int16)
+    assert torch.equal(torchac._to_int_rows(t64), rows64)
+    b_f64 = torchac.encode_float_cdf(t64, torch.tensor(sym))
+    assert b_f64 == torchac.encode_int16_normalized_cdf(rows64, torch.tensor(sym))
+    assert torch.equal(torchac.decode_float_cdf(t64, b_f64), torch.tensor(sym))
     assert np.array_equal(torchac.decode_float_cdf(t32, b_fly).numpy(), torchac.decode_int16_normalized_cdf(torch.tensor(rows_torch), b_fly).numpy())
 
 

@@ -85,20 +85,30 @@ def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None
         from gauspcc_amd.synth import SyntheticGaussianModelPlus
         encp = SyntheticGaussianModelPlus(n_anchors, seed=3)
         with tempfile.TemporaryDirectory() as d:
-            hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")
-        with tempfile.TemporaryDirectory() as d:
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            logp = hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            decp = SyntheticGaussianModelPlus(64, seed=9)
-            decp.encoding_xyz, decp.mlp_grid, decp.mlp_deform = encp.encoding_xyz, encp.mlp_grid, encp.mlp_deform
-            decp._anchor_feat = torch.zeros(1, encp.feat_dim, device=dev)
-            t2 = time.perf_counter()
-            hac_plus_codec.conduct_decoding(decp, d, ckpt_path="synthetic")
-            torch.cuda.synchronize(); t3 = time.perf_counter()
-            sizep = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
-        out["attribute_loop_hac_plus"] = {"anchors_coded": int(decp._anchor.shape[0]), "files_bytes": sizep, "conduct_encoding_s": round(t1 - t0, 3),
-                                          "conduct_decoding_s": round(t3 - t2, 3), "log": logp.strip()}
+            hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")     # warm-up: model upload, workspace growth, file-system caches
+        # three warm repetitions on the default temporary directory (the box's disk) and three on tmpfs: the 2 343 slice files of a
+        # 1 M-anchor scene make the figure depend on where they land (one number in DESIGN.md and under profiles/)
+        reps = {}
+        logp, sizep, decp = "", 0, None
+        for where, root in (("disk", None), ("tmpfs", "/dev/shm" if os.path.isdir("/dev/shm") else None)):
+            te, td = [], []
+            for _ in range(3):
+                with tempfile.TemporaryDirectory(dir=root) as d:
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    logp = hac_plus_codec.conduct_encoding(encp, d, ckpt_path="synthetic")
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    decp = SyntheticGaussianModelPlus(64, seed=9)
+                    decp.encoding_xyz, decp.mlp_grid, decp.mlp_deform = encp.encoding_xyz, encp.mlp_grid, encp.mlp_deform
+                    decp._anchor_feat = torch.zeros(1, encp.feat_dim, device=dev)
+                    t2 = time.perf_counter()
+                    hac_plus_codec.conduct_decoding(decp, d, ckpt_path="synthetic")
+                    torch.cuda.synchronize(); t3 = time.perf_counter()
+                    sizep = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))
+                    te.append(t1 - t0); td.append(t3 - t2)
+            reps[where] = {"conduct_encoding_s": [round(x, 3) for x in te], "conduct_decoding_s": [round(x, 3) for x in td]}
+        out["attribute_loop_hac_plus"] = {"anchors_coded": int(decp._anchor.shape[0]), "files_bytes": sizep,
+                                          "conduct_encoding_s": sorted(reps["disk"]["conduct_encoding_s"])[1], "conduct_decoding_s": sorted(reps["disk"]["conduct_decoding_s"])[1],
+                                          "repetitions": reps, "log": logp.strip()}
         del encp, decp
     except Exception as e:   # a side figure must not take the line down
         out["attribute_loop_hac_plus"] = {"error": repr(e)}

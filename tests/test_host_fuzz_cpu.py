@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_host_parsers_and_oracle_under_asan_ubsan():
-    r = subprocess.run([os.path.join(ROOT, "tools", "asan_host.sh"), "--parse", "120000", "--decode", "600", "--coder", "10000"], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([os.path.join(ROOT, "tools", "asan_host.sh"), "--parse", "200000", "--decode", "2000", "--coder", "20000"], capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "fuzz_host: ok" in r.stdout, tail
@@ -28,7 +28,7 @@ def test_host_parsers_and_oracle_under_asan_ubsan():
     m = re.search(r"parsers: (\d+) mutants \((\d+) parsed, (\d+) refused\) \| oracle decode: (\d+) mutants \((\d+) clouds, (\d+) refused\) \| coders: (\d+) rounds", line)
     assert m, line
     n_parse, ok_p, bad_p, n_dec, ok_d, bad_d, n_cod = map(int, m.groups())
-    assert n_parse >= 100_000 and ok_p > 1000 and bad_p > 1000 and n_dec >= 600 and ok_d > 0 and bad_d > 0 and n_cod >= 10_000
+    assert n_parse >= 200_000 and ok_p > 1000 and bad_p > 1000 and n_dec >= 2000 and ok_d > 0 and bad_d > 0 and n_cod >= 20_000
 
 
 def test_fuzz_regression_fixtures(orc, golden_dir, synth_model_k3):

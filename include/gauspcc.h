@@ -143,7 +143,7 @@ GPCC_API int gpcc_decode_to(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *b
  * context-owned host buffer holding the containers one after the other, scene i at [offsets_out[i], offsets_out[i + 1])
  * (offsets_out: nscenes + 1 entries, caller-owned).  stats (nullable): nscenes records; conv_pairs and device_ms of the whole
  * batch are in stats[0].  *batched_out (nullable): 1 when the scenes shared one tree, 0 when they were coded one by one (the
- * reference container layout chunk_log2 = 0, a scene whose extent reaches 2^20, more than 256 scenes, or more scenes than the
+ * reference container layout chunk_log2 = 0, a scene whose extent exceeds 2^18 voxels, more than 256 scenes, or more scenes than the
  * 21-bit coordinate frame stacks: same bytes either way). */
 GPCC_API int gpcc_encode_batch(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *const *xyz_dev, const int64_t *n, int nscenes,
                 int chunk_log2, const uint16_t *posq_f16, const uint8_t **bytes_out, int64_t *offsets_out,

@@ -222,3 +222,26 @@ def test_cli_batch_gives_the_same_files(gh, tmp_path):
         assert a == b
         pa, pb = (io.read_points(str(r / f"c{i}.ply.bin.ply")) for _, r in recs)
         assert np.array_equal(pa, pb)
+
+
+def test_identical_and_tiny_scenes_share_a_tree(gh, orc, dev_model_k3, synth_model_k3):
+    """Edge cases of the merged tree: the SAME cloud three times (the scenes' own frames coincide; only the z slabs keep them apart), a single
+    point, seven points (a base level and nothing coded), a cloud of 64 points (one coded level) -- all in one batch, every container == the oracle's."""
+    same = _cloud(3_000, seed=401)
+    clouds = [same, np.array([[5, -3, 11]], dtype=np.int32), same.copy(), _cloud(7, seed=402), _cloud(64, seed=403, extent_log2=6), same.copy(), _cloud(200, seed=404, extent_log2=17, negative=True)[:100]]
+    blobs = _check_batch(gh, dev_model_k3, clouds)
+    for b, c in zip(blobs, clouds):
+        assert b == orc.encode(synth_model_k3, c, chunk_log2=11)
+    assert blobs[0] == blobs[2] == blobs[5]
+
+
+def test_more_scenes_than_a_tree_holds(gh, dev_model_k3):
+    """257 scenes exceed FOREST_MAX_SCENES: the entry points code them one by one (batched flag 0), same bytes; 256 share a tree."""
+    clouds = [_cloud(40 + (i % 7) * 30, seed=500 + i, extent_log2=8) for i in range(257)]
+    blobs, _, batched = _enc_batch(gh, dev_model_k3, clouds)
+    assert not batched
+    b256, _, batched256 = _enc_batch(gh, dev_model_k3, clouds[:256])
+    assert batched256 and b256 == blobs[:256]
+    outs, _, _, _ = _dec_batch(gh, dev_model_k3, b256)
+    for o, c in zip(outs[::17], clouds[:256:17]):
+        assert np.array_equal(o[np.lexsort((o[:, 0], o[:, 1], o[:, 2]))], c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))])

@@ -536,15 +536,19 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
             at += (nbytes[u] + 15) & ~(int64_t)15;
         }
     }
-    // ---- lane tables of every level: [stage][lanes of the level, scene after scene]
+    // ---- lane tables of every level: [stage][lanes of the level, scene after scene].  Parsed in two batches like the solo decoder's
+    // (codec.hip: upload_tables): the tables of the first TAB_EARLY coded levels -- small levels, few lanes -- go up behind the containers;
+    // the rest is parsed once the first level's device work is queued (0.4 ms of host time at 32 scenes that the device no longer waits for)
     RcChunk *hdesc = reinterpret_cast<RcChunk *>(pin + pin_desc);
-    size_t desc_at[MAXLV] = {0};
+    size_t desc_at[MAXLV + 1] = {0};
     uint32_t win_bytes[MAXLV][4] = {};
-    {
-        size_t at = 0;
+    for (int d = 1; d < L; ++d) desc_at[d + 1] = desc_at[d] + 4 * (size_t)nch_tot[d];
+    TAKE(dchunks_all, RcChunk, std::max<size_t>(desc_total, 1));
+    constexpr int TAB_EARLY = 5;
+    auto parse_levels = [&](int d0, int d1, hipEvent_t ev) -> int {
         std::vector<RcChunk> tmp;
-        for (int d = 1; d < L; ++d) {
-            desc_at[d] = at;
+        for (int d = d0; d < d1; ++d) {
+            const size_t at = desc_at[d];
             for (int qi = 0; qi < F.Kd[d]; ++qi) {
                 const int u = order[(size_t)qi];
                 const ContainerHdr &h = H[(size_t)u];
@@ -568,12 +572,14 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
                     }
                 }
             }
-            at += 4 * (size_t)nch_tot[d];
         }
-    }
-    TAKE(dchunks_all, RcChunk, std::max<size_t>(desc_total, 1));
-    if (desc_total) HIP_TRY(hipMemcpyAsync(dchunks_all, hdesc, sizeof(RcChunk) * desc_total, hipMemcpyHostToDevice, ctx->xfer));
-    HIP_TRY(hipEventRecord(ctx->ev_bytes, ctx->xfer));
+        if (d1 > d0 && desc_at[d1] > desc_at[d0])
+            HIP_TRY(hipMemcpyAsync(dchunks_all + desc_at[d0], hdesc + desc_at[d0], sizeof(RcChunk) * (desc_at[d1] - desc_at[d0]), hipMemcpyHostToDevice, ctx->xfer));
+        HIP_TRY(hipEventRecord(ev, ctx->xfer));
+        return GPCC_OK;
+    };
+    const int d_early = std::min(L, 1 + TAB_EARLY);
+    GP_TRY(parse_levels(1, d_early, ctx->ev_bytes));   // (ev_bytes: behind the containers AND the early tables)
     GP_TRY(forest_upload_segs(ctx, st, &F, seg, pin + pin_seg, pin_seg_b));
     // ---- base and root levels
     auto alloc_level = [&](Level *lv, int64_t n, int lvl) -> int {
@@ -705,6 +711,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         TAKE_TOP(cdf, uint16_t, rc_rows_capacity(nch, S) * 16);
         uint8_t *sym[4];
         for (int s = 0; s < 4; ++s) { TAKE_TOP(sy, uint8_t, symlen[g + 1]); sym[s] = sy; }
+        if (g + 1 == d_early && d_early < L) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_tables, 0));   // the first level whose tables went up in the second batch
         if (child_plan && fmode == 1) {
             // the level's whole chain in one persistent launch (fused.hip)
             if (g == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
@@ -751,6 +758,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         { StageTimer tm(ctx, st, ST_ELEM, (double)nc * (4 + 4 + 1)); GP_TRY(assemble_occ(st, sym, spos, nc, chi.occ)); }
         }
         HIP_TRY(hipEventRecord(ctx->ev_main, st));
+        if (g == 0 && d_early < L) GP_TRY(parse_levels(d_early, L, ctx->ev_tables));   // the other levels' tables: parsed while the device runs the first coded level
         ctx->arena.top_rewind(top_mk);
         cellP = cellC; tilesP = tilesC; planP = child_plan ? planC : PairPlan(); planP_np = np;
         ht.mark("bdec level queued", g + 1, nc);

@@ -132,6 +132,331 @@ __global__ __launch_bounds__(TB) void k_assemble(AsmArgs a)
     for (int k = 0; k < 3; ++k) a.xyz[3 * p + k] = a.anchor[3 * i + k] + a.offsets[g * 3 + k] * sc[k];
 }
 
+
+// ---- the same function on the matrix pipe (round 5) ------------------------------------------------------------------
+// k_anchor_mlps spends 13.6 k scalar-operand fmas per anchor at one lane each (1.78 ms per million anchors, 15 TFLOP/s) and
+// hands the K x 10 head outputs of EVERY candidate Gaussian to the assembly through HBM (400 MB written, 400 MB read) although
+// about half of them are dropped.  Here a wave owns 16 anchors: [feat | view | dist] staged in its LDS slice, every layer a
+// chain of v_mfma_f32_16x16x4_f32 with the bias as the initial accumulator (lane (g, e) supplies row e / output e at
+// k = 4 kk + g and receives rows 4 g .. 4 g + 3 of output e), all weights of the launch in LDS at bank-conflict-free
+// pitches.  Two launches around the scan of the keep flags:
+//   k_ng_opacity   x -> opacity MLP -> tanh * mask -> nopa, keep                 (the flags the scan needs; 69 MFMAs per tile)
+//   k_ng_emit      x again -> colour and covariance MLPs -> the tile's 16 x 10 K outputs in LDS -> the surviving Gaussians
+//                  written straight to their final rows (position from the scan): no (n K, 10) intermediate, no assembly pass.
+// x is rebuilt rather than kept: 200 MB of feature reads against 430 MB of x written and read back.  n_offsets <= 16 (the
+// reference's configurations use 10: HAC/arguments/__init__.py:55); wider models stay on k_anchor_mlps.
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+#define NG_MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
+
+template <int F> struct NGM {
+    static constexpr int DINP = (F + 4 + 3) / 4 * 4;   // [feat | view | dist] padded to whole k-steps: 56 / 36
+    static constexpr int DHP = (F + 3) / 4 * 4;        // hidden width padded: 52 / 32
+    static constexpr int NT1 = (F + 15) / 16;          // hidden output tiles: 4 / 2
+    static constexpr int P1 = DINP + 2, P2 = DHP + 2, PB = 6;   // LDS pitches of W1 / W2 / the bank's W1 (4 inputs)
+};
+
+struct MlpLds { const float *w1, *b1, *w2, *b2; };
+
+// floats of one MLP's weights in LDS (first-layer pitch p1, nt2 output tiles)
+template <int F> __host__ __device__ constexpr int ng_mlp_floats(int p1, int nt2) { return NGM<F>::NT1 * 16 * p1 + nt2 * 16 * NGM<F>::P2 + NGM<F>::NT1 * 16 + nt2 * 16; }
+
+template <int F>
+__device__ __forceinline__ MlpLds ng_stage(float *&sm, const Mlp &m, int din, int dinp, int p1, int dout, int nt2, int tid, int nthreads)
+{
+    using M = NGM<F>;
+    float *W1s = sm, *W2s = W1s + M::NT1 * 16 * p1, *B1s = W2s + nt2 * 16 * M::P2, *B2s = B1s + M::NT1 * 16;
+    sm = B2s + nt2 * 16;
+    for (int i = tid; i < M::NT1 * 16 * dinp; i += nthreads) { const int c = i / dinp, k = i - c * dinp; W1s[c * p1 + k] = (c < F && k < din) ? m.w1[c * din + k] : 0.0f; }
+    for (int i = tid; i < nt2 * 16 * M::DHP; i += nthreads) { const int c = i / M::DHP, k = i - c * M::DHP; W2s[c * M::P2 + k] = (c < dout && k < F) ? m.w2[c * F + k] : 0.0f; }
+    for (int i = tid; i < M::NT1 * 16; i += nthreads) B1s[i] = i < F ? m.b1[i] : 0.0f;
+    for (int i = tid; i < nt2 * 16; i += nthreads) B2s[i] = i < dout ? m.b2[i] : 0.0f;
+    return MlpLds{W1s, B1s, W2s, B2s};
+}
+
+__device__ __forceinline__ void ng_wave_sync()
+{   // LDS operations of a wave execute in program order; this only keeps the compiler from moving them across a phase boundary
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// relu(x W1^T + b1) of the tile: A operands in registers, result into hs[16][P2] (columns F .. DHP - 1 come out as zeros)
+template <int F, int NK>
+__device__ __forceinline__ void ng_hidden(const float (&a)[NK], const float *W1s, int p1, const float *B1s, float *hs, int e, int g)
+{
+    using M = NGM<F>;
+    f32x4n acc[M::NT1];
+#pragma unroll
+    for (int t = 0; t < M::NT1; ++t) {
+        const float bias = B1s[16 * t + e];
+        acc[t] = f32x4n{bias, bias, bias, bias};
+        const float *wr = W1s + (16 * t + e) * p1 + g;
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) NG_MF(acc[t], a[kk], wr[4 * kk]);
+    }
+#pragma unroll
+    for (int t = 0; t < M::NT1; ++t)
+        if (16 * t + e < M::DHP) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hs[(4 * g + i) * M::P2 + 16 * t + e] = acc[t][i] > 0.0f ? acc[t][i] : 0.0f;
+        }
+}
+
+template <int F>
+__device__ __forceinline__ f32x4n ng_out_tile(const float (&a)[NGM<F>::DHP / 4], const MlpLds &m, int t, int e, int g)
+{
+    using M = NGM<F>;
+    const float bias = m.b2[16 * t + e];
+    f32x4n acc = {bias, bias, bias, bias};
+    const float *wr = m.w2 + (16 * t + e) * M::P2 + g;
+#pragma unroll
+    for (int kk = 0; kk < M::DHP / 4; ++kk) NG_MF(acc, a[kk], wr[4 * kk]);
+    return acc;
+}
+
+// [feat | view | dist | 0] of anchors row0 .. row0 + 15 into xs[16][px] (rows past n: the last anchor again), the feature bank applied
+template <int F>
+__device__ __forceinline__ void ng_build_x(const NGArgs &a, int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane)
+{
+    using M = NGM<F>;
+    const int e = lane & 15, g = lane >> 4;
+    for (int i = lane; i < 16 * (F / 2); i += 64) {
+        const int r = i / (F / 2), c2 = i - r * (F / 2);
+        const int64_t row = row0 + r < a.n ? row0 + r : a.n - 1;
+        *reinterpret_cast<float2 *>(xs + r * px + 2 * c2) = *reinterpret_cast<const float2 *>(a.feat + row * F + 2 * c2);
+    }
+    if (lane < 16) {   // ob_view / ob_dist (:116-118)
+        const int64_t row = row0 + lane < a.n ? row0 + lane : a.n - 1;
+        const float vx = a.anchor[3 * row] - a.cam[0], vy = a.anchor[3 * row + 1] - a.cam[1], vz = a.anchor[3 * row + 2] - a.cam[2];
+        const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
+        float *x = xs + lane * px + F;
+        x[0] = vx / dist; x[1] = vy / dist; x[2] = vz / dist; x[3] = dist;
+        for (int k = F + 4; k < M::DINP; ++k) xs[lane * px + k] = 0.0f;
+    }
+    ng_wave_sync();
+    if (!bank) return;
+    // view-adaptive feature (:121-132): softmax(bank MLP(view, dist)) mixes the feature at strides 4 / 2 / 1
+    {
+        const float av[1] = {xs[e * px + F + g]};
+        ng_hidden<F, 1>(av, bk.w1, M::PB, bk.b1, hs, e, g);
+    }
+    ng_wave_sync();
+    float a2[M::DHP / 4];
+#pragma unroll
+    for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
+    const f32x4n z = ng_out_tile<F>(a2, bk, 0, e, g);
+    ng_wave_sync();
+    if (e < 3) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hs[(4 * g + i) * M::P2 + e] = z[i];
+    }
+    ng_wave_sync();
+    if (lane < 16) {
+        float z0 = hs[lane * M::P2], z1 = hs[lane * M::P2 + 1], z2 = hs[lane * M::P2 + 2];
+        const float zm = fmaxf(z0, fmaxf(z1, z2));
+        z0 = expf(z0 - zm); z1 = expf(z1 - zm); z2 = expf(z2 - zm);
+        const float zs = z0 + z1 + z2;
+        hs[lane * M::P2] = z0 / zs; hs[lane * M::P2 + 1] = z1 / zs; hs[lane * M::P2 + 2] = z2 / zs;
+    }
+    ng_wave_sync();
+    constexpr int NIT = (16 * F + 63) / 64;
+    float y[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx < 16 * F) {
+            const int r = idx / F, k = idx - r * F;
+            const float *x = xs + r * px, *w = hs + r * M::P2;
+            y[it] = x[(k % (F / 4)) * 4] * w[0] + x[(k % (F / 2)) * 2] * w[1] + x[k] * w[2];
+        }
+    }
+    ng_wave_sync();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = lane + 64 * it;
+        if (idx < 16 * F) { const int r = idx / F, k = idx - r * F; xs[r * px + k] = y[it]; }
+    }
+    ng_wave_sync();
+}
+
+template <int F>
+__global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
+{
+    using M = NGM<F>;
+    extern __shared__ __attribute__((aligned(16))) float ngsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6, e = lane & 15, g = lane >> 4;
+    float *sm = ngsm;
+    const bool bank = a.bank.w1 != nullptr;
+    MlpLds bk = {};
+    if (bank) bk = ng_stage<F>(sm, a.bank, 4, 4, M::PB, 3, 1, tid, blockDim.x);
+    const MlpLds op = ng_stage<F>(sm, a.opacity, F + 4, M::DINP, M::P1, a.K, 1, tid, blockDim.x);
+    __syncthreads();
+    constexpr int PX = M::P1;
+    float *xs = sm + wave * 16 * (PX + M::P2), *hs = xs + 16 * PX;
+    const int64_t ntiles = (a.n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
+        const int64_t row0 = tile * 16;
+        ng_build_x<F>(a, row0, xs, PX, hs, bank, bk, lane);
+        float a1[M::DINP / 4];
+#pragma unroll
+        for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
+        ng_hidden<F, M::DINP / 4>(a1, op.w1, M::P1, op.b1, hs, e, g);
+        ng_wave_sync();
+        float a2[M::DHP / 4];
+#pragma unroll
+        for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
+        const f32x4n v = ng_out_tile<F>(a2, op, 0, e, g);
+        // opacity: tanh head, times the binary grid mask; a Gaussian survives when the product is positive (:136-141)
+        if (e < a.K) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t row = row0 + 4 * g + i;
+                if (row < a.n) {
+                    const float o = tanhf(v[i]) * a.mask[row * a.K + e];
+                    a.nopa[row * a.K + e] = o;
+                    a.keep[row * a.K + e] = o > 0.0f ? 1u : 0u;
+                }
+            }
+        }
+        ng_wave_sync();
+    }
+}
+
+struct EmitArgs {
+    const float *offsets, *scaling;
+    const uint32_t *pos;
+    int px;                            // pitch of the wave's tile buffer: even, >= DINP + 2 and >= 10 K
+    float *xyz, *color, *opacity, *scale, *rot;
+};
+
+template <int F>
+__global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
+{
+    using M = NGM<F>;
+    extern __shared__ __attribute__((aligned(16))) float ngsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, waves = blockDim.x >> 6, e = lane & 15, g = lane >> 4;
+    const int K = a.K, ntc = (3 * K + 15) / 16, ntv = (7 * K + 15) / 16, PX = o.px;
+    float *sm = ngsm;
+    const bool bank = a.bank.w1 != nullptr;
+    MlpLds bk = {};
+    if (bank) bk = ng_stage<F>(sm, a.bank, 4, 4, M::PB, 3, 1, tid, blockDim.x);
+    const MlpLds col = ng_stage<F>(sm, a.color, F + 4, M::DINP, M::P1, 3 * K, ntc, tid, blockDim.x);
+    const MlpLds cov = ng_stage<F>(sm, a.cov, F + 4, M::DINP, M::P1, 7 * K, ntv, tid, blockDim.x);
+    __syncthreads();
+    float *xs = sm + wave * 16 * (PX + M::P2), *hs = xs + 16 * PX;
+    const int64_t ntiles = (a.n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
+        const int64_t row0 = tile * 16;
+        ng_build_x<F>(a, row0, xs, PX, hs, bank, bk, lane);
+        float a1[M::DINP / 4];
+#pragma unroll
+        for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
+        float a2[M::DHP / 4];
+        // colour: sigmoid head (:147-148) -> columns 0 .. 3 K - 1 of the tile buffer (x is in registers now)
+        ng_hidden<F, M::DINP / 4>(a1, col.w1, M::P1, col.b1, hs, e, g);
+        ng_wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
+        for (int t = 0; t < ntc; ++t) {
+            const f32x4n v = ng_out_tile<F>(a2, col, t, e, g);
+            const int c = 16 * t + e;
+            if (c < 3 * K) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + c] = 1.0f / (1.0f + expf(-v[i]));
+            }
+        }
+        ng_wave_sync();
+        // covariance: linear head, 7 per Gaussian (:151-152) -> columns 3 K .. 10 K - 1
+        ng_hidden<F, M::DINP / 4>(a1, cov.w1, M::P1, cov.b1, hs, e, g);
+        ng_wave_sync();
+#pragma unroll
+        for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
+        for (int t = 0; t < ntv; ++t) {
+            const f32x4n v = ng_out_tile<F>(a2, cov, t, e, g);
+            const int c = 16 * t + e;
+            if (c < 7 * K) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + 3 * K + c] = v[i];
+            }
+        }
+        ng_wave_sync();
+        // the surviving Gaussians of the tile, each to its final row (:160-171)
+        for (int idx = lane; idx < 16 * K; idx += 64) {
+            const int r = idx / K, j = idx - r * K;
+            const int64_t i = row0 + r;
+            if (i >= a.n) continue;
+            const int64_t gi = i * K + j;
+            if (!a.keep[gi]) continue;
+            const uint32_t p = o.pos[gi];
+            const float *c3 = xs + r * PX + 3 * j, *d = xs + r * PX + 3 * K + 7 * j, *sc = o.scaling + i * 6;
+            o.opacity[p] = a.nopa[gi];
+            o.color[3 * p] = c3[0]; o.color[3 * p + 1] = c3[1]; o.color[3 * p + 2] = c3[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.scale[3 * p + k] = sc[3 + k] * (1.0f / (1.0f + expf(-d[k])));
+            const float q0 = d[3], q1 = d[4], q2 = d[5], q3 = d[6];
+            const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+            o.rot[4 * p] = q0 / nrm; o.rot[4 * p + 1] = q1 / nrm; o.rot[4 * p + 2] = q2 / nrm; o.rot[4 * p + 3] = q3 / nrm;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o.xyz[3 * p + k] = a.anchor[3 * i + k] + o.offsets[gi * 3 + k] * sc[k];
+        }
+        ng_wave_sync();
+    }
+}
+
+constexpr size_t NG_LDS_MAX = 160 * 1024;
+
+template <int F> static size_t ng_lds_opacity(bool bank, int waves)
+{
+    using M = NGM<F>;
+    return 4 * ((size_t)(bank ? ng_mlp_floats<F>(M::PB, 1) : 0) + ng_mlp_floats<F>(M::P1, 1) + (size_t)waves * 16 * (M::P1 + M::P2));
+}
+template <int F> static int ng_emit_pitch(int K) { const int px = std::max(NGM<F>::P1, 10 * K); return px + (px & 1); }
+template <int F> static size_t ng_lds_emit(bool bank, int K, int waves)
+{
+    using M = NGM<F>;
+    return 4 * ((size_t)(bank ? ng_mlp_floats<F>(M::PB, 1) : 0) + ng_mlp_floats<F>(M::P1, (3 * K + 15) / 16) + ng_mlp_floats<F>(M::P1, (7 * K + 15) / 16) +
+                (size_t)waves * 16 * (ng_emit_pitch<F>(K) + M::P2));
+}
+
+// number of waves per workgroup for the two launches, 0 when the model does not fit the matrix-pipe path
+template <int F> static int ng_mfma_waves(bool bank, int K)
+{
+    if (K > 16) return 0;
+    for (int waves = 8; waves >= 4; waves -= 4)
+        if (ng_lds_emit<F>(bank, K, waves) <= NG_LDS_MAX && ng_lds_opacity<F>(bank, waves) <= NG_LDS_MAX) return waves;
+    return 0;
+}
+
+template <int F>
+static int ng_mfma_opacity(gpcc_ctx *ctx, const NGArgs &a, int waves, hipStream_t st)
+{
+    const size_t lds = ng_lds_opacity<F>(a.bank.w1 != nullptr, waves);
+    static PerDeviceOnce attr;
+    GP_TRY(attr.run(ctx->device, [&]() -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_opacity<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
+        return GPCC_OK;
+    }));
+    const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(a.n, 16), waves));
+    k_ng_opacity<F><<<grid, 64 * waves, lds, st>>>(a);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
+template <int F>
+static int ng_mfma_emit(gpcc_ctx *ctx, const NGArgs &a, EmitArgs o, int waves, hipStream_t st)
+{
+    const size_t lds = ng_lds_emit<F>(a.bank.w1 != nullptr, a.K, waves);
+    o.px = ng_emit_pitch<F>(a.K);
+    static PerDeviceOnce attr;
+    GP_TRY(attr.run(ctx->device, [&]() -> int {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_emit<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
+        return GPCC_OK;
+    }));
+    const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(a.n, 16), waves));
+    k_ng_emit<F><<<grid, 64 * waves, lds, st>>>(a, o);
+    LAUNCH_CHECK();
+    return GPCC_OK;
+}
+
 }  // namespace
 
 extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
@@ -151,9 +476,11 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     const int64_t nk = n * n_offsets;
-    GP_TRY(ctx->arena.reserve((size_t)nk * (4 + 40 + 4 + 4) + ((size_t)4 << 20)));
+    static const bool use_mfma = dev_env_int("GAUSPCC_NG_MFMA", 1) != 0;
+    const int waves = !use_mfma ? 0 : feat_dim == 32 ? ng_mfma_waves<32>(mlp[0] != nullptr, n_offsets) : ng_mfma_waves<50>(mlp[0] != nullptr, n_offsets);
+    GP_TRY(ctx->arena.reserve((size_t)nk * (4 + (waves ? 0 : 40) + 4 + 4) + ((size_t)4 << 20)));
     ctx->arena.reset();
-    TAKE(nopa, float, nk); TAKE(dense, float, nk * 10); TAKE(keep, uint32_t, nk); TAKE(pos, uint32_t, nk + 1);
+    TAKE(nopa, float, nk); TAKE(keep, uint32_t, nk); TAKE(pos, uint32_t, nk + 1);
     NGArgs a = {};
     a.anchor = anchor; a.feat = feat; a.offsets = offsets; a.scaling = scaling; a.mask = mask; a.n = n; a.K = n_offsets;
     float cam[3];
@@ -164,16 +491,26 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
     a.opacity = Mlp{mlp[4], mlp[5], mlp[6], mlp[7]};
     a.cov = Mlp{mlp[8], mlp[9], mlp[10], mlp[11]};
     a.color = Mlp{mlp[12], mlp[13], mlp[14], mlp[15]};
-    a.nopa = nopa; a.dense = dense; a.keep = keep;
-    if (feat_dim == 32) k_anchor_mlps<32><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(a);
-    else k_anchor_mlps<50><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(a);
-    LAUNCH_CHECK();
-    GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
+    a.nopa = nopa; a.keep = keep;
     uint32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
-    AsmArgs b = {anchor, offsets, scaling, nopa, dense, keep, pos, nk, n_offsets, xyz_out, color_out, opacity_out, scale_out, rot_out};
-    k_assemble<<<(unsigned)cdiv(nk, TB), TB, 0, st>>>(b);
-    LAUNCH_CHECK();
+    if (waves) {   // matrix pipe: flags -> scan -> colour / covariance and the surviving rows in one launch
+        if (feat_dim == 32) GP_TRY(ng_mfma_opacity<32>(ctx, a, waves, st)); else GP_TRY(ng_mfma_opacity<50>(ctx, a, waves, st));
+        GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
+        HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
+        EmitArgs o = {offsets, scaling, pos, 0, xyz_out, color_out, opacity_out, scale_out, rot_out};
+        if (feat_dim == 32) GP_TRY(ng_mfma_emit<32>(ctx, a, o, waves, st)); else GP_TRY(ng_mfma_emit<50>(ctx, a, o, waves, st));
+    } else {
+        TAKE(dense, float, nk * 10);
+        a.dense = dense;
+        if (feat_dim == 32) k_anchor_mlps<32><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(a);
+        else k_anchor_mlps<50><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(a);
+        LAUNCH_CHECK();
+        GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
+        HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
+        AsmArgs b = {anchor, offsets, scaling, nopa, dense, keep, pos, nk, n_offsets, xyz_out, color_out, opacity_out, scale_out, rot_out};
+        k_assemble<<<(unsigned)cdiv(nk, TB), TB, 0, st>>>(b);
+        LAUNCH_CHECK();
+    }
     HIP_TRY(hipStreamSynchronize(st));
     *count_out = (int64_t)total;
     return GPCC_OK;

@@ -71,7 +71,8 @@ def _torch_reference(torch, cam, pc, visible_mask):
     return xyz, color, opacity, scaling, rot, neural_opacity.view(-1)
 
 
-@pytest.mark.parametrize("F,K,bank,n", [(50, 10, False, 20011), (32, 10, True, 7001), (32, 5, False, 300)])
+@pytest.mark.parametrize("F,K,bank,n", [(50, 10, False, 20011), (32, 10, True, 7001), (32, 5, False, 300), (32, 12, True, 9001), (32, 16, True, 4099), (50, 16, False, 15),
+                                        (50, 17, False, 2000)])   # n_offsets > 16: the one-lane-per-anchor kernel
 def test_generate_neural_gaussians_matches_torch(torch_cuda, F, K, bank, n):
     torch = torch_cuda
     from gauspcc_amd.neural_gaussians import generate_neural_gaussians

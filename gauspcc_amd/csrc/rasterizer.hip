@@ -121,14 +121,52 @@ __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restric
         }
 }
 
-__global__ __launch_bounds__(TB) void k_tile_ranges(int L, const uint64_t *__restrict__ keys, uint2 *__restrict__ ranges)
+// Two-level form of the (tile | depth) sort (round 5).  The reference sorts the L duplicated (tile << 32 | depth) keys in one radix sort
+// (six 8-bit passes over 18 M pairs at 1 M anchors: the largest part of a frame).  A stable sort by depth of the P Gaussians (four passes over
+// 5.4 M), the duplicates emitted in THAT order, and a stable sort of the duplicates by tile alone (two passes) give the same permutation:
+// within a tile, depth ascending, equal depths in Gaussian order -- exactly what the stable sort of the combined key produces.
+__global__ __launch_bounds__(TB) void k_depth_keys(int P, const float *__restrict__ depth, const int *__restrict__ radii, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i >= P) return;
+    keys[i] = radii[i] > 0 ? (uint64_t)__float_as_uint(depth[i]) : 0xFFFFFFFFull;   // visible depths are positive: their bit patterns order as the values do
+    vals[i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(TB) void k_gather_touched(int P, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ touched, uint32_t *__restrict__ out)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    if (i < P) out[i] = touched[perm[i]];
+}
+
+__global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *__restrict__ perm, const float2 *__restrict__ xy, const uint32_t *__restrict__ offs,
+                                                         const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int s = blockIdx.x * TB + threadIdx.x;
+    if (s >= P) return;
+    const uint32_t i = perm[s];
+    if (radii[i] <= 0) return;
+    uint32_t off = offs[s];
+    const float r = (float)radii[i];
+    const float2 p = xy[i];
+    const int rx0 = min(gx, max(0, (int)((p.x - r) / BX))), ry0 = min(gy, max(0, (int)((p.y - r) / BY)));
+    const int rx1 = min(gx, max(0, (int)((p.x + r + BX - 1) / BX))), ry1 = min(gy, max(0, (int)((p.y + r + BY - 1) / BY)));
+    for (int y = ry0; y < ry1; ++y)
+        for (int x = rx0; x < rx1; ++x) {
+            keys[off] = (uint64_t)(uint32_t)(y * gx + x);
+            vals[off] = i;
+            ++off;
+        }
+}
+
+__global__ __launch_bounds__(TB) void k_tile_ranges(int L, const uint64_t *__restrict__ keys, int shift, uint2 *__restrict__ ranges)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= L) return;
-    const uint32_t t = (uint32_t)(keys[i] >> 32);
+    const uint32_t t = (uint32_t)(keys[i] >> shift);
     if (i == 0) ranges[t].x = 0;
     else {
-        const uint32_t pt = (uint32_t)(keys[i - 1] >> 32);
+        const uint32_t pt = (uint32_t)(keys[i - 1] >> shift);
         if (t != pt) { ranges[pt].y = (uint32_t)i; ranges[t].x = (uint32_t)i; }
     }
     if (i == L - 1) ranges[t].y = (uint32_t)L;
@@ -282,7 +320,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
     float bg[3];
     HIP_TRY(hipMemcpy(bg, background, 12, hipMemcpyDeviceToHost));
     const int ntiles = cam.gx * cam.gy;
-    size_t want = (size_t)std::max(P, 1) * 64 + (size_t)ntiles * 8 + ((size_t)8 << 20);
+    size_t want = (size_t)std::max(P, 1) * 96 + (size_t)ntiles * 8 + ((size_t)8 << 20);
     uint32_t L = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         GP_TRY(ctx->arena.reserve(want + (size_t)L * 40));
@@ -290,11 +328,27 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
         TAKE(xy, float2, std::max(P, 1)); TAKE(depth, float, std::max(P, 1)); TAKE(conic_op, float4, std::max(P, 1));
         TAKE(touched, uint32_t, std::max(P, 1) + 1); TAKE(ranges, uint2, ntiles);
         HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st));
+        static const bool two_level = dev_env_int("GAUSPCC_RASTER_SORT2", 1) != 0;
+        const uint32_t *perm = nullptr;          // Gaussians in depth order (two-level sort)
+        const uint32_t *offs = touched;
         if (P > 0) {
             k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched);
             LAUNCH_CHECK();
-            GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
-            HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
+            if (two_level) {
+                TAKE(dka, uint64_t, P); TAKE(dkb, uint64_t, P); TAKE(dva, uint32_t, P); TAKE(dvb, uint32_t, P); TAKE(ts, uint32_t, P + 1);
+                k_depth_keys<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, depth, radii, dka, dva);
+                LAUNCH_CHECK();
+                uint64_t *k0 = dka, *k1 = dkb; uint32_t *v0 = dva, *v1 = dvb;
+                GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, P, 32));
+                k_gather_touched<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, v0, touched, ts);
+                LAUNCH_CHECK();
+                GP_TRY(exclusive_scan_u32(ctx, st, ts, ts, P, ts + P));
+                HIP_TRY(hipMemcpyAsync(&L, ts + P, 4, hipMemcpyDeviceToHost, st));
+                perm = v0; offs = ts;
+            } else {
+                GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
+                HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
+            }
             HIP_TRY(hipStreamSynchronize(st));
         }
         if (num_rendered_out) *num_rendered_out = L;
@@ -303,13 +357,20 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             uint64_t *ka = ctx->arena.take<uint64_t>(L), *kb = ctx->arena.take<uint64_t>(L);
             uint32_t *va = ctx->arena.take<uint32_t>(L), *vb = ctx->arena.take<uint32_t>(L);
             if (!ka || !kb || !va || !vb || ctx->arena.cap - ctx->arena.off < (size_t)L * 2 + ((size_t)2 << 20)) { want += (size_t)L * 4; continue; }  // grow and redo
-            k_duplicate<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, xy, depth, touched, radii, cam.gx, cam.gy, ka, va);
-            LAUNCH_CHECK();
             int tbits = 1;
             while ((1 << tbits) < ntiles) ++tbits;
             uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
-            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, 32 + tbits));
-            k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, ranges);
+            if (perm) {
+                k_duplicate_sorted<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, perm, xy, offs, radii, cam.gx, cam.gy, ka, va);
+                LAUNCH_CHECK();
+                GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, tbits));
+                k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, 0, ranges);
+            } else {
+                k_duplicate<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, xy, depth, offs, radii, cam.gx, cam.gy, ka, va);
+                LAUNCH_CHECK();
+                GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, 32 + tbits));
+                k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, 32, ranges);
+            }
             LAUNCH_CHECK();
             vals_sorted = v0;
         }

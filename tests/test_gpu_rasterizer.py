@@ -93,3 +93,40 @@ def test_empty_and_background():
     img, radii = rast(means3D=t["means"], means2D=None, shs=None, colors_precomp=t["colors"], opacities=t["opac"], scales=t["scales"], rotations=t["rots"])
     assert int(radii.sum()) == 0
     assert torch.allclose(img, torch.tensor(bg).cuda().view(3, 1, 1).expand(3, H, W))
+
+
+def test_two_level_sort_equals_combined_key_sort():
+    """The (tile | depth) order through a depth sort of the Gaussians + a tile sort of the duplicates (csrc/rasterizer.hip, round 5) against
+    the reference's single sort of the combined key (GAUSPCC_RASTER_SORT2=0, developer knob): the same image bit for bit, on a scene where a
+    third of the Gaussians share their depth with others (equal keys: the stable order by Gaussian index decides)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests.test_gpu_rasterizer import _scene, _settings
+from gauspcc_amd.rasterizer import GaussianRasterizer
+W, H, n = 400, 300, 60000
+sc = _scene(n, 11, W, H)
+sc["means"][::3, 2] = np.float32(0.5)          # shared depth
+sc["means"][1::7, 2] = np.float32(-1.25)
+rast = GaussianRasterizer(_settings(torch, sc, W, H, np.array([0.1, 0.2, 0.3], np.float32)))
+t = {k: torch.tensor(v).cuda() for k, v in sc.items() if isinstance(v, np.ndarray)}
+img, radii = rast(means3D=t["means"], means2D=None, shs=None, colors_precomp=t["colors"], opacities=t["opac"], scales=t["scales"], rotations=t["rots"])
+print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), rast.num_rendered)
+""" % root
+    out = []
+    for v in ("1", "0"):
+        e = dict(os.environ)
+        e["GAUSPCC_DEV"] = "1"
+        e["GAUSPCC_RASTER_SORT2"] = v
+        r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
+    assert out[0] == out[1] and int(out[0].split()[-1]) > 100000

@@ -45,7 +45,7 @@ EXPORTS = [
     "gpcc_last_error", "gpcc_version", "gpcc_ctx_create", "gpcc_ctx_destroy", "gpcc_ctx_bytes", "gpcc_ctx_set_container_version", "gpcc_raster_order", "gpcc_voxelise",
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_encode_batch", "gpcc_decode_batch", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
-    "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get", "gpcc_debug_exclusive_scan", "gpcc_debug_launches",
+    "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get", "gpcc_debug_exclusive_scan", "gpcc_debug_launches", "gpcc_device_error_check",
     "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_host_encode_f32", "gsac_host_decode_f32", "gpcc_write_files", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gsac_encode_gaussian_mixed_slices", "gsac_decode_gaussian_mixed_slices", "gshac_mlp2", "gshac_mlp2_act", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
 ]
 
@@ -96,6 +96,7 @@ def lib():
     L.gpcc_debug_capture_get.argtypes = [vp, i32, vp, C.c_longlong]
     L.gpcc_debug_exclusive_scan.argtypes = [vp, vp, vp, vp, vp, i64, vp, vp]
     L.gpcc_debug_launches.argtypes = [i32]
+    L.gpcc_device_error_check.argtypes = [vp]
     L.gpcc_debug_launches.restype = C.c_longlong
     L.gpcc_profile_get.argtypes = [vp, C.POINTER(Profile)]
     L.gpcc_profile_stages.argtypes = [vp, C.POINTER(Stage), i32, C.POINTER(i32)]

@@ -45,6 +45,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     fused_ctx_release(c);
     if (c->fused_state) (void)hipFree(c->fused_state);
     for (auto &ss : c->scan_states) if (ss.status) (void)hipFree(ss.status);
+    if (c->dev_err) (void)hipHostFree(c->dev_err);
     if (c->hbytes.p) (void)hipHostFree(c->hbytes.p);
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
@@ -57,6 +58,14 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
 // carry-propagating coder in the lanes) or 3 (torchac's coder in the lanes: what round 3 wrote).  Readers take 0-4.
 // kernel launches enqueued by the calling thread since the last reset (every launch site of the library passes LAUNCH_CHECK);
 // bench.py's `kernels per decode` and the batch's launch-count bar read it
+// the sticky device-side error word of the context (primitives.hpp: device_error_check): for callers of the stage-level entry points that
+// do not synchronise themselves -- call after synchronising the stream
+extern "C" int gpcc_device_error_check(gpcc_ctx *ctx)
+{
+    if (!ctx) return fail(GPCC_ERR_ARG, "null argument");
+    return device_error_check(ctx);
+}
+
 extern "C" long long gpcc_debug_launches(int reset)
 {
     const long long v = gpcc::g_launches;
@@ -520,7 +529,7 @@ extern "C" int gpcc_sort_zyx(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, uint3
     GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, n, 63));
     HIP_TRY(hipMemcpyAsync(perm, v0, 4 * (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return GPCC_OK;
+    return device_error_check(ctx);
 }
 
 extern "C" int gpcc_build_octree(gpcc_ctx *ctx, const int32_t *xyz, int64_t n, int32_t *levels_out, int64_t *level_nodes_out,
@@ -669,7 +678,7 @@ extern "C" int gpcc_head_cdf(gpcc_ctx *ctx, const float *x_dev, int64_t n, int c
     ha.prob = prob_dev; ha.cdf = cdf_dev; ha.mode = 2;
     GP_TRY(head_cdf(st, ha));
     HIP_TRY(hipStreamSynchronize(st));
-    return GPCC_OK;
+    return device_error_check(ctx);
 }
 
 // One stream of the container as gpcc_encode writes it for a level of n nodes (rangecoder.hpp: rc_plan, version 3):
@@ -744,5 +753,5 @@ extern "C" int gpcc_rc_decode(gpcc_ctx *ctx, const uint16_t *cdf_dev, int lp, co
     GP_TRY(rc_decode_launch(st, rows, lp, db, dch, nch, win, pl.dual, symbuf, chunk_log2 ? rc_coder_of_version(version) : RC_CODER_CARRYLESS));
     HIP_TRY(hipMemcpyAsync(sym_dev, symbuf, (size_t)n, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return GPCC_OK;
+    return device_error_check(ctx);
 }

@@ -385,6 +385,7 @@ static int gsac_encode_impl(gpcc_ctx *ctx, const int16_t *sym, CT cdf, int chunk
     HIP_TRY(hipMemcpyAsync(hcnt, dcnt, 4 * (size_t)nch, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hcnt + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    GP_TRY(device_error_check(ctx));
     const size_t total = hcnt[nch];
     GP_TRY(ctx->hbytes.reserve(total + 16));
     if (total) HIP_TRY(hipMemcpyAsync(ctx->hbytes.p, payload, total, hipMemcpyDeviceToHost, st));
@@ -930,6 +931,7 @@ static int encode_slices_impl(gpcc_ctx *ctx, const float *x, CT table, const flo
     HIP_TRY(hipMemcpyAsync(hcnt + nch, doff + nch, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hmm, mm, 8 * (size_t)nslices, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    GP_TRY(device_error_check(ctx));
     for (int s = 0; s < nslices; ++s) {
         if (hmm[2 * s + 1] - hmm[2 * s] + 2 > 32767) return fail(GPCC_ERR_RANGE, "slice %d: quantised values span %d levels (int16 symbols)", s, hmm[2 * s + 1] - hmm[2 * s] + 1);
         min_out[s] = (float)hmm[2 * s]; max_out[s] = (float)hmm[2 * s + 1];

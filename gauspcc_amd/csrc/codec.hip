@@ -766,6 +766,7 @@ extern "C" int gpcc_encode(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xy
         want *= 2;  // deep / very sparse trees: more nodes per point than the estimate
     }
     if (rc == GPCC_OK && stats) stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const int de = device_error_check(ctx)) rc = de;   // a device-side fault outranks whatever the garbage it left behind was taken for
     return rc;
 }
 
@@ -809,6 +810,7 @@ static int decode_entry(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *bytes
     }
     if (rc == GPCC_OK && xyz_dev_out) *xyz_dev_out = xyz;
     if (rc == GPCC_OK && stats) stats->device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const int de = device_error_check(ctx)) rc = de;
     return rc;
 }
 

@@ -880,6 +880,7 @@ extern "C" int gpcc_encode_batch(gpcc_ctx *ctx, const gpcc_model *m, const int32
         rc = GPCC_OK;
     }
     if (rc == GPCC_OK && stats) stats[0].device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const int de = device_error_check(ctx)) rc = de;
     return rc;
 }
 
@@ -955,5 +956,6 @@ extern "C" int gpcc_decode_batch(gpcc_ctx *ctx, const gpcc_model *m, const uint8
         rc = GPCC_OK;
     }
     if (rc == GPCC_OK && stats) stats[0].device_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (const int de = device_error_check(ctx)) rc = de;
     return rc;
 }

@@ -512,6 +512,7 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
         LAUNCH_CHECK();
     }
     HIP_TRY(hipStreamSynchronize(st));
+    GP_TRY(device_error_check(ctx));
     *count_out = (int64_t)total;
     return GPCC_OK;
 }

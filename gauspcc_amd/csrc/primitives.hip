@@ -8,6 +8,7 @@
 //                    running per-digit counters in LDS across the 16 rounds of a tile.
 // HBM-bound integer work: per pass it reads keys twice and writes them once.
 #include "primitives.hpp"
+#include <atomic>
 
 namespace gpcc {
 
@@ -236,7 +237,7 @@ constexpr unsigned long long LB_AGG = 1ull << 32, LB_INC = 2ull << 32;
 __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag, uint32_t v) { return ((unsigned long long)epoch << 34) | flag | v; }
 
 __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n, unsigned long long *status, uint32_t *ticket,
-                                                        uint32_t epoch, uint32_t *__restrict__ total_out)
+                                                        uint32_t epoch, uint32_t *__restrict__ total_out, uint32_t *err, uint32_t spin_limit, uint32_t skip_tile)
 {
     const int lane = threadIdx.x;
     uint32_t t = 0;
@@ -251,7 +252,8 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
     wave_tile_load(in, base, n, lane, v);
     const uint32_t total = wave_tile_scan(v, lane, ex);
     uint32_t excl = 0;
-    if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, tile == 0 ? LB_INC : LB_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (skip_tile: developer fault injection -- that tile never publishes; 0xFFFFFFFF: none)
+    if (lane == 0 && tile != skip_tile) __hip_atomic_store(status + tile, lb_pack(epoch, tile == 0 ? LB_INC : LB_AGG, total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tile > 0) {
         int64_t j = (int64_t)tile - 1;       // nearest predecessor not yet accounted for
         uint32_t idle = 0;
@@ -273,14 +275,32 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
             if (take == 0) {
                 __builtin_amdgcn_s_sleep(1);
                 // predecessors are running workgroups (tickets are drawn in start order): no progress for ~10 s means the launch's
-                // state was damaged -- end the launch loudly (the stream reports an error) rather than spin for ever
-                if (++idle > (1u << 24)) __builtin_trap();
+                // state was damaged.  Raise the context's sticky error word (host memory: the caller reads it after its final sync and
+                // fails the call, device_error_check) and let the launch run out -- this tile publishes an inclusive prefix, so its
+                // successors stop waiting too; the output is garbage, the process and its other contexts live on (a trap would end them all)
+                if (++idle > spin_limit) {
+                    if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
             } else idle = 0;
         }
         if (lane == 0) __hip_atomic_store(status + tile, lb_pack(epoch, LB_INC, excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (lane == 0 && total_out && tile == gridDim.x - 1u) *total_out = excl + total;
     wave_tile_store(out, base, n, lane, v, ex, excl);
+}
+
+int device_error_check(gpcc_ctx *ctx)
+{
+    if (!ctx || !ctx->dev_err || *static_cast<volatile uint32_t *>(ctx->dev_err) == 0u) return GPCC_OK;
+    *static_cast<volatile uint32_t *>(ctx->dev_err) = 0u;
+    for (auto &ss : ctx->scan_states) {   // tickets and status words of an abandoned launch are undefined: start every stream's state over
+        (void)hipStreamSynchronize(ss.st);
+        (void)hipMemsetAsync(ss.status, 0, 8 * (size_t)LB_MAX_TILES + 256, ss.st);
+        ss.epoch = 0u;
+    }
+    (void)hipGetLastError();
+    return fail(GPCC_ERR_HIP, "a device-wide scan made no progress (look-back state damaged): the results of this call are invalid; the scan state was reset");
 }
 
 // the scan state of (context, stream): created on first use (one hipMalloc + memset per stream of a context)
@@ -297,6 +317,12 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
         (void)hipGetLastError();
         if (old.status) (void)hipFree(old.status);
         ctx->scan_states.erase(ctx->scan_states.begin());
+    }
+    if (!ctx->dev_err) {
+        void *h = nullptr;
+        HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
+        *static_cast<volatile uint32_t *>(h) = 0u;
+        ctx->dev_err = static_cast<uint32_t *>(h);
     }
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
     void *p = nullptr;
@@ -353,7 +379,15 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
             HIP_TRY(hipMemsetAsync(ss->status, 0, 8 * (size_t)LB_MAX_TILES, st));
             ss->epoch = 1u;
         }
-        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev);
+        // developer fault injection (tests/test_gpu_robustness.py): in the N-th look-back launch of the process tile 0 never publishes -- tile 1 waits
+        // for it until the (shortened) limit and the error word goes up
+        static const int fault_at = dev_env_int("GAUSPCC_SCAN_FAULT", 0);
+        static std::atomic<int> launches{0};
+        uint32_t limit = 1u << 24, skip = 0xFFFFFFFFu;
+        if (fault_at > 0 && ++launches == fault_at) { limit = 1u << 12; skip = 0u; }
+        void *derr = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&derr, ctx->dev_err, 0));
+        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev, static_cast<uint32_t *>(derr), limit, skip);
         LAUNCH_CHECK();
         return GPCC_OK;
     }

@@ -16,4 +16,9 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
 int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t **keys_tmp_io,
                    uint32_t **vals_io, uint32_t **vals_tmp_io, int64_t n, int bits);
 
+// Device-side faults that must not abort the process: a look-back scan whose predecessors made no progress for ~10 s (status words damaged)
+// raises the context's sticky error word and lets the launch run out with garbage instead of trapping.  Every entry point that scans calls this after
+// its final sync: GPCC_OK, or GPCC_ERR_HIP once (the word and the scan states are reset: the next call starts clean).
+int device_error_check(gpcc_ctx *ctx);
+
 }  // namespace gpcc

@@ -388,7 +388,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
         k_render<<<(unsigned)ntiles, RT, 0, st>>>(ranges, tile_order, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
         LAUNCH_CHECK();
         HIP_TRY(hipStreamSynchronize(st));
-        return GPCC_OK;
+        return device_error_check(ctx);
     }
     return fail(GPCC_ERR_NOMEM, "rasteriser workspace");
 }

@@ -55,6 +55,12 @@ GPCC_API int gpcc_ctx_bytes(const gpcc_ctx *ctx, int64_t *device_bytes, int64_t 
  * zeroes it); memcpy / memset nodes are not counted.  bench.py reports kernels per decode with it. */
 GPCC_API long long gpcc_debug_launches(int reset);
 
+/* Device-side faults that must not abort the process (today: a device-wide scan whose tiles made no progress for ~10 s) raise a sticky
+ * word in the context instead of trapping.  Every entry point that synchronises checks it and returns GPCC_ERR_HIP once (the word and
+ * the scan state are reset: the next call starts clean); callers of the stage-level entry points that return before their work has run
+ * call this after synchronising the stream.  GPCC_OK when nothing was raised. */
+GPCC_API int gpcc_device_error_check(gpcc_ctx *ctx);
+
 /* ---- a2  calculate_morton_order            src/gs_compress/HAC/utils/pcc_utils.py:12-22
  * perm_out[N] (int64, device): argsort of x + y*M + z*M^2 after the per-axis min shift
  * (M = max over all axes + 1), i.e. the (z,y,x) raster order; stable for equal keys. */

@@ -127,3 +127,43 @@ print("recoded at chunk_log2", used)
     e["GAUSPCC_TEST_CHUNK_BYTES"] = "400"
     r = subprocess.run([sys.executable, "-c", snippet], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "recoded at chunk_log2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_stalled_lookback_scan_raises_an_error_instead_of_a_trap():
+    """A device-wide scan whose predecessor tile never publishes (csrc/primitives.hip: k_scan_lookback; GAUSPCC_SCAN_FAULT=2 makes tile 0 of the
+    process's second look-back launch stay silent and shortens the wait) used to end in a trap: the process and every context in it gone.  Now the
+    context's sticky error word goes up: the call that synchronises returns GPCC_ERR_HIP once, the state is reset, and the next scan -- and a whole
+    encode + decode round trip on the same context -- are correct."""
+    snippet = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests import gpu_helpers as gh
+from tests.test_gpu_primitives import _scan
+from gauspcc_amd import _lib, runtime
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+ctx = runtime.context(torch.device("cuda", 0))
+x = np.random.RandomState(1).randint(0, 9, size=300000).astype(np.uint32)
+ref = np.concatenate([[0], np.cumsum(x[:-1], dtype=np.uint64)]).astype(np.uint32)
+out, total = _scan(x)                                   # launch 1: fine
+assert np.array_equal(out, ref) and _lib.lib().gpcc_device_error_check(ctx) == 0
+out, total = _scan(x)                                   # launch 2: tile 0 silent -> tile 1 gives up, the launch runs out
+rc = _lib.lib().gpcc_device_error_check(ctx)
+assert rc == -1, rc                                     # GPCC_ERR_HIP, once
+assert not np.array_equal(out, ref)
+assert _lib.lib().gpcc_device_error_check(ctx) == 0
+out, total = _scan(x)                                   # state was reset
+assert np.array_equal(out, ref) and total == int(x.sum())
+dm = runtime.Model(synthetic_state_dict(32, 3), 32, 3, 0)
+pts = synthetic_cloud(200000, seed=5)
+data, st = gh.encode(dm, pts, 10)
+dec, _, _ = gh.decode(dm, data)
+assert np.array_equal(np.asarray(dec)[gh.sort_zyx(np.asarray(dec))], pts[gh.sort_zyx(pts)])
+print("scan fault ok")
+""" % ROOT
+    e = dict(os.environ)
+    e["GAUSPCC_DEV"] = "1"
+    e["GAUSPCC_SCAN_FAULT"] = "2"
+    r = subprocess.run([sys.executable, "-c", snippet], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "scan fault ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

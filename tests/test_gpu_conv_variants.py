@@ -79,6 +79,12 @@ def test_conv_kernel_variant_bit_exact(env):
         # the parked loops are not in the product library: their parity tests run on the variant build when it exists
         if not os.path.exists(PARKED_LIB):
             pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is not built (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS)")
+        import ctypes
+
+        from gauspcc_amd import _lib
+        stale = [n for n in _lib.EXPORTS if not hasattr(ctypes.CDLL(PARKED_LIB), n)]
+        if stale:
+            pytest.skip(f"gauspcc_amd/variants/libgauspcc_parked.so is older than the product library (no {stale[0]}): rebuild it (tools/build_variants.sh)")
         e["GAUSPCC_LIB"] = PARKED_LIB
     e.setdefault("GAUSPCC_FUSED", "0")   # these variants are about the block-tile kernels: keep the decoder's small levels on them
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -79,12 +79,11 @@ def test_conv_kernel_variant_bit_exact(env):
         # the parked loops are not in the product library: their parity tests run on the variant build when it exists
         if not os.path.exists(PARKED_LIB):
             pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is not built (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS)")
-        import ctypes
-
-        from gauspcc_amd import _lib
-        stale = [n for n in _lib.EXPORTS if not hasattr(ctypes.CDLL(PARKED_LIB), n)]
-        if stale:
-            pytest.skip(f"gauspcc_amd/variants/libgauspcc_parked.so is older than the product library (no {stale[0]}): rebuild it (tools/build_variants.sh)")
+        # (checked in a child: this process keeps ONE copy of the library)
+        probe = "import ctypes, sys; sys.path.insert(0, %r); from gauspcc_amd import _lib; import torch; L = ctypes.CDLL(%r); print('stale', [n for n in _lib.EXPORTS if not hasattr(L, n)])" % (ROOT, PARKED_LIB)
+        pr = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, capture_output=True, text=True, timeout=300)
+        if "stale []" not in pr.stdout:
+            pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is older than the product library: rebuild it (tools/build_variants.sh) " + pr.stdout[-200:])
         e["GAUSPCC_LIB"] = PARKED_LIB
     e.setdefault("GAUSPCC_FUSED", "0")   # these variants are about the block-tile kernels: keep the decoder's small levels on them
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)

@@ -52,6 +52,7 @@ rm -rf "$OUT"/sp_*
 # 4b. the rasteriser's compute side: VALU instructions and busy cycles of k_render / k_preprocess (one pass)
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_LDS SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq_r" -o pmc -- python3 tools/bench_side_paths.py 1000000 > /dev/null 2>&1
 python3 tools/pmc_summary.py "$OUT/sq_r" "k_render" > "$OUT/${R}_render_counters.txt"; python3 tools/pmc_summary.py "$OUT/sq_r" "k_preprocess" >> "$OUT/${R}_render_counters.txt"
+python3 tools/pmc_summary.py "$OUT/sq_r" "k_ng_emit" >> "$OUT/${R}_render_counters.txt"; python3 tools/pmc_summary.py "$OUT/sq_r" "k_ng_opacity" >> "$OUT/${R}_render_counters.txt"
 rm -rf "$OUT/sq_r"
 # 5. the grid-barrier / launch-chain microbenchmark behind the small-level fusion decision (built by tools/build_variants.sh or by hand)
 [ -x tools/ubench/grid_sync ] && timeout 300 ./tools/ubench/grid_sync > "$OUT/${R}_grid_sync.txt" 2>&1

@@ -245,3 +245,17 @@ def test_more_scenes_than_a_tree_holds(gh, dev_model_k3):
     outs, _, _, _ = _dec_batch(gh, dev_model_k3, b256)
     for o, c in zip(outs[::17], clouds[:256:17]):
         assert np.array_equal(o[np.lexsort((o[:, 0], o[:, 1], o[:, 2]))], c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))])
+
+
+def test_random_batch_shapes_against_the_solo_path():
+    """tools/batch_soak.py for 25 s: random batches (1-40 scenes of 1-300 k points, extents 2^6-2^17, shifted clouds, k 3 / 5, chunk_log2 6-11) --
+    every scene's batched bytes == its solo bytes, the batched decode == the solo decode == the input set (reference loop:
+    HAC/utils/pcc_utils.py:73-131 once per scene)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "batch_soak.py"), "25", "7"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " 0 bad" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert int(r.stdout.strip().splitlines()[-1].split()[2]) >= 20      # batches run

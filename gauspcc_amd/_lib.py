@@ -126,7 +126,7 @@ def lib():
     f32 = C.c_float
     L.gsr_visible_filter.argtypes = [vp, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp]
     L.gsr_forward.argtypes = [vp, i32, vp, i32, i32, vp, vp, vp, vp, f32, vp, vp, vp, vp, f32, f32, i32, vp, vp, C.POINTER(i64), vp]
-    L.gsnn_generate.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp]
+    L.gsnn_generate.argtypes = [vp, i64, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(i64), vp]
     _lib = L
     return L
 

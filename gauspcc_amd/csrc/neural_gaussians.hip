@@ -24,6 +24,7 @@ struct Mlp { const float *w1, *b1, *w2, *b2; };   // Linear(din, F) - ReLU - Lin
 
 struct NGArgs {
     const float *anchor, *feat, *offsets, *scaling, *mask;   // (n,3) (n,F) (n,K,3) (n,6) (n,K)
+    const int32_t *rows;                                      // anchors of the model this call is about (visible_mask as an index list), or null: rows 0 .. n - 1
     int64_t n;
     int K;
     float cam[3];
@@ -61,14 +62,15 @@ __global__ __launch_bounds__(TB) void k_anchor_mlps(NGArgs a)
 {
     const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i >= a.n) return;
+    const int64_t src = a.rows ? a.rows[i] : i;     // row of the model's tensors; outputs are indexed by i
     constexpr int DIN = F + 4;
     float x[DIN];
     // ob_view / ob_dist (:116-118)
-    const float vx = a.anchor[3 * i] - a.cam[0], vy = a.anchor[3 * i + 1] - a.cam[1], vz = a.anchor[3 * i + 2] - a.cam[2];
+    const float vx = a.anchor[3 * src] - a.cam[0], vy = a.anchor[3 * src + 1] - a.cam[1], vz = a.anchor[3 * src + 2] - a.cam[2];
     const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
     x[F] = vx / dist; x[F + 1] = vy / dist; x[F + 2] = vz / dist; x[F + 3] = dist;
 #pragma unroll
-    for (int k = 0; k < F; ++k) x[k] = a.feat[i * F + k];
+    for (int k = 0; k < F; ++k) x[k] = a.feat[src * F + k];
     if (a.bank.w1) {   // view-adaptive feature (:121-132): softmax-weighted mix of the feature at strides 4 / 2 / 1
         float hb[F];
         const float cv[4] = {x[F], x[F + 1], x[F + 2], x[F + 3]};
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(TB) void k_anchor_mlps(NGArgs a)
     // opacity: tanh head, times the binary grid mask; a Gaussian survives when the product is positive (:136-141)
     hidden_layer<F, DIN>(x, a.opacity, h);
     for (int j = 0; j < K; ++j) {
-        const float o = tanhf(out_unit<F>(h, a.opacity, j)) * a.mask[i * K + j];
+        const float o = tanhf(out_unit<F>(h, a.opacity, j)) * a.mask[src * K + j];
         a.nopa[i * K + j] = o;
         a.keep[i * K + j] = o > 0.0f ? 1u : 0u;
     }
@@ -106,6 +108,7 @@ __global__ __launch_bounds__(TB) void k_anchor_mlps(NGArgs a)
 
 struct AsmArgs {
     const float *anchor, *offsets, *scaling, *nopa, *dense;
+    const int32_t *rows;
     const uint32_t *keep, *pos;
     int64_t nk;
     int K;
@@ -116,7 +119,8 @@ __global__ __launch_bounds__(TB) void k_assemble(AsmArgs a)
 {
     const int64_t g = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (g >= a.nk || !a.keep[g]) return;
-    const int64_t i = g / a.K;
+    const int64_t i = a.rows ? (int64_t)a.rows[g / a.K] : g / a.K;
+    const int64_t gs = i * a.K + g % a.K;      // the candidate's row in the model's (n, K, 3) offsets
     const uint32_t p = a.pos[g];
     const float *d = a.dense + g * 10, *sc = a.scaling + i * 6;
     a.opacity[p] = a.nopa[g];
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(TB) void k_assemble(AsmArgs a)
     a.rot[4 * p] = q0 / nrm; a.rot[4 * p + 1] = q1 / nrm; a.rot[4 * p + 2] = q2 / nrm; a.rot[4 * p + 3] = q3 / nrm;
     // xyz = anchor + offsets * scaling[:3] (:170-171)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a.xyz[3 * p + k] = a.anchor[3 * i + k] + a.offsets[g * 3 + k] * sc[k];
+    for (int k = 0; k < 3; ++k) a.xyz[3 * p + k] = a.anchor[3 * i + k] + a.offsets[gs * 3 + k] * sc[k];
 }
 
 
@@ -214,18 +218,23 @@ __device__ __forceinline__ f32x4n ng_out_tile(const float (&a)[NGM<F>::DHP / 4],
 }
 
 // [feat | view | dist | 0] of anchors row0 .. row0 + 15 into xs[16][px] (rows past n: the last anchor again), the feature bank applied
-template <int F>
+// ROWS (a.rows != nullptr) is a template parameter, not a run-time test: hipcc 7.2 materialised the uniform `a.rows != nullptr` as a lane mask under the
+// partial EXEC of the feature-load loop and branched on it again inside the divergent emission loop -- lanes that were inactive at the first place read
+// rows[] through the null pointer (found by tests/test_gpu_hac_plus_codec.py on an un-decoded model: a memory fault that depended on which Gaussians survive)
+template <int F, bool ROWS>
 __device__ __forceinline__ void ng_build_x(const NGArgs &a, int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane)
 {
     using M = NGM<F>;
     const int e = lane & 15, g = lane >> 4;
     for (int i = lane; i < 16 * (F / 2); i += 64) {
         const int r = i / (F / 2), c2 = i - r * (F / 2);
-        const int64_t row = row0 + r < a.n ? row0 + r : a.n - 1;
+        int64_t row = row0 + r < a.n ? row0 + r : a.n - 1;
+        if (ROWS) row = a.rows[row];
         *reinterpret_cast<float2 *>(xs + r * px + 2 * c2) = *reinterpret_cast<const float2 *>(a.feat + row * F + 2 * c2);
     }
     if (lane < 16) {   // ob_view / ob_dist (:116-118)
-        const int64_t row = row0 + lane < a.n ? row0 + lane : a.n - 1;
+        int64_t row = row0 + lane < a.n ? row0 + lane : a.n - 1;
+        if (ROWS) row = a.rows[row];
         const float vx = a.anchor[3 * row] - a.cam[0], vy = a.anchor[3 * row + 1] - a.cam[1], vz = a.anchor[3 * row + 2] - a.cam[2];
         const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
         float *x = xs + lane * px + F;
@@ -278,7 +287,7 @@ __device__ __forceinline__ void ng_build_x(const NGArgs &a, int64_t row0, float 
     ng_wave_sync();
 }
 
-template <int F>
+template <int F, bool ROWS>
 __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
 {
     using M = NGM<F>;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
     const int64_t ntiles = (a.n + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
-        ng_build_x<F>(a, row0, xs, PX, hs, bank, bk, lane);
+        ng_build_x<F, ROWS>(a, row0, xs, PX, hs, bank, bk, lane);
         float a1[M::DINP / 4];
 #pragma unroll
         for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
@@ -311,7 +320,8 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
             for (int i = 0; i < 4; ++i) {
                 const int64_t row = row0 + 4 * g + i;
                 if (row < a.n) {
-                    const float o = tanhf(v[i]) * a.mask[row * a.K + e];
+                    const int64_t src = ROWS ? (int64_t)a.rows[row] : row;
+                    const float o = tanhf(v[i]) * a.mask[src * a.K + e];
                     a.nopa[row * a.K + e] = o;
                     a.keep[row * a.K + e] = o > 0.0f ? 1u : 0u;
                 }
@@ -328,7 +338,7 @@ struct EmitArgs {
     float *xyz, *color, *opacity, *scale, *rot;
 };
 
-template <int F>
+template <int F, bool ROWS>
 __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
 {
     using M = NGM<F>;
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
     const int64_t ntiles = (a.n + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
-        ng_build_x<F>(a, row0, xs, PX, hs, bank, bk, lane);
+        ng_build_x<F, ROWS>(a, row0, xs, PX, hs, bank, bk, lane);
         float a1[M::DINP / 4];
 #pragma unroll
         for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
             const int64_t gi = i * K + j;
             if (!a.keep[gi]) continue;
             const uint32_t p = o.pos[gi];
-            const float *c3 = xs + r * PX + 3 * j, *d = xs + r * PX + 3 * K + 7 * j, *sc = o.scaling + i * 6;
+            const int64_t src = ROWS ? (int64_t)a.rows[i] : i;
+            const float *c3 = xs + r * PX + 3 * j, *d = xs + r * PX + 3 * K + 7 * j, *sc = o.scaling + src * 6;
             o.opacity[p] = a.nopa[gi];
             o.color[3 * p] = c3[0]; o.color[3 * p + 1] = c3[1]; o.color[3 * p + 2] = c3[2];
 #pragma unroll
@@ -396,7 +407,7 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
             const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
             o.rot[4 * p] = q0 / nrm; o.rot[4 * p + 1] = q1 / nrm; o.rot[4 * p + 2] = q2 / nrm; o.rot[4 * p + 3] = q3 / nrm;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) o.xyz[3 * p + k] = a.anchor[3 * i + k] + o.offsets[gi * 3 + k] * sc[k];
+            for (int k = 0; k < 3; ++k) o.xyz[3 * p + k] = a.anchor[3 * src + k] + o.offsets[(src * K + j) * 3 + k] * sc[k];
         }
         ng_wave_sync();
     }
@@ -426,40 +437,40 @@ template <int F> static int ng_mfma_waves(bool bank, int K)
     return 0;
 }
 
-template <int F>
+template <int F, bool ROWS>
 static int ng_mfma_opacity(gpcc_ctx *ctx, const NGArgs &a, int waves, hipStream_t st)
 {
     const size_t lds = ng_lds_opacity<F>(a.bank.w1 != nullptr, waves);
     static PerDeviceOnce attr;
     GP_TRY(attr.run(ctx->device, [&]() -> int {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_opacity<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_opacity<F, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
         return GPCC_OK;
     }));
     const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(a.n, 16), waves));
-    k_ng_opacity<F><<<grid, 64 * waves, lds, st>>>(a);
+    k_ng_opacity<F, ROWS><<<grid, 64 * waves, lds, st>>>(a);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
-template <int F>
+template <int F, bool ROWS>
 static int ng_mfma_emit(gpcc_ctx *ctx, const NGArgs &a, EmitArgs o, int waves, hipStream_t st)
 {
     const size_t lds = ng_lds_emit<F>(a.bank.w1 != nullptr, a.K, waves);
     o.px = ng_emit_pitch<F>(a.K);
     static PerDeviceOnce attr;
     GP_TRY(attr.run(ctx->device, [&]() -> int {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_emit<F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_emit<F, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
         return GPCC_OK;
     }));
     const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(a.n, 16), waves));
-    k_ng_emit<F><<<grid, 64 * waves, lds, st>>>(a, o);
+    k_ng_emit<F, ROWS><<<grid, 64 * waves, lds, st>>>(a, o);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
 
 }  // namespace
 
-extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
+extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
                              const float *scaling, const float *mask, const float *cam_center, const float *const *mlp /* 16 pointers */,
                              float *xyz_out, float *color_out, float *opacity_out, float *scale_out, float *rot_out, int64_t *count_out, void *stream)
 {
@@ -482,7 +493,7 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
     ctx->arena.reset();
     TAKE(nopa, float, nk); TAKE(keep, uint32_t, nk); TAKE(pos, uint32_t, nk + 1);
     NGArgs a = {};
-    a.anchor = anchor; a.feat = feat; a.offsets = offsets; a.scaling = scaling; a.mask = mask; a.n = n; a.K = n_offsets;
+    a.anchor = anchor; a.feat = feat; a.offsets = offsets; a.scaling = scaling; a.mask = mask; a.rows = rows; a.n = n; a.K = n_offsets;
     float cam[3];
     HIP_TRY(hipMemcpyAsync(cam, cam_center, 12, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -494,11 +505,13 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
     a.nopa = nopa; a.keep = keep;
     uint32_t total = 0;
     if (waves) {   // matrix pipe: flags -> scan -> colour / covariance and the surviving rows in one launch
-        if (feat_dim == 32) GP_TRY(ng_mfma_opacity<32>(ctx, a, waves, st)); else GP_TRY(ng_mfma_opacity<50>(ctx, a, waves, st));
+        if (rows) { if (feat_dim == 32) GP_TRY((ng_mfma_opacity<32, true>(ctx, a, waves, st))); else GP_TRY((ng_mfma_opacity<50, true>(ctx, a, waves, st))); }
+        else { if (feat_dim == 32) GP_TRY((ng_mfma_opacity<32, false>(ctx, a, waves, st))); else GP_TRY((ng_mfma_opacity<50, false>(ctx, a, waves, st))); }
         GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
         HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
         EmitArgs o = {offsets, scaling, pos, 0, xyz_out, color_out, opacity_out, scale_out, rot_out};
-        if (feat_dim == 32) GP_TRY(ng_mfma_emit<32>(ctx, a, o, waves, st)); else GP_TRY(ng_mfma_emit<50>(ctx, a, o, waves, st));
+        if (rows) { if (feat_dim == 32) GP_TRY((ng_mfma_emit<32, true>(ctx, a, o, waves, st))); else GP_TRY((ng_mfma_emit<50, true>(ctx, a, o, waves, st))); }
+        else { if (feat_dim == 32) GP_TRY((ng_mfma_emit<32, false>(ctx, a, o, waves, st))); else GP_TRY((ng_mfma_emit<50, false>(ctx, a, o, waves, st))); }
     } else {
         TAKE(dense, float, nk * 10);
         a.dense = dense;
@@ -507,7 +520,7 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offse
         LAUNCH_CHECK();
         GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
         HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
-        AsmArgs b = {anchor, offsets, scaling, nopa, dense, keep, pos, nk, n_offsets, xyz_out, color_out, opacity_out, scale_out, rot_out};
+        AsmArgs b = {anchor, offsets, scaling, nopa, dense, rows, keep, pos, nk, n_offsets, xyz_out, color_out, opacity_out, scale_out, rot_out};
         k_assemble<<<(unsigned)cdiv(nk, TB), TB, 0, st>>>(b);
         LAUNCH_CHECK();
     }

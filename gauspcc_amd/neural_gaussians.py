@@ -12,7 +12,8 @@ Inference only (`is_training=False`): the training branches add noise and rate t
 is used through the attributes the reference uses.  When `pc.decoded_version` is false the attributes are first quantised
 with the context model's step sizes exactly as the reference does (:103-114); everything after that -- view vectors,
 feature bank, the three MLPs, masking, assembly -- is ONE call into libgauspcc (gsnn_generate: two kernels and a scan
-instead of ~40 PyTorch kernels and an (n K, 22) concatenate / mask / split).
+instead of ~40 PyTorch kernels and an (n K, 22) concatenate / mask / split).  For a decoded model the visible anchors go in as an
+index list: the kernels read those rows of the model's tensors in place instead of five `tensor[visible_mask]` copies.
 """
 import ctypes as C
 import time
@@ -49,22 +50,33 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
     if is_training:
         raise NotImplementedError("gauspcc_amd.generate_neural_gaussians is the inference path (RD evaluation); training needs autograd")
     time_sub = 0
-    if visible_mask is None:
-        visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=pc.get_anchor.device)
-    anchor = pc.get_anchor[visible_mask]
-    feat = pc._anchor_feat[visible_mask]
-    grid_offsets = pc._offset[visible_mask]
-    grid_scaling = pc.get_scaling[visible_mask]
-    binary_grid_masks = pc.get_mask[visible_mask]
-    if not pc.decoded_version:      # quantise as the encoder would (:103-114)
+    f32 = lambda t: t.detach().float().contiguous()
+    dev = pc.get_anchor.device
+    K, F = pc.n_offsets, pc.feat_dim
+    rows = None
+    if not pc.decoded_version:      # quantise as the encoder would (:103-114): on the gathered rows, as the reference does
+        if visible_mask is None:
+            visible_mask = torch.ones(pc.get_anchor.shape[0], dtype=torch.bool, device=dev)
+        anchor = pc.get_anchor[visible_mask]
+        feat = pc._anchor_feat[visible_mask]
+        grid_offsets = pc._offset[visible_mask]
+        grid_scaling = pc.get_scaling[visible_mask]
+        binary_grid_masks = pc.get_mask[visible_mask]
         torch.cuda.synchronize(); t1 = time.time()
         q_feat, q_scaling, q_offsets = quant_steps(pc, anchor)
         feat = ste_multistep(feat, q_feat, pc._anchor_feat.mean())
         grid_scaling = ste_multistep(grid_scaling, q_scaling, pc.get_scaling.mean())
         grid_offsets = ste_multistep(grid_offsets.reshape(anchor.shape[0], -1), q_offsets, pc._offset.mean()).view_as(grid_offsets)
         torch.cuda.synchronize(); time_sub = time.time() - t1
-    n, K, F = anchor.shape[0], pc.n_offsets, pc.feat_dim
-    dev = anchor.device
+        n = anchor.shape[0]
+    else:
+        # decoded model: the kernels read the visible rows of the model's tensors in place (the reference's five `tensor[visible_mask]`
+        # gathers, :54-58, are 0.8 GB of copies per million anchors)
+        anchor, feat, grid_offsets, grid_scaling, binary_grid_masks = pc.get_anchor, pc._anchor_feat, pc._offset, pc.get_scaling, pc.get_mask
+        n = anchor.shape[0]
+        if visible_mask is not None:
+            rows = torch.nonzero(visible_mask).view(-1).to(torch.int32)
+            n = rows.numel()
     tensors = []
     if getattr(pc, "use_feat_bank", False):
         tensors += _linears(pc.get_featurebank_mlp)
@@ -72,15 +84,14 @@ def generate_neural_gaussians(viewpoint_camera, pc, visible_mask=None, is_traini
         tensors += [None] * 4
     tensors += _linears(pc.get_opacity_mlp) + _linears(pc.get_cov_mlp) + _linears(pc.get_color_mlp)
     ptrs = (C.c_void_p * 16)(*[None if t is None else t.data_ptr() for t in tensors])
-    f32 = lambda t: t.detach().float().contiguous()
     anchor, feat, grid_offsets, grid_scaling = f32(anchor), f32(feat), f32(grid_offsets), f32(grid_scaling)
-    mask = f32(binary_grid_masks).view(n, K)
+    mask = f32(binary_grid_masks).view(-1, K)
     cam = f32(viewpoint_camera.camera_center).view(3)
     xyz = torch.empty(n * K, 3, device=dev); color = torch.empty(n * K, 3, device=dev); opacity = torch.empty(n * K, 1, device=dev)
     scaling = torch.empty(n * K, 3, device=dev); rot = torch.empty(n * K, 4, device=dev)
     m = C.c_int64()
-    _lib.check(_lib.lib().gsnn_generate(runtime.context(dev), n, F, K, anchor.data_ptr(), feat.data_ptr(), grid_offsets.data_ptr(), grid_scaling.data_ptr(),
-                                        mask.data_ptr(), cam.data_ptr(), ptrs, xyz.data_ptr(), color.data_ptr(), opacity.data_ptr(), scaling.data_ptr(),
-                                        rot.data_ptr(), C.byref(m), runtime.stream_ptr(dev)))
+    _lib.check(_lib.lib().gsnn_generate(runtime.context(dev), n, None if rows is None else rows.data_ptr(), F, K, anchor.data_ptr(), feat.data_ptr(),
+                                        grid_offsets.data_ptr(), grid_scaling.data_ptr(), mask.data_ptr(), cam.data_ptr(), ptrs, xyz.data_ptr(), color.data_ptr(),
+                                        opacity.data_ptr(), scaling.data_ptr(), rot.data_ptr(), C.byref(m), runtime.stream_ptr(dev)))
     m = m.value
     return xyz[:m], color[:m], opacity[:m], scaling[:m], rot[:m], time_sub

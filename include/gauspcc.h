@@ -380,10 +380,13 @@ GPCC_API int gsge_forward(gpcc_ctx *ctx, const float *inputs_dev, const float *e
  * view direction / distance (:116-118), optional feature bank (:121-132), opacity / colour / covariance MLPs on
  * [feat | view | dist] (:134-152), masking by neural opacity > 0 (:136-141, 160-162) and the assembly of position,
  * scale and rotation (:165-171).  n visible anchors, feat_dim in {32, 50}, K = n_offsets.
+ * rows: the visible anchors as n ascending row indices into the model's tensors (the reference gathers `tensor[visible_mask]` five
+ * times, :54-58 -- 0.8 GB of copies per million anchors; here the kernels read the rows in place), or NULL: the tensors hold exactly
+ * the n anchors of the call.
  * mlp: 16 device pointers = {w1, b1, w2, b2} of mlp_feature_bank (all four NULL when use_feat_bank is off), mlp_opacity,
  * mlp_cov, mlp_color (nn.Linear layouts; gaussian_model.py:229-256).  mask (n, K) in {0, 1}; cam_center (3) device.
  * Outputs have room for n*K Gaussians; *count_out of them are written (anchor-major, the reference's order). */
-GPCC_API int gsnn_generate(gpcc_ctx *ctx, int64_t n, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
+GPCC_API int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int feat_dim, int n_offsets, const float *anchor, const float *feat, const float *offsets,
                            const float *scaling, const float *mask, const float *cam_center, const float *const *mlp, float *xyz_out,
                            float *color_out, float *opacity_out, float *scale_out, float *rot_out, int64_t *count_out, void *stream);
 

@@ -106,3 +106,27 @@ def test_generate_neural_gaussians_matches_torch(torch_cuda, F, K, bank, n):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= tol, float((a - b).abs().max())
     assert opacity.min() > 0
+
+
+@pytest.mark.parametrize("mask_kind", ["ones", "binary", "sparse"])
+def test_without_a_visible_mask_and_with_few_survivors(torch_cuda, mask_kind):
+    """visible_mask=None (the kernels index the model's rows directly) with masks that leave whole lane groups of a wave without a survivor: the
+    shape that exposed a compiler-materialised lane mask being reused under a different EXEC (csrc/neural_gaussians.hip: the ROWS template parameter)."""
+    torch = torch_cuda
+    from gauspcc_amd.neural_gaussians import generate_neural_gaussians
+
+    n, F, K = 5396, 50, 10
+    pc, cam = _model(torch, n, F, K, False, seed=77)
+    if mask_kind == "ones":
+        pc.get_mask = torch.ones_like(pc.get_mask)
+    elif mask_kind == "sparse":
+        pc.get_mask = (torch.rand(n, K, 1, device="cuda") > 0.97).float()
+    vis = torch.ones(n, dtype=torch.bool, device="cuda")
+    with torch.no_grad():
+        rx, rc, ro, rs, rr, nopa = _torch_reference(torch, cam, pc, vis)
+    xyz, color, opacity, scaling, rot, _ = generate_neural_gaussians(cam, pc, None)
+    borderline = int((nopa.abs() < 1e-4).sum())
+    assert abs(xyz.shape[0] - rx.shape[0]) <= borderline
+    if xyz.shape[0] == rx.shape[0]:
+        for a, b, tol in ((xyz, rx, 2e-5), (color, rc, 2e-5), (opacity, ro, 2e-5), (scaling, rs, 2e-5), (rot, rr, 5e-5)):
+            assert float((a - b).abs().max()) <= tol

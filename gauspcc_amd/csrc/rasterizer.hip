@@ -28,15 +28,46 @@ struct Cam {
 
 __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * (float)S - 1.0f) * 0.5f; }
 
+// Exact tile culling (round 5).  The reference bins a Gaussian into every tile of the 3-sigma bounding square of its larger axis; the blend then
+// skips it at every pixel where alpha = op exp(power) < 1 / 255.  A pair (Gaussian, tile) whose `power` stays below -ln(255 op) over the whole
+// tile is therefore dead weight in the sort and in the tile's list -- about a third of all pairs (corners of the squares, thin or faint splats).
+// q(d) = -power(d) = 0.5 (A dx^2 + C dy^2) + B dx dy is convex with its minimum 0 at the centre, so its minimum over the tile's rectangle of
+// pixel centres is 0 when the centre lies inside and is attained on one of the four edges otherwise (a 1-D quadratic each, clamped).  The pair is
+// kept when that minimum <= ln(255 op) + margin; the margin (2e-3, twice k_render's own pre-test) leaves every borderline pixel to the exact test
+// in the blend, so the image is bit-identical with and without culling (tests/test_gpu_rasterizer.py) and only the lists get shorter.
+__device__ __forceinline__ float edge_min(float c, float lo, float hi, float Ac, float Bm, float Cv)
+{   // min over v in [lo, hi] of 0.5 Ac c^2 + Bm c v + 0.5 Cv v^2
+    const float v = fminf(hi, fmaxf(lo, -Bm * c / Cv));
+    return 0.5f * Ac * c * c + Bm * c * v + 0.5f * Cv * v * v;
+}
+__device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, float B, float C, float lim, int tx, int ty)
+{
+    // d = centre - pixel, pixels tx*16 .. tx*16 + 15 (the last tiles' pixels beyond the image only make the rectangle larger)
+    const float dx_hi = gx_ - (float)(tx * BX), dx_lo = dx_hi - (float)(BX - 1);
+    const float dy_hi = gy_ - (float)(ty * BY), dy_lo = dy_hi - (float)(BY - 1);
+    if (dx_lo <= 0.0f && dx_hi >= 0.0f && dy_lo <= 0.0f && dy_hi >= 0.0f) return true;
+    const float m = fminf(fminf(edge_min(dx_lo, dy_lo, dy_hi, A, B, C), edge_min(dx_hi, dy_lo, dy_hi, A, B, C)),
+                          fminf(edge_min(dy_lo, dx_lo, dx_hi, C, B, A), edge_min(dy_hi, dx_lo, dx_hi, C, B, A)));
+    return m <= lim;
+}
+// the bound on q for a Gaussian of opacity op: +inf for conics the argument above does not cover (never culled), -1 when op < 1 / 255 (never blended)
+__device__ __forceinline__ float cull_limit(float A, float B, float C, float op)
+{
+    if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return __builtin_inff();
+    if (!(op > 0.0f)) return -1.0f;
+    return __logf(255.0f * op) + 2e-3f;
+}
+
 __global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
                                                    const float *__restrict__ cov3d_pre, const float *__restrict__ opac, Cam cam, int *__restrict__ radii,
                                                    float2 *__restrict__ xy, float *__restrict__ depth, float4 *__restrict__ conic_op,
-                                                   uint32_t *__restrict__ tiles_touched)
+                                                   uint32_t *__restrict__ tiles_touched, int cull, uint32_t *__restrict__ rect_area)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= P) return;
     radii[i] = 0;
     if (tiles_touched) tiles_touched[i] = 0;
+    if (rect_area) rect_area[i] = 0;
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
     const float *V = cam.view, *M = cam.proj;
     // transformPoint4x3 / 4x4 with the row-vector (transposed) matrices the Python side passes
@@ -95,15 +126,34 @@ __global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restric
     if (area == 0) return;
     radii[i] = (int)my_radius;
     if (tiles_touched) {
-        tiles_touched[i] = (uint32_t)area;
+        const float4 co = make_float4(cyy * det_inv, -cxy * det_inv, cxx * det_inv, opac[i]);
+        uint32_t cnt = (uint32_t)area;
+        if (cull) {
+            const float lim = cull_limit(co.x, co.y, co.z, co.w);
+            cnt = 0;
+            for (int y = ry0; y < ry1; ++y)
+                for (int x = rx0; x < rx1; ++x) cnt += tile_touches(ix, iy, co.x, co.y, co.z, lim, x, y) ? 1u : 0u;
+            rect_area[i] = (uint32_t)area;   // summed by k_sum_u32: what the reference calls num_rendered
+        }
+        tiles_touched[i] = cnt;
         xy[i] = make_float2(ix, iy);
         depth[i] = tz;
-        conic_op[i] = make_float4(cyy * det_inv, -cxy * det_inv, cxx * det_inv, opac[i]);
+        conic_op[i] = co;
     }
 }
 
+__global__ __launch_bounds__(TB) void k_sum_u32(const uint32_t *__restrict__ v, int n, unsigned long long *__restrict__ total)
+{
+    unsigned long long acc = 0;
+    for (int i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) acc += v[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, d, 64);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
+}
+
 __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restrict__ xy, const float *__restrict__ depth, const uint32_t *__restrict__ offs,
-                                                  const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                  const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                  const float4 *__restrict__ conic_op, int cull)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
     if (i >= P || radii[i] <= 0) return;
@@ -113,8 +163,11 @@ __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restric
     const int rx0 = min(gx, max(0, (int)((p.x - r) / BX))), ry0 = min(gy, max(0, (int)((p.y - r) / BY)));
     const int rx1 = min(gx, max(0, (int)((p.x + r + BX - 1) / BX))), ry1 = min(gy, max(0, (int)((p.y + r + BY - 1) / BY)));
     const uint32_t dbits = __float_as_uint(depth[i]);
+    const float4 co = conic_op[i];
+    const float lim = cull ? cull_limit(co.x, co.y, co.z, co.w) : 0.0f;
     for (int y = ry0; y < ry1; ++y)
         for (int x = rx0; x < rx1; ++x) {
+            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, lim, x, y)) continue;
             keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
             vals[off] = (uint32_t)i;
             ++off;
@@ -140,7 +193,8 @@ __global__ __launch_bounds__(TB) void k_gather_touched(int P, const uint32_t *__
 }
 
 __global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *__restrict__ perm, const float2 *__restrict__ xy, const uint32_t *__restrict__ offs,
-                                                         const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+                                                         const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+                                                         const float4 *__restrict__ conic_op, int cull)
 {
     const int s = blockIdx.x * TB + threadIdx.x;
     if (s >= P) return;
@@ -151,8 +205,11 @@ __global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *
     const float2 p = xy[i];
     const int rx0 = min(gx, max(0, (int)((p.x - r) / BX))), ry0 = min(gy, max(0, (int)((p.y - r) / BY)));
     const int rx1 = min(gx, max(0, (int)((p.x + r + BX - 1) / BX))), ry1 = min(gy, max(0, (int)((p.y + r + BY - 1) / BY)));
+    const float4 co = conic_op[i];
+    const float lim = cull ? cull_limit(co.x, co.y, co.z, co.w) : 0.0f;
     for (int y = ry0; y < ry1; ++y)
         for (int x = rx0; x < rx1; ++x) {
+            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, lim, x, y)) continue;
             keys[off] = (uint64_t)(uint32_t)(y * gx + x);
             vals[off] = i;
             ++off;
@@ -297,7 +354,7 @@ extern "C" int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const floa
     HIP_TRY(hipStreamSynchronize(st));
     Cam cam;
     GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
-    k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr);
+    k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -320,7 +377,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
     float bg[3];
     HIP_TRY(hipMemcpy(bg, background, 12, hipMemcpyDeviceToHost));
     const int ntiles = cam.gx * cam.gy;
-    size_t want = (size_t)std::max(P, 1) * 96 + (size_t)ntiles * 8 + ((size_t)8 << 20);
+    size_t want = (size_t)std::max(P, 1) * 100 + (size_t)ntiles * 8 + ((size_t)8 << 20);
     uint32_t L = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         GP_TRY(ctx->arena.reserve(want + (size_t)L * 40));
@@ -329,11 +386,16 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
         TAKE(touched, uint32_t, std::max(P, 1) + 1); TAKE(ranges, uint2, ntiles);
         HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st));
         static const bool two_level = dev_env_int("GAUSPCC_RASTER_SORT2", 1) != 0;
+        static const int cull = dev_env_int("GAUSPCC_RASTER_CULL", 1) != 0 ? 1 : 0;   // exact tile culling (tile_touches); 0: the reference's lists
+        TAKE(rect_total, unsigned long long, 1); TAKE(rect_area, uint32_t, std::max(P, 1));
+        HIP_TRY(hipMemsetAsync(rect_total, 0, 8, st));
+        unsigned long long rect_host = 0;
         const uint32_t *perm = nullptr;          // Gaussians in depth order (two-level sort)
         const uint32_t *offs = touched;
         if (P > 0) {
-            k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched);
+            k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched, cull, cull ? rect_area : nullptr);
             LAUNCH_CHECK();
+            if (cull) { k_sum_u32<<<256, TB, 0, st>>>(rect_area, P, rect_total); LAUNCH_CHECK(); }
             if (two_level) {
                 TAKE(dka, uint64_t, P); TAKE(dkb, uint64_t, P); TAKE(dva, uint32_t, P); TAKE(dvb, uint32_t, P); TAKE(ts, uint32_t, P + 1);
                 k_depth_keys<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, depth, radii, dka, dva);
@@ -349,9 +411,12 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
                 GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
                 HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
             }
+            if (cull) HIP_TRY(hipMemcpyAsync(&rect_host, rect_total, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
-        if (num_rendered_out) *num_rendered_out = L;
+        static const bool stats = dev_env_int("GAUSPCC_RASTER_STATS", 0) != 0;
+        if (stats) fprintf(stderr, "[gauspcc] rasteriser: %u (Gaussian, tile) pairs sorted and blended, %llu in the bounding squares\n", L, cull ? rect_host : (unsigned long long)L);
+        if (num_rendered_out) *num_rendered_out = cull ? (int64_t)rect_host : (int64_t)L;   // the reference's count: every tile of every bounding square
         uint32_t *vals_sorted = nullptr;
         if (L > 0) {
             uint64_t *ka = ctx->arena.take<uint64_t>(L), *kb = ctx->arena.take<uint64_t>(L);
@@ -361,12 +426,12 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             while ((1 << tbits) < ntiles) ++tbits;
             uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
             if (perm) {
-                k_duplicate_sorted<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, perm, xy, offs, radii, cam.gx, cam.gy, ka, va);
+                k_duplicate_sorted<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, perm, xy, offs, radii, cam.gx, cam.gy, ka, va, conic_op, cull);
                 LAUNCH_CHECK();
                 GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, tbits));
                 k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, 0, ranges);
             } else {
-                k_duplicate<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, xy, depth, offs, radii, cam.gx, cam.gy, ka, va);
+                k_duplicate<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, xy, depth, offs, radii, cam.gx, cam.gy, ka, va, conic_op, cull);
                 LAUNCH_CHECK();
                 GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, 32 + tbits));
                 k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, 32, ranges);

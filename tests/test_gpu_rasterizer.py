@@ -122,11 +122,12 @@ img, radii = rast(means3D=t["means"], means2D=None, shs=None, colors_precomp=t["
 print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), rast.num_rendered)
 """ % root
     out = []
-    for v in ("1", "0"):
+    for v, cull in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         e = dict(os.environ)
         e["GAUSPCC_DEV"] = "1"
         e["GAUSPCC_RASTER_SORT2"] = v
+        e["GAUSPCC_RASTER_CULL"] = cull      # exact tile culling (csrc/rasterizer.hip: tile_touches): shorter lists, the same image, the reference's num_rendered
         r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=root, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
-    assert out[0] == out[1] and int(out[0].split()[-1]) > 100000
+    assert out[0] == out[1] == out[2] == out[3] and int(out[0].split()[-1]) > 100000

@@ -5,8 +5,9 @@
 // Forward only: RD evaluation (render -> PSNR) never needs the backward.
 //
 // gfx950 mapping:
-//   k_preprocess     one lane per Gaussian, coalesced SoA outputs (HBM-bound)
-//   scan / sort      the library's own wave-ballot radix sort on (tile << 32 | depth bits)
+//   k_preprocess     one lane per Gaussian, coalesced SoA outputs (HBM-bound); counts the tiles the splat can reach (tile_touches: exact tile culling)
+//   scan / sort      the library's own wave-ballot radix sort: the Gaussians by depth (4 passes), the duplicates emitted in that order, then by tile (2 passes)
+//                    -- the permutation of the reference's single sort on (tile << 32 | depth bits), which GAUSPCC_RASTER_SORT2=0 still runs
 //   k_tile_ranges    boundary detection on the sorted keys
 //   k_render         one 128-lane workgroup per 16x16 tile, two pixels per lane; batches of 128 Gaussians staged in LDS
 //                    (id -> xy, conic+opacity, rgb = 36 B each), every lane blends its pixels front to

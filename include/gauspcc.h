@@ -396,7 +396,9 @@ GPCC_API int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int fe
  * TC-GS/SIBR_viewers/src/projects/gaussianviewer/renderer/GaussianView.cpp:535-553, 660-688; Python call
  * sites HAC/gaussian_renderer/__init__.py:199-225, 268-303.  All pointers are device pointers; viewmatrix /
  * projmatrix are the 4x4 row-vector (transposed) matrices of HAC/scene/cameras.py:48-57; colours are
- * precomputed (shs = None in every call site); out_color is (3, H, W). */
+ * precomputed (shs = None in every call site); out_color is (3, H, W).  *num_rendered_out is the reference's count -- the tiles of every
+ * splat's 3-sigma bounding square -- although the lists that are sorted and blended hold only the (splat, tile) pairs that can reach alpha >=
+ * 1 / 255 somewhere in the tile (csrc/rasterizer.hip: tile_touches; the image is bit-identical either way). */
 GPCC_API int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const float *means3D, const float *scales, float scale_modifier,
                                 const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
                                 float tan_fovx, float tan_fovy, int prefiltered, int *radii, void *stream);

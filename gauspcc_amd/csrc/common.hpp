@@ -214,6 +214,7 @@ struct gpcc_ctx {
     // epoch (status words of earlier launches are invalid by their epoch: no reset between launches)
     struct ScanState { hipStream_t st; unsigned long long *status; uint32_t *ticket; uint32_t epoch; };
     std::vector<ScanState> scan_states;
+    uint32_t *dev_err_dev = nullptr;   // the device's address of dev_err (hipHostGetDevicePointer, once)
     uint32_t *dev_err = nullptr;   // sticky device-side error word in pinned, device-visible host memory (primitives.hip: the look-back scan's bounded wait);
                                    // read after a call's final sync by device_error_check()
     int container_version = 4;     // what gpcc_encode / gpcc_rc_encode write for chunk_log2 != 0 (gpcc_ctx_set_container_version: 3 or 4)

@@ -322,7 +322,10 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
         void *h = nullptr;
         HIP_TRY(hipHostMalloc(&h, 64, hipHostMallocMapped));
         *static_cast<volatile uint32_t *>(h) = 0u;
+        void *d = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&d, h, 0));
         ctx->dev_err = static_cast<uint32_t *>(h);
+        ctx->dev_err_dev = static_cast<uint32_t *>(d);
     }
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
     void *p = nullptr;
@@ -385,9 +388,7 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
         static std::atomic<int> launches{0};
         uint32_t limit = 1u << 24, skip = 0xFFFFFFFFu;
         if (fault_at > 0 && ++launches == fault_at) { limit = 1u << 12; skip = 0u; }
-        void *derr = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(&derr, ctx->dev_err, 0));
-        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev, static_cast<uint32_t *>(derr), limit, skip);
+        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev, ctx->dev_err_dev, limit, skip);
         LAUNCH_CHECK();
         return GPCC_OK;
     }

@@ -121,6 +121,9 @@ struct WaveBits {  // every lane holds the same reader state (wave-uniform addre
     {
         uint32_t w;
         __builtin_memcpy(&w, q, 4);
+        // every lane read the same word (wave-uniform address, not dword-aligned: a vector load): as a scalar, the reader's state and the coder's
+        // range stay in SGPRs and their arithmetic runs on the scalar unit, beside the other waves' erfc passes
+        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
         w = __builtin_bswap32(w);
         const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem));
         return w & keep;
@@ -137,70 +140,142 @@ struct WaveBits {  // every lane holds the same reader state (wave-uniform addre
         const uint32_t r = (uint32_t)((buf >> 1) >> (63 - k));
         buf <<= k;
         n -= k;
+        buf = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(buf >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)buf);
+        n = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
         return r;
     }
 };
 
 __device__ __forceinline__ int clz32(uint32_t x) { return x ? __clz((int)x) : 32; }
+// value of lane `l` (wave-uniform index) as a scalar: v_readlane_b32 -- the result lives in an SGPR, so what is computed from it (the coder's range
+// update) runs on the scalar unit beside the other waves' VALU work; __shfl with a uniform index is a ds_bpermute whose result is a VGPR
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int64_t uniform64(int64_t v) { return (int64_t)(((uint64_t)uniform((uint32_t)((uint64_t)v >> 32)) << 32) | uniform((uint32_t)v)); }
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l)); }
+
+// Row parameters of 64 consecutive symbols at once (round 5): lane j loads row i0 + j -- three coalesced loads per 64 symbols for a GaussTable instead
+// of three broadcast loads per symbol whose latency (~1 us from HBM) sat in the decode chain four symbols at a time -- and a row is handed to the
+// wave by lane broadcasts.  Table rows (float / uint16) are pointers: nothing to load.
+template <typename CT> struct RowLoader {
+    __device__ __forceinline__ static auto load(const CT &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
+    template <typename R> __device__ __forceinline__ static auto get(const CT &t, const R &, int64_t idx, int lp, int) { return row_of(t, idx, lp); }
+    template <typename R> __device__ __forceinline__ static int centre(const R &, int max_symbol) { return max_symbol / 2; }
+};
+template <> struct RowLoader<GaussTable> {
+    __device__ __forceinline__ static GaussRow load(const GaussTable &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
+    __device__ __forceinline__ static GaussRow get(const GaussTable &, const GaussRow &mine, int64_t, int, int u)
+    {
+        return GaussRow{__shfl(mine.mean, u), __shfl(mine.scale, u), __shfl(mine.q, u), mine.min_value};
+    }
+    // index of the symbol nearest the mean: where a window of 64 candidates is put when the alphabet is wider than a wave
+    __device__ __forceinline__ static int centre(const GaussRow &r, int) { return (int)__builtin_rintf(r.mean / r.q) - r.min_value; }
+};
+template <> struct RowLoader<MixTable> {
+    __device__ __forceinline__ static MixRow load(const MixTable &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
+    __device__ __forceinline__ static MixRow get(const MixTable &, const MixRow &mine, int64_t, int, int u)
+    {
+        MixRow r;
+        r.q = __shfl(mine.q, u); r.k = mine.k; r.min_value = mine.min_value;
+#pragma unroll
+        for (int i = 0; i < MIX_MAX; ++i)
+            if (i < mine.k) { r.mean[i] = __shfl(mine.mean[i], u); r.scale[i] = __shfl(mine.scale[i], u); r.prob[i] = __shfl(mine.prob[i], u); }
+        return r;
+    }
+    __device__ __forceinline__ static int centre(const MixRow &r, int)
+    {
+        int best = 0;
+#pragma unroll
+        for (int i = 1; i < MIX_MAX; ++i)
+            if (i < r.k && r.prob[i] > r.prob[best]) best = i;
+        float m = r.mean[0];
+#pragma unroll
+        for (int i = 1; i < MIX_MAX; ++i) m = best == i ? r.mean[i] : m;
+        return (int)__builtin_rintf(m / r.q) - r.min_value;
+    }
+};
 
 // One wave decodes one chunk: `cn` symbols whose rows are base .. base+cn-1 of `cdf`; out(row, symbol) stores the result.
+// A symbol is the highest index m with  (span * cdf_int(m)) >> 16  <=  value - low  (index 0 always qualifies; the integerised row is strictly
+// increasing: rint(cdf * scale) + m).  The kernel is bound by VALU issue -- one erfc (~100 instructions with its fp64 steps; k of them for HAC++'s
+// mixtures) per candidate PASS of the wave, whatever the number of useful lanes -- and the candidates of a row do not depend on the decoder's state.
+// So a pass serves FOUR rows: lane (g, c) evaluates candidate s0[g] + c of row g, a window of 16 around the element's mean (the whole row when the
+// alphabet has <= 16 symbols); the serial part per symbol is then a scaled compare, a ballot over the row's 16 lanes and the range update.  Round 4
+// spent a full 64-candidate pass per symbol (and, for alphabets wider than a wave, a wave-uniform binary search: seven dependent erfc per symbol).
+// A window that does not bracket the value falls back to a 64-wide window of the row's own and then to the binary search: the same index either way.
 template <typename CT, typename OUT>
 __device__ __forceinline__ void hac_decode_chunk(const CT &cdf, const uint8_t *__restrict__ chunk_bytes, uint32_t chunk_nbytes, int64_t base, int cn, int lp,
                                                  OUT out)
 {
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
     const float scale = (float)(65536 - (lp - 1));
-    const int max_symbol = lp - 2;
+    const int max_symbol = lp - 2;            // indices 0 .. lp-2 are searched
     WaveBits in;
     in.init(chunk_bytes, chunk_nbytes);
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = in.take(32);
-    const int nseg = (lp - 1 + 63) / 64;  // indices 0 .. lp-2 are searched
-    for (int i0 = 0; i0 < cn; i0 += 4) {
-        // prefetch the first segment of the next four rows (rows do not depend on decoded symbols)
-        uint32_t pre[4];
+    typedef RowLoader<CT> RL;
+    for (int j0 = 0; j0 < cn; j0 += 64) {
+        const auto mine = RL::load(cdf, base + min(j0 + lane, cn - 1), lp);
+        const int jn = min(64, cn - j0);
+        for (int u0 = 0; u0 < jn; u0 += 4) {
+            // one pass: 16 candidates of each of the next four rows (rows do not depend on decoded symbols)
+            const int ug = min(u0 + g, jn - 1);
+            const auto rowg = RL::get(cdf, mine, base + j0 + ug, lp, ug);
+            const int s0g = max_symbol > 15 ? max(0, min(RL::centre(rowg, max_symbol) - 7, max_symbol - 15)) : 0;
+            const int mg = s0g + c;
+            const uint32_t preg = mg <= max_symbol ? cdf_int(rowg, mg, scale) : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pre[u] = (i0 + u < cn && lane <= max_symbol) ? cdf_int(row_of(cdf, base + i0 + u, lp), lane, scale) : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u;
-            if (i >= cn) break;
-            const auto row = row_of(cdf, base + i, lp);
-            const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-            const uint32_t x = value - low;
-            int s;
-            uint32_t lo, hi;
-            if (nseg == 1) {
-                // the whole row in one go: lane m integerises and scales cdf[m]; the symbol is the highest lane
-                // whose scaled bound is <= value - low (index 0 is never compared: binsearch starts with left = 0)
-                const uint32_t v = pre[u];
-                const uint32_t t = (uint32_t)((span * (uint64_t)v) >> 16);
-                const uint64_t bal = __ballot(lane <= max_symbol && (lane == 0 || t <= x));
-                s = 63 - __clzll((long long)bal);
-                lo = __shfl(t, s);
-                const uint32_t nxt = __shfl(t, min(s + 1, 63));
-                hi = s == max_symbol ? (uint32_t)span : nxt;
-            } else {
-                // alphabets wider than a wave: wave-uniform binary search (broadcast loads)
-                int left = 0, right = max_symbol + 1;
-                while (left + 1 < right) {
-                    const int m = (left + right) / 2;
-                    const uint32_t v = cdf_int(row, m, scale);
-                    if ((uint32_t)((span * (uint64_t)v) >> 16) <= x) left = m; else right = m;
+            for (int u = 0; u < 4; ++u) {
+                if (u0 + u >= jn) break;
+                const int64_t r = base + j0 + u0 + u;
+                const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+                const uint32_t x = value - low;
+                const uint32_t t = (uint32_t)((span * (uint64_t)preg) >> 16);
+                const uint32_t bal = (uint32_t)(__ballot(g == u && mg <= max_symbol && (mg == 0 || t <= x)) >> (16 * u)) & 0xFFFFu;
+                const int top = 31 - clz32(bal);                   // -1: no candidate qualifies
+                int s = (int)lane_value((uint32_t)s0g, 16 * u) + top;
+                uint32_t lo, hi;
+                if (bal != 0u && (top < 15 || s == max_symbol)) {
+                    lo = lane_value(t, 16 * u + top);
+                    const uint32_t nxt = lane_value(t, 16 * u + min(top + 1, 15));
+                    hi = s == max_symbol ? (uint32_t)span : nxt;
+                } else {
+                    // the narrow window does not bracket the value: a 64-wide window of this row alone, then the wave-uniform binary search
+                    const auto row = RL::get(cdf, mine, r, lp, u0 + u);
+                    const int w0 = max_symbol > 63 ? max(0, min(RL::centre(row, max_symbol) - 31, max_symbol - 63)) : 0;
+                    const int m = w0 + lane;
+                    const uint32_t tw = m <= max_symbol ? (uint32_t)((span * (uint64_t)cdf_int(row, m, scale)) >> 16) : 0u;
+                    const uint64_t balw = __ballot(m <= max_symbol && (m == 0 || tw <= x));
+                    const int topw = 63 - __clzll((long long)balw);
+                    s = w0 + topw;
+                    if (balw != 0ull && (topw < 63 || s == max_symbol)) {
+                        lo = lane_value(tw, topw);
+                        const uint32_t nxt = lane_value(tw, min(topw + 1, 63));
+                        hi = s == max_symbol ? (uint32_t)span : nxt;
+                    } else {
+                        int left = 0, right = max_symbol + 1;
+                        while (left + 1 < right) {
+                            const int mid = (left + right) / 2;
+                            const uint32_t v = uniform(cdf_int(row, mid, scale));     // (every lane computed the same number)
+                            if ((uint32_t)((span * (uint64_t)v) >> 16) <= x) left = mid; else right = mid;
+                        }
+                        s = left;
+                        lo = (uint32_t)((span * (uint64_t)uniform(cdf_int(row, s, scale))) >> 16);
+                        hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)uniform(cdf_int(row, s + 1, scale))) >> 16);
+                    }
                 }
-                s = left;
-                lo = (uint32_t)((span * (uint64_t)cdf_int(row, s, scale)) >> 16);
-                hi = s == max_symbol ? (uint32_t)span : (uint32_t)((span * (uint64_t)cdf_int(row, s + 1, scale)) >> 16);
+                if (lane == 0) out(r, s);
+                high = (low - 1u) + hi;
+                low = low + lo;
+                const int n1 = clz32(low ^ high);
+                low <<= n1; high = (high << n1) | ((1u << n1) - 1u); value = (value << n1) | in.take((uint32_t)n1);
+                const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
+                low = (low << n2) & (n2 ? 0x7FFFFFFFu : 0xFFFFFFFFu);
+                high = (high << n2) | (n2 ? 0x80000000u : 0u) | ((1u << n2) - 1u);
+                value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
+                // the coder's state is wave-uniform; saying so keeps it (and the arithmetic above) in scalar registers
+                low = uniform(low); high = uniform(high); value = uniform(value);
             }
-            if (lane == 0) out(base + i, s);
-            high = (low - 1u) + hi;
-            low = low + lo;
-            const int n1 = clz32(low ^ high);
-            low <<= n1; high = (high << n1) | ((1u << n1) - 1u); value = (value << n1) | in.take((uint32_t)n1);
-            const int n2 = min(min(clz32(~(low << 1)), clz32(high << 1)), 31);
-            low = (low << n2) & (n2 ? 0x7FFFFFFFu : 0xFFFFFFFFu);
-            high = (high << n2) | (n2 ? 0x80000000u : 0u) | ((1u << n2) - 1u);
-            value = ((value << n2) ^ (n2 ? 0x80000000u : 0u)) | in.take((uint32_t)n2);
         }
     }
 }
@@ -211,7 +286,7 @@ __global__ __launch_bounds__(64) void k_hac_decode(const CT cdf, const uint8_t *
 {
     const int c = blockIdx.x;
     const int64_t base = (int64_t)c * chunk;
-    hac_decode_chunk(cdf, bytes + cnt_cum[c], (uint32_t)cnt[c], base, (int)min((int64_t)chunk, n - base), lp,
+    hac_decode_chunk(cdf, bytes + uniform(cnt_cum[c]), uniform((uint32_t)cnt[c]), base, (int)min((int64_t)chunk, n - base), lp,
                      [&](int64_t r, int s) { sym[r] = (int16_t)s; });
 }
 
@@ -224,11 +299,14 @@ template <typename CT>
 __global__ __launch_bounds__(64) void k_hac_decode_slices(CT table, const SliceChunk *__restrict__ chunks, const int32_t *__restrict__ smin,
                                                           const int32_t *__restrict__ slp, const uint8_t *__restrict__ bytes, float *__restrict__ x)
 {
+    // (the chunk record comes in through a vector load; as scalars, the chunk's loop bounds, the bit reader and the coder's range are wave-uniform
+    //  for the compiler too and run on the scalar unit)
     const SliceChunk ch = chunks[blockIdx.x];
-    const int mn = smin[ch.slice];
+    const int slice = (int)uniform((uint32_t)ch.slice);
+    const int mn = (int)uniform((uint32_t)smin[slice]);
     table.min_value = mn;
     const float *__restrict__ q = table.q;
-    hac_decode_chunk(table, bytes + ch.byte_off, ch.nbytes, ch.base, ch.n, slp[ch.slice],
+    hac_decode_chunk(table, bytes + uniform(ch.byte_off), uniform(ch.nbytes), uniform64(ch.base), (int)uniform((uint32_t)ch.n), (int)uniform((uint32_t)slp[slice]),
                      [&](int64_t r, int s) { x[r] = ((float)s + (float)mn) * q[r]; });
 }
 

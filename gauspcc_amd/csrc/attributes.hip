@@ -111,31 +111,47 @@ __global__ __launch_bounds__(TB) void k_hac_pack(const CT cdf, const int16_t *__
 }
 
 // ------------------------------------------------------------------ decode: one wave per chunk
-struct WaveBits {  // every lane holds the same reader state (wave-uniform addresses: broadcast loads); see BitIn in rangecoder.hip
-    const uint8_t *p;
-    int32_t rem;
+// Bit reader of a wave: the chunk's bytes come in 64 words at a time -- lane j loads big-endian word j of the current block, one coalesced load per
+// 2 048 bits -- and the coder draws the next word with v_readlane.  (Until round 5 every refill was a load of its own whose latency, ~1 us from HBM
+// and never less than an L1 round trip, sat in the symbol chain every 32 bits.)  Bytes past the chunk's end read as zero and are never loaded.
+// The state is wave-uniform and kept in scalar registers (readfirstlane): the range arithmetic of the caller runs on the scalar unit.
+struct WaveBits {
+    const uint8_t *p;     // first byte of the current block of 64 words
+    int32_t rem;          // bytes of the chunk from p on
+    uint32_t words;       // per lane: word `lane` of the block
+    uint32_t widx;        // next word of the block to hand out (64: block exhausted)
     uint32_t nw;
     uint64_t buf;
     uint32_t n;
-    __device__ __forceinline__ static uint32_t fetch(const uint8_t *q, int32_t rem)
+    __device__ __forceinline__ void load_block()
     {
-        uint32_t w;
-        __builtin_memcpy(&w, q, 4);
-        // every lane read the same word (wave-uniform address, not dword-aligned: a vector load): as a scalar, the reader's state and the coder's
-        // range stay in SGPRs and their arithmetic runs on the scalar unit, beside the other waves' erfc passes
-        w = (uint32_t)__builtin_amdgcn_readfirstlane((int)w);
-        w = __builtin_bswap32(w);
-        const uint32_t keep = rem >= 4 ? 0xFFFFFFFFu : rem <= 0 ? 0u : ~(0xFFFFFFFFu >> (8 * rem));
-        return w & keep;
+        const int lane = threadIdx.x & 63;
+        const int32_t left = rem - 4 * lane;          // bytes of the chunk at this lane's word
+        uint32_t w = 0u;
+        if (left >= 4) {
+            __builtin_memcpy(&w, p + 4 * lane, 4);
+            w = __builtin_bswap32(w);
+        } else if (left > 0) {                        // the chunk's last, partial word: byte by byte (nothing behind the chunk is touched)
+            for (int b = 0; b < left; ++b) w |= (uint32_t)p[4 * lane + b] << (24 - 8 * b);
+        }
+        words = w;
+        widx = 0u;
     }
-    __device__ __forceinline__ void init(const uint8_t *base, uint32_t nbytes) { p = base; rem = (int32_t)nbytes; buf = 0; n = 0; nw = fetch(p, rem); }
+    __device__ __forceinline__ uint32_t next_word()
+    {
+        if (widx == 64u) { p += 256; rem -= 256; load_block(); }
+        widx = (uint32_t)__builtin_amdgcn_readfirstlane((int)widx);
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)words, (int)widx);
+        widx += 1u;
+        return w;
+    }
+    __device__ __forceinline__ void init(const uint8_t *base, uint32_t nbytes) { p = base; rem = (int32_t)nbytes; buf = 0; n = 0; load_block(); nw = next_word(); }
     __device__ __forceinline__ uint32_t take(uint32_t k)
     {
         if (n <= 32) {
             buf |= (uint64_t)nw << (32 - n);
             n += 32;
-            p += 4; rem -= 4;
-            nw = fetch(p, rem);
+            nw = next_word();
         }
         const uint32_t r = (uint32_t)((buf >> 1) >> (63 - k));
         buf <<= k;
@@ -160,6 +176,7 @@ template <typename CT> struct RowLoader {
     __device__ __forceinline__ static auto load(const CT &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
     template <typename R> __device__ __forceinline__ static auto get(const CT &t, const R &, int64_t idx, int lp, int) { return row_of(t, idx, lp); }
     template <typename R> __device__ __forceinline__ static int centre(const R &, int max_symbol) { return max_symbol / 2; }
+    template <typename R> __device__ __forceinline__ static int estimate(const R &, float p, int max_symbol) { return (int)(p * (float)max_symbol); }
 };
 template <> struct RowLoader<GaussTable> {
     __device__ __forceinline__ static GaussRow load(const GaussTable &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
@@ -169,6 +186,12 @@ template <> struct RowLoader<GaussTable> {
     }
     // index of the symbol nearest the mean: where a window of 64 candidates is put when the alphabet is wider than a wave
     __device__ __forceinline__ static int centre(const GaussRow &r, int) { return (int)__builtin_rintf(r.mean / r.q) - r.min_value; }
+    // index whose CDF entry is about p: the Gaussian's quantile (an ESTIMATE: the window put around it is checked like any other)
+    __device__ __forceinline__ static int estimate(const GaussRow &r, float p, int)
+    {
+        const float z = normcdfinvf(fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f));
+        return (int)__builtin_rintf((r.mean + fmaxf(r.scale, 1e-9f) * z) / r.q) - r.min_value;
+    }
 };
 template <> struct RowLoader<MixTable> {
     __device__ __forceinline__ static MixRow load(const MixTable &t, int64_t idx, int lp) { return row_of(t, idx, lp); }
@@ -191,6 +214,18 @@ template <> struct RowLoader<MixTable> {
 #pragma unroll
         for (int i = 1; i < MIX_MAX; ++i) m = best == i ? r.mean[i] : m;
         return (int)__builtin_rintf(m / r.q) - r.min_value;
+    }
+    __device__ __forceinline__ static int estimate(const MixRow &r, float p, int)
+    {   // the quantile of the heaviest component: a starting point
+        int best = 0;
+#pragma unroll
+        for (int i = 1; i < MIX_MAX; ++i)
+            if (i < r.k && r.prob[i] > r.prob[best]) best = i;
+        float m = r.mean[0], sc = r.scale[0];
+#pragma unroll
+        for (int i = 1; i < MIX_MAX; ++i) { m = best == i ? r.mean[i] : m; sc = best == i ? r.scale[i] : sc; }
+        const float z = normcdfinvf(fminf(fmaxf(p, 1e-7f), 1.0f - 1e-7f));
+        return (int)__builtin_rintf((m + fmaxf(sc, 1e-9f) * z) / r.q) - r.min_value;
     }
 };
 
@@ -242,7 +277,8 @@ __device__ __forceinline__ void hac_decode_chunk(const CT &cdf, const uint8_t *_
                 } else {
                     // the narrow window does not bracket the value: a 64-wide window of this row alone, then the wave-uniform binary search
                     const auto row = RL::get(cdf, mine, r, lp, u0 + u);
-                    const int w0 = max_symbol > 63 ? max(0, min(RL::centre(row, max_symbol) - 31, max_symbol - 63)) : 0;
+                    // (centred on the quantile of value - low within the range: wide rows -- HAC's scaling attribute has sigma / Q ~ 50 -- land in it)
+                    const int w0 = max_symbol > 63 ? max(0, min(RL::estimate(row, (float)x / (float)span, max_symbol) - 31, max_symbol - 63)) : 0;
                     const int m = w0 + lane;
                     const uint32_t tw = m <= max_symbol ? (uint32_t)((span * (uint64_t)cdf_int(row, m, scale)) >> 16) : 0u;
                     const uint64_t balw = __ballot(m <= max_symbol && (m == 0 || tw <= x));

@@ -183,6 +183,38 @@ def decoder_gaussian_slices(mean, scale, Q, slice_start, file_names):
                                              np.concatenate(cnts), chunk_size_cuda)
 
 
+def decoder_gaussian_slices_multi(jobs):
+    """decoder_gaussian_slices for SEVERAL attributes in one device call: jobs = [(mean, scale, Q, slice_start, file_names), ...]; returns the decoded
+    tensor of every job.  The decoder is one wave per 10 000-symbol chunk and bound by the chain of a chunk, not by the GPU (HAC's scaling attribute:
+    667 chunks, 12.8 ms; feat: 5 000 chunks, 9.4 ms; offsets 7.2 ms) -- decoded one after the other the three leave most SIMDs idle most of the time;
+    as ONE list of slices (each with its own min / max, as in the files) their chunks run side by side and the call takes what its longest chain takes."""
+    dev = jobs[0][0].device
+    parts, mins, maxs, cnts, datas, lens_all, sizes = [], [], [], [], [], [], []
+    for mean, scale, Q, slice_start, file_names in jobs:
+        ss = np.asarray(slice_start, dtype=np.int64)
+        lens = np.diff(ss)
+        keep = np.nonzero(lens > 0)[0]
+        for i in keep:
+            with open(file_names[i].replace('.b', '_0.b'), 'rb') as fin:
+                mins.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+                maxs.append(np.frombuffer(fin.read(4), dtype=np.float32)[0])
+                len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
+                cnts.append(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32))
+                datas.append(np.frombuffer(fin.read(), dtype=np.uint8))
+        sel = torch.cat([torch.arange(int(ss[i]), int(ss[i + 1]), device=dev) for i in keep]) if (keep.size != len(lens) and keep.size) else None
+        pick = (lambda t: t.reshape(-1)) if sel is None else (lambda t, sel=sel: t.reshape(-1)[sel])
+        if keep.size:
+            parts.append((pick(mean), pick(scale), pick(Q)))
+            lens_all.append(lens[keep])
+        sizes.append(int(lens[keep].sum()) if keep.size else 0)
+    if not parts:
+        return [torch.empty(0, dtype=torch.float32, device=dev) for _ in jobs]
+    cs = np.concatenate([[0], np.cumsum(np.concatenate(lens_all))])
+    cat = lambda k: torch.cat([p[k].float() for p in parts]).contiguous()
+    out = arithmetic.decode_gaussian_slices(cat(0), cat(1), cat(2), cs, np.array(mins), np.array(maxs), np.concatenate(datas), np.concatenate(cnts), chunk_size_cuda)
+    return list(torch.split(out, sizes))
+
+
 def encoder_gaussian_mixed_slices(x, mean_list, scale_list, prob_list, Q, slice_start, file_names, chunk_size=1000_0000):
     """encoder_gaussian_mixed_chunk (HAC-plus/utils/encodings_cuda.py:177-225) for MANY slices in one device call: slice s =
     elements [slice_start[s], slice_start[s+1]) goes to file_names[s] (as in the reference the file written is `*_0.b`) with its

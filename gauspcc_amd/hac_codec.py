@@ -29,7 +29,7 @@ import time
 import torch
 
 from . import _lib, runtime
-from .encodings_cuda import decoder, decoder_gaussian_slices, deferred_writes, encoder, encoder_gaussian_slices
+from .encodings_cuda import decoder, decoder_gaussian_slices, decoder_gaussian_slices_multi, deferred_writes, encoder, encoder_gaussian_slices
 from .pcc_utils import calculate_morton_order, compress_point_cloud, decompress_point_cloud
 
 bit2MB_scale = 8 * 1024 * 1024     # HAC/scene/gaussian_model.py:30
@@ -204,16 +204,20 @@ def conduct_decoding(self, pre_path_name, patched_infos, ckpt_path=None):
     c = _context(self, anchor_decoded)
     names = lambda stem: [os.path.join(pre_path_name, f'{stem}.b').replace('.b', f'_{s}.b') for s in range(steps)]
     bounds = [min(s * max_batch, N) for s in range(steps + 1)]
-    feat_decoded = decoder_gaussian_slices(c["mean"].reshape(-1), c["scale"].reshape(-1), c["Q_feat"].reshape(-1),
-                                           [b * self.feat_dim for b in bounds], names('feat')).view(N, self.feat_dim)
-    scaling_decoded = decoder_gaussian_slices(c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), c["Q_scaling"].reshape(-1),
-                                              [b * 6 for b in bounds], names('scaling')).view(N, 6)
     mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
     kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
     off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
     mo = c["mean_offsets"].reshape(-1)
+    # the three attributes in ONE device call: their chunks side by side (encodings_cuda.decoder_gaussian_slices_multi); the reference decodes
+    # slice after slice, attribute after attribute (:1304-1331)
+    feat_decoded, scaling_decoded, offs = decoder_gaussian_slices_multi([
+        (c["mean"].reshape(-1), c["scale"].reshape(-1), c["Q_feat"].reshape(-1), [b * self.feat_dim for b in bounds], names('feat')),
+        (c["mean_scaling"].reshape(-1), c["scale_scaling"].reshape(-1), c["Q_scaling"].reshape(-1), [b * 6 for b in bounds], names('scaling')),
+        (mo[mask], c["scale_offsets"].reshape(-1)[mask], c["Q_offsets"].reshape(-1)[mask], off_bounds, names('offsets'))])
+    feat_decoded = feat_decoded.view(N, self.feat_dim)
+    scaling_decoded = scaling_decoded.view(N, 6)
     offsets_decoded = torch.zeros_like(mo)
-    offsets_decoded[mask] = decoder_gaussian_slices(mo[mask], c["scale_offsets"].reshape(-1)[mask], c["Q_offsets"].reshape(-1)[mask], off_bounds, names('offsets'))
+    offsets_decoded[mask] = offs
     offsets_decoded = offsets_decoded.view(N, n_off, 3)
 
     torch.cuda.synchronize(); t2 = time.time()

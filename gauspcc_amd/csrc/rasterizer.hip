@@ -46,10 +46,11 @@ __device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, floa
     // d = centre - pixel, pixels tx*16 .. tx*16 + 15 (the last tiles' pixels beyond the image only make the rectangle larger)
     const float dx_hi = gx_ - (float)(tx * BX), dx_lo = dx_hi - (float)(BX - 1);
     const float dy_hi = gy_ - (float)(ty * BY), dy_lo = dy_hi - (float)(BY - 1);
+    if (!(lim < __builtin_inff())) return true;     // conics outside the argument (cull_limit): the reference's lists
     if (dx_lo <= 0.0f && dx_hi >= 0.0f && dy_lo <= 0.0f && dy_hi >= 0.0f) return true;
     const float m = fminf(fminf(edge_min(dx_lo, dy_lo, dy_hi, A, B, C), edge_min(dx_hi, dy_lo, dy_hi, A, B, C)),
                           fminf(edge_min(dy_lo, dx_lo, dx_hi, C, B, A), edge_min(dy_hi, dx_lo, dx_hi, C, B, A)));
-    return m <= lim;
+    return !(m > lim);                              // (a NaN anywhere keeps the pair)
 }
 // the bound on q for a Gaussian of opacity op: +inf for conics the argument above does not cover (never culled), -1 when op < 1 / 255 (never blended)
 __device__ __forceinline__ float cull_limit(float A, float B, float C, float op)

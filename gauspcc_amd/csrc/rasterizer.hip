@@ -56,6 +56,7 @@ __device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, floa
 __device__ __forceinline__ float cull_limit(float A, float B, float C, float op)
 {
     if (!(A > 0.0f && C > 0.0f && A * C - B * B > 0.0f)) return __builtin_inff();
+    if (op != op) return __builtin_inff();          // a NaN opacity blends as alpha 0.99 (fminf): keep the pair
     if (!(op > 0.0f)) return -1.0f;
     return __logf(255.0f * op) + 2e-3f;
 }

@@ -619,27 +619,29 @@ namespace {
 // read group hit 32 different banks), every wave takes whole 16-row tiles: the rows staged in LDS, the hidden layer written
 // back over them, no block barrier after the weights have landed.
 typedef float f32x4m __attribute__((ext_vector_type(4)));
-constexpr int MLPM_WAVES = 4;
+constexpr int MLPM_WAVES_MAX = 8;   // waves per workgroup: 8 (two per SIMD: one's row loads, stores and drains under the other's MFMA chains) when the class's LDS allows, else 4
 // DIN / DH / DOUT are the CLASS of the kernel (register arrays and LDS pitches are compile-time); the layer's own sizes din <= DIN,
 // dh <= DH, dout <= DOUT are run-time: weights, biases and input columns beyond them are zeros in LDS, so the chain of an output
 // is its own k = 0 .. din - 1 steps followed by fmaf(0, 0, acc) steps, which leave acc unchanged.  HAC's 96-100-175 runs in its
 // exact class (no padding); HAC++'s mlp_grid (48-100-195 / 225) and its five channel-context MLPs (150 + 10 c - 40 - 30,
 // LeakyReLU) in classes <48, 100, 240> and <192, 40, 32> (HAC-plus/scene/gaussian_model.py:117-168, 370-374).
 template <int DIN, int DH, int DOUT>
-__global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
+__global__ __launch_bounds__(64 * MLPM_WAVES_MAX) void k_mlp2_mfma(const float *__restrict__ x, const float *__restrict__ w1, const float *__restrict__ b1,
                                                               const float *__restrict__ w2, const float *__restrict__ b2, int64_t n, int din, int dh, int dout,
-                                                              float slope, float *__restrict__ y)
+                                                              float slope, float *__restrict__ y, int PX)
 {
     static_assert(DIN % 4 == 0 && DH % 4 == 0, "whole MFMA k-steps");
-    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2, PX = (DIN > DH ? DIN : DH) + 2;
+    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2;
+    // W1 holds DH rows and W2 DOUT rows, not whole tiles of 16: the B operands of the last tile's padding outputs are read from whatever follows
+    // (inside the allocation) -- they only reach accumulator columns that are never stored (hidden units >= DH, outputs >= dout)
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float *W1s = sm, *W2s = W1s + NT1 * 16 * P1, *B1s = W2s + NT2 * 16 * P2, *B2s = B1s + NT1 * 16, *XS = B2s + NT2 * 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *W1s = sm, *W2s = W1s + DH * P1, *B1s = W2s + DOUT * P2, *B2s = B1s + NT1 * 16, *XS = B2s + NT2 * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, MLPM_WAVES = nthreads >> 6;
     const int e = lane & 15, g = lane >> 4;
-    for (int i = tid; i < NT1 * 16 * DIN; i += 64 * MLPM_WAVES) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = (c < dh && k < din) ? w1[(size_t)c * din + k] : 0.0f; }
-    for (int i = tid; i < NT2 * 16 * DH; i += 64 * MLPM_WAVES) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = (c < dout && k < dh) ? w2[(size_t)c * dh + k] : 0.0f; }
-    for (int i = tid; i < NT1 * 16; i += 64 * MLPM_WAVES) B1s[i] = i < dh ? b1[i] : 0.0f;
-    for (int i = tid; i < NT2 * 16; i += 64 * MLPM_WAVES) B2s[i] = i < dout ? b2[i] : 0.0f;
+    for (int i = tid; i < DH * DIN; i += nthreads) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = (c < dh && k < din) ? w1[(size_t)c * din + k] : 0.0f; }
+    for (int i = tid; i < DOUT * DH; i += nthreads) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = (c < dout && k < dh) ? w2[(size_t)c * dh + k] : 0.0f; }
+    for (int i = tid; i < NT1 * 16; i += nthreads) B1s[i] = i < dh ? b1[i] : 0.0f;
+    for (int i = tid; i < NT2 * 16; i += nthreads) B2s[i] = i < dout ? b2[i] : 0.0f;
     __syncthreads();
     float *xs = XS + wave * 16 * PX;
     const int64_t ntiles = (n + 15) / 16;
@@ -661,14 +663,29 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
         float a[DIN / 4 > DH / 4 ? DIN / 4 : DH / 4];
 #pragma unroll
         for (int kk = 0; kk < DIN / 4; ++kk) a[kk] = xs[e * PX + 4 * kk + g];        // A operand: row e, k = 4 kk + g
+        // The weight operands of output tile t + 1 are read from LDS while the MFMAs of tile t run (two register sets, the scheduler held to that order):
+        // left to itself the compiler placed every ds_read directly in front of the two MFMAs that use it, with one register pair for all of them --
+        // a full LDS round trip (~110 cycles) per 64 cycles of matrix work, which is what "32 % of the fp32 matrix peak" was (round 3's figure).
         f32x4m hid[NT1];
+        float wb[2][DIN / 4 > DH / 4 ? DIN / 4 : DH / 4];
+        {
+            const float *wr = W1s + e * P1 + g;                                    // B operand: output 16 t + e, k = 4 kk + g
+#pragma unroll
+            for (int kk = 0; kk < DIN / 4; ++kk) wb[0][kk] = wr[4 * kk];
+        }
 #pragma unroll
         for (int t = 0; t < NT1; ++t) {
             const float bias = B1s[16 * t + e];
             f32x4m acc = {bias, bias, bias, bias};
-            const float *wr = W1s + (16 * t + e) * P1 + g;                         // B operand: output 16 t + e, k = 4 kk + g
+            if (t + 1 < NT1) {
+                const float *wr = W1s + (16 * (t + 1) + e) * P1 + g;
 #pragma unroll
-            for (int kk = 0; kk < DIN / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wr[4 * kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < DIN / 4; ++kk) wb[(t + 1) & 1][kk] = wr[4 * kk];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < DIN / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wb[t & 1][kk], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             hid[t] = acc;
         }
         // hidden = relu(...) over the rows' slots: lane (g, e) holds rows 4 g .. 4 g + 3 of output 16 t + e (LDS operations of a
@@ -681,13 +698,24 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
             }
 #pragma unroll
         for (int kk = 0; kk < DH / 4; ++kk) a[kk] = xs[e * PX + 4 * kk + g];
+        {
+            const float *wr = W2s + e * P2 + g;
+#pragma unroll
+            for (int kk = 0; kk < DH / 4; ++kk) wb[0][kk] = wr[4 * kk];
+        }
 #pragma unroll
         for (int t = 0; t < NT2; ++t) {
             const float bias = B2s[16 * t + e];
             f32x4m acc = {bias, bias, bias, bias};
-            const float *wr = W2s + (16 * t + e) * P2 + g;
+            if (t + 1 < NT2) {
+                const float *wr = W2s + (16 * (t + 1) + e) * P2 + g;
 #pragma unroll
-            for (int kk = 0; kk < DH / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wr[4 * kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < DH / 4; ++kk) wb[(t + 1) & 1][kk] = wr[4 * kk];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < DH / 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk], wb[t & 1][kk], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             const int c = 16 * t + e;
             if (c < dout) {
 #pragma unroll
@@ -698,10 +726,10 @@ __global__ __launch_bounds__(64 * MLPM_WAVES) void k_mlp2_mfma(const float *__re
     }
 }
 template <int DIN, int DH, int DOUT>
-static size_t mlpm_lds_bytes()
+static size_t mlpm_lds_bytes(int waves, int px)
 {
-    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2, PX = (DIN > DH ? DIN : DH) + 2;
-    return sizeof(float) * ((size_t)NT1 * 16 * P1 + (size_t)NT2 * 16 * P2 + NT1 * 16 + NT2 * 16 + (size_t)MLPM_WAVES * 16 * PX);
+    constexpr int NT1 = (DH + 15) / 16, NT2 = (DOUT + 15) / 16, P1 = DIN + 2, P2 = DH + 2;
+    return sizeof(float) * ((size_t)DH * P1 + (size_t)DOUT * P2 + NT1 * 16 + NT2 * 16 + (size_t)waves * 16 * px);
 }
 }  // namespace
 
@@ -710,13 +738,20 @@ static int mlp2_mfma_launch(gpcc_ctx *ctx, const float *x, const float *w1, cons
                             float slope, float *y, hipStream_t st)
 {
     static PerDeviceOnce attr;
-    const size_t lds = mlpm_lds_bytes<DIN, DH, DOUT>();
+    // eight waves when they fit (if need be with the rows' LDS pitch without its two padding words: two-way conflicts on the 49 A-operand reads of a
+    // tile, nothing on the 443 B-operand reads), else four
+    constexpr int PXW = (DIN > DH ? DIN : DH);
+    constexpr size_t LDS_MAX = 160 * 1024;
+    int waves = 8, px = PXW + 2;
+    if (mlpm_lds_bytes<DIN, DH, DOUT>(8, px) > LDS_MAX) px = PXW;
+    if (mlpm_lds_bytes<DIN, DH, DOUT>(8, px) > LDS_MAX) { waves = 4; px = PXW + 2; }
+    const size_t lds = mlpm_lds_bytes<DIN, DH, DOUT>(waves, px);
     GP_TRY(attr.run(ctx->device, [&]() -> int {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<DIN, DH, DOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp2_mfma<DIN, DH, DOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
         return GPCC_OK;
     }));
-    const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), MLPM_WAVES));
-    k_mlp2_mfma<DIN, DH, DOUT><<<grid, 64 * MLPM_WAVES, lds, st>>>(x, w1, b1, w2, b2, n, din, dh, dout, slope, y);
+    const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(n, 16), waves));
+    k_mlp2_mfma<DIN, DH, DOUT><<<grid, 64 * waves, lds, st>>>(x, w1, b1, w2, b2, n, din, dh, dout, slope, y, px);
     LAUNCH_CHECK();
     return GPCC_OK;
 }

@@ -183,19 +183,38 @@ __device__ __forceinline__ void ng_wave_sync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// The weight operands of output tile t + 1 are read from LDS while the MFMAs of tile t run -- two register sets and the scheduler held to that order
+// (__builtin_amdgcn_sched_barrier): left to itself the compiler re-read BOTH operands from LDS directly in front of every pair of MFMAs, one LDS round
+// trip per 64 cycles of matrix work (the same finding as in attributes.hip: k_mlp2_mfma).
+template <int NK>
+__device__ __forceinline__ void ng_load_w(float (&w)[NK], const float *wr)
+{
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) w[kk] = wr[4 * kk];
+}
+template <int NK>
+__device__ __forceinline__ f32x4n ng_chain(const float (&a)[NK], const float (&w)[NK], float bias)
+{
+    f32x4n acc = {bias, bias, bias, bias};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) NG_MF(acc, a[kk], w[kk]);
+    __builtin_amdgcn_sched_barrier(0);
+    return acc;
+}
+
 // relu(x W1^T + b1) of the tile: A operands in registers, result into hs[16][P2] (columns F .. DHP - 1 come out as zeros)
 template <int F, int NK>
 __device__ __forceinline__ void ng_hidden(const float (&a)[NK], const float *W1s, int p1, const float *B1s, float *hs, int e, int g)
 {
     using M = NGM<F>;
     f32x4n acc[M::NT1];
+    float wb[2][NK];
+    ng_load_w<NK>(wb[0], W1s + e * p1 + g);
 #pragma unroll
     for (int t = 0; t < M::NT1; ++t) {
-        const float bias = B1s[16 * t + e];
-        acc[t] = f32x4n{bias, bias, bias, bias};
-        const float *wr = W1s + (16 * t + e) * p1 + g;
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) NG_MF(acc[t], a[kk], wr[4 * kk]);
+        if (t + 1 < M::NT1) ng_load_w<NK>(wb[(t + 1) & 1], W1s + (16 * (t + 1) + e) * p1 + g);
+        acc[t] = ng_chain<NK>(a, wb[t & 1], B1s[16 * t + e]);
     }
 #pragma unroll
     for (int t = 0; t < M::NT1; ++t)
@@ -209,12 +228,27 @@ template <int F>
 __device__ __forceinline__ f32x4n ng_out_tile(const float (&a)[NGM<F>::DHP / 4], const MlpLds &m, int t, int e, int g)
 {
     using M = NGM<F>;
-    const float bias = m.b2[16 * t + e];
-    f32x4n acc = {bias, bias, bias, bias};
-    const float *wr = m.w2 + (16 * t + e) * M::P2 + g;
-#pragma unroll
-    for (int kk = 0; kk < M::DHP / 4; ++kk) NG_MF(acc, a[kk], wr[4 * kk]);
-    return acc;
+    float w[M::DHP / 4];
+    ng_load_w<M::DHP / 4>(w, m.w2 + (16 * t + e) * M::P2 + g);
+    return ng_chain<M::DHP / 4>(a, w, m.b2[16 * t + e]);
+}
+
+// the output tiles 0 .. nt - 1 of a second layer, two per trip so that the register set of a tile is a compile-time choice: fn(t, acc)
+template <int F, typename FN>
+__device__ __forceinline__ void ng_layer2(const float (&a)[NGM<F>::DHP / 4], const MlpLds &m, int nt, int e, int g, FN fn)
+{
+    using M = NGM<F>;
+    constexpr int NK = M::DHP / 4;
+    float w0[NK], w1[NK];
+    ng_load_w<NK>(w0, m.w2 + e * M::P2 + g);
+    for (int t = 0; t < nt; t += 2) {
+        if (t + 1 < nt) ng_load_w<NK>(w1, m.w2 + (16 * (t + 1) + e) * M::P2 + g);
+        fn(t, ng_chain<NK>(a, w0, m.b2[16 * t + e]));
+        if (t + 1 < nt) {
+            if (t + 2 < nt) ng_load_w<NK>(w0, m.w2 + (16 * (t + 2) + e) * M::P2 + g);
+            fn(t + 1, ng_chain<NK>(a, w1, m.b2[16 * (t + 1) + e]));
+        }
+    }
 }
 
 // [feat | view | dist | 0] of anchors row0 .. row0 + 15 into xs[16][px] (rows past n: the last anchor again), the feature bank applied
@@ -366,28 +400,26 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
         ng_wave_sync();
 #pragma unroll
         for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
-        for (int t = 0; t < ntc; ++t) {
-            const f32x4n v = ng_out_tile<F>(a2, col, t, e, g);
+        ng_layer2<F>(a2, col, ntc, e, g, [&](int t, const f32x4n &v) {
             const int c = 16 * t + e;
             if (c < 3 * K) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + c] = 1.0f / (1.0f + expf(-v[i]));
             }
-        }
+        });
         ng_wave_sync();
         // covariance: linear head, 7 per Gaussian (:151-152) -> columns 3 K .. 10 K - 1
         ng_hidden<F, M::DINP / 4>(a1, cov.w1, M::P1, cov.b1, hs, e, g);
         ng_wave_sync();
 #pragma unroll
         for (int kk = 0; kk < M::DHP / 4; ++kk) a2[kk] = hs[e * M::P2 + 4 * kk + g];
-        for (int t = 0; t < ntv; ++t) {
-            const f32x4n v = ng_out_tile<F>(a2, cov, t, e, g);
+        ng_layer2<F>(a2, cov, ntv, e, g, [&](int t, const f32x4n &v) {
             const int c = 16 * t + e;
             if (c < 7 * K) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) xs[(4 * g + i) * PX + 3 * K + c] = v[i];
             }
-        }
+        });
         ng_wave_sync();
         // the surviving Gaussians of the tile, each to its final row (:160-171)
         for (int idx = lane; idx < 16 * K; idx += 64) {

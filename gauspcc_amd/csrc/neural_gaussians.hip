@@ -372,7 +372,8 @@ struct EmitArgs {
     float *xyz, *color, *opacity, *scale, *rot;
 };
 
-template <int F, bool ROWS>
+// NIT = candidates per lane in the emission = ceil(16 K / 64): a template parameter so that their attributes stay in registers
+template <int F, bool ROWS, int NIT>
 __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
 {
     using M = NGM<F>;
@@ -421,25 +422,59 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
             }
         });
         ng_wave_sync();
-        // the surviving Gaussians of the tile, each to its final row (:160-171)
-        for (int idx = lane; idx < 16 * K; idx += 64) {
-            const int r = idx / K, j = idx - r * K;
-            const int64_t i = row0 + r;
-            if (i >= a.n) continue;
-            const int64_t gi = i * K + j;
-            if (!a.keep[gi]) continue;
-            const uint32_t p = o.pos[gi];
-            const int64_t src = ROWS ? (int64_t)a.rows[i] : i;
-            const float *c3 = xs + r * PX + 3 * j, *d = xs + r * PX + 3 * K + 7 * j, *sc = o.scaling + src * 6;
-            o.opacity[p] = a.nopa[gi];
-            o.color[3 * p] = c3[0]; o.color[3 * p + 1] = c3[1]; o.color[3 * p + 2] = c3[2];
+        // the surviving Gaussians of the tile, each to its final row (:160-171).  Flags, then positions, then attributes of ALL the lane's candidates
+        // (16 K / 64 <= 4) are requested together -- three round trips per tile instead of three per candidate: the kernel's emission is bound by these
+        // dependent loads, not by its stores
+        {
+            const uint32_t *__restrict__ keepp = a.keep, *__restrict__ posp = o.pos;
+            const float *__restrict__ nopap = a.nopa, *__restrict__ scalp = o.scaling, *__restrict__ anchp = a.anchor, *__restrict__ offp = o.offsets;
+            float *__restrict__ oop = o.opacity, *__restrict__ ocol = o.color, *__restrict__ osc = o.scale, *__restrict__ orot = o.rot, *__restrict__ oxyz = o.xyz;
+            bool kp[NIT];
+            int64_t gis[NIT], srcs[NIT];
+            int rr[NIT], jj[NIT];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) o.scale[3 * p + k] = sc[3 + k] * (1.0f / (1.0f + expf(-d[k])));
-            const float q0 = d[3], q1 = d[4], q2 = d[5], q3 = d[6];
-            const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
-            o.rot[4 * p] = q0 / nrm; o.rot[4 * p + 1] = q1 / nrm; o.rot[4 * p + 2] = q2 / nrm; o.rot[4 * p + 3] = q3 / nrm;
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = lane + 64 * it;
+                rr[it] = idx / K; jj[it] = idx - rr[it] * K;
+                gis[it] = (row0 + rr[it]) * K + jj[it];
+                kp[it] = idx < 16 * K && row0 + rr[it] < a.n;
+            }
+            uint32_t kf[NIT];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) o.xyz[3 * p + k] = a.anchor[3 * src + k] + o.offsets[(src * K + j) * 3 + k] * sc[k];
+            for (int it = 0; it < NIT; ++it) kf[it] = kp[it] ? keepp[gis[it]] : 0u;
+            uint32_t pp[NIT];
+            float no[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                kp[it] = kf[it] != 0u;
+                pp[it] = kp[it] ? posp[gis[it]] : 0u;
+                no[it] = kp[it] ? nopap[gis[it]] : 0.0f;
+                srcs[it] = ROWS ? (kp[it] ? (int64_t)a.rows[row0 + rr[it]] : 0) : row0 + rr[it];
+            }
+            float sc[NIT][6], an[NIT][3], of[NIT][3];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (kp[it]) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) sc[it][k] = scalp[srcs[it] * 6 + k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { an[it][k] = anchp[3 * srcs[it] + k]; of[it][k] = offp[(srcs[it] * K + jj[it]) * 3 + k]; }
+                }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (kp[it]) {
+                    const uint32_t p = pp[it];
+                    const float *c3 = xs + rr[it] * PX + 3 * jj[it], *d = xs + rr[it] * PX + 3 * K + 7 * jj[it];
+                    oop[p] = no[it];
+                    ocol[3 * p] = c3[0]; ocol[3 * p + 1] = c3[1]; ocol[3 * p + 2] = c3[2];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) osc[3 * p + k] = sc[it][3 + k] * (1.0f / (1.0f + expf(-d[k])));
+                    const float q0 = d[3], q1 = d[4], q2 = d[5], q3 = d[6];
+                    const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
+                    orot[4 * p] = q0 / nrm; orot[4 * p + 1] = q1 / nrm; orot[4 * p + 2] = q2 / nrm; orot[4 * p + 3] = q3 / nrm;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) oxyz[3 * p + k] = an[it][k] + of[it][k] * sc[it][k];
+                }
         }
         ng_wave_sync();
     }
@@ -484,20 +519,31 @@ static int ng_mfma_opacity(gpcc_ctx *ctx, const NGArgs &a, int waves, hipStream_
     return GPCC_OK;
 }
 
-template <int F, bool ROWS>
-static int ng_mfma_emit(gpcc_ctx *ctx, const NGArgs &a, EmitArgs o, int waves, hipStream_t st)
+template <int F, bool ROWS, int NIT>
+static int ng_mfma_emit_n(gpcc_ctx *ctx, const NGArgs &a, EmitArgs o, int waves, hipStream_t st)
 {
     const size_t lds = ng_lds_emit<F>(a.bank.w1 != nullptr, a.K, waves);
     o.px = ng_emit_pitch<F>(a.K);
     static PerDeviceOnce attr;
     GP_TRY(attr.run(ctx->device, [&]() -> int {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_emit<F, ROWS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_ng_emit<F, ROWS, NIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)NG_LDS_MAX));
         return GPCC_OK;
     }));
     const unsigned grid = (unsigned)std::min<int64_t>(256, cdiv(cdiv(a.n, 16), waves));
-    k_ng_emit<F, ROWS><<<grid, 64 * waves, lds, st>>>(a, o);
+    k_ng_emit<F, ROWS, NIT><<<grid, 64 * waves, lds, st>>>(a, o);
     LAUNCH_CHECK();
     return GPCC_OK;
+}
+
+template <int F, bool ROWS>
+static int ng_mfma_emit(gpcc_ctx *ctx, const NGArgs &a, const EmitArgs &o, int waves, hipStream_t st)
+{
+    switch ((16 * a.K + 63) / 64) {
+    case 1: return ng_mfma_emit_n<F, ROWS, 1>(ctx, a, o, waves, st);
+    case 2: return ng_mfma_emit_n<F, ROWS, 2>(ctx, a, o, waves, st);
+    case 3: return ng_mfma_emit_n<F, ROWS, 3>(ctx, a, o, waves, st);
+    default: return ng_mfma_emit_n<F, ROWS, 4>(ctx, a, o, waves, st);
+    }
 }
 
 }  // namespace

@@ -3,6 +3,6 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && rocprofv3 --kernel-trace
 import csv,sys,json
 rows=list(csv.DictReader(open('$f')))
 rows.sort(key=lambda r:-float(r['TotalDurationNs']))
-for r in rows[:28]: print('%-60s %6s %12.1f %8.2f'%(r['Name'][:60], r['Calls'], float(r['AverageNs']), float(r['Percentage'])))
+for r in rows[:28] + [r for r in rows[28:] if 'k_ng' in r['Name'] or 'k_render' in r['Name']]: print('%-60s %6s %12.1f %8.2f'%(r['Name'][:60], r['Calls'], float(r['AverageNs']), float(r['Percentage'])))
 d=json.load(open('gpurun_out/ng_side.json')); print(d.get('rd_loop'))
 "; rm -rf gpurun_out/ts

@@ -338,6 +338,14 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
     const int64_t ntiles = (a.n + 15) / 16;
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
+        // the grid masks of this lane's four outputs: requested now, used after the MLP (their round trip is off the tile's chain)
+        float mk[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + 4 * g + i;
+            mk[i] = 0.0f;
+            if (e < a.K && row < a.n) mk[i] = a.mask[(ROWS ? (int64_t)a.rows[row] : row) * a.K + e];
+        }
         ng_build_x<F, ROWS>(a, row0, xs, PX, hs, bank, bk, lane);
         float a1[M::DINP / 4];
 #pragma unroll
@@ -354,8 +362,7 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
             for (int i = 0; i < 4; ++i) {
                 const int64_t row = row0 + 4 * g + i;
                 if (row < a.n) {
-                    const int64_t src = ROWS ? (int64_t)a.rows[row] : row;
-                    const float o = tanhf(v[i]) * a.mask[src * a.K + e];
+                    const float o = tanhf(v[i]) * mk[i];
                     a.nopa[row * a.K + e] = o;
                     a.keep[row * a.K + e] = o > 0.0f ? 1u : 0u;
                 }

@@ -27,7 +27,7 @@ struct NGArgs {
     const int32_t *rows;                                      // anchors of the model this call is about (visible_mask as an index list), or null: rows 0 .. n - 1
     int64_t n;
     int K;
-    float cam[3];
+    const float *cam;                // camera centre (3), device memory: read by the kernels, no copy to the host in front of the call
     Mlp bank, opacity, cov, color;   // bank.w1 == nullptr: no feature bank
     float *nopa;                     // (n K)     neural opacity * mask
     float *dense;                    // (n K, 10) colour (3) | scale_rot (7)
@@ -579,10 +579,7 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int 
     TAKE(nopa, float, nk); TAKE(keep, uint32_t, nk); TAKE(pos, uint32_t, nk + 1);
     NGArgs a = {};
     a.anchor = anchor; a.feat = feat; a.offsets = offsets; a.scaling = scaling; a.mask = mask; a.rows = rows; a.n = n; a.K = n_offsets;
-    float cam[3];
-    HIP_TRY(hipMemcpyAsync(cam, cam_center, 12, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    a.cam[0] = cam[0]; a.cam[1] = cam[1]; a.cam[2] = cam[2];
+    a.cam = cam_center;
     a.bank = Mlp{mlp[0], mlp[1], mlp[2], mlp[3]};
     a.opacity = Mlp{mlp[4], mlp[5], mlp[6], mlp[7]};
     a.cov = Mlp{mlp[8], mlp[9], mlp[10], mlp[11]};

@@ -22,7 +22,7 @@ constexpr int TB = 256;
 constexpr int BX = 16, BY = 16;
 
 struct Cam {
-    float view[16], proj[16];
+    const float *view, *proj;   // the caller's 4 x 4 matrices, read where they lie (device memory): no blocking copies to the host in front of a frame
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int W, H, gx, gy;
 };
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restric
     if (tiles_touched) tiles_touched[i] = 0;
     if (rect_area) rect_area[i] = 0;
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
-    const float *V = cam.view, *M = cam.proj;
+    const float *__restrict__ V = cam.view, *__restrict__ M = cam.proj;   // wave-uniform addresses: scalar / broadcast loads
     // transformPoint4x3 / 4x4 with the row-vector (transposed) matrices the Python side passes
     const float tx0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
     const float ty0 = V[1] * px + V[5] * py + V[9] * pz + V[13];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(TB) void k_tile_order_keys(const uint2 *__restrict_
 
 __global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges, const uint32_t *__restrict__ tile_order, const uint32_t *__restrict__ point_list, int W, int H, int gx,
                                                const float2 *__restrict__ xy, const float *__restrict__ colors, const float4 *__restrict__ conic_op,
-                                               float bg0, float bg1, float bg2, float *__restrict__ out)
+                                               const float *__restrict__ bg, float *__restrict__ out)
 {
     __shared__ float4 s_a[RT];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[RT];   // conic.z, opacity, r, g
@@ -321,6 +321,7 @@ __global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges,
         }
     }
     const size_t plane = (size_t)W * H;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     if (in0) {
         const size_t pix = (size_t)py0 * W + pxi;
         out[pix] = A0 + T0 * bg0; out[plane + pix] = A1 + T0 * bg1; out[2 * plane + pix] = A2 + T0 * bg2;
@@ -333,8 +334,7 @@ __global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges,
 
 int make_cam(Cam *cam, int W, int H, const float *view_dev, const float *proj_dev, float tan_fovx, float tan_fovy, float scale_modifier)
 {
-    HIP_TRY(hipMemcpy(cam->view, view_dev, 64, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(cam->proj, proj_dev, 64, hipMemcpyDeviceToHost));
+    cam->view = view_dev; cam->proj = proj_dev;
     cam->tan_fovx = tan_fovx; cam->tan_fovy = tan_fovy;
     cam->focal_x = (float)W / (2.0f * tan_fovx); cam->focal_y = (float)H / (2.0f * tan_fovy);
     cam->scale_modifier = scale_modifier;
@@ -354,7 +354,6 @@ extern "C" int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const floa
     if (P <= 0) return GPCC_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(st));
     Cam cam;
     GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
     k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
@@ -374,11 +373,8 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
     if (W <= 0 || H <= 0) return fail(GPCC_ERR_ARG, "bad image size");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(hipStreamSynchronize(st));
     Cam cam;
     GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
-    float bg[3];
-    HIP_TRY(hipMemcpy(bg, background, 12, hipMemcpyDeviceToHost));
     const int ntiles = cam.gx * cam.gy;
     size_t want = (size_t)std::max(P, 1) * 100 + (size_t)ntiles * 8 + ((size_t)8 << 20);
     uint32_t L = 0;
@@ -453,7 +449,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, ntiles, 20));
             tile_order = v0;
         }
-        k_render<<<(unsigned)ntiles, RT, 0, st>>>(ranges, tile_order, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, bg[0], bg[1], bg[2], out_color);
+        k_render<<<(unsigned)ntiles, RT, 0, st>>>(ranges, tile_order, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, background, out_color);
         LAUNCH_CHECK();
         HIP_TRY(hipStreamSynchronize(st));
         return device_error_check(ctx);

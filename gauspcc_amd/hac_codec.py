@@ -142,8 +142,9 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
         mask = _mask.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)        # [N*K*3]
         Q = c["Q_offsets"].reshape(-1)
         offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
-        kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()           # masked elements up to each anchor
-        off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+        # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
+        kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
+        off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
         bit_offsets_list = encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask],
                                                    off_bounds, names('offsets'))
     torch.cuda.synchronize(); t_codec += time.time() - t0
@@ -205,8 +206,9 @@ def conduct_decoding(self, pre_path_name, patched_infos, ckpt_path=None):
     names = lambda stem: [os.path.join(pre_path_name, f'{stem}.b').replace('.b', f'_{s}.b') for s in range(steps)]
     bounds = [min(s * max_batch, N) for s in range(steps + 1)]
     mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
-    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0).cpu().tolist()
-    off_bounds = [0] + [int(kept[b - 1]) for b in bounds[1:]]
+    # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
+    kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
+    off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
     mo = c["mean_offsets"].reshape(-1)
     # the three attributes in ONE device call: their chunks side by side (encodings_cuda.decoder_gaussian_slices_multi); the reference decodes
     # slice after slice, attribute after attribute (:1304-1331)

@@ -24,6 +24,14 @@ import torch
 from . import _lib, runtime
 
 
+
+def _owned(ptr, count, dtype):
+    """count elements at the library's (pinned, reused) output buffer as an array the caller owns: ONE copy (string_at + frombuffer + copy made two)."""
+    if not count:
+        return np.empty(0, dtype=dtype)
+    nbytes = int(count) * np.dtype(dtype).itemsize
+    return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr.value), dtype=dtype).copy()
+
 def _chk(t, name):
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA tensor")      # CHECK_CUDA  (include/utils.h:3)
@@ -62,8 +70,7 @@ def arithmetic_encode(sym, cdf, chunk_size, N, Lp):
     pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
     _lib.check(_lib.lib().gsac_encode(runtime.context(sym.device), sym.data_ptr(), cdf.data_ptr(), int(chunk_size), int(N), int(Lp),
                                       C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(sym.device)))
-    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
-    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    out, cnt = _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
     return torch.from_numpy(out).to(sym.device), torch.from_numpy(cnt).to(sym.device)
 
 
@@ -91,8 +98,7 @@ def encode_gaussian(x, mean, scale, Q, chunk_size):
     _lib.check(_lib.lib().gsac_encode_gaussian(runtime.context(x.device), x32.data_ptr(), m32.data_ptr(), s32.data_ptr(),
                                                q32.data_ptr(), n, int(chunk_size), C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb),
                                                C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
-    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
-    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    out, cnt = _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
     return mn.value, mx.value, torch.from_numpy(out).to(x.device), torch.from_numpy(cnt).to(x.device)
 
 
@@ -124,8 +130,7 @@ def encode_gaussian_slices(x, mean, scale, Q, slice_start, chunk_size):
     _lib.check(_lib.lib().gsac_encode_gaussian_slices(runtime.context(x.device), x32.data_ptr(), m32.data_ptr(), s32.data_ptr(),
                                                       q32.data_ptr(), ss.ctypes.data, ns, int(chunk_size), mins.ctypes.data, maxs.ctypes.data,
                                                       C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(x.device)))
-    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
-    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    out, cnt = _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
     return mins, maxs, out, cnt
 
 
@@ -184,8 +189,7 @@ def encode_gaussian_mixed(x, mean_list, scale_list, prob_list, Q, chunk_size):
     _lib.check(_lib.lib().gsac_encode_gaussian_mixed(runtime.context(x.device), x32.data_ptr(), pm, ps, pp, k, q32.data_ptr(), n, int(chunk_size),
                                                      C.byref(mn), C.byref(mx), C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc),
                                                      runtime.stream_ptr(x.device)))
-    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
-    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    out, cnt = _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
     return mn.value, mx.value, torch.from_numpy(out).to(x.device), torch.from_numpy(cnt).to(x.device)
 
 
@@ -216,8 +220,7 @@ def encode_gaussian_mixed_slices(x, mean_list, scale_list, prob_list, Q, slice_s
     _lib.check(_lib.lib().gsac_encode_gaussian_mixed_slices(runtime.context(x.device), x32.data_ptr(), pm, ps, pp, k, q32.data_ptr(), ss.ctypes.data, ns,
                                                             int(chunk_size), mins.ctypes.data, maxs.ctypes.data, C.byref(pb), C.byref(nb), C.byref(pc),
                                                             C.byref(nc), runtime.stream_ptr(x.device)))
-    out = np.frombuffer(C.string_at(pb, nb.value), dtype=np.uint8).copy()
-    cnt = np.frombuffer(C.string_at(pc, 4 * nc.value), dtype=np.int32).copy()
+    out, cnt = _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
     return mins, maxs, out, cnt
 
 

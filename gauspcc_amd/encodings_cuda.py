@@ -28,12 +28,10 @@ def _write_one(job):
         fout.write(job[1])
 
 
-def _write_files(jobs):
-    """The per-slice `.b` files of an attribute (334 per million anchors and attribute; HAC++: 2 338 files per million anchors): written by
-    libgauspcc on native threads (gpcc_write_files) -- in Python every file costs ~55 us of interpreter time under the GIL, thread pool or not
-    (0.13 s of HAC++'s 0.27 s per million anchors)."""
-    if not jobs:
-        return
+_deferred = None      # the active deferred_writes context, if any
+
+
+def _write_files_now(jobs):
     import ctypes as C
     from . import _lib
     n = len(jobs)
@@ -44,14 +42,56 @@ def _write_files(jobs):
     _lib.check(_lib.lib().gpcc_write_files(paths, data, sizes, n, 8))
 
 
+def _write_files(jobs):
+    """The per-slice `.b` files of an attribute (334 per million anchors and attribute; HAC++: 2 338 files per million anchors): written by
+    libgauspcc on native threads (gpcc_write_files) -- in Python every file costs ~55 us of interpreter time under the GIL, thread pool or not
+    (0.13 s of HAC++'s 0.27 s per million anchors).  Inside a `deferred_writes()` block the call is handed to a background thread (the library call
+    releases the GIL) and the next attribute is coded while the files of this one go to disk."""
+    if not jobs:
+        return
+    if _deferred is not None:
+        _deferred.submit(jobs)
+    else:
+        _write_files_now(jobs)
+
+
 class deferred_writes:
-    """(round 4, first form: slice files handed to Python writer threads and joined at the end of the attribute loop.  With the native writer the
-    files of an attribute take a few ms; the context is kept so that callers need not change, and does nothing.)"""
+    """`with deferred_writes():` -- the slice files written inside the block are handed to background threads and are all on disk when the block ends
+    (an error of any of them is raised there).  On a real file system the 1 002 (HAC) / 2 343 (HAC++) files of a million anchors take 0.1-0.2 s, as long
+    as the coding itself; the reference writes each slice's file inside its loop."""
 
     def __enter__(self):
+        global _deferred
+        import queue
+        import threading
+        self._q, self._errors, self._outer = queue.Queue(), [], _deferred
+        # ONE worker: attributes' files go out one attribute after the other (eight native threads each, as before) -- several attributes at once
+        # contend for the directory (measured on the GPU box's overlay file system: 2 343 files 0.25 -> 0.9 s)
+        self._worker = threading.Thread(target=self._run, daemon=True)
+        self._worker.start()
+        _deferred = self
         return self
 
+    def _run(self):
+        while True:
+            jobs = self._q.get()
+            if jobs is None:
+                return
+            try:
+                _write_files_now(jobs)
+            except BaseException as e:      # noqa: BLE001 -- re-raised by __exit__ on the caller's thread
+                self._errors.append(e)
+
+    def submit(self, jobs):
+        self._q.put(jobs)
+
     def __exit__(self, et, ev, tb):
+        global _deferred
+        _deferred = self._outer
+        self._q.put(None)
+        self._worker.join()
+        if self._errors and et is None:
+            raise self._errors[0]
         return False
 
 

@@ -146,7 +146,10 @@ def test_conduct_encoding_decoding_roundtrip(torch_cuda, tmp_path):
     def close(got, want, Q):
         d = (got - want).abs()
         bad = d > 2e-5 * (1 + want.abs())
-        assert float(bad.float().mean()) <= 1e-4, float(bad.float().mean())
+        # elements that sit on a rounding boundary of x / Q may fall on either side when the step Q comes out of a different GEMM (here torch's, in the
+        # codec the matrix-pipe kernel with the oracle's chain; torch's own result is not reproducible to the ulp from run to run): a handful per slice of
+        # 18 000 -- 1 in 50 runs exceeded 1e-4 with three of them -- and each off by exactly one step (next line)
+        assert float(bad.float().mean()) <= 5e-4, float(bad.float().mean())
         assert bool((d[bad] <= Q[bad] * 1.001).all())
 
     fd, K = enc.feat_dim, enc.n_offsets

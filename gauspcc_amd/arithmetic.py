@@ -74,6 +74,28 @@ def arithmetic_encode(sym, cdf, chunk_size, N, Lp):
     return torch.from_numpy(out).to(sym.device), torch.from_numpy(cnt).to(sym.device)
 
 
+def encode_const_row(sym, row, chunk_size):
+    """arithmetic_encode with the SAME CDF row for every symbol (row: 2 .. 4 floats): byte-identical to arithmetic_encode on the table that repeats the
+    row -- without the table (gsac_encode_const).  Returns (bytes, cnt) as numpy arrays."""
+    _chk(sym, "sym")
+    sym = sym.to(torch.int16).contiguous()
+    r = (C.c_float * len(row))(*[float(v) for v in row])
+    pb, nb, pc, nc = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().gsac_encode_const(runtime.context(sym.device), sym.data_ptr(), C.cast(r, C.c_void_p), int(chunk_size), int(sym.numel()), len(row),
+                                            C.byref(pb), C.byref(nb), C.byref(pc), C.byref(nc), runtime.stream_ptr(sym.device)))
+    return _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
+
+
+def decode_const_row(row, data, cnt, chunk_size, N, device):
+    """Inverse of encode_const_row (data, cnt: numpy arrays); int16 symbols on `device`."""
+    data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    r = (C.c_float * len(row))(*[float(v) for v in row])
+    out = torch.zeros(int(N), dtype=torch.int16, device=device)
+    _lib.check(_lib.lib().gsac_decode_const(runtime.context(out.device), C.cast(r, C.c_void_p), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
+                                            int(N), len(row), out.data_ptr(), runtime.stream_ptr(out.device)))
+    return out
+
+
 def arithmetic_decode(cdf, in_cache_all, in_cnt_all, chunk_size, N, Lp):
     _chk(cdf, "cdf")
     cdf = cdf.to(torch.float32).contiguous()

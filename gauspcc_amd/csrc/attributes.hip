@@ -51,11 +51,17 @@ struct GaussRow { float mean, scale, q; int min_value; };
 constexpr int MIX_MAX = 4;
 struct MixTable { const float *mean[MIX_MAX], *scale[MIX_MAX], *prob[MIX_MAX]; const float *q; int k, min_value; };
 struct MixRow { float mean[MIX_MAX], scale[MIX_MAX], prob[MIX_MAX]; float q; int k, min_value; };
+// one CDF row for every symbol: the Bernoulli coder of the hash tables and masks (encodings_cuda.py: encoder / decoder build an (n, 3) table whose rows
+// are all (0, 1 - p, 1) -- 120 MB written and read back for the ten million mask bits of a million anchors)
+struct ConstTable { float c[4]; };
+struct ConstRow { float c0, c1, c2, c3; };
 template <typename CT> struct RowOf { typedef const CT *type; };
+template <> struct RowOf<ConstTable> { typedef ConstRow type; };
 template <> struct RowOf<GaussTable> { typedef GaussRow type; };
 template <> struct RowOf<MixTable> { typedef MixRow type; };
 __device__ __forceinline__ const float *row_of(const float *t, int64_t idx, int lp) { return t + idx * lp; }
 __device__ __forceinline__ const uint16_t *row_of(const uint16_t *t, int64_t idx, int lp) { return t + idx * lp; }
+__device__ __forceinline__ ConstRow row_of(const ConstTable &t, int64_t, int) { return ConstRow{t.c[0], t.c[1], t.c[2], t.c[3]}; }
 __device__ __forceinline__ GaussRow row_of(const GaussTable &t, int64_t idx, int) { return GaussRow{t.mean[idx], t.scale[idx], t.q[idx], t.min_value}; }
 __device__ __forceinline__ MixRow row_of(const MixTable &t, int64_t idx, int)
 {
@@ -89,6 +95,11 @@ __global__ __launch_bounds__(TB) void k_mixture_cdf(MixTable t, int64_t n, int l
 // uint16 rows (torchac's *_int16_normalized_cdf) are used as they are
 __device__ __forceinline__ uint32_t cdf_int(const float *row, int m, float scale) { return (uint32_t)((int)__builtin_rintf(row[m] * scale) + m); }
 __device__ __forceinline__ uint32_t cdf_int(const uint16_t *row, int m, float) { return row[m]; }
+__device__ __forceinline__ uint32_t cdf_int(const ConstRow &row, int m, float scale)
+{
+    const float v = m == 0 ? row.c0 : m == 1 ? row.c1 : m == 2 ? row.c2 : row.c3;
+    return (uint32_t)((int)__builtin_rintf(v * scale) + m);
+}
 __device__ __forceinline__ uint32_t cdf_int(const GaussRow &row, int m, float scale)
 {
     return (uint32_t)((int)__builtin_rintf(gaussian_cdf_entry(row.mean, row.scale, row.q, row.min_value, m) * scale) + m);
@@ -516,6 +527,17 @@ extern "C" int gsac_encode(gpcc_ctx *ctx, const int16_t *sym, const float *cdf, 
     return gsac_encode_impl<const float *>(ctx, sym, cdf, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
 }
 
+// the same with ONE row for all symbols (lp <= 4 entries, e.g. (0, 1 - p, 1) for a Bernoulli source): byte-identical to gsac_encode on the table that
+// repeats the row n times
+extern "C" int gsac_encode_const(gpcc_ctx *ctx, const int16_t *sym, const float *row_host, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
+                                 int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
+{
+    if (!row_host || lp < 2 || lp > 4) return fail(GPCC_ERR_ARG, "constant-row coder: 2 <= lp <= 4");
+    ConstTable t = {};
+    for (int i = 0; i < lp; ++i) t.c[i] = row_host[i];
+    return gsac_encode_impl<ConstTable>(ctx, sym, t, chunk_size, n, lp, bytes_out, nbytes_out, cnt_out, nchunks_out, stream);
+}
+
 extern "C" int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym, const uint16_t *cdf, int chunk_size, int64_t n, int lp, const uint8_t **bytes_out,
                                int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream)
 {
@@ -563,6 +585,15 @@ extern "C" int gsac_decode(gpcc_ctx *ctx, const float *cdf, const uint8_t *bytes
 {
     if (!cdf) return fail(GPCC_ERR_ARG, "null argument");
     return gsac_decode_impl<const float *>(ctx, cdf, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
+}
+
+extern "C" int gsac_decode_const(gpcc_ctx *ctx, const float *row_host, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,
+                                 int16_t *sym_out, void *stream)
+{
+    if (!row_host || lp < 2 || lp > 4) return fail(GPCC_ERR_ARG, "constant-row coder: 2 <= lp <= 4");
+    ConstTable t = {};
+    for (int i = 0; i < lp; ++i) t.c[i] = row_host[i];
+    return gsac_decode_impl<ConstTable>(ctx, t, bytes, nbytes, cnt, chunk_size, n, lp, sym_out, stream);
 }
 
 extern "C" int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size, int64_t n, int lp,

@@ -131,23 +131,17 @@ def decoder_gaussian(mean, scale, Q, file_name='tmp.b'):
     return arithmetic.decode_gaussian(mean.contiguous(), scale.contiguous(), Q.contiguous(), min_value, max_value, data, cnt, chunk_size_cuda)
 
 
-def _bernoulli_cdf(p1: torch.Tensor, n: int, device):
-    p = torch.zeros(size=[n], dtype=torch.float32, device=device)
-    p[...] = p1
-    p_u = 1 - p.unsqueeze(-1)
-    return torch.cat([torch.zeros_like(p_u), p_u, torch.ones_like(p_u)], dim=-1).contiguous()
-
-
 def encoder(x, file_name='tmp.b'):
+    """Bernoulli coder of the hash tables and the masks (HAC/utils/encodings_cuda.py:228-245): every symbol has the row (0, 1 - p, 1), so no (n, 3)
+    table is built (120 MB for a million anchors' mask bits) and the payload stays on the host -- the same bytes in the same file."""
     assert file_name[-2:] == '.b'
     x = x.detach().view(-1)
     prob_1 = x.sum() / x.numel()
-    output_cdf = _bernoulli_cdf(prob_1, x.numel(), x.device)
+    p_u = float((1 - prob_1.to(torch.float32)).item())             # the table's middle entry, as the reference computes it (float32)
     sym = torch.floor(x).to(torch.int16)
-    byte_stream_torch, cnt_torch = arithmetic.arithmetic_encode(sym.contiguous(), output_cdf, chunk_size_cuda,
-                                                                int(output_cdf.shape[0]), int(output_cdf.shape[1]))
-    cnt_bytes = cnt_torch.cpu().numpy().tobytes()
-    byte_stream_bytes = byte_stream_torch.cpu().numpy().tobytes()
+    data, cnt = arithmetic.encode_const_row(sym.contiguous(), (0.0, p_u, 1.0), chunk_size_cuda)
+    cnt_bytes = cnt.tobytes()
+    byte_stream_bytes = data.tobytes()
     with open(file_name, 'wb') as fout:
         fout.write(prob_1.to(torch.float32).cpu().numpy().tobytes())
         fout.write(np.array([len(cnt_bytes)]).astype(np.int32).tobytes())
@@ -161,11 +155,10 @@ def decoder(N_len, file_name='tmp.b', device='cuda'):
     with open(file_name, 'rb') as fin:
         prob_1 = torch.tensor(np.frombuffer(fin.read(4), dtype=np.float32).copy())
         len_cnt_bytes = np.frombuffer(fin.read(4), dtype=np.int32)[0]
-        cnt_torch = torch.tensor(np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32).copy(), device=device)
-        byte_stream_torch = torch.tensor(np.frombuffer(fin.read(), dtype=np.uint8).copy(), device=device)
-    output_cdf = _bernoulli_cdf(prob_1.to(device), N_len, device)
-    return arithmetic.arithmetic_decode(output_cdf, byte_stream_torch, cnt_torch, chunk_size_cuda,
-                                        int(output_cdf.shape[0]), int(output_cdf.shape[1]))
+        cnt = np.frombuffer(fin.read(len_cnt_bytes), dtype=np.int32)
+        data = np.frombuffer(fin.read(), dtype=np.uint8)
+    p_u = float((1 - prob_1.to(torch.float32)).item())
+    return arithmetic.decode_const_row((0.0, p_u, 1.0), data, cnt, chunk_size_cuda, N_len, torch.device(device))
 
 
 # ---------------------------------------------------------------- all slices of an attribute at once

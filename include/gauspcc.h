@@ -286,6 +286,14 @@ GPCC_API int gsac_encode_u16(gpcc_ctx *ctx, const int16_t *sym_dev, const uint16
 GPCC_API int gsac_decode_u16(gpcc_ctx *ctx, const uint16_t *cdf_dev, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
                              int64_t n, int lp, int16_t *sym_out_dev, void *stream);
 
+/* The same coder with ONE row for all n symbols (lp = 2 .. 4 entries, host floats): the Bernoulli coder of HAC's hash tables and masks
+ * (HAC/utils/encodings_cuda.py:228-262 builds an (n, 3) table whose rows are all (0, 1 - p, 1) -- 120 MB for the ten million mask bits of a
+ * million anchors).  Byte-identical to gsac_encode / gsac_decode on that table. */
+GPCC_API int gsac_encode_const(gpcc_ctx *ctx, const int16_t *sym_dev, const float *row_host, int chunk_size, int64_t n, int lp,
+                               const uint8_t **bytes_out, int64_t *nbytes_out, const int32_t **cnt_out, int64_t *nchunks_out, void *stream);
+GPCC_API int gsac_decode_const(gpcc_ctx *ctx, const float *row_host, const uint8_t *bytes, int64_t nbytes, const int32_t *cnt, int chunk_size,
+                               int64_t n, int lp, int16_t *sym_out_dev, void *stream);
+
 /* torchac's coder itself, on HOST arrays and one host thread -- the drop-in for torchac.encode_int16_normalized_cdf /
  * decode_int16_normalized_cdf (torchac 0.9.3; call sites TC-GS/utils/encodings.py:84-176, CAT-3DGS/utils/encodings.py:39-175,
  * HAC/utils/pcc_utils.py:174-177): ONE stream for the whole tensor, byte-identical to torchac's.  A single stream is a single

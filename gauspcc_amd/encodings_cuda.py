@@ -28,7 +28,9 @@ def _write_one(job):
         fout.write(job[1])
 
 
-_deferred = None      # the active deferred_writes context, if any
+import threading as _threading
+
+_tls = _threading.local()      # .deferred: the calling thread's active deferred_writes context, if any (per thread: contexts of two threads must not see each other)
 
 
 def _write_files_now(jobs):
@@ -49,8 +51,9 @@ def _write_files(jobs):
     releases the GIL) and the next attribute is coded while the files of this one go to disk."""
     if not jobs:
         return
-    if _deferred is not None:
-        _deferred.submit(jobs)
+    d = getattr(_tls, 'deferred', None)
+    if d is not None:
+        d.submit(jobs)
     else:
         _write_files_now(jobs)
 
@@ -61,15 +64,14 @@ class deferred_writes:
     as the coding itself; the reference writes each slice's file inside its loop."""
 
     def __enter__(self):
-        global _deferred
         import queue
         import threading
-        self._q, self._errors, self._outer = queue.Queue(), [], _deferred
+        self._q, self._errors, self._outer = queue.Queue(), [], getattr(_tls, 'deferred', None)
         # ONE worker: attributes' files go out one attribute after the other (eight native threads each, as before) -- several attributes at once
         # contend for the directory (measured on the GPU box's overlay file system: 2 343 files 0.25 -> 0.9 s)
         self._worker = threading.Thread(target=self._run, daemon=True)
         self._worker.start()
-        _deferred = self
+        _tls.deferred = self
         return self
 
     def _run(self):
@@ -86,8 +88,7 @@ class deferred_writes:
         self._q.put(jobs)
 
     def __exit__(self, et, ev, tb):
-        global _deferred
-        _deferred = self._outer
+        _tls.deferred = self._outer
         self._q.put(None)
         self._worker.join()
         if self._errors and et is None:

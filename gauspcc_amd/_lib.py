@@ -46,7 +46,7 @@ EXPORTS = [
     "gpcc_model_create", "gpcc_model_destroy", "gpcc_encode", "gpcc_decode", "gpcc_decode_to", "gpcc_encode_batch", "gpcc_decode_batch", "gpcc_sort_zyx",
     "gpcc_build_octree", "gpcc_conv3d", "gpcc_head_cdf", "gpcc_rc_encode", "gpcc_rc_decode", "gpcc_memcpy_d2d",
     "gpcc_profile_enable", "gpcc_profile_get", "gpcc_profile_stages", "gpcc_debug_trace_enable", "gpcc_debug_trace_get", "gpcc_debug_capture", "gpcc_debug_capture_get", "gpcc_debug_exclusive_scan", "gpcc_debug_launches", "gpcc_device_error_check",
-    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_encode_const", "gsac_decode_const", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_host_encode_f32", "gsac_host_decode_f32", "gpcc_write_files", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gsac_encode_gaussian_mixed_slices", "gsac_decode_gaussian_mixed_slices", "gshac_mlp2", "gshac_mlp2_act", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
+    "gsac_calculate_cdf", "gsac_encode", "gsac_decode", "gsac_encode_u16", "gsac_decode_u16", "gsac_encode_const", "gsac_decode_const", "gsac_host_encode_u16", "gsac_host_decode_u16", "gsac_host_encode_f32", "gsac_host_decode_f32", "gpcc_write_files", "gpcc_read_files", "gsac_encode_gaussian", "gsac_decode_gaussian", "gsac_encode_gaussian_mixed", "gsac_decode_gaussian_mixed", "gsac_calculate_cdf_mixed", "gsac_encode_gaussian_slices", "gsac_decode_gaussian_slices", "gsac_encode_gaussian_mixed_slices", "gsac_decode_gaussian_mixed_slices", "gshac_mlp2", "gshac_mlp2_act", "gsge_forward", "gsr_visible_filter", "gsr_forward", "gsnn_generate",
 ]
 
 
@@ -112,6 +112,7 @@ def lib():
     L.gsac_host_encode_f32.argtypes = L.gsac_host_encode_u16.argtypes
     L.gsac_host_decode_f32.argtypes = L.gsac_host_decode_u16.argtypes
     L.gpcc_write_files.argtypes = [vp, vp, vp, i32, i32]
+    L.gpcc_read_files.argtypes = [vp, i32, i32, C.POINTER(vp), vp]
     fp = C.POINTER(C.c_float)
     L.gsac_encode_gaussian.argtypes = [vp, vp, vp, vp, vp, i64, i32, fp, fp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), vp]
     L.gsac_decode_gaussian.argtypes = [vp, vp, vp, vp, i64, C.c_float, C.c_float, vp, i64, vp, i32, vp, vp]

@@ -218,3 +218,52 @@ extern "C" int gpcc_write_files(const char *const *paths, const uint8_t *const *
     if (bad.load() >= 0) return gpcc::fail(GPCC_ERR_ARG, "cannot write %s", paths[bad.load()] ? paths[bad.load()] : "(null path)");
     return GPCC_OK;
 }
+
+// The read side: n whole files into one blob (offsets[i] .. offsets[i + 1] = file i), read by native threads.  The 1 002 / 2 343 slice files of a
+// million anchors cost the decoders 14 / 27 ms of interpreter time (open + five reads + frombuffer per file under the GIL).  The blob belongs to the
+// calling thread and stays valid until its next gpcc_read_files call.
+extern "C" int gpcc_read_files(const char *const *paths, int n, int threads, const uint8_t **blob_out, int64_t *offsets_out)
+{
+    if (n < 0 || !blob_out || !offsets_out || (n > 0 && !paths)) return gpcc::fail(GPCC_ERR_ARG, "bad argument");
+    if (threads <= 0) threads = 8;
+    threads = threads < n ? threads : (n > 0 ? n : 1);
+    std::vector<std::vector<uint8_t>> files((size_t)n);
+    std::atomic<int> next{0}, bad{-1};
+    auto work = [&]() {
+        for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= n) return;
+            bool ok = paths[i] != nullptr;
+            if (ok) {
+                FILE *f = fopen(paths[i], "rb");
+                ok = f != nullptr;
+                if (f) {
+                    ok = fseek(f, 0, SEEK_END) == 0;
+                    const long sz = ok ? ftell(f) : -1;
+                    ok = ok && sz >= 0 && fseek(f, 0, SEEK_SET) == 0;
+                    if (ok) {
+                        files[(size_t)i].resize((size_t)sz);
+                        ok = sz == 0 || fread(files[(size_t)i].data(), 1, (size_t)sz, f) == (size_t)sz;
+                    }
+                    fclose(f);
+                }
+            }
+            if (!ok) { int expect = -1; bad.compare_exchange_strong(expect, i); }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (bad.load() >= 0) return gpcc::fail(GPCC_ERR_ARG, "cannot read %s", paths[bad.load()] ? paths[bad.load()] : "(null path)");
+    static thread_local std::vector<uint8_t> blob;
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { offsets_out[i] = (int64_t)total; total += files[(size_t)i].size(); }
+    offsets_out[n] = (int64_t)total;
+    blob.resize(total + 16);
+    for (int i = 0; i < n; ++i)
+        if (!files[(size_t)i].empty()) memcpy(blob.data() + offsets_out[i], files[(size_t)i].data(), files[(size_t)i].size());
+    *blob_out = blob.data();
+    return GPCC_OK;
+}
+

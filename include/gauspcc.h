@@ -216,6 +216,12 @@ GPCC_API int gpcc_debug_exclusive_scan(gpcc_ctx *ctx, const uint32_t *in_dev, ui
  * path that failed in gpcc_last_error().  No context, no GPU call. */
 GPCC_API int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads);
 
+/* The read side: n whole files into one blob, file i at offsets_out[i] .. offsets_out[i + 1] (offsets_out has n + 1 entries), read by `threads`
+ * native threads (<= 0: 8).  The decoders of the attribute loops read 1 002 (HAC) / 2 343 (HAC++) slice files per million anchors: 14 / 27 ms of
+ * interpreter time in Python.  *blob_out belongs to the calling thread and is valid until its next call.  GPCC_OK or GPCC_ERR_ARG with the first
+ * file that could not be read. */
+GPCC_API int gpcc_read_files(const char *const *paths, int n, int threads, const uint8_t **blob_out, int64_t *offsets_out);
+
 /* Copy out of a context-owned device buffer (e.g. gpcc_decode's points) into caller memory,
  * ordered on `stream`; returns after the copy has completed. */
 GPCC_API int gpcc_memcpy_d2d(gpcc_ctx *ctx, void *dst_dev, const void *src_dev, int64_t nbytes, void *stream);

@@ -5,7 +5,7 @@
 //
 // Readers being hardened: the container reader of HAC/utils/pcc_utils.py:271-276 and GausPcgc/kit/op.py:40-48 (here:
 // container_parse, rc_parse_table / rc_table_get, LEB128 varints, the v0-v4 stream splitter), torchac's decode loop
-// (gsac_host_decode_{u16,f32}), gpcc_write_files, and the oracle's orc_decode / orc_stream_decode / orc_chunk_table_get.
+// (gsac_host_decode_{u16,f32}), gpcc_write_files / gpcc_read_files, and the oracle's orc_decode / orc_stream_decode / orc_chunk_table_get.
 //
 //   fuzz_host [--parse N] [--decode N] [--coder N] [--seed S]
 // Seeds are made in-process: the oracle encodes a few tiny seeded clouds with seeded random weights in every container layout
@@ -45,6 +45,7 @@ int gsac_host_decode_u16(const uint16_t *cdf, const uint8_t *bytes, int64_t nbyt
 int gsac_host_encode_f32(const int16_t *sym, const float *cdf, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out);
 int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out);
 int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads);
+int gpcc_read_files(const char *const *paths, int n, int threads, const uint8_t **blob_out, int64_t *offsets_out);
 }
 
 using namespace gpcc;
@@ -332,6 +333,14 @@ int main(int argc, char **argv)
             const char *np[1] = {nullptr};
             (void)gpcc_write_files(np, data, sz, 1, 1);
             (void)gpcc_write_files(nullptr, nullptr, nullptr, 0, 0);
+            // ... and the reader: the two files back (one empty), a missing file, null entries
+            const uint8_t *blob = nullptr;
+            int64_t offs[4] = {0, 0, 0, 0};
+            if (gpcc_read_files(paths, 2, 4, &blob, offs) != GPCC_OK || offs[1] != 5 || offs[2] != 5 || memcmp(blob, payload, 5) != 0) { fprintf(stderr, "fuzz_host: gpcc_read_files failed on good paths\n"); return 3; }
+            if (gpcc_read_files(paths, 3, 4, &blob, offs) == GPCC_OK) { fprintf(stderr, "fuzz_host: gpcc_read_files read a missing file\n"); return 3; }
+            (void)gpcc_read_files(np, 1, 1, &blob, offs);
+            (void)gpcc_read_files(nullptr, 0, 0, &blob, offs);
+            (void)gpcc_read_files(paths, 2, 2, nullptr, offs);
             remove(a.c_str()); remove(b.c_str()); rmdir(dir);
         }
     }

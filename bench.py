@@ -47,16 +47,27 @@ def launcher_selftest(args, rank, world):
 
     from gauspcc_amd.dist import SceneStats, collate_stats, max_over_ranks, scene_seed
 
+    from gauspcc_amd.dist import scene_order, scenes_for_rank
+
+    if args.selftest_fail_rank == rank:
+        raise SystemExit(3)          # a rank that dies before the rendezvous: the launcher must end the others and relay a non-zero code
     dist.init_process_group("gloo")
     cpu = torch.device("cpu")
-    mine = SceneStats(num_points=args.points, num_bytes=100 + rank, enc_s=0.01 * (rank + 1), dec_s=0.02, coded_nodes=scene_seed(1234, rank),
-                      conv_pairs=1, levels=3, status=0)
-    scenes = collate_stats([mine], cpu)
+    # the batch as main() shards it: --selftest-scenes S scenes in all (default: scenes_per_gpu x world), scene i on rank i mod world -- an S that
+    # is not a multiple of the world size leaves the last ranks one scene short (or with none)
+    total = args.selftest_scenes if args.selftest_scenes > 0 else max(1, args.scenes_per_gpu) * world
+    mine = [SceneStats(num_points=args.points, num_bytes=100 + s, enc_s=0.01 * (s + 1), dec_s=0.02, coded_nodes=scene_seed(1234, s),
+                       conv_pairs=1, levels=3, status=0) for s in scenes_for_rank(total, rank, world)]
+    scenes = collate_stats(mine, cpu)
     elapsed = max_over_ranks(1.0 + rank, cpu)
+    cpus = sorted(os.sched_getaffinity(0))
+    cpu_rows = collate_stats([SceneStats(num_points=len(cpus), num_bytes=cpus[0], coded_nodes=cpus[-1], status=rank)], cpu)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": len(scenes), "seeds": [s.coded_nodes for s in scenes],
-                          "max_elapsed": elapsed, "value": args.points * world / elapsed / 1e6}), flush=True)
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": len({s.status for s in cpu_rows}), "scenes_seen": len(scenes),
+                          "seeds": [s.coded_nodes for s in scenes], "scene_order": scene_order(total, world),
+                          "max_elapsed": elapsed, "value": args.points * len(scenes) / elapsed / 1e6,
+                          "rank_cpus": [[s.num_points, s.num_bytes, s.coded_nodes] for s in cpu_rows]}), flush=True)
     dist.destroy_process_group()
 
 
@@ -85,6 +96,8 @@ def main():
     ap.add_argument("--skip-sizes", action="store_true", help="do not run the untimed passes behind `sizes` (one scene of 10 k / 100 k / 1 M points) and `batched` "
                     "(K scenes through one chain of launches: gpcc_encode_batch / gpcc_decode_batch)")
     ap.add_argument("--selftest-launcher", action="store_true", help=argparse.SUPPRESS)   # tests/test_dist_cpu.py: the N > 1 launch path on gloo, no GPU
+    ap.add_argument("--selftest-scenes", type=int, default=0, help=argparse.SUPPRESS)     # (selftest) scenes of the batch in all; 0 = scenes_per_gpu x ranks
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)  # (selftest) this rank exits before the rendezvous
     args = ap.parse_args()
 
     import torch
@@ -100,6 +113,10 @@ def main():
         sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    # each rank keeps to its own share of the host cores (parser / writer / OpenMP threads): before anything touches the GPU
+    from gauspcc_amd.dist import pin_rank_threads
+
+    pin_rank_threads(local_rank)
     if args.selftest_launcher:
         return launcher_selftest(args, rank, world)
     if not torch.cuda.is_available():
@@ -331,6 +348,63 @@ def main():
             del xs_b
         data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
 
+    # The reference's own container layout, timed: chunk_log2 = 0 writes one torchac-compatible stream per level
+    # and stage (pcc_utils.py:174-177, layout :198-203) -- the only layout the reference can read.  Every stream is ONE dependent chain, so
+    # the coder runs on one lane per stream; untimed pass behind the timed region, `value` stays the chunked container's figure.
+    # low_rate (item 3b): the same codec at a realistic rate -- (i) the bench cloud under the `peaky` model (synth.peaky_state_dict: head biases
+    # = log of the stage symbols' empirical frequencies, i.e. the context-free entropy of the occupancy symbols; 3-6 bpp on this cloud needs
+    # spatial context, i.e. a trained checkpoint), (ii) a SOLID cloud (synth.solid_cloud) under its own peaky model: 2.5 bits per coded node,
+    # the range coder's low-entropy regime.  chunk_overhead_frac is measured (chunked bytes against chunk_log2 = 0 bytes), not extrapolated.
+    reference_layout, low_rate = None, None
+    if rank == 0 and world == 1 and not args.skip_sizes and args.chunk_log2:
+        from gauspcc_amd.synth import peaky_state_dict, solid_cloud, stage_symbol_frequencies
+
+        def timed2(fn, reps):
+            fn()
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize(device)
+            return (time.perf_counter() - t0) / reps
+
+        def sorted_rows(a):
+            return a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+
+        def layout_point(xs_l, pts_l, model_l, clog, reps):
+            blob = bytes(_encode_view(xs_l, model_l, clog, 1)[0])
+            te_l = timed2(lambda: _encode_view(xs_l, model_l, clog, 1), reps)
+            td_l = timed2(lambda: _decode_bytes(blob, model_l, device), reps)
+            out_l, _, st_l = _decode_bytes(blob, model_l, device)
+            good = bool(np.array_equal(sorted_rows(out_l.cpu().numpy()), sorted_rows(pts_l)))
+            return blob, te_l, td_l, st_l, good
+
+        n_l = args.points
+        blob0, te0, td0, st0_, ok0 = layout_point(x, pts, model, 0, 2)
+        reference_layout = {"container": "v0: one torchac-compatible stream per level and stage (pcc_utils.py:174-177, :198-203), chunk_log2 = 0",
+                            "points": n_l, "enc_ms": round(te0 * 1e3, 3), "dec_ms": round(td0 * 1e3, 3), "value": round(n_l / (te0 + td0) / 1e6, 4),
+                            "unit": "Mpoints/s", "bytes": len(blob0), "bpp": round(len(blob0) * 8 / n_l, 4), "roundtrip_bit_identical": ok0,
+                            # four symbols per coded node; a stream is one dependent chain, so the decode is bounded by what ONE lane decodes
+                            "coded_symbols": int(4 * st0_.coded_nodes),
+                            "decode_Msymbols_per_s": round(4 * st0_.coded_nodes / td0 / 1e6, 2), "encode_Msymbols_per_s": round(4 * st0_.coded_nodes / te0 / 1e6, 2)}
+        low_rate = []
+        for label, cloud_fn, sd_fn in (
+                ("bench cloud, peaky model (head biases = log stage-symbol frequencies, head weights x 0.25)", lambda: (x, pts), lambda p_: peaky_state_dict(32, k)),
+                ("solid cloud (every voxel inside 12 seeded balls), its own peaky model (conv gain 1)",
+                 lambda: (lambda c_: (torch.tensor(c_, device=device), c_))(solid_cloud(n_l)), lambda p_: peaky_state_dict(32, k, gain=1.0, freq=stage_symbol_frequencies(p_)))):
+            xs_l, pts_l = cloud_fn()
+            model_l = runtime.Model(sd_fn(pts_l), 32, k, local_rank)
+            blob4, te4, td4, st4, ok4 = layout_point(xs_l, pts_l, model_l, args.chunk_log2, 5)
+            blobv0, tev0, tdv0, _, okv0 = layout_point(xs_l, pts_l, model_l, 0, 1)
+            low_rate.append({"case": label, "points": n_l, "coded_nodes": int(st4.coded_nodes), "bpp": round(len(blob4) * 8 / n_l, 4),
+                             "bits_per_coded_node": round(len(blob4) * 8 / max(1, st4.coded_nodes), 3),
+                             "enc_ms": round(te4 * 1e3, 3), "dec_ms": round(td4 * 1e3, 3), "value": round(n_l / (te4 + td4) / 1e6, 4), "unit": "Mpoints/s",
+                             "container_bytes": len(blob4), "bytes_v0": len(blobv0), "bpp_v0": round(len(blobv0) * 8 / n_l, 4),
+                             "chunk_overhead_frac": round((len(blob4) - len(blobv0)) / len(blobv0), 5),
+                             "v0_enc_ms": round(tev0 * 1e3, 3), "v0_dec_ms": round(tdv0 * 1e3, 3), "roundtrip_bit_identical": bool(ok4 and okv0)})
+            del model_l
+        data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
+
     # correctness of what was just timed: decoded geometry == input geometry (as sets; bit-identical)
     d = dec.cpu().numpy()
     ok = d.shape == pts.shape and np.array_equal(d[np.lexsort((d[:, 0], d[:, 1], d[:, 2]))], pts[np.lexsort((pts[:, 0], pts[:, 1], pts[:, 2]))])
@@ -349,7 +423,7 @@ def main():
         # (tools/pmc_traffic.sh); the corrected per-launch figure is kept under profiles/
         traffic, traffic_source, pmc_extra = None, None, {}
         if not args.measure_traffic:
-            for name in ("r05_pmc_conv.json", "r04_pmc_conv.json", "r03_pmc_conv.json", "r02_pmc_conv.json"):
+            for name in ("r06_pmc_conv.json", "r05_pmc_conv.json", "r04_pmc_conv.json", "r03_pmc_conv.json", "r02_pmc_conv.json"):
                 try:
                     with open(os.path.join(ROOT, "profiles", name)) as f:
                         pj = json.load(f)
@@ -408,6 +482,8 @@ def main():
             "scenes_in_flight": inflight,
             "sizes": sizes,
             "batched": batched,
+            "reference_layout": reference_layout,
+            "low_rate": low_rate,
             "coded_nodes": int(allstats[0, 3]),
             "ranks": [{"bytes": int(r_[0]), "coded_nodes": int(r_[3]), "enc_ms": round(float(r_[1]) * 1e3, 3), "dec_ms": round(float(r_[2]) * 1e3, 3)} for r_ in allstats],
             "roundtrip_bit_identical": True,

@@ -86,9 +86,24 @@ def encode_const_row(sym, row, chunk_size):
     return _owned(pb, nb.value, np.uint8), _owned(pc, nc.value, np.int32)
 
 
+def _check_cnt(cnt, lengths, chunk_size, what):
+    """The chunk byte-count table of a `.b` file comes off disk, and the library reads cnt[c] for every chunk c of every stream it is
+    asked to decode (arithmetic_kernel.cu:290-303 does the same): a table shorter than ceil(n / chunk_size) entries per stream would be
+    read past its end on the host.  Checked here, at the one layer every decoder goes through, before the pointer crosses the C ABI."""
+    cs = int(chunk_size)
+    if cs <= 0:
+        raise ValueError(f"{what}: chunk_size must be positive")
+    want = sum(-(-int(n) // cs) for n in lengths)
+    if int(cnt.size) != want:
+        raise ValueError(f"{what}: the chunk table has {int(cnt.size)} entries, {want} chunks of {cs} symbols are coded (corrupt or truncated .b file)")
+    if cnt.size and int(cnt.min()) < 0:
+        raise ValueError(f"{what}: negative chunk byte count (corrupt .b file)")
+
+
 def decode_const_row(row, data, cnt, chunk_size, N, device):
     """Inverse of encode_const_row (data, cnt: numpy arrays); int16 symbols on `device`."""
     data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    _check_cnt(cnt, [N], chunk_size, "decode_const_row")
     r = (C.c_float * len(row))(*[float(v) for v in row])
     out = torch.zeros(int(N), dtype=torch.int16, device=device)
     _lib.check(_lib.lib().gsac_decode_const(runtime.context(out.device), C.cast(r, C.c_void_p), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
@@ -102,6 +117,7 @@ def arithmetic_decode(cdf, in_cache_all, in_cnt_all, chunk_size, N, Lp):
     data = in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False)
     cnt = in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False)
     data = np.ascontiguousarray(data); cnt = np.ascontiguousarray(cnt)
+    _check_cnt(cnt, [N], chunk_size, "arithmetic_decode")
     out = torch.zeros(int(N), dtype=torch.int16, device=cdf.device)
     _lib.check(_lib.lib().gsac_decode(runtime.context(cdf.device), cdf.data_ptr(), data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size),
                                       int(N), int(Lp), out.data_ptr(), runtime.stream_ptr(cdf.device)))
@@ -131,6 +147,7 @@ def decode_gaussian(mean, scale, Q, min_value, max_value, in_cache_all, in_cnt_a
     data = np.ascontiguousarray(in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False))
     cnt = np.ascontiguousarray(in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False))
     n = int(mean.shape[0])
+    _check_cnt(cnt, [n], chunk_size, "decode_gaussian")
     out = torch.empty(n, dtype=torch.float32, device=mean.device)
     m32, s32, q32 = _f32(mean, scale, Q)
     _lib.check(_lib.lib().gsac_decode_gaussian(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(), n,
@@ -163,6 +180,9 @@ def decode_gaussian_slices(mean, scale, Q, slice_start, mins, maxs, data, cnt, c
     ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
     mins = np.ascontiguousarray(mins, dtype=np.float32); maxs = np.ascontiguousarray(maxs, dtype=np.float32)
     data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    _check_cnt(cnt, np.diff(ss), chunk_size, "decode_gaussian_slices")
+    if mins.size != ss.size - 1 or maxs.size != ss.size - 1:
+        raise ValueError("decode_gaussian_slices: one (min, max) per slice")
     out = torch.empty(int(ss[-1]), dtype=torch.float32, device=mean.device)
     m32, s32, q32 = _f32(mean, scale, Q)
     _lib.check(_lib.lib().gsac_decode_gaussian_slices(runtime.context(mean.device), m32.data_ptr(), s32.data_ptr(), q32.data_ptr(),
@@ -221,6 +241,7 @@ def decode_gaussian_mixed(mean_list, scale_list, prob_list, Q, min_value, max_va
     data = np.ascontiguousarray(in_cache_all.detach().cpu().numpy().astype(np.uint8, copy=False))
     cnt = np.ascontiguousarray(in_cnt_all.detach().cpu().numpy().astype(np.int32, copy=False))
     n = int(q32.shape[0])
+    _check_cnt(cnt, [n], chunk_size, "decode_gaussian_mixed")
     out = torch.empty(n, dtype=torch.float32, device=q32.device)
     _lib.check(_lib.lib().gsac_decode_gaussian_mixed(runtime.context(q32.device), pm, ps, pp, k, q32.data_ptr(), n, float(min_value), float(max_value),
                                                      data.ctypes.data, data.size, cnt.ctypes.data, int(chunk_size), out.data_ptr(),
@@ -252,6 +273,9 @@ def decode_gaussian_mixed_slices(mean_list, scale_list, prob_list, Q, slice_star
     ss = np.ascontiguousarray(np.asarray(slice_start, dtype=np.int64))
     mins = np.ascontiguousarray(mins, dtype=np.float32); maxs = np.ascontiguousarray(maxs, dtype=np.float32)
     data = np.ascontiguousarray(data, dtype=np.uint8); cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    _check_cnt(cnt, np.diff(ss), chunk_size, "decode_gaussian_mixed_slices")
+    if mins.size != ss.size - 1 or maxs.size != ss.size - 1:
+        raise ValueError("decode_gaussian_mixed_slices: one (min, max) per slice")
     out = torch.empty(int(ss[-1]), dtype=torch.float32, device=q32.device)
     _lib.check(_lib.lib().gsac_decode_gaussian_mixed_slices(runtime.context(q32.device), pm, ps, pp, k, q32.data_ptr(), ss.ctypes.data, ss.size - 1,
                                                             mins.ctypes.data, maxs.ctypes.data, data.ctypes.data, data.size, cnt.ctypes.data,

@@ -696,8 +696,11 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         xyz = own;
     }
     GP_TRY(leaves_reference_order(ctx, st, &cur, bias_leaf, xyz, npts));
-    unsigned long long hpairs[MAXLV];
-    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
+    // (pinned -- bytes 512 .. 703 of the staging area, behind htotal's words -- not the stack: an error return between this copy and the
+    // sync must not leave a transfer pending into a dead frame)
+    unsigned long long *hpairs = reinterpret_cast<unsigned long long *>(ctx->hstage.p + 512);
+    static_assert(512 + sizeof(unsigned long long) * MAXLV <= 1024, "hpairs sits in front of the base level's staging bytes");
+    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof(unsigned long long) * MAXLV, hipMemcpyDeviceToHost, st));
     htotal[40] = 0;
     if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(htotal + 40, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -519,7 +519,7 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     const size_t pin_leaf = pin_seg + pin_seg_b, pin_leaf_b = (size_t)K * sizeof(ForestLeafScene);
     const size_t pin_base = (pin_leaf + pin_leaf_b + 63) & ~(size_t)63, pin_base_b = (size_t)bn * (8 + 1 + 4) + (size_t)nroot * (8 + 1) + (size_t)(nroot + 1) * 4 + (size_t)(K + 1) * 4 + 64;
     const size_t pin_desc = (pin_base + pin_base_b + 63) & ~(size_t)63, pin_desc_b = sizeof(RcChunk) * std::max<size_t>(desc_total, 1);
-    const size_t pin_cnt = (pin_desc + pin_desc_b + 63) & ~(size_t)63, pin_cnt_b = 4 * (size_t)(K + MAXLV * (K + 1) + MAXLV + 64);
+    const size_t pin_cnt = (pin_desc + pin_desc_b + 63) & ~(size_t)63, pin_cnt_b = 4 * (size_t)(K + MAXLV * (K + 1) + MAXLV + 64) + 8 * (size_t)MAXLV + 8;   // + the pair counts (8-byte aligned behind the words)
     GP_TRY(ctx->hbatch.reserve(pin_cnt + pin_cnt_b + 64));
     uint8_t *pin = ctx->hbatch.p;
     GP_TRY(ctx->side_init());
@@ -786,8 +786,9 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     uint32_t *h_leaf = hcnt, *h_lvl = hcnt + K;
     HIP_TRY(hipMemcpyAsync(h_leaf, dleaf_cnt, 4 * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_lvl, dlevel_tot, 4 * (size_t)MAXLV, hipMemcpyDeviceToHost, st));
-    unsigned long long hpairs[MAXLV];
-    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof hpairs, hipMemcpyDeviceToHost, st));
+    // (pinned, not the stack: an error return between this copy and the sync must not leave a transfer pending into a dead frame)
+    unsigned long long *hpairs = reinterpret_cast<unsigned long long *>(pin + ((pin_cnt + 4 * (size_t)(K + MAXLV * (K + 1) + MAXLV + 64) + 7) & ~(size_t)7));
+    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof(unsigned long long) * MAXLV, hipMemcpyDeviceToHost, st));
     uint32_t *h_tmo = hcnt + K + MAXLV;
     *h_tmo = 0;
     if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(h_tmo, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));

@@ -79,6 +79,40 @@ def max_over_ranks(seconds: float, device, group=None) -> float:
     return float(t.item())
 
 
+def rank_cpu_set(local_rank: int, local_world: int, allowed=None):
+    """The host threads of rank `local_rank` of `local_world` ranks on this node: an even, contiguous share of the CPUs this process may
+    use (sorted ids, so that on the usual numbering a share stays inside one socket / NUMA node).  Eight ranks each start parser, writer
+    and OpenMP threads (gpcc_write_files / gpcc_read_files run 8 native threads per call); unpinned they pile onto the cores of one
+    NUMA node while the others idle.  Never returns an empty set: with fewer CPUs than ranks the shares wrap around."""
+    cpus = sorted(os.sched_getaffinity(0) if allowed is None else allowed)
+    local_world = max(1, int(local_world))
+    local_rank = int(local_rank) % local_world
+    if len(cpus) < local_world:
+        return {cpus[local_rank % len(cpus)]}
+    per = len(cpus) // local_world
+    return set(cpus[local_rank * per:(local_rank + 1) * per])
+
+
+def pin_rank_threads(local_rank=None, local_world=None) -> int:
+    """Give this rank its share of the node's host threads (rank_cpu_set) -- call it BEFORE anything touches the GPU or starts a thread
+    pool, so that every thread the process creates later inherits the mask.  Reads LOCAL_RANK / LOCAL_WORLD_SIZE (torch.distributed.run)
+    when not given; a single rank is left alone.  Returns the number of CPUs in the mask now in force.  GAUSPCC_NO_PIN=1 disables it."""
+    if local_rank is None:
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if local_world is None:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if local_world <= 1 or os.environ.get("GAUSPCC_NO_PIN") == "1" or not hasattr(os, "sched_setaffinity"):
+        return len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    mine = rank_cpu_set(local_rank, local_world)
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        pass
+    n = len(os.sched_getaffinity(0))
+    os.environ["OMP_NUM_THREADS"] = str(max(1, min(int(os.environ.get("OMP_NUM_THREADS", n)), n)))
+    return n
+
+
 def free_port() -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -106,6 +140,7 @@ def init_from_env(prefer_gpu: bool = True):
     import torch.distributed as dist
 
     rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    pin_rank_threads(local)          # before the first GPU call: every later thread inherits the rank's share of the host cores
     gpu = prefer_gpu and torch.cuda.is_available()
     device = torch.device("cuda", local) if gpu else torch.device("cpu")
     if gpu:

@@ -58,8 +58,10 @@ def _write_files(jobs):
         _write_files_now(jobs)
 
 
-def _read_slice_files(paths):
-    """The `[min, max, len(cnt) * 4, cnt..., payload]` files of many slices (encoder_gaussian*_slices) read by libgauspcc on native threads
+def _read_slice_files(paths, lens=None):
+    """lens: the symbol count of every slice -- a file whose chunk table is not exactly ceil(len / chunk_size_cuda) int32 entries is rejected here
+    (the library reads one count per chunk: a shorter table would be read past its end, a longer one would shift every later slice's counts).
+    The `[min, max, len(cnt) * 4, cnt..., payload]` files of many slices (encoder_gaussian*_slices) read by libgauspcc on native threads
     (gpcc_read_files: 2 343 files cost ~27 ms of open / read / frombuffer in Python): (mins, maxs, cnts, datas) with numpy views into one blob that
     is valid until this thread's next call -- callers concatenate them at once."""
     import ctypes as C
@@ -79,8 +81,10 @@ def _read_slice_files(paths):
         head = blob[a:a + 12]
         mins.append(head[0:4].view(np.float32)[0]); maxs.append(head[4:8].view(np.float32)[0])
         lc = int(head[8:12].view(np.int32)[0])
-        if lc < 0 or a + 12 + lc > b:
+        if lc < 0 or lc % 4 or a + 12 + lc > b:
             raise RuntimeError(f"{paths[i]}: bad chunk table")
+        if lens is not None and lc != 4 * (-(-int(lens[i]) // chunk_size_cuda)):
+            raise RuntimeError(f"{paths[i]}: chunk table of {lc // 4} entries, the slice's {int(lens[i])} symbols are {-(-int(lens[i]) // chunk_size_cuda)} chunks")
         cnts.append(blob[a + 12:a + 12 + lc].view(np.int32))
         datas.append(blob[a + 12 + lc:b])
     return mins, maxs, cnts, datas
@@ -230,7 +234,7 @@ def decoder_gaussian_slices(mean, scale, Q, slice_start, file_names):
     keep = np.nonzero(lens > 0)[0]
     if keep.size == 0:
         return torch.empty(0, dtype=torch.float32, device=mean.device)
-    mins, maxs, cnts, datas = _read_slice_files([file_names[i].replace('.b', '_0.b') for i in keep])
+    mins, maxs, cnts, datas = _read_slice_files([file_names[i].replace('.b', '_0.b') for i in keep], lens[keep])
     sel = torch.cat([torch.arange(int(ss[i]), int(ss[i + 1]), device=mean.device) for i in keep]) if keep.size != len(lens) else None
     pick = (lambda t: t.contiguous()) if sel is None else (lambda t: t[sel].contiguous())
     cs = np.concatenate([[0], np.cumsum(lens[keep])])
@@ -258,7 +262,7 @@ def decoder_gaussian_slices_multi(jobs):
         sizes.append(int(lens[keep].sum()) if keep.size else 0)
     if not parts:
         return [torch.empty(0, dtype=torch.float32, device=dev) for _ in jobs]
-    mins, maxs, cnts, datas = _read_slice_files(paths)          # every job's files in one call (the blob is per thread and per call)
+    mins, maxs, cnts, datas = _read_slice_files(paths, np.concatenate(lens_all))          # every job's files in one call (the blob is per thread and per call)
     cs = np.concatenate([[0], np.cumsum(np.concatenate(lens_all))])
     cat = lambda k: torch.cat([p[k].float() for p in parts]).contiguous()
     out = arithmetic.decode_gaussian_slices(cat(0), cat(1), cat(2), cs, np.array(mins), np.array(maxs), np.concatenate(datas), np.concatenate(cnts), chunk_size_cuda)
@@ -295,7 +299,7 @@ def decoder_gaussian_mixed_slices(mean_list, scale_list, prob_list, Q, slice_sta
     """Inverse of encoder_gaussian_mixed_slices: every chunk of every slice decoded concurrently; the decoded values of all
     slices concatenated in slice order."""
     ss = np.asarray(slice_start, dtype=np.int64)
-    mins, maxs, cnts, datas = _read_slice_files([fn.replace('.b', '_0.b') for fn in file_names])
+    mins, maxs, cnts, datas = _read_slice_files([fn.replace('.b', '_0.b') for fn in file_names], np.diff(ss))
     cont = lambda lst: [t.contiguous() for t in lst]
     return arithmetic.decode_gaussian_mixed_slices(cont(mean_list), cont(scale_list), cont(prob_list), Q.contiguous(), ss - ss[0], np.array(mins), np.array(maxs),
                                                    np.concatenate(datas), np.concatenate(cnts), chunk_size_cuda)

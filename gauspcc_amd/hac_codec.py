@@ -144,7 +144,7 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
         offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, offsets_mean)
         # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
         kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
-        off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
+        off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], dtype=torch.long, device=kept.device)].cpu().tolist()   # (dtype: an empty list is float32 otherwise and cannot index)
         bit_offsets_list = encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask],
                                                    off_bounds, names('offsets'))
     torch.cuda.synchronize(); t_codec += time.time() - t0
@@ -208,7 +208,7 @@ def conduct_decoding(self, pre_path_name, patched_infos, ckpt_path=None):
     mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
     # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
     kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
-    off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
+    off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], dtype=torch.long, device=kept.device)].cpu().tolist()   # (dtype: an empty list is float32 otherwise and cannot index)
     mo = c["mean_offsets"].reshape(-1)
     # the three attributes in ONE device call: their chunks side by side (encodings_cuda.decoder_gaussian_slices_multi); the reference decodes
     # slice after slice, attribute after attribute (:1304-1331)

@@ -176,7 +176,7 @@ def conduct_encoding(self, pre_path_name, ckpt_path=None):
         offsets = ste_multistep(_grid_offsets.reshape(-1, 3 * n_off).reshape(-1), Q, self._offset.mean())
         # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
         kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
-        off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
+        off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], dtype=torch.long, device=kept.device)].cpu().tolist()   # (dtype: an empty list is float32 otherwise and cannot index)
         bit_offsets = sum(encoder_gaussian_slices(offsets[mask], c["mean_offsets"].reshape(-1)[mask], c["scale_offsets"].reshape(-1)[mask], Q[mask], off_bounds,
                                                   _names(pre_path_name, 'offsets', steps), chunk_size=10_0000))
         t_offset = get_time() - t_offset_0
@@ -278,7 +278,7 @@ def conduct_decoding(self, pre_path_name, ckpt_path=None):
     mask = masks_decoded.repeat(1, 1, 3).view(-1, 3 * n_off).view(-1).to(torch.bool)
     # masked elements up to each slice boundary: only the sums at the slice boundaries leave the device (a million-entry .tolist() was 10 ms)
     kept = torch.cumsum(mask.view(N, -1).sum(dim=1), dim=0)
-    off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], device=kept.device)].cpu().tolist()
+    off_bounds = [0] + kept[torch.tensor([b - 1 for b in bounds[1:]], dtype=torch.long, device=kept.device)].cpu().tolist()   # (dtype: an empty list is float32 otherwise and cannot index)
     mo = c["mean_offsets"].reshape(-1)
     offsets_decoded = torch.zeros_like(mo)
     offsets_decoded[mask] = decoder_gaussian_slices(mo[mask], c["scale_offsets"].reshape(-1)[mask], c["Q_offsets"].reshape(-1)[mask], off_bounds,

@@ -167,15 +167,22 @@ def _encode_view(xyz_int32: torch.Tensor, model, chunk_log2: int, posQ):
     return (C.c_ubyte * nb.value).from_address(pb.value), st
 
 
-def _header_points(head: bytes):
+def _header_points(head: bytes, nbytes: int = None):
     """Point count from a chunked container's header (FF FF | version | chunk_log2 | posQ | L | 0 | u32 n[L] | u32 N), else None.
-    The header is untrusted: a count that the last level cannot expand to (more than 8 children per node, or fewer than one)
-    is reported as None, and the caller takes the path on which the library sizes the output from what it decoded."""
+    The header is untrusted and this count sizes a device allocation BEFORE the library's own checks run, so the same cheap bounds
+    apply here (csrc/container.hpp: container_precheck): the last level must be able to expand to the count (1..8 children per node),
+    every level at most 8x the one above, and no level may claim more nodes than the file could code (a node costs at least ~2^-13
+    bytes: all nodes <= nbytes << 13).  Anything else is reported as None, and the caller takes the path on which the library sizes the
+    output from what it decoded."""
     if len(head) >= 12 and head[0] == 0xFF and head[1] == 0xFF and 1 <= head[6] <= 21 and len(head) >= 12 + 4 * head[6]:
         L = head[6]
         npts = int.from_bytes(head[8 + 4 * L: 12 + 4 * L], "little")
-        last = int.from_bytes(head[8 + 4 * (L - 1): 8 + 4 * L], "little")
-        if last <= npts <= 8 * last:
+        lv = [int.from_bytes(head[8 + 4 * d: 12 + 4 * d], "little") for d in range(L)]
+        if lv[0] <= 0 or any(b <= 0 or b > 8 * a for a, b in zip(lv, lv[1:])):
+            return None
+        if nbytes is not None and sum(lv) > (int(nbytes) << 13):
+            return None
+        if lv[-1] <= npts <= 8 * lv[-1]:
             return npts
     return None
 
@@ -191,7 +198,7 @@ def _decode_bytes(data, model, device):
         if not isinstance(data, bytes):
             data = bytes(data)
         ptr, nbytes, head = C.cast(C.c_char_p(data), C.c_void_p), len(data), data[:96]   # the bytes object's own storage: only read
-    npts = _header_points(head)
+    npts = _header_points(head, nbytes)
     if npts is not None and 0 < npts < (1 << 31):
         out = torch.empty((npts, 3), dtype=torch.int32, device=device)
         _lib.check(_lib.lib().gpcc_decode_to(ctx, model.handle, ptr, nbytes, out.data_ptr(), npts, C.byref(n), C.byref(pq),
@@ -287,7 +294,7 @@ def _decode_batch(datas, model, device):
     K = len(datas)
     datas = [d if isinstance(d, (bytes, C.Array)) else bytes(d) for d in datas]
     ctx = runtime.context(device)
-    npts = [_header_points(bytes(d[:96])) for d in datas]
+    npts = [_header_points(bytes(d[:96]), len(d)) for d in datas]
     if any(n is None or not (0 < n < (1 << 31)) for n in npts):
         # a container without a point count (the reference layout): one by one
         outs, pqs, sts = [], [], []

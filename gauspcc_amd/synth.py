@@ -83,6 +83,39 @@ def synthetic_cloud(n_points: int, seed: int = 1234, negative: bool = False, ext
     return np.ascontiguousarray(pts.astype(np.int32))
 
 
+def solid_cloud(n_points: int, seed: int = 4321, extent_log2: int = 12) -> np.ndarray:
+    """(n_points, 3) int32, duplicate-free: every voxel inside a union of seeded balls -- a SOLID cloud.  Interior octree nodes have all
+    eight children (occupancy 255), so the marginal symbol distributions are sharply peaked (2.5 bits per coded node at 1 M points, 3.6
+    at 200 k, instead of the 5.2 of the sparse bench cloud) and there are only ~0.16 coded nodes per point: with
+    peaky_state_dict(gain=1, freq=stage_symbol_frequencies(cloud)) the codec runs at 0.4 - 0.6 bits per point, the range coder in its
+    low-entropy regime (long carry runs, a few bytes per chunk).  (gain = 1: every node of a solid level sees all 125 taps, so the
+    nominal initialiser already keeps the activations O(1); the sparse clouds' gain = 4 makes the logits explode here.)"""
+    rng = CounterRNG(seed)
+    ext = 1 << extent_log2
+    n_balls = 12
+    # radii so that the balls' volumes add up to ~1.25 n (overlaps and the trim below take the rest)
+    rel = 0.6 + 0.8 * rng.uniform(1, n_balls)
+    r = rel * (1.25 * n_points / (4.18879 * np.sum(rel ** 3))) ** (1.0 / 3.0)
+    margin = int(np.ceil(r.max())) + 2
+    if ext <= 2 * margin + 2:
+        raise ValueError("solid_cloud: extent too small for this many points")
+    ctr = margin + rng.uniform(2, n_balls * 3).reshape(n_balls, 3) * (ext - 2 * margin)
+    keys = []
+    for b in range(n_balls):
+        R = int(np.ceil(r[b]))
+        c = np.rint(ctr[b]).astype(np.int64)
+        g = np.arange(-R, R + 1, dtype=np.int64)
+        z, y, x = np.meshgrid(g, g, g, indexing="ij")
+        inside = x * x + y * y + z * z <= r[b] * r[b]
+        keys.append(((z[inside] + c[2]) << 42) | ((y[inside] + c[1]) << 21) | (x[inside] + c[0]))
+    key = np.unique(np.concatenate(keys))
+    if key.shape[0] < n_points:
+        raise ValueError("solid_cloud: the balls hold fewer voxels than requested")
+    key = key[:n_points]                 # raster-order trim: removes whole slabs of the last balls, punches no holes
+    m = (1 << 21) - 1
+    return np.ascontiguousarray(np.stack([key & m, (key >> 21) & m, key >> 42], axis=1).astype(np.int32))
+
+
 # --------------------------------------------------------------------------- weights
 STAGE_M = (2, 2, 4, 16)
 
@@ -132,6 +165,50 @@ def synthetic_state_dict(channels: int = 32, kernel_size: int = 5, seed: int = 7
         if s > 0:
             sd[f"pred_head_s{s}_emb.weight"] = nrm((2 ** (1, 2, 4)[s - 1], C))
     sd["fog.conv.kernel"] = np.ones((8, 1, 1), dtype=np.float32)
+    return sd
+
+
+def stage_symbol_frequencies(points: np.ndarray):
+    """Empirical frequencies of the four stage symbols over every coded octree node of a cloud (closed form: no network).
+    A node's occupancy byte o = sum over children of 2^(x%2 + 2(y%2) + 4(z%2)) (kit/nn.py:38-55) is coded as four symbols
+    o>>7&1, o>>6&1, o>>4&3, o&15 (pcc_utils.py:118-142); levels are halved until fewer than 64 nodes remain, as the codec does
+    (pcc_utils.py:83-89).  Returns four float64 arrays of 2 / 2 / 4 / 16 frequencies."""
+    c = np.unique(np.asarray(points, dtype=np.int64), axis=0)
+    counts = [np.zeros(m, dtype=np.int64) for m in STAGE_M]
+    while c.shape[0] >= 64:
+        par = c >> 1
+        bit = (c[:, 0] & 1) + 2 * (c[:, 1] & 1) + 4 * (c[:, 2] & 1)
+        up, inv = np.unique(par, axis=0, return_inverse=True)
+        occ = np.zeros(up.shape[0], dtype=np.int64)
+        np.add.at(occ, inv.reshape(-1), np.int64(1) << bit)
+        for s, sym in enumerate((occ >> 7 & 1, occ >> 6 & 1, occ >> 4 & 3, occ & 15)):
+            counts[s] += np.bincount(sym, minlength=STAGE_M[s])
+        c = up
+    return [cn / max(1, cn.sum()) for cn in counts]
+
+
+# stage_symbol_frequencies(synthetic_cloud(1_000_000, seed=1234)), rounded to 4 digits: the "peaky" model's head biases are the logs
+# of these, so that the model is the same on every box without the 1 M cloud having to be rebuilt (tests check the table against the function)
+PEAKY_FREQ_S1M = (
+    (0.829, 0.171),
+    (0.8287, 0.1713),
+    (0.6867, 0.1422, 0.1419, 0.0292),
+    (0.4359, 0.1192, 0.1192, 0.0125, 0.1191, 0.0127, 0.006, 0.004, 0.1195, 0.0061, 0.0124, 0.004, 0.0126, 0.004, 0.0039, 0.0088),
+)   # marginal entropy 0.66 + 0.66 + 1.32 + 2.58 = 5.22 bits per coded node (x 2.7 coded nodes per point of that cloud = 14.1 bpp)
+
+
+def peaky_state_dict(channels: int = 32, kernel_size: int = 5, seed: int = 7, gain: float = 4.0, freq=None, head_scale: float = 0.25) -> dict:
+    """A low-rate operating point without training: the seeded weights of synthetic_state_dict with the
+    LAST layer of every prediction head (network_ue_4stage_conv.py:65-94) re-targeted -- weights x head_scale, bias = log of the
+    stage's empirical symbol frequencies (PEAKY_FREQ_S1M unless `freq` is given).  The predicted distributions are then the
+    marginals of the occupancy symbols, modulated by the context network: peaked rows (most nodes of a sparse cloud have one child),
+    long carry runs and few bytes per chunk in the range coder -- the regime a trained GausPcgc checkpoint works in."""
+    sd = synthetic_state_dict(channels, kernel_size, seed, gain)
+    fr = PEAKY_FREQ_S1M if freq is None else freq
+    for s, m in enumerate(STAGE_M):
+        f = np.maximum(np.asarray(fr[s], dtype=np.float64), 1e-6)
+        sd[f"pred_head_s{s}.2.weight"] = (sd[f"pred_head_s{s}.2.weight"] * np.float32(head_scale)).astype(np.float32)
+        sd[f"pred_head_s{s}.2.bias"] = np.log(f / f.sum()).astype(np.float32)
     return sd
 
 

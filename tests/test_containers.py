@@ -208,3 +208,26 @@ def test_device_reproduces_stored_stream(fixture, k, cl, tag):
     dec, posq, _ = gh.decode(model, stored)
     assert float(posq) == 1.0
     assert np.array_equal(_rows(dec), _rows(fixture["points"]))
+
+
+def test_header_points_applies_the_precheck_bounds_before_anything_is_sized():
+    """ADVICE (round 5): the wrapper sizes the output tensor from the header's point count before the library's consistency checks run;
+    the same cheap bounds (csrc/container.hpp: container_precheck) therefore apply in Python -- a corrupt 100-byte file must not ask
+    for gigabytes."""
+    import struct
+
+    from gauspcc_amd.pcc_utils import _header_points
+
+    def hdr(levels, npts, pad=200):
+        return b"\xff\xff\x04\x0b" + struct.pack("<H", 0x3C00) + bytes([len(levels), 0]) + b"".join(struct.pack("<I", v) for v in levels) + struct.pack("<I", npts) + bytes(pad)
+
+    good = hdr([8, 40, 200], 900)
+    assert _header_points(good[:96], len(good)) == 900
+    assert _header_points(hdr([8, 40, 200], 1601)[:96], 300) is None            # more than 8 points per finest node
+    assert _header_points(hdr([8, 40, 200], 199)[:96], 300) is None             # fewer points than finest nodes
+    assert _header_points(hdr([8, 65, 200], 900)[:96], 300) is None             # a level more than 8x its parent
+    assert _header_points(hdr([8, 0, 200], 900)[:96], 300) is None
+    big = hdr([60, 480, 3840, 30720, 245760, 1966080, 15728640, 125829120, 1006632960], 2**31 - 2, pad=0)
+    assert _header_points(big[:96], len(big)) is None                            # 1.1 G nodes cannot come from a 48-byte file
+    assert _header_points(big[:96]) is not None                                  # (without the file size only the tree-shape bounds apply)
+    assert _header_points(b"\x03\x00" + bytes(94), 96) is None                   # the reference layout carries no count

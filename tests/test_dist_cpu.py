@@ -146,3 +146,58 @@ def test_batch_cli_jobs_and_decompress_under_two_ranks(tmp_path):
     for i in range(7):
         for sub, ext in (("bin", ".npy.bin"), ("ply", ".npy.bin.ply")):
             assert (tmp_path / "one" / sub / f"c{i}{ext}").read_bytes() == (tmp_path / "two" / sub / f"c{i}{ext}").read_bytes()
+
+
+def _bench_selftest(extra, timeout=600):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["OMP_NUM_THREADS"] = "1"
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--points", "1000", "--selftest-launcher"] + extra,
+                          capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+
+
+def test_eight_ranks_uneven_batch_and_disjoint_host_threads():
+    """The shape of the first 8-GPU box, pinned on gloo (scene i -> rank i mod 8, one all_gather of the stats, MAX of the
+    times): `bench.py --gpus 8 --scenes-per-gpu 3` starts its own eight ranks; a batch of 21 scenes (not a multiple of 8) leaves ranks
+    5-7 one scene short; every scene is collated exactly once, in (rank, local index) order; and every rank has pinned itself to its own
+    share of the host cores before anything else (dist.pin_rank_threads) -- disjoint where the box has at least eight."""
+    r = _bench_selftest(["--gpus", "8", "--scenes-per-gpu", "3"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == 8 and out["scenes_seen"] == 24
+    assert out["seeds"] == [1234 + s for s in out["scene_order"]] and sorted(out["scene_order"]) == list(range(24))
+    assert out["max_elapsed"] == 8.0
+    r = _bench_selftest(["--gpus", "8", "--selftest-scenes", "21"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["scenes_seen"] == 21 and sorted(out["scene_order"]) == list(range(21))
+    assert out["scene_order"][:3] == [0, 8, 16] and out["scene_order"][-2:] == [7, 15]           # rank 0 has three scenes, rank 7 two
+    assert out["seeds"] == [1234 + s for s in out["scene_order"]]
+    cpus = out["rank_cpus"]                                                                      # [count, first id, last id] per rank
+    assert len(cpus) == 8 and all(c[0] >= 1 for c in cpus)
+    have = len(os.sched_getaffinity(0))
+    if have >= 8:
+        assert all(c[0] == have // 8 for c in cpus)
+        spans = sorted((c[1], c[2]) for c in cpus)
+        assert all(a[1] < b[0] for a, b in zip(spans, spans[1:])), spans                          # disjoint, contiguous shares
+
+
+def test_eight_ranks_one_failing_rank_ends_the_job():
+    """A rank that dies before the rendezvous (a GPU that does not come up): the launcher ends the other seven and `bench.py --gpus 8` relays a
+    non-zero exit code instead of hanging in the rendezvous or printing a line for a partial job."""
+    r = _bench_selftest(["--gpus", "8", "--selftest-fail-rank", "5"], timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+
+
+def test_rank_cpu_sets_partition_the_allowed_cpus():
+    from gauspcc_amd.dist import rank_cpu_set
+
+    allowed = set(range(4, 68))                                         # e.g. a cgroup's 64 CPUs
+    shares = [rank_cpu_set(r, 8, allowed) for r in range(8)]
+    assert all(len(s) == 8 for s in shares) and set().union(*shares) == allowed
+    assert all(a.isdisjoint(b) for i, a in enumerate(shares) for b in shares[i + 1:])
+    assert shares[0] == set(range(4, 12)) and shares[7] == set(range(60, 68))
+    few = [rank_cpu_set(r, 8, {0, 1, 2}) for r in range(8)]             # fewer CPUs than ranks: one each, wrapping
+    assert all(len(s) == 1 for s in few) and set().union(*few) == {0, 1, 2}
+    assert rank_cpu_set(0, 1, allowed) == allowed

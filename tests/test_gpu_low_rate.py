@@ -1,0 +1,82 @@
+"""The codec at a realistic (low) rate -- VERDICT round 5, item 3b.  Seeded random weights code ~22 bpp; a trained GausPcgc
+checkpoint (README.md:73-77, not shipped) codes a few.  Low entropy is where the range coder behaves differently (long carry runs,
+a few bytes per chunk), so the byte identity with the oracle is pinned there too, on both containers:
+  * the bench generator's cloud under synth.peaky_state_dict (head biases = log of the stage symbols' empirical frequencies), and
+  * synth.solid_cloud under its own peaky model (2.5 - 3.6 bits per coded node: peaked rows on every level).
+Estimator the rates are compared with: network_ue_4stage_conv.py:100-182 (sum of -log2 p of the coded symbols); coder call sites
+pcc_utils.py:146-177, container :198-203."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gh():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need an MI355X: the HIP path has no fallback")
+    from tests import gpu_helpers
+
+    return gpu_helpers
+
+
+def _models(orc, sd):
+    from gauspcc_amd import runtime
+    from gauspcc_amd.model import tensor_table
+
+    return runtime.Model(sd, 32, 5, 0), orc.Model(tensor_table(sd, 32, 5), 32, 5)
+
+
+def _sorted_rows(a):
+    return a[np.lexsort((a[:, 0], a[:, 1], a[:, 2]))]
+
+
+def _case(kind, n):
+    from gauspcc_amd.synth import peaky_state_dict, solid_cloud, stage_symbol_frequencies, synthetic_cloud
+
+    if kind == "peaky":
+        return synthetic_cloud(n, seed=77), peaky_state_dict(32, 5)
+    pts = solid_cloud(n)
+    return pts, peaky_state_dict(32, 5, gain=1.0, freq=stage_symbol_frequencies(pts))
+
+
+@pytest.mark.parametrize("chunk_log2", [11, 0])
+@pytest.mark.parametrize("kind,n", [("peaky", 10_000), ("peaky", 200_000), ("solid", 10_000), ("solid", 200_000)])
+def test_low_rate_bitstream_identical_to_oracle(gh, orc, kind, n, chunk_log2):
+    pts, sd = _case(kind, n)
+    dm, om = _models(orc, sd)
+    data, st = gh.encode(dm, pts, chunk_log2, ideal_bits=True)
+    ref = orc.encode(om, pts, chunk_log2=chunk_log2)
+    assert len(data) == len(ref), (len(data), len(ref))
+    assert data == ref, f"first differing byte at {next(i for i, (a, b) in enumerate(zip(data, ref)) if a != b)}"
+    dec, _, _ = gh.decode(dm, data)
+    odec, _ = orc.decode(om, ref, cap_pts=n)
+    assert np.array_equal(dec, odec)
+    assert np.array_equal(_sorted_rows(dec), _sorted_rows(pts))
+    # the operating point is what the docstrings say it is: well below the random weights' 8 bits per coded node, and the coder sits on
+    # the estimator (flush bytes and chunk tables on top: a few percent at these rates)
+    bits_per_node = st.ideal_bits / st.coded_nodes
+    assert bits_per_node < (5.6 if kind == "peaky" else 5.0), bits_per_node
+    assert 8 * len(data) >= st.ideal_bits
+    if n >= 200_000:
+        assert 8 * len(data) <= 1.10 * st.ideal_bits + 8 * 4096, (8 * len(data), st.ideal_bits)
+
+
+def test_low_rate_batch_equals_solo(gh, orc):
+    """Two low-rate scenes through one chain of launches: each scene's container equals its solo encode (and so the oracle's)."""
+    import torch
+
+    from gauspcc_amd.pcc_utils import _decode_batch, _encode_batch
+
+    pts_a, sd = _case("solid", 60_000)
+    dm, om = _models(orc, sd)
+    pts_b = pts_a[: 30_000] + np.array([7, 3, 5], dtype=np.int32)
+    xs = [torch.tensor(p, device="cuda:0") for p in (pts_a, pts_b)]
+    blobs, _, _ = _encode_batch(xs, dm, 11, [1, 1])
+    for p, b in zip((pts_a, pts_b), blobs):
+        assert bytes(b) == orc.encode(om, p, chunk_log2=11)
+    outs, _, _, _ = _decode_batch([bytes(b) for b in blobs], dm, torch.device("cuda", 0))
+    for p, o in zip((pts_a, pts_b), outs):
+        assert np.array_equal(_sorted_rows(o.cpu().numpy()), _sorted_rows(p))

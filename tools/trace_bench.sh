@@ -5,7 +5,7 @@ OUT=$1
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --side-anchors 0 --skip-stages --skip-v0 --scenes-in-flight 0 > "$OUT/bench.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/t" -o tr -- python3 bench.py --steps 2 --warmup 1 --cpu-sample 0 --side-anchors 0 --skip-stages --skip-v0 --skip-sizes --scenes-in-flight 0 > "$OUT/bench.log" 2>&1
 f=$(find "$OUT/t" -name "*kernel_trace.csv" | head -1)
 python3 tools/conv_by_level.py "$f" > "$OUT/conv_by_level.txt"
 cp $(find "$OUT/t" -name "*kernel_stats.csv" | head -1) "$OUT/kernel_stats.csv"

@@ -374,6 +374,19 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     return GPCC_OK;
 }
 
+// The words a decode hands back at its one sync -- what every level's occupancy expanded to (cstart[n] of its parent level, left there by
+// the expansion's own scan), the leaves' count, the pair counters of the profile, the sticky timeout word of the persistent launches -- gathered
+// by ONE single-wave launch straight into pinned memory.  Until round 6 each of them was a runtime blit of its own (per level a 4-byte
+// device-to-device copy and a 4-byte device-to-host copy: ~30 __amd_rocclr_copyBuffer launches per decode).
+struct DecTail { const uint32_t *tot[MAXLV + 1]; int ntot; const unsigned long long *pairs; const uint32_t *tmo; };
+__global__ __launch_bounds__(64) void k_dec_tail(DecTail t, uint32_t *__restrict__ h_tot, unsigned long long *__restrict__ h_pairs, uint32_t *__restrict__ h_tmo)
+{
+    const int l = (int)threadIdx.x;
+    if (l < t.ntot) h_tot[l] = *t.tot[l];
+    if (l < MAXLV) h_pairs[l] = t.pairs[l];
+    if (l == 0) *h_tmo = t.tmo ? *t.tmo : 0u;
+}
+
 // out_user / out_cap: optional caller-owned device buffer for the points (capacity in points); else a context-owned one
 int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t nbytes, const int32_t **xyz_out, int64_t *n_out,
                 uint16_t *posq_out, gpcc_stats *stats, hipStream_t st, int32_t *out_user, int64_t out_cap)
@@ -513,6 +526,7 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         GP_TRY(tiles_view(ctx, st, pool, 0, 1, zero_base, &tilesP));
     }
     int64_t coded = 0;
+    DecTail tail = {};
     // Small levels (fused.hpp): a chunked container's levels of at most FUSE_MAX_NODES nodes get a pair plan instead of a tile list,
     // their chain runs as one persistent launch (plus one for the finished level's prior trunk).  planP: the plan of `cur`.
     const bool fuse_ctx = fused_enabled() && !ctx->fused_off && v1 && version >= 1 && m->C == 32;   // (the persistent kernels are the 32-channel MFMA path)
@@ -564,10 +578,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         {
             const int hbl = std::min(21, std::max(1, hb + g + 1));
             StageTimer tm(ctx, sd, ST_OCTREE, (double)np * 13 + (double)nc * 12 + (double)cdiv(3 * hbl, 8) * (double)nc * 24 + (double)nc * 8);
-            GP_TRY(level_expand_rank(ctx, sd, &cur, &chi, dtotal, hb + g + 1));
-            if (v1) {  // verify the header against the occupancy actually decoded (checked at the final sync)
-                HIP_TRY(hipMemcpyAsync(htotal + 1 + g, dtotal, 4, hipMemcpyDeviceToHost, sd));
-            }
+            // chunked containers: the count the occupancy expanded to stays where the expansion's scan left it (cur.cstart[np]); every level's
+            // word is compared with the header at the final sync (k_dec_tail)
+            GP_TRY(level_expand_rank(ctx, sd, &cur, &chi, v1 ? nullptr : dtotal, hb + g + 1));
+            tail.tot[1 + g] = cur.cstart + np;
         }
         int32_t *cellC = nullptr;
         if (g + 2 < L) { TAKE(cm, int32_t, (int64_t)NPc * nc); cellC = cm; }      // the last level has no level below it
@@ -677,8 +691,9 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
         ht.mark("dec level queued", g + 1, nc);
     }
     // ---- leaves
-    GP_TRY(level_expand(ctx, st, &cur, nullptr, dtotal));
-    HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
+    GP_TRY(level_expand(ctx, st, &cur, nullptr, v1 ? nullptr : dtotal));
+    if (!v1) HIP_TRY(hipMemcpyAsync(htotal, dtotal, 4, hipMemcpyDeviceToHost, st));
+    tail.tot[0] = cur.cstart + cur.n;
     // chunked containers carry the point count: the leaves are queued behind the last level without a sync and every count
     // of the header is compared with what the decoded occupancy expanded to at the one sync below (the expansions are
     // bounded by the header's sizes, so a wrong header produced garbage, not out-of-bounds accesses)
@@ -700,9 +715,15 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
     // sync must not leave a transfer pending into a dead frame)
     unsigned long long *hpairs = reinterpret_cast<unsigned long long *>(ctx->hstage.p + 512);
     static_assert(512 + sizeof(unsigned long long) * MAXLV <= 1024, "hpairs sits in front of the base level's staging bytes");
-    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof(unsigned long long) * MAXLV, hipMemcpyDeviceToHost, st));
     htotal[40] = 0;
-    if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(htotal + 40, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
+    if (v1) {
+        tail.ntot = L; tail.pairs = pairs_dev; tail.tmo = any_fused ? fused_timeout_word(ctx) : nullptr;
+        k_dec_tail<<<1, 64, 0, st>>>(tail, htotal, hpairs, htotal + 40);
+        LAUNCH_CHECK();
+    } else {
+        HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof(unsigned long long) * MAXLV, hipMemcpyDeviceToHost, st));
+        if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(htotal + 40, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
     ht.mark("dec leaves done (sync)");
     if (htotal[40]) {

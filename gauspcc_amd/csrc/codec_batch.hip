@@ -389,6 +389,23 @@ int parse_chunked(const uint8_t *in, int64_t nbytes, int scene, ContainerHdr *h)
     return GPCC_OK;
 }
 
+
+// The words a batched decode hands back at its one sync, gathered by ONE single-wave launch straight into pinned memory (codec.hip: k_dec_tail is
+// the one-scene form): per level what the merged occupancy expanded to (cstart[rows with children] of the parent level), the moved-boundary flag
+// of forest_check_bounds, the leaves of every scene, the pair counters, the sticky timeout word.  (Until round 6: two 4-byte blits per level.)
+struct BDecTail { const uint32_t *tot[MAXLV]; int ntot; const uint32_t *bounds_flag, *leaf_cnt; int K; const unsigned long long *pairs; const uint32_t *tmo; };
+__global__ __launch_bounds__(64) void k_bdec_tail(BDecTail t, uint32_t *__restrict__ h_leaf, uint32_t *__restrict__ h_lvl, unsigned long long *__restrict__ h_pairs,
+                                                  uint32_t *__restrict__ h_tmo)
+{
+    const int l = (int)threadIdx.x;
+    for (int i = l; i < t.K; i += 64) h_leaf[i] = t.leaf_cnt[i];
+    if (l < MAXLV) {
+        h_lvl[l] = l == MAXLV - 1 ? *t.bounds_flag : l < t.ntot ? *t.tot[l] : 0u;
+        h_pairs[l] = t.pairs[l];
+    }
+    if (l == 0) *h_tmo = t.tmo ? *t.tmo : 0u;
+}
+
 int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *in, const int64_t *nbytes, int K, int32_t *const *xyz_out, const int64_t *cap_out, int64_t *n_out,
                       uint16_t *posq_out, gpcc_stats *stats, hipStream_t st)
 {
@@ -579,7 +596,6 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         return GPCC_OK;
     };
     const int d_early = std::min(L, 1 + TAB_EARLY);
-    GP_TRY(parse_levels(1, d_early, ctx->ev_bytes));   // (ev_bytes: behind the containers AND the early tables)
     GP_TRY(forest_upload_segs(ctx, st, &F, seg, pin + pin_seg, pin_seg_b));
     // ---- base and root levels
     auto alloc_level = [&](Level *lv, int64_t n, int lvl) -> int {
@@ -645,7 +661,12 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     PairPlan planP;
     int64_t planP_np = 0;
     bool any_fused = false;
+    BDecTail tail = {};
     HIP_TRY(hipEventRecord(ctx->ev_main, st));
+    // the early lane tables: parsed HERE, with the base level's launches (root cells, raster ranks, tile list) already queued -- until round 6 the
+    // host parsed them before the first launch, with the device idle (their first reader is the host itself: win_bytes decides the first
+    // coded level's class a few lines down; on the device the first range-decoder phase, behind ev_bytes = containers AND early tables)
+    GP_TRY(parse_levels(1, d_early, ctx->ev_bytes));
     for (int g = 0; g + 1 < L; ++g) {
         const size_t top_mk = ctx->arena.top_mark();
         Level &cur = T.lv[g];
@@ -674,8 +695,8 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
         {
             Level pv = cur; pv.n = np_in;
             StageTimer tm(ctx, sd, ST_OCTREE, (double)np * 13 + (double)nc * 12 + (double)nc * 8);
-            GP_TRY(level_expand_rank(ctx, sd, &pv, &chi, dtotal, F.hb0 + g + 1));
-            HIP_TRY(hipMemcpyAsync(dlevel_tot + g, dtotal, 4, hipMemcpyDeviceToDevice, sd));
+            GP_TRY(level_expand_rank(ctx, sd, &pv, &chi, nullptr, F.hb0 + g + 1));
+            tail.tot[g] = cur.cstart + np_in;   // what the occupancy expanded to: left there by the expansion's scan, gathered at the one sync (k_bdec_tail)
             GP_TRY(forest_check_bounds(sd, cur.cstart, F.seg_dev[g], F.seg_dev[g + 1], F.Kd[g + 1], dlevel_tot + MAXLV - 1));
         }
         int32_t *cellC = nullptr;
@@ -784,14 +805,15 @@ int decode_batch_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *const *
     // ---- one sync: every count of every header against what the decoded occupancy expanded to
     uint32_t *hcnt = reinterpret_cast<uint32_t *>(pin + pin_cnt);
     uint32_t *h_leaf = hcnt, *h_lvl = hcnt + K;
-    HIP_TRY(hipMemcpyAsync(h_leaf, dleaf_cnt, 4 * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_lvl, dlevel_tot, 4 * (size_t)MAXLV, hipMemcpyDeviceToHost, st));
+
     // (pinned, not the stack: an error return between this copy and the sync must not leave a transfer pending into a dead frame)
     unsigned long long *hpairs = reinterpret_cast<unsigned long long *>(pin + ((pin_cnt + 4 * (size_t)(K + MAXLV * (K + 1) + MAXLV + 64) + 7) & ~(size_t)7));
-    HIP_TRY(hipMemcpyAsync(hpairs, pairs_dev, sizeof(unsigned long long) * MAXLV, hipMemcpyDeviceToHost, st));
     uint32_t *h_tmo = hcnt + K + MAXLV;
     *h_tmo = 0;
-    if (any_fused && fused_timeout_word(ctx)) HIP_TRY(hipMemcpyAsync(h_tmo, fused_timeout_word(ctx), 4, hipMemcpyDeviceToHost, st));
+    tail.ntot = L - 1; tail.bounds_flag = dlevel_tot + MAXLV - 1; tail.leaf_cnt = dleaf_cnt; tail.K = K; tail.pairs = pairs_dev;
+    tail.tmo = any_fused ? fused_timeout_word(ctx) : nullptr;
+    k_bdec_tail<<<1, 64, 0, st>>>(tail, h_leaf, h_lvl, hpairs, h_tmo);
+    LAUNCH_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     ht.mark("bdec leaves done (sync)");
     if (*h_tmo) {

@@ -22,7 +22,7 @@ int fused_device_cap();   // below: workgroups of a persistent launch the curren
 bool fused_level_ok(int64_t n, int k)
 {
     if (fused_device_cap() < 16) return false;   // a partitioned / masked device too small for a persistent grid: the launch-per-layer path
-    static const int64_t nmax = std::min<int64_t>(dev_env_ll("GAUSPCC_FUSED_MAX", FUSE_MAX_NODES), FUSE_MAX_NODES);
+    static const int64_t nmax = std::min<int64_t>(dev_env_ll("GAUSPCC_FUSED_MAX", FUSE_MAX_NODES), FUSE_HARD_MAX);
     const int64_t K = (int64_t)k * k * k;
     return fused_enabled() && n >= 1 && n <= nmax && (n * K + 1) * 128 <= ((int64_t)768 << 20);
 }

@@ -25,7 +25,8 @@
 
 namespace gpcc {
 
-constexpr int64_t FUSE_MAX_NODES = 16384;
+constexpr int64_t FUSE_MAX_NODES = 16384;        // default class boundary (GAUSPCC_FUSED_MAX, developer knob, moves it up to FUSE_HARD_MAX)
+constexpr int64_t FUSE_HARD_MAX = 65536;         // what the plan builder and the persistent kernels are written for
 #ifndef FUSE_THREADS_N
 #define FUSE_THREADS_N 512
 #endif

@@ -515,23 +515,24 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     static const int pair_min = dev_env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
     pool->paired = (H > 64 && R == CONV_R_MAX && pair_on && !(nlv == 1 && conv_half_level(lv[0].lv->n, R))) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block); half-channel levels run the one-tile loop
     pool->pflag = nullptr;
-    if (pool->paired) {
-        TAKE(pf, uint8_t, nblk);
-        HIP_TRY(hipMemsetAsync(pf, 0, (size_t)nblk, st));   // the base level's block (built by k_base_tiles) is never paired
-        pool->pflag = pf;
+    // Three arrays that start zeroed -- the pair flags (the base level's block, built by k_base_tiles, is never paired), the per-chunk counts of
+    // the tall blocks (blocks of 2 or 3 chunks leave the other columns untouched) and the spread pair counters -- carved back to back and
+    // zeroed by ONE memset (until round 6: one runtime fill each, per tile pool = per decoded level)
+    unsigned long long *spread = nullptr;
+    {
+        const size_t b_sp = pairs_dev ? 8 * (size_t)nlv * 64 : 0;
+        const size_t b_cq = H > 64 ? (((size_t)nblk * K * 4 + 15) & ~(size_t)15) : 0;
+        const size_t b_pf = pool->paired ? (((size_t)nblk + 15) & ~(size_t)15) : 0;
+        if (b_sp + b_cq + b_pf) {
+            TAKE(z, unsigned long long, (b_sp + b_cq + b_pf) / 8);
+            uint8_t *zb = reinterpret_cast<uint8_t *>(z);
+            HIP_TRY(hipMemsetAsync(zb, 0, b_sp + b_cq + b_pf, st));
+            if (b_sp) spread = z;
+            if (b_cq) a.cnt_oq = zb + b_sp;
+            if (b_pf) pool->pflag = zb + b_sp + b_cq;
+        }
     }
     a.H = H; a.paired = pool->paired; a.pflag = pool->pflag; a.per_block = first;
-    if (H > 64) {   // blocks of 2 or 3 chunks leave the other columns untouched: zero them
-        TAKE(cq, uint8_t, (size_t)nblk * K * 4);
-        a.cnt_oq = cq;
-        HIP_TRY(hipMemsetAsync(cq, 0, (size_t)nblk * K * 4, st));
-    }
-    unsigned long long *spread = nullptr;
-    if (pairs_dev) {
-        TAKE(sp, unsigned long long, (size_t)nlv * 64);
-        spread = sp;
-        HIP_TRY(hipMemsetAsync(sp, 0, 8 * (size_t)nlv * 64, st));
-    }
     // a pool of several levels (the encoder's whole tree; only its first level may be a base level without a parent): the
     // count passes stay one launch per level (a level reads the cell map its parent's pass wrote), everything that is
     // independent across levels -- the sums of the tall blocks, the fill pass, the tile words -- is one launch over the pool

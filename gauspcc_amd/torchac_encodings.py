@@ -17,6 +17,13 @@ from . import torchac
 
 _SLAB_ENTRIES = 1 << 26          # table entries built at a time (256 MB of float32)
 
+# encodings.py:14 -- the reference's switch between ONE torchac stream per attribute file and its ten-way fan-out (multiprocess_encoder /
+# multiprocess_deoder: `<name>_<m>.b`, m = 0..9, each chunk of ceil(n / 10) rows its own stream).  Upstream says "Always False plz. Not yet
+# implemented for True" (its fan-out forks ten processes that pickle the table); here both settings work and give the files the reference's
+# functions would write.  A single stream is one dependent chain (36 Msymbols/s on one host thread); the ten chunks are independent chains
+# and run on ten native threads (the library calls release the GIL) -- the shape to use for attribute sets of 10^7 symbols and more.
+use_multiprocessor = False
+
 
 def _as_q(Q, like):
     if not isinstance(Q, torch.Tensor):
@@ -41,6 +48,53 @@ def _int_rows(mean, scale, Q, min_value, max_value):
     return torch.cat(out, dim=0) if out else torch.zeros((0, lp), dtype=torch.int16, device=mean.device)
 
 
+def _chunk_rows(n, chunk_num):
+    chunk_len = -(-int(n) // int(chunk_num)) if n else 0                    # int(math.ceil(encoding_len / chunk_num)) (:45, :66)
+    return [(m, m * chunk_len, min(n, (m + 1) * chunk_len)) for m in range(chunk_num)]
+
+
+def multiprocess_encoder(lower, symbol, file_name, chunk_num=10):
+    """encodings.py:36-59: rows [m c, (m + 1) c) of the table and their symbols -> `<name>_<m>.b`, m = 0 .. chunk_num - 1 (an empty chunk
+    writes an empty file, as torchac does for no symbols); returns the total bit length.  `lower`: float CDF rows (any device) or int16 rows."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    assert file_name.endswith('.b')
+    n = lower.shape[0]
+    enc = torchac.encode_int16_normalized_cdf if lower.dtype == torch.int16 else (lambda l, s_: torchac.encode_float_cdf(l, s_, check_input_bounds=True))
+
+    def one(job):
+        m, a, b = job
+        byte_stream = enc(lower[a:b], symbol[a:b]) if b > a else b""
+        with open(file_name.replace('.b', f'_{m}.b'), 'wb') as fout:
+            fout.write(byte_stream)
+        return len(byte_stream) * 8
+
+    with ThreadPoolExecutor(max_workers=chunk_num) as pool:
+        return sum(pool.map(one, _chunk_rows(n, chunk_num)))
+
+
+def multiprocess_deoder(lower, file_name, chunk_num=10):
+    """encodings.py:62-82 (the reference's spelling): the inverse -- every chunk file decoded on its own thread, results concatenated on
+    lower's device (the reference returns `.cuda()`: the same thing for its callers, whose tables are built on the GPU)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    assert file_name.endswith('.b')
+    n = lower.shape[0]
+    dec = torchac.decode_int16_normalized_cdf if lower.dtype == torch.int16 else torchac.decode_float_cdf
+
+    def one(job):
+        m, a, b = job
+        with open(file_name.replace('.b', f'_{m}.b'), 'rb') as fin:
+            byte_stream_d = fin.read()
+        if b <= a:
+            return torch.zeros(0, dtype=torch.float32, device=lower.device)
+        return dec(lower[a:b], byte_stream_d).to(torch.float32)
+
+    with ThreadPoolExecutor(max_workers=chunk_num) as pool:
+        parts = list(pool.map(one, _chunk_rows(n, chunk_num)))
+    return torch.cat(parts, dim=0).to(lower.device)
+
+
 def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
     """encodings.py:84-120.  Returns (bit_len, min_value, max_value) -- the two bounds as 0-d tensors, as the reference's."""
     assert file_name.endswith('.b')
@@ -52,6 +106,8 @@ def encoder_gaussian(x, mean, scale, Q, file_name='tmp.b'):
     x_int_round_idx = (x_int_round - min_value).to(torch.int16)
     assert (x_int_round_idx.to(torch.int32) == x_int_round - min_value).all()
     rows = _int_rows(mean, scale, Q, min_value.item(), max_value.item())
+    if use_multiprocessor:                                                   # (:114)
+        return multiprocess_encoder(rows, x_int_round_idx, file_name), min_value, max_value
     byte_stream = torchac.encode_int16_normalized_cdf(rows, x_int_round_idx)
     with open(file_name, 'wb') as fout:
         fout.write(byte_stream)
@@ -66,6 +122,9 @@ def decoder_gaussian(mean, scale, Q, file_name='tmp.b', min_value=-100, max_valu
     lo = min_value.item() if isinstance(min_value, torch.Tensor) else min_value
     hi = max_value.item() if isinstance(max_value, torch.Tensor) else max_value
     rows = _int_rows(mean, scale, Q, lo, hi)
+    if use_multiprocessor:                                                   # (:136)
+        sym_out = multiprocess_deoder(rows, file_name, chunk_num=10).to(mean.device).to(torch.float32)
+        return (sym_out + min_value) * Q
     with open(file_name, 'rb') as fin:
         byte_stream_d = fin.read()
     sym_out = torchac.decode_int16_normalized_cdf(rows, byte_stream_d).to(mean.device).to(torch.float32)

@@ -96,3 +96,38 @@ def test_degenerate_ranges_and_empty_masks(orc, tmp_path):
     fb = str(tmp_path / "m.b")
     bits = te.encoder(xb, p, fb)
     assert bits <= 8 * 16 and torch.equal(te.decoder(p, fb), xb)       # 300 x 0.15 bits
+
+
+@pytest.mark.parametrize("n", [3, 25_001])
+def test_ten_way_fan_out_writes_the_reference_chunk_files(orc, tmp_path, n, monkeypatch):
+    """use_multiprocessor = True (encodings.py:14, :36-82, :114, :136): rows [m c, (m + 1) c), c = ceil(n / 10), of the table and their symbols are
+    one torchac stream each in `<name>_<m>.b` -- every file equals the oracle's coder on that chunk of the reference's table, the decoder
+    concatenates the chunks, and the total bit length is the sum.  Ten native threads; a chunk past the end is an empty file."""
+    import os
+
+    from gauspcc_amd import torchac_encodings as te
+
+    x, mean, scale, Q = _scene(n, 11)
+    monkeypatch.setattr(te, "use_multiprocessor", True)
+    f = str(tmp_path / "feat.b")
+    bits, lo, hi = te.encoder_gaussian(x, mean, scale, Q, file_name=f)
+    xi = torch.round(x / Q)
+    lower = _reference_table(mean, scale, Q, lo.item(), hi.item())
+    rows = orc.cdf_to_int16(lower.numpy()).view(np.uint16)
+    sym = (xi - lo).numpy().astype(np.uint8)
+    c = -(-n // 10)
+    total = 0
+    for m in range(10):
+        data = open(str(tmp_path / f"feat_{m}.b"), "rb").read()
+        a, b = m * c, min(n, (m + 1) * c)
+        assert data == (orc.rc_encode(rows[a:b], sym[a:b]) if b > a else b""), m
+        total += 8 * len(data)
+    assert bits == total and not os.path.exists(f)
+    dec = te.decoder_gaussian(mean, scale, Q, file_name=f, min_value=lo, max_value=hi)
+    assert dec.dtype == torch.float32 and torch.equal(dec, xi * Q)
+    # the stand-alone entry points on a float table, as the reference calls them (:114, :136)
+    f2 = str(tmp_path / "g.b")
+    assert te.multiprocess_encoder(lower, (xi - lo).to(torch.int16), f2) == total
+    assert torch.equal(te.multiprocess_deoder(lower, f2, chunk_num=10), (xi - lo).to(torch.float32))
+    for m in range(10):
+        assert open(str(tmp_path / f"g_{m}.b"), "rb").read() == open(str(tmp_path / f"feat_{m}.b"), "rb").read()

@@ -33,3 +33,12 @@ for it in range(iters):
     t2 = time.perf_counter()
     print(f"iter {it}: {K} x {n} points, one tree {b and db}: encode {1e3 * (t1 - t0):.2f} ms, decode {1e3 * (t2 - t1b):.2f} ms, {K * n / ((t1 - t0) + (t2 - t1b)) / 1e6:.2f} Mpoints/s", flush=True)
 assert all(o.shape[0] == n for o in outs)
+from gauspcc_amd import _lib  # noqa: E402
+
+L = _lib.lib()
+L.gpcc_debug_launches(1)
+_encode_batch(xs, model, 11, [1] * K, view=True)
+ke = int(L.gpcc_debug_launches(1))
+_decode_batch(blobs, model, dev)
+kd = int(L.gpcc_debug_launches(1))
+print(f"kernels per batched encode {ke}, per batched decode {kd}", flush=True)

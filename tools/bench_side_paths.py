@@ -168,6 +168,21 @@ def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None
                            "cpu_tensors_encode_Msym_per_s": round(nt / t_ce / 1e6, 2), "cpu_tensors_decode_Msym_per_s": round(nt / t_cd / 1e6, 2),
                            "coder": "host thread (csrc/hostcoder.hip): one stream is one dependent chain; int16 rows built on the tensor's device",
                            "roundtrip": bool(torch.equal(sd.to(dev), sym_t)) and blob == blob_c}
+    # ... and the reference's ten-way fan-out (TC-GS/utils/encodings.py:36-82: ten chunk files, ten independent streams) on 2 M symbols: ten native threads
+    import tempfile
+
+    from gauspcc_amd import torchac_encodings as te
+    nf = 2_000_000
+    pf_ = torch.softmax(torch.randn(nf, lp_t - 1, generator=gm), dim=-1)
+    cdf_f = torch.cat([torch.zeros(nf, 1), torch.cumsum(pf_, dim=-1)], dim=-1).clamp(0, 1).to(dev)
+    sym_f = torch.multinomial(pf_, 1).view(-1).to(torch.int16).to(dev)
+    rows_f = tac._to_int_rows(cdf_f)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        fn = os.path.join(td, "fan.b")
+        t_fe, _ = timed(lambda: te.multiprocess_encoder(rows_f, sym_f, fn), 2)
+        t_fd, sf = timed(lambda: te.multiprocess_deoder(rows_f, fn), 2)
+    out["torchac_shim"].update({"fan_out_symbols": nf, "fan_out_chunks": 10, "fan_out_encode_Msym_per_s": round(nf / t_fe / 1e6, 2),
+                                "fan_out_decode_Msym_per_s": round(nf / t_fd / 1e6, 2), "fan_out_roundtrip": bool(torch.equal(sf.to(torch.int16), sym_f))})
     return out
 
 

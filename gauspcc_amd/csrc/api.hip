@@ -276,10 +276,9 @@ extern "C" int gpcc_model_create(gpcc_ctx *ctx, int channels, int kernel_size, c
         if (!fast) { push_raw(t[GPCC_T_CONV0 + ci], (size_t)K * C * C); continue; }
         off.push_back(h.size());
         size_t b = h.size();
-        h.resize(b + 3 * (size_t)K * C * C);
+        h.resize(b + 2 * (size_t)K * C * C);
         conv_weight_fragments(t[GPCC_T_CONV0 + ci], K, h.data() + b);
         conv_weight_fragments_t(t[GPCC_T_CONV0 + ci], K, h.data() + b + (size_t)K * C * C);
-        conv_weight_fragments_q(t[GPCC_T_CONV0 + ci], K, h.data() + b + 2 * (size_t)K * C * C);
     }
     push_rows_phys(t[GPCC_T_TEMB], 8);
     for (int s = 0; s < 4; ++s) push_raw(t[GPCC_T_HW1 + s], (size_t)C * C);
@@ -613,11 +612,10 @@ extern "C" int gpcc_conv3d(gpcc_ctx *ctx, const int32_t *xyz_sorted, int64_t n, 
             const int64_t zero_base[1] = {0};
             GP_TRY(tiles_view(ctx, st, pool, T.L - 1, T.L, zero_base, &tiles));
             // weights -> B-fragment order (32 channels); other widths keep the upstream (K, C, C) layout (network_any.hip)
-            std::vector<float> wf(C == CH ? (size_t)K * 3072 : (size_t)K * C * C);
+            std::vector<float> wf(C == CH ? (size_t)K * 2048 : (size_t)K * C * C);
             if (C == CH) {
                 conv_weight_fragments(w_host, K, wf.data());
                 conv_weight_fragments_t(w_host, K, wf.data() + (size_t)K * 1024);
-                conv_weight_fragments_q(w_host, K, wf.data() + (size_t)K * 2048);
             } else std::copy(w_host, w_host + (size_t)K * C * C, wf.begin());
             TAKE(dw, float, wf.size()); TAKE(xin, float, n * C); TAKE(xres, float, n * C); TAKE(xout, float, n * C);
             HIP_TRY(hipMemcpyAsync(dw, wf.data(), wf.size() * 4, hipMemcpyHostToDevice, st));

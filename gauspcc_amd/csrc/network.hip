@@ -28,14 +28,9 @@
 #endif
 #include CONV_LOOP_INC
 #include "conv_loop2_gfx950.inc"               // generated: tools/gen_conv_loop2.py (the pair-step loop of paired tile lists)
-// Two loops that were built, proven bit-exact, measured slower everywhere and parked (the 32x32x2 pair step -7 %,
-// half-channel waves -6 .. -35 %): they compile only with -DGAUSPCC_PARKED_VARIANTS (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
-// -> gauspcc_amd/variants/libgauspcc_parked.so, where their parity tests run them), not into the product library.
-#ifdef GAUSPCC_PARKED_VARIANTS
-#include "conv_loop3_gfx950.inc"               // generated: tools/gen_conv_loop3.py (the same step on v_mfma_f32_32x32x2_f32)
-#include "conv_looph_gfx950.inc"               // generated: CONV_ASM_HALF=1 tools/gen_conv_loop.py (the one-tile loop on 16 of the 32 output channels)
-static_assert(CONV_LOOP3_ROW_BYTES == CONV_LDS_ROW_BYTES, "all asm loops address the running sums at one LDS row pitch");
-#endif
+// (Two more loops were built, proven bit-exact and measured slower everywhere in round 4 -- the pair step on v_mfma_f32_32x32x2_f32, -7 %, and
+// half-channel waves, -6 .. -35 % -- and a 4-row tail packing on v_mfma_f32_4x4x1_16B_f32 failed its gate in round 6: their code left the tree with
+// the kernel's freeze, their numbers are profiles/r04_conv_quad_ablation.txt and profiles/r06_conv_tail_gate.txt.)
 static_assert(CONV_LOOP2_ROW_BYTES == CONV_LDS_ROW_BYTES, "both asm loops address the running sums at one LDS row pitch");
 
 namespace gpcc {
@@ -68,7 +63,7 @@ static int conv_rows_forced()
 }
 static int64_t conv_tall_min()
 {
-    static const int64_t tall_min = dev_env_ll("GAUSPCC_CONV_TALL_MIN", 64 * 256 + 1);   // 245 64-row workgroups: 22.2 us against 23.1 for 977 16-row waves at 15.6 k nodes
+    static const int64_t tall_min = 64 * 256 + 1;   // 245 64-row workgroups: 22.2 us against 23.1 for 977 16-row waves at 15.6 k nodes
     return tall_min;
 }
 
@@ -91,17 +86,6 @@ bool conv_is_coop(int64_t n, int R)
     return (R == 32 || R == 64) && !conv_rows_forced() && n < conv_tall_min() && n <= 64 * 256;
 }
 
-// GAUSPCC_CONV_QUAD: the paired blocks of the 255-row class run the 32x32x2 pair step (1) or the 16x16x4 one (0)
-bool conv_quad()
-{
-#ifdef GAUSPCC_PARKED_VARIANTS
-    static const bool q = dev_env_int("GAUSPCC_CONV_QUAD", 0) != 0;
-    return q;
-#else
-    return false;
-#endif
-}
-
 int conv_pick_rows(int64_t n, int k)
 {
     if (conv_rows_forced()) return conv_rows_forced();
@@ -120,29 +104,10 @@ int conv_pick_rows(int64_t n, int k)
 // 255-row class, 2 below); with a handful of blocks per slot the last round is mostly idle slots
 // (3.06 blocks per slot take as long as 4).  The rows are therefore cut into slots x k equal blocks, k the smallest
 // number of rounds the class allows -- slightly lower blocks, every round full.
-// Half-channel waves (k_sparse_conv_half): single levels of the 255-row class below GAUSPCC_CONV_HALF_MAX nodes, when GAUSPCC_CONV_HALF is on
-bool conv_half_level(int64_t n, int R)
-{
-#ifdef GAUSPCC_PARKED_VARIANTS
-    static const int on = dev_env_int("GAUSPCC_CONV_HALF", 0);
-    static const int64_t maxn = dev_env_int("GAUSPCC_CONV_HALF_MAX", 300000);
-    return on != 0 && R == CONV_R_MAX && n < maxn && !conv_is_coop(n, R);
-#else
-    (void)n; (void)R;
-    return false;
-#endif
-}
-
 int conv_pick_height(int64_t n, int R)
 {
     static const int balance = dev_env_int("GAUSPCC_CONV_BALANCE", 2);
     if (!balance || R <= 16 || conv_is_coop(n, R)) return R;
-    if (conv_half_level(n, R)) {
-        // two waves per block: GAUSPCC_CONV_HALF_BLOCKS blocks (1 024: two waves per SIMD; 512: one, on blocks twice as tall) in one round
-        static const int64_t hb = std::max(64, dev_env_int("GAUSPCC_CONV_HALF_BLOCKS", 1024));
-        const int64_t k = cdiv(n, hb * R);
-        return (int)std::min<int64_t>(R, std::max<int64_t>(cdiv(n, hb * k), 16));
-    }
     const int64_t slots = 1024 * (int64_t)(R >= 255 ? 1 : 2);
     const int64_t k = cdiv(n, slots * R);
     // measured (MI355X, 1 M-point cloud): with the longest-first order a last round that is mostly full costs nothing
@@ -174,7 +139,6 @@ __device__ unsigned long long g_conv_timing[16];
 // PAIR (with ASM): the pool holds paired lists (tiles.hip: every run an even number of tiles) for the blocks whose runs are long
 // enough (T.pflag); those run the pair-step loop of conv_loop2_gfx950.inc -- two tiles of one kernel offset per step, one
 // weight fragment for both -- the others the one-tile loop.
-// PAIR = 2: the pair-step loop on v_mfma_f32_32x32x2_f32 (conv_loop3_gfx950.inc) for the paired blocks
 template <int R, int DIST, bool ASM, int PAIR = 0>
 __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_sparse_conv(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
 {
@@ -335,15 +299,6 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
                 atomicAdd(&g_conv_timing[14], (unsigned long long)sw2); atomicAdd(&g_conv_timing[15], (unsigned long long)sw3);
             }
 #else
-#ifdef GAUSPCC_PARKED_VARIANTS
-            if (PAIR == 2 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
-                asm volatile(CONV_LOOP3_ASM
-                             : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
-                             : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 2048), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
-                               [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
-                             : CONV_LOOP3_CLOBBERS);
-            else
-#endif
             if (PAIR == 1 && __builtin_amdgcn_readfirstlane((int)T.pflag[blk]))
                 asm volatile(CONV_LOOP2_ASM
                              : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
@@ -496,105 +451,6 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     }
 }
 
-#ifdef GAUSPCC_PARKED_VARIANTS
-// HALF-CHANNEL waves (round 4; levels whose blocks do not fill the chip's 1 024 wave slots -- a decoder's levels of 16 k .. ~300 k nodes).
-// A block is given to TWO waves: wave h computes output channels 16 h .. 16 h + 15 of every tile -- 8 of the 16 MFMAs, half a weight
-// fragment, one 16-byte piece of running sums per lane at a 64-byte LDS pitch -- from the same tile list and the same gathered rows.
-// A workgroup is 8 waves (2 per SIMD) on 4 blocks; per wave (R + 1) x 64 B of sums + its own header ring: 8 x 20.4 KB = the CU's LDS.
-// The two waves never meet: a row's 32 sums are two independent halves, each the same chain of additions in offset order as in the
-// whole-row kernels -- bit-identical.  What it buys: twice the waves for the same block height (or the same waves on blocks twice as
-// tall: fewer, fuller tiles), and the second wave of a SIMD runs while the first waits.  What it costs: every gathered row is loaded by
-// both waves (L1 traffic per MFMA x 1.5) and one accumulator chain per wave (40 instead of 32 cycles per dependent MFMA when alone).
-constexpr int ROWF_H = CONV_LDS_ROW_BYTES_H / 4;
-static_assert(ROWF_H == 16, "half rows: 16 channels, no pad");
-__host__ __device__ constexpr int conv_lds_wave_floats_half(int R) { return (R + 1) * ROWF_H + HDR_DWORDS; }
-
-template <int R>
-__global__ __launch_bounds__(128 * SC_WAVES, 1) void k_sparse_conv_half(ConvBatch jobs, ConvTiles T, int n, int relu, int njobs)
-{
-    constexpr int LDS_WAVE = conv_lds_wave_floats_half(R);
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int half = wave & 1;
-    const uint32_t total = (uint32_t)T.nblk * (uint32_t)njobs;
-    const uint32_t w = (uint32_t)(blockIdx.x * SC_WAVES + (wave >> 1));
-    if (w >= total) return;
-    const uint32_t job = w % (uint32_t)njobs, slot = w / (uint32_t)njobs;
-    ConvJob J = jobs.job[0];
-    if (job == 1) J = jobs.job[1];
-    if (job == 2) J = jobs.job[2];
-    if (job == 3) J = jobs.job[3];
-    const int blk = __builtin_amdgcn_readfirstlane((int)T.order[slot]);
-    int lvi = 0;
-    for (int i = 1; i < T.nlv; ++i) lvi = blk >= (int)T.lv_blk0[i] ? i : lvi;
-    const int lrow0 = (blk - (int)T.lv_blk0[lvi]) * T.H;
-    const int nrows = min(T.H, (int)T.lv_rows[lvi] - lrow0);
-    const int row0 = (int)T.lv_row0[lvi] + lrow0;
-    J.in += (size_t)T.lv_row0[lvi] * 32;
-    float *acc = lds + wave * LDS_WAVE;
-    float4 *acc4 = reinterpret_cast<float4 *>(acc);
-    int32_t *hdr = reinterpret_cast<int32_t *>(acc + (R + 1) * ROWF_H);
-    constexpr int RQ = ROWF_H / 4;              // 16-byte units per LDS half row
-#pragma unroll
-    for (int it = 0; it < (R * RQ + 63) / 64; ++it)
-        if (it * 64 + lane < R * RQ) acc4[RQ + it * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // slots 1..R
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk]), t1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)T.first[blk + 1]);
-    if (t0 < t1) {
-        const uint32_t nt = t1 - t0;
-        const int4 *__restrict__ gtj = reinterpret_cast<const int4 *>(T.tj + (size_t)t0 * 16) + lane;
-        const uint32_t *__restrict__ gtr = reinterpret_cast<const uint32_t *>(T.tr + (size_t)t0 * 16) + lane;
-        const uint32_t *__restrict__ gto = T.toc + t0 + (lane & 15);
-        int4 *sj = reinterpret_cast<int4 *>(hdr) + lane;
-        int32_t *sr = hdr + HDR_R + lane;
-        int32_t *so = hdr + HDR_O + (lane & 15);
-        {   // header batches 0 and 1 straight into the ring (and batch 0 into its mirror behind slot 31), as in k_sparse_conv
-            const int4 a0 = gtj[0], a1 = gtj[64];
-            const uint32_t b0 = gtr[0], b1 = gtr[64], c0 = gto[0], c1 = gto[16];
-            sj[0] = a0; sj[64] = a1;
-            sr[0] = (int32_t)b0; sr[64] = (int32_t)b1;
-            so[0] = (int32_t)(c0 & 0xFFFFu); so[16] = (int32_t)(c1 & 0xFFFFu);
-            sj[128] = a0;
-            sr[128] = (int32_t)b0;
-            so[32] = (int32_t)(c0 & 0xFFFFu);
-        }
-        uint32_t su, st0, st1;
-        const uint32_t acc_lds = __builtin_amdgcn_groupstaticsize() + (uint32_t)(wave * LDS_WAVE * 4);
-        const uint32_t hdr_lds = acc_lds + (uint32_t)((R + 1) * ROWF_H * 4);
-        // the transposed fragments (conv_weight_fragments_t): [o][half][...] -- this wave's half is 512 floats into an offset's 1 024
-        asm volatile(CONV_LOOPH_ASM
-                     : [u] "=&s"(su), [t0] "=&s"(st0), [t1] "=&s"(st1)
-                     : [in] "s"(J.in), [w] "s"(J.w + (size_t)T.K * 1024 + (size_t)half * 512), [tj] "s"(T.tj + (size_t)t0 * 16), [tr] "s"(T.tr + (size_t)t0 * 16), [toc] "s"(T.toc + t0),
-                       [nt] "s"(nt), [acc] "s"(acc_lds), [hdr] "s"(hdr_lds), [lane] "v"(lane)
-                     : CONV_LOOPH_CLOBBERS);
-    }
-    // epilogue: this wave's 64-byte halves of the block's rows; a wave instruction copies 16 rows (lane / 4 = row of the group, lane % 4 =
-    // 16-byte piece).  Residual rows requested up front, loads on clamped addresses, only the stores predicated (as in k_sparse_conv).
-    {
-        const int nvec = nrows * 4;                 // float4 elements of this wave's half block
-        const bool has_res = J.res != nullptr;
-        const float4 *__restrict__ res4 = reinterpret_cast<const float4 *>(J.res) + (size_t)row0 * 8 + half * 4;
-        float4 *__restrict__ out4 = reinterpret_cast<float4 *>(J.out) + (size_t)row0 * 8 + half * 4;
-        const float4 *src = acc4 + RQ + lane;       // slot 1 = row 0; 64 consecutive 16-byte units = 16 half rows
-        constexpr int NG = (R * 4 + 63) / 64;       // 16-row groups of a full-height block
-        const int goff = (lane >> 2) * 8 + (lane & 3);   // float4 index of my piece inside a 16-row group of the (n, 32) array
-        float4 r[NG];
-        if (has_res) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) { const int v = min(g * 64 + lane, nvec - 1); r[g] = res4[(size_t)(v >> 2) * 8 + (v & 3)]; }
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g * 64 < nvec) {   // wave-uniform
-                float4 v = src[g * 64];
-                if (has_res) { v.x = v.x + r[g].x; v.y = v.y + r[g].y; v.z = v.z + r[g].z; v.w = v.w + r[g].w; }
-                if (relu) { v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f; }
-                if (g * 64 + lane < nvec) out4[(size_t)g * 128 + goff] = v;
-            }
-        }
-    }
-}
-#endif   // GAUSPCC_PARKED_VARIANTS
 
 
 // Small levels (16-row blocks: every (block, offset) pair is exactly one tile, a block's list is a serial chain of up to
@@ -896,7 +752,6 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     ConvRec rec = {0, 0, level, njobs, T.R, T.H, (long long)n, (long long)T.nblk, 1};
     if (chained) { ConvRec &c = ctx->prof.chain; c.level = level; c.njobs = njobs; c.R = T.R; c.H = T.H; c.n = (long long)n; c.nblk = (long long)T.nblk; c.launches += 1; }
     if (prof) GP_TRY(prof_event(ctx, st, &rec.e0));
-    static const int dist = [] { const int d = dev_env_int("GAUSPCC_CONV_DIST", 1); return d < 1 || d > 3 ? 1 : d; }();
     static const int use_asm = dev_env_int("GAUSPCC_CONV_ASM", 1) != 0;
     static PerDeviceOnce lds_attr;
     int cur_dev = 0;
@@ -906,14 +761,8 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
-#ifdef GAUSPCC_PARKED_VARIANTS
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_half<255>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SC_WAVES * conv_lds_wave_floats_half(255) * 4));
-#endif
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<255, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, SC_WAVES * conv_lds_wave_floats(255) * 4));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv<128, 3, false>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(343, 16)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(125, 32)));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sparse_conv_coop<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)coop_lds_bytes(125, 64)));
@@ -927,7 +776,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     // (A second cooperative kernel -- 8 waves, two workgroups per CU, transposed products parked with 16-byte swizzled
     // stores, operands one tile ahead -- was built and measured in round 3: 25.1 / 34.3 / 24.7 us at 160 / 263 / 315 blocks
     // against 25.8 / 36.5 / 22.5: a block's ~100 tiles move ~750 KB through one CU's L1 whatever the schedule.  Dropped.)
-    static const int split_max = dev_env_int("GAUSPCC_CONV_SPLIT_MAX", 64);
+    static const int split_max = 64;
     const size_t prod_floats = ((size_t)T.nblk * (size_t)T.K + CONV_HDR_PAD) * 512;
     if (T.R == 16 && use_coop && use_split && ctx && T.K <= 343 && T.nblk <= split_max && prod_floats * 4 <= ((size_t)768 << 20)) {
         if (ctx->conv_products_cap < prod_floats) {
@@ -992,7 +841,7 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     }
     dim3 grid((unsigned)cdiv(T.nblk * njobs, SC_WAVES), 1u);   // work items = blocks x jobs, one per wave
     const size_t lds_bytes = (size_t)SC_WAVES * conv_lds_wave_floats(T.R) * 4;
-    const bool asm_ok = use_asm && dist == 1 && n < ((int64_t)1 << 25);   // the asm loop addresses rows with 32-bit byte offsets
+    const bool asm_ok = use_asm && n < ((int64_t)1 << 25);   // the asm loop addresses rows with 32-bit byte offsets
 #define CONV_LAUNCH(RR, DD, AA) k_sparse_conv<RR, DD, AA><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs)
     switch (T.R) {
     case 16: if (asm_ok) CONV_LAUNCH(16, 1, true); else CONV_LAUNCH(16, 1, false); break;
@@ -1000,20 +849,12 @@ int sparse_conv(gpcc_ctx *ctx, int level, hipStream_t st, const ConvBatch &jobs,
     case 64: if (asm_ok) CONV_LAUNCH(64, 1, true); else CONV_LAUNCH(64, 1, false); break;
     case 96: if (asm_ok) CONV_LAUNCH(96, 1, true); else CONV_LAUNCH(96, 1, false); break;
     case 255:
-#ifdef GAUSPCC_PARKED_VARIANTS
-        if (asm_ok && !T.paired && T.nlv == 1 && conv_half_level(n, T.R))
-            k_sparse_conv_half<255><<<grid, 128 * SC_WAVES, (size_t)2 * SC_WAVES * conv_lds_wave_floats_half(255) * 4, st>>>(jobs, T, (int)n, relu, njobs);
-        else if (asm_ok && T.paired && conv_quad()) k_sparse_conv<255, 1, true, 2><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
-        else
-#endif
         if (asm_ok && T.paired) k_sparse_conv<255, 1, true, 1><<<grid, 64 * SC_WAVES, lds_bytes, st>>>(jobs, T, (int)n, relu, njobs);
         else if (asm_ok) CONV_LAUNCH(255, 1, true);
         else CONV_LAUNCH(255, 1, false);
         break;
     default:
         if (asm_ok) CONV_LAUNCH(128, 1, true);
-        else if (dist == 3) CONV_LAUNCH(128, 3, false);
-        else if (dist == 2) CONV_LAUNCH(128, 2, false);
         else CONV_LAUNCH(128, 1, false);
         break;
     }

@@ -63,24 +63,11 @@ inline void conv_weight_fragments_t(const float *W, int K, float *out)
                     }
 }
 
-// The same kernel as the A operand of the 32x32x2 pair step (tools/gen_conv_loop3.py): MFMA row m = PHYSICAL output channel m (lane
-// l supplies row l % 32), MFMA number s of a step multiplies logical input channels k = 2 s + l / 32:
-// [o][q][lane][r] = W[o][2 (4 q + r) + lane / 32][logical_of(lane % 32)]      (four coalesced 1 KiB loads per offset, as the others)
-inline void conv_weight_fragments_q(const float *W, int K, float *out)
-{
-    for (int o = 0; o < K; ++o)
-        for (int q = 0; q < 4; ++q)
-            for (int lane = 0; lane < 64; ++lane)
-                for (int r = 0; r < 4; ++r)
-                    out[(((size_t)o * 4 + q) * 64 + lane) * 4 + r] = W[((size_t)o * 32 + (2 * (4 * q + r) + (lane >> 5))) * 32 + logical_of(lane & 31)];
-}
-
 constexpr int STAGE_M[4] = {2, 2, 4, 16};
 
 struct ConvJob {
     const float *in;   // (n,32) physical
-    const float *w;    // K x 1024 floats in B-fragment order, then K x 1024 in the transposed order (conv_weight_fragments_t), then K x 1024 in the
-                       // 32x32x2 order (conv_weight_fragments_q)
+    const float *w;    // K x 1024 floats in B-fragment order, then K x 1024 in the transposed order (conv_weight_fragments_t)
     const float *res;  // nullable, physical
     float *out;        // physical
 };
@@ -116,8 +103,7 @@ struct ConvTiles {
 };
 int conv_pick_rows(int64_t n, int k = 5);  // policy (env GAUSPCC_CONV_R overrides)
 bool conv_is_coop(int64_t n, int R);     // does a level of n nodes at block class R run the cooperative kernel (16 / 32 / 64-row blocks, H = R)?
-int conv_pick_height(int64_t n, int R);
-bool conv_half_level(int64_t n, int R);   // the level runs on half-channel waves (k_sparse_conv_half): its tile list is not paired  // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
+int conv_pick_height(int64_t n, int R);   // rows per block for capacity class R (env GAUSPCC_CONV_BALANCE=0: H = R)
 
 // Tile lists of several levels in one pool (tiles.hip).  Level l is built from its parent level's cell map (par == nullptr:
 // a base level of < 64 nodes, searched directly); cell_own, when not null, receives the level's own cell map

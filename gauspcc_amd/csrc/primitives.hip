@@ -7,6 +7,7 @@
 //                    lanes that hold the same digit, popcount of the lower lanes is the rank),
 //                    running per-digit counters in LDS across the 16 rounds of a tile.
 // HBM-bound integer work: per pass it reads keys twice and writes them once.
+#include <algorithm>
 #include "primitives.hpp"
 #include <atomic>
 
@@ -306,17 +307,30 @@ int device_error_check(gpcc_ctx *ctx)
 // the scan state of (context, stream): created on first use (one hipMalloc + memset per stream of a context)
 static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
 {
-    for (auto &ss : ctx->scan_states)
-        if (ss.st == st) { *out = &ss; return GPCC_OK; }
+    for (size_t i = 0; i < ctx->scan_states.size(); ++i)
+        if (ctx->scan_states[i].st == st) {
+            // most recently used last: the context's own streams and the caller's usual stream stay, a stream seen once is what goes
+            if (i + 1 != ctx->scan_states.size()) std::rotate(ctx->scan_states.begin() + (ptrdiff_t)i, ctx->scan_states.begin() + (ptrdiff_t)i + 1, ctx->scan_states.end());
+            *out = &ctx->scan_states.back();
+            return GPCC_OK;
+        }
     // A caller that cycles through raw stream handles must not grow this for ever (a context's own calls use its three streams and
-    // the caller's): beyond SCAN_STATES_MAX the oldest state is retired -- its stream is drained first, so no scan of it is in flight.
+    // the caller's): beyond SCAN_STATES_MAX the LEAST RECENTLY USED state of a foreign stream is retired (never one of the context's own
+    // streams: round 5 evicted first-in-first-out, i.e. exactly those, and paid a drain + free + malloc on every later call).  Its handle may
+    // already be destroyed, so it is not synchronised -- the device is: nothing of any stream is in flight when the buffer changes hands.
     constexpr size_t SCAN_STATES_MAX = 8;
+    unsigned long long *recycled = nullptr;
     if (ctx->scan_states.size() >= SCAN_STATES_MAX) {
-        gpcc_ctx::ScanState old = ctx->scan_states.front();
-        (void)hipStreamSynchronize(old.st);   // (a destroyed stream reports an error here: nothing of it is in flight either)
+        size_t victim = ctx->scan_states.size();
+        for (size_t i = 0; i < ctx->scan_states.size(); ++i) {
+            const hipStream_t s = ctx->scan_states[i].st;
+            if (s != ctx->side && s != ctx->xfer) { victim = i; break; }
+        }
+        if (victim == ctx->scan_states.size()) victim = 0;
+        (void)hipDeviceSynchronize();
         (void)hipGetLastError();
-        if (old.status) (void)hipFree(old.status);
-        ctx->scan_states.erase(ctx->scan_states.begin());
+        recycled = ctx->scan_states[victim].status;
+        ctx->scan_states.erase(ctx->scan_states.begin() + (ptrdiff_t)victim);
     }
     if (!ctx->dev_err) {
         void *h = nullptr;
@@ -328,8 +342,8 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
         ctx->dev_err_dev = static_cast<uint32_t *>(d);
     }
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
-    void *p = nullptr;
-    HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + 256));
+    void *p = recycled;
+    if (!p) HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + 256));
     // ON THE STREAM that will use it: a hipMemset on the null stream is not ordered with a non-blocking stream, and may return before it
     // has run -- it then zeroed the ticket word under a running scan (found with tools/inflight_side.py: tiles drawn twice, others
     // never, their successors spinning for ever)

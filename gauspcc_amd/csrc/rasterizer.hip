@@ -34,12 +34,16 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 // tile is therefore dead weight in the sort and in the tile's list -- about a third of all pairs (corners of the squares, thin or faint splats).
 // q(d) = -power(d) = 0.5 (A dx^2 + C dy^2) + B dx dy is convex with its minimum 0 at the centre, so its minimum over the tile's rectangle of
 // pixel centres is 0 when the centre lies inside and is attained on one of the four edges otherwise (a 1-D quadratic each, clamped).  The pair is
-// kept when that minimum <= ln(255 op) + margin; the margin (2e-3, twice k_render's own pre-test) leaves every borderline pixel to the exact test
-// in the blend, so the image is bit-identical with and without culling (tests/test_gpu_rasterizer.py) and only the lists get shorter.
+// kept when that minimum <= ln(255 op) + margin; the margin leaves every borderline pixel to the exact test in the blend, so the image is
+// bit-identical with and without culling (tests/test_gpu_rasterizer.py) and only the lists get shorter.  The margin has an absolute part (2e-3,
+// twice k_render's own pre-test) and, since round 6, a part that SCALES WITH THE TERMS: for a long thin splat far from its centre each of the
+// three terms of q is ~1e6 and they cancel down to q ~ 5, so the fp32 edge minimum here and the per-pixel power of k_render (another order of
+// the same operations) may differ by several ulp of 1e6 -- far more than 2e-3.  8 eps x (|term| summed) bounds both sides' error.
 __device__ __forceinline__ float edge_min(float c, float lo, float hi, float Ac, float Bm, float Cv)
-{   // min over v in [lo, hi] of 0.5 Ac c^2 + Bm c v + 0.5 Cv v^2
+{   // min over v in [lo, hi] of 0.5 Ac c^2 + Bm c v + 0.5 Cv v^2, less the rounding slack of its evaluation (Ac, Cv > 0)
     const float v = fminf(hi, fmaxf(lo, -Bm * c / Cv));
-    return 0.5f * Ac * c * c + Bm * c * v + 0.5f * Cv * v * v;
+    const float t0 = 0.5f * Ac * c * c, t1 = Bm * c * v, t2 = 0.5f * Cv * v * v;
+    return (t0 + t1 + t2) - 9.6e-7f * (t0 + fabsf(t1) + t2);
 }
 __device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, float B, float C, float lim, int tx, int ty)
 {
@@ -290,7 +294,8 @@ __global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges,
             s_a[threadIdx.x] = make_float4(p.x, p.y, co.x, co.y);
             s_b[threadIdx.x] = make_float4(co.z, co.w, colors[3 * id], colors[3 * id + 1]);
             // alpha = op * exp(power) >= 1 / 255  <=>  power >= -ln(255 op); a margin keeps the borderline pixels on the exact test below
-            s_c[threadIdx.x] = make_float2(colors[3 * id + 2], co.w > 0.0f ? -__logf(255.0f * co.w) - 1e-3f : __builtin_inff());
+            // (a NaN opacity blends as alpha 0.99 in the reference -- fminf(0.99, NaN) -- so it must pass the pre-test: threshold -inf)
+            s_c[threadIdx.x] = make_float2(colors[3 * id + 2], co.w > 0.0f ? -__logf(255.0f * co.w) - 1e-3f : (co.w != co.w ? -__builtin_inff() : __builtin_inff()));
         } else {
             // behind the list: a Gaussian of opacity 0 (alpha 0 < 1 / 255: never blended), so that the loop below runs in pairs
             s_a[threadIdx.x] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[threadIdx.x] = make_float4(1.f, 0.f, 0.f, 0.f); s_c[threadIdx.x] = make_float2(0.f, __builtin_inff());
@@ -310,11 +315,11 @@ __global__ __launch_bounds__(RT) void k_render(const uint2 *__restrict__ ranges,
             const float pb1 = -0.5f * (a2.z * dxb * dxb + bq2.x * dyb1 * dyb1) - a2.w * dxb * dyb1;
             // a Gaussian whose footprint misses all 128 pixels of the wave (most of a tile's list at the corners of the 3-sigma boxes, and
             // every Gaussian that only touches the tile's other half) costs the twelve instructions above and no exponential
-            if (__builtin_amdgcn_ballot_w64((!done0 && pa0 >= cb.y && !(pa0 > 0.0f)) || (!done1 && pa1 >= cb.y && !(pa1 > 0.0f))) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64((!done0 && !(pa0 < cb.y) && !(pa0 > 0.0f)) || (!done1 && !(pa1 < cb.y) && !(pa1 > 0.0f))) != 0ull) {   // (a NaN power passes, as in the reference's `if (power > 0) continue`)
                 blend_one(pa0, bq.y, bq.z, bq.w, cb.x, done0, T0, A0, A1, A2);
                 blend_one(pa1, bq.y, bq.z, bq.w, cb.x, done1, T1, B0, B1, B2);
             }
-            if (__builtin_amdgcn_ballot_w64((!done0 && pb0 >= cb2.y && !(pb0 > 0.0f)) || (!done1 && pb1 >= cb2.y && !(pb1 > 0.0f))) != 0ull) {
+            if (__builtin_amdgcn_ballot_w64((!done0 && !(pb0 < cb2.y) && !(pb0 > 0.0f)) || (!done1 && !(pb1 < cb2.y) && !(pb1 > 0.0f))) != 0ull) {
                 blend_one(pb0, bq2.y, bq2.z, bq2.w, cb2.x, done0, T0, A0, A1, A2);
                 blend_one(pb1, bq2.y, bq2.z, bq2.w, cb2.x, done1, T1, B0, B1, B2);
             }

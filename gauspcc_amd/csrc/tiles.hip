@@ -512,8 +512,8 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     pool->first = first;
     LevelTilesArgs a = {};
     static const bool pair_on = dev_env_int("GAUSPCC_CONV_PAIR", 1) != 0;
-    static const int pair_min = dev_env_int("GAUSPCC_CONV_PAIR_MIN", 150);   // x 0.01 tiles per run
-    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on && !(nlv == 1 && conv_half_level(lv[0].lv->n, R))) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block); half-channel levels run the one-tile loop
+    static const int pair_min = 150;   // x 0.01 tiles per run (sweep 100 .. 250: profiles/r03_*, DESIGN history round 3)
+    pool->paired = (H > 64 && R == CONV_R_MAX && pair_on) ? std::max(pair_min, 1) : 0;   // tall blocks of the wave-serial class may be paired (block by block)
     pool->pflag = nullptr;
     // Three arrays that start zeroed -- the pair flags (the base level's block, built by k_base_tiles, is never paired), the per-chunk counts of
     // the tall blocks (blocks of 2 or 3 chunks leave the other columns untouched) and the spread pair counters -- carved back to back and
@@ -567,18 +567,10 @@ int tiles_build(gpcc_ctx *ctx, hipStream_t st, const TileLevel *lv, int nlv, int
     if (H <= 16) cap = nblk * K + CONV_HDR_PAD;
     else if (H <= 64 && H % 16 == 0 && conv_is_coop(rows_total, R)) cap = nblk * K * (H / 16) + CONV_HDR_PAD;
     else {
-        // A single level (the decoder builds one per level, beside the parent trunk) CAN be sized by the bound as well -- a (block, offset)
-        // run holds at most ceil(H / 16) tiles, one more where odd runs are padded to pairs: ~660 B per node at 255 rows -- so that the host
-        // never waits for the count pass (GAUSPCC_TILES_BOUND=1).  Measured in round 4 (S1M, 10 steps, same box): dec_ms 26.93 with the
-        // bound, 26.95 with the five syncs -- they fall on the second stream while the first runs a parent trunk, and the host is ahead
-        // either way.  Off by default: the exact size keeps the workspace smaller.
-        static const bool by_bound = dev_env_int("GAUSPCC_TILES_BOUND", 0) != 0;
-        int64_t tpr = cdiv(H, 16);
-        if (pool->paired) tpr = (tpr + 1) & ~(int64_t)1;
-        const int64_t bound = nblk * K * tpr;
-        if (!batch && by_bound && bound < (int64_t)1 << 27) {
-            cap = bound + CONV_HDR_PAD;   // (profiling: the 84 B per tile written are not counted for a list whose length stays on the device)
-        } else {
+        // (A single level COULD be sized by a bound as well -- a (block, offset) run holds at most ceil(H / 16) tiles: ~660 B per node at 255 rows --
+        // so that the host never waits for the count pass.  Measured in round 4: dec_ms 26.93 with the bound, 26.95 with the five syncs -- they
+        // fall on the second stream while the first runs a parent trunk.  The exact size keeps the workspace smaller; the bound left the tree.)
+        {
             uint32_t total = 0;
             HIP_TRY(hipMemcpyAsync(&total, first + nblk, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));

@@ -49,9 +49,6 @@ print("variant ok", pairs)
 """
 
 
-PARKED_LIB = os.path.join(ROOT, "gauspcc_amd", "variants", "libgauspcc_parked.so")   # tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS
-
-
 @pytest.mark.parametrize("env", [
     {"GAUSPCC_CONV_R": "255"},
     {"GAUSPCC_CONV_R": "128"},
@@ -61,10 +58,6 @@ PARKED_LIB = os.path.join(ROOT, "gauspcc_amd", "variants", "libgauspcc_parked.so
     {"GAUSPCC_COOP_TALL": "0"},                              # the cooperative kernel on 16-row blocks only (default: 16 / 32 / 64 by level size)
     {"GAUSPCC_CONV_SPLIT": "0"},                             # no products-over-the-chip kernels on the tiniest levels
     {"GAUSPCC_CONV_PAIR": "0"},                              # one-tile asm loop everywhere
-    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "1"},    # the pair step on v_mfma_f32_32x32x2_f32 (tools/gen_conv_loop3.py)
-    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_QUAD": "0"},
-    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_HALF": "1"},    # half-channel waves: two waves per block, 16 output channels each (k_sparse_conv_half)
-    {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_HALF": "1", "GAUSPCC_CONV_HALF_BLOCKS": "64"},   # ... on tall blocks
     {"GAUSPCC_CONV_R": "128", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_ASM": "0"},
     {"GAUSPCC_CONV_R": "255", "GAUSPCC_CONV_BALANCE": "0"},
@@ -75,16 +68,6 @@ def test_conv_kernel_variant_bit_exact(env):
     e = dict(os.environ)
     e.update(env)
     e["GAUSPCC_DEV"] = "1"               # kernel-selection knobs are developer switches: ignored without it (csrc/common.hpp: dev_env_int)
-    if "GAUSPCC_CONV_QUAD" in env or "GAUSPCC_CONV_HALF" in env:
-        # the parked loops are not in the product library: their parity tests run on the variant build when it exists
-        if not os.path.exists(PARKED_LIB):
-            pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is not built (tools/build_variants.sh parked::-DGAUSPCC_PARKED_VARIANTS)")
-        # (checked in a child: this process keeps ONE copy of the library)
-        probe = "import ctypes, sys; sys.path.insert(0, %r); from gauspcc_amd import _lib; import torch; L = ctypes.CDLL(%r); print('stale', [n for n in _lib.EXPORTS if not hasattr(L, n)])" % (ROOT, PARKED_LIB)
-        pr = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, capture_output=True, text=True, timeout=300)
-        if "stale []" not in pr.stdout:
-            pytest.skip("gauspcc_amd/variants/libgauspcc_parked.so is older than the product library: rebuild it (tools/build_variants.sh) " + pr.stdout[-200:])
-        e["GAUSPCC_LIB"] = PARKED_LIB
     e.setdefault("GAUSPCC_FUSED", "0")   # these variants are about the block-tile kernels: keep the decoder's small levels on them
     r = subprocess.run([sys.executable, "-c", SNIPPET % ROOT], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

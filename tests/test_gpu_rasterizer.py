@@ -131,3 +131,46 @@ print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), rast.nu
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
     assert out[0] == out[1] == out[2] == out[3] and int(out[0].split()[-1]) > 100000
+
+
+def test_needle_splats_survive_exact_culling():
+    """ADVICE (round 5): long thin splats far from their centre -- sigma of a few hundred pixels along one axis, a fraction of a pixel across --
+    make the three terms of q = 0.5 A dx^2 + B dx dy + 0.5 C dy^2 ~1e6 each while q sits near the 1 / 255 threshold (~5): the fp32 edge minimum
+    of the tile test and k_render's per-pixel power then differ by far more than the old absolute margin, and a tile could be culled although
+    one of its pixels passes the blend test.  With the margin scaled by the magnitude of the terms the image is the same with and without
+    culling (GAUSPCC_RASTER_CULL, developer knob), bit for bit.  Contract: HAC/gaussian_renderer/__init__.py:199-225."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    snippet = r"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests.test_gpu_rasterizer import _scene, _settings
+from gauspcc_amd.rasterizer import GaussianRasterizer
+W, H, n = 1600, 1060, 4000
+sc = _scene(n, 23, W, H)
+rng = np.random.RandomState(5)
+sc["scales"][:, 0] = np.exp(rng.rand(n).astype(np.float32) * 1.5 + 0.2)      # 1.2 .. 5.5 world units: hundreds to thousands of pixels
+sc["scales"][:, 1:] = np.exp(rng.rand(n, 2).astype(np.float32) * 1.0 - 7.0)   # ~1e-3 world units: well under a pixel
+sc["opac"][:] = np.float32(0.9)
+sc["means"][:, 2] = np.abs(sc["means"][:, 2])                                  # all in front of the camera
+rast = GaussianRasterizer(_settings(torch, sc, W, H, np.array([0.0, 0.0, 0.0], np.float32)))
+t = {k: torch.tensor(v).cuda() for k, v in sc.items() if isinstance(v, np.ndarray)}
+img, radii = rast(means3D=t["means"], means2D=None, shs=None, colors_precomp=t["colors"], opacities=t["opac"], scales=t["scales"], rotations=t["rots"])
+assert bool(torch.isfinite(img).all()) and float(img.max()) > 0.05
+print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), int((radii > 200).sum()), rast.num_rendered)
+""" % root
+    out = []
+    for cull in ("1", "0"):
+        e = dict(os.environ)
+        e["GAUSPCC_DEV"] = "1"
+        e["GAUSPCC_RASTER_CULL"] = cull
+        r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0].split())
+    assert out[0][1] == out[1][1], "the image changed with exact tile culling"
+    assert int(out[0][2]) > 500                    # the scene really is needles: radii of hundreds of pixels

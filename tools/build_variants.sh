@@ -5,8 +5,6 @@
 #   rb128:CONV_ASM_ROWB=128    LDS row pitch of 128 bytes (the bank-conflicted layout of rounds 1-2)
 #   timing::-DCONV_TIMING      shader-clock stamps per phase
 #   noepi::-DCONV_NO_EPILOGUE  ablation: no copy-out (results are WRONG on purpose)
-#   parked::-DGAUSPCC_PARKED_VARIANTS   the two parked loops (32x32x2 pair step, half-channel waves: DESIGN.md section 4, round 4) compiled in;
-#                              tests/test_gpu_conv_variants.py runs their parity tests on this library when it exists
 # (the other objects come from the regular build: run `make -C gauspcc_amd/csrc` first; pair-loop ablations: CONV_ASM_EXP2=.. tools/gen_conv_loop2.py, then
 #  rebuild network.o by hand and regenerate the include)
 # Time them with  GAUSPCC_LIB=gauspcc_amd/variants/libgauspcc_<name>.so python tools/enc_only.py

@@ -43,7 +43,7 @@ EXP = int(os.environ.get("CONV_ASM_EXP", "0"))   # developer experiments: 1 no s
                                                  # 32 as 16, but the odd tiles still issue four loads -- of one 16-byte address for all lanes, into scratch registers (issue slots kept, L1 traffic gone)
 DX = int(os.environ.get("CONV_ASM_DX", "3"))     # issue distance of the gathered rows (steps); X ring = DX + 1 sets (7: measured, no gain)
 DW = 3                                           # issue distance of the weight fragments; W ring = DW + 1 sets
-HALF = int(os.environ.get("CONV_ASM_HALF", "0"))   # 1: the HALF-CHANNEL loop (round 4): the wave computes 16 of the 32 output channels of its block -- 8 MFMAs a tile, one
+HALF = 0   # (the half-channel loop of round 4 -- 16 of the 32 output channels per wave, measured -6 .. -35 % -- left the tree with the kernel's freeze in round 6; the HALF branches below document what it changed)
                                                      # 16-byte piece of running sums per lane, half a weight fragment (two loads); two such waves share a block's tile list
 ROWB = int(os.environ.get("CONV_ASM_ROWB", "64" if HALF else "144"))   # LDS bytes per row of running sums (128 + one 16-byte pad: bank rotation, network.hip; half rows: 64, no pad)
 assert DX in (3, 7) and ROWB % 16 == 0 and ROWB >= (64 if HALF else 128)

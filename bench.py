@@ -355,7 +355,7 @@ def main():
     # = log of the stage symbols' empirical frequencies, i.e. the context-free entropy of the occupancy symbols; 3-6 bpp on this cloud needs
     # spatial context, i.e. a trained checkpoint), (ii) a SOLID cloud (synth.solid_cloud) under its own peaky model: 2.5 bits per coded node,
     # the range coder's low-entropy regime.  chunk_overhead_frac is measured (chunked bytes against chunk_log2 = 0 bytes), not extrapolated.
-    reference_layout, low_rate = None, None
+    reference_layout, low_rate, chunk_sweep = None, None, None
     if rank == 0 and world == 1 and not args.skip_sizes and args.chunk_log2:
         from gauspcc_amd.synth import peaky_state_dict, solid_cloud, stage_symbol_frequencies
 
@@ -387,6 +387,13 @@ def main():
                             # four symbols per coded node; a stream is one dependent chain, so the decode is bounded by what ONE lane decodes
                             "coded_symbols": int(4 * st0_.coded_nodes),
                             "decode_Msymbols_per_s": round(4 * st0_.coded_nodes / td0 / 1e6, 2), "encode_Msymbols_per_s": round(4 * st0_.coded_nodes / te0 / 1e6, 2)}
+        # The chunk size trades bytes for decode latency (a lane of 2^(chunk_log2 - 1) symbols is one dependent chain; chunks cost ~2.3 bytes each):
+        # the same cloud and weights at other chunk sizes, so that the operating point of `value` (chunk_log2 = 11) can be judged against its neighbours
+        chunk_sweep = []
+        for cl in (9, 10, 11, 12, 13):
+            blob_c, te_c, td_c, _, ok_c = layout_point(x, pts, model, cl, 4)
+            chunk_sweep.append({"chunk_log2": cl, "enc_ms": round(te_c * 1e3, 3), "dec_ms": round(td_c * 1e3, 3), "value": round(n_l / (te_c + td_c) / 1e6, 4),
+                                "bytes": len(blob_c), "overhead_frac_vs_v0": round((len(blob_c) - len(blob0)) / len(blob0), 5), "roundtrip_bit_identical": ok_c})
         low_rate = []
         for label, cloud_fn, sd_fn in (
                 ("bench cloud, peaky model (head biases = log stage-symbol frequencies, head weights x 0.25)", lambda: (x, pts), lambda p_: peaky_state_dict(32, k)),
@@ -484,6 +491,7 @@ def main():
             "batched": batched,
             "reference_layout": reference_layout,
             "low_rate": low_rate,
+            "chunk_sweep": chunk_sweep,
             "coded_nodes": int(allstats[0, 3]),
             "ranks": [{"bytes": int(r_[0]), "coded_nodes": int(r_[3]), "enc_ms": round(float(r_[1]) * 1e3, 3), "dec_ms": round(float(r_[2]) * 1e3, 3)} for r_ in allstats],
             "roundtrip_bit_identical": True,

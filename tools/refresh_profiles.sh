@@ -3,7 +3,7 @@
 # (every step under its own `timeout`; PMC passes never combined with tracing)
 set -u
 OUT=$1
-R=${2:-r05}
+R=${2:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
@@ -54,6 +54,10 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES 
 python3 tools/pmc_summary.py "$OUT/sq_r" "k_render" > "$OUT/${R}_render_counters.txt"; python3 tools/pmc_summary.py "$OUT/sq_r" "k_preprocess" >> "$OUT/${R}_render_counters.txt"
 python3 tools/pmc_summary.py "$OUT/sq_r" "k_ng_emit" >> "$OUT/${R}_render_counters.txt"; python3 tools/pmc_summary.py "$OUT/sq_r" "k_ng_opacity" >> "$OUT/${R}_render_counters.txt"
 rm -rf "$OUT/sq_r"
+# 4c. the conv tail-packing gate (round 6): the 4x4x1_16B micro-benchmark (the list-length model is a CPU script: tools/tile_fill_model.py)
+[ -x tools/ubench/mfma_tail ] && timeout 120 ./tools/ubench/mfma_tail > "$OUT/${R}_mfma_tail.txt" 2>&1
+# 4d. the persistent-class boundary (round 6): batches and the solo scene with merged levels of up to 40 k / 64 k nodes on the persistent launches
+{ for fm in 16384 40000 65536; do for cfg in "8 100000" "32 10000" "2 1000000"; do echo "== GAUSPCC_FUSED_MAX=$fm  batch_probe $cfg"; GAUSPCC_DEV=1 GAUSPCC_FUSED_MAX=$fm timeout 200 python3 tools/batch_probe.py $cfg 4 2>&1 | grep -E "^iter [23]|kernels per"; done; done; } > "$OUT/${R}_batch_fused_max.txt" 2>&1
 # 5. the grid-barrier / launch-chain microbenchmark behind the small-level fusion decision (built by tools/build_variants.sh or by hand)
 [ -x tools/ubench/grid_sync ] && timeout 300 ./tools/ubench/grid_sync > "$OUT/${R}_grid_sync.txt" 2>&1
 tail -1 "$OUT/${R}_bench.json"

@@ -513,7 +513,7 @@ def main():
                 # every bracket is a hipEventRecord on the kernel's stream and costs it ~5 us; `event_steps` of the timed
                 # steps carry them (launches / avg_launch_us / achieved are over those steps)
                 "event_steps": ev_steps,
-                # the HBM-bound stages either side of the convolutions: algorithmic bytes over the
+                # the HBM-bound stages either side of the convolutions: algorithmic bytes (HISTORY.md section 4) over the
                 # event-bracketed time of one extra untimed step; latency- / launch-bound at this size, not bandwidth-bound
                 "stages": stages,
                 # the decoder's levels of at most 16 k nodes run as persistent launches (csrc/fused.hpp), not as k_sparse_conv: their time

@@ -4,7 +4,7 @@ Importing the package has no side effects on the host application.  A process th
 on a GPU (two scenes in flight, `--jobs 2`) should call `gauspcc_amd.export_hw_queues()` -- or export GPU_MAX_HW_QUEUES=8
 itself -- BEFORE its first GPU call: the HIP runtime maps a process's streams onto four hardware queues by default, a
 context of this library uses three streams, and two contexts that share queues run in lockstep (19.2 against 22.1
-Mpoints/s).  The command-line tools and bench.py do this for themselves."""
+Mpoints/s, HISTORY.md section 7).  The command-line tools and bench.py do this for themselves."""
 import os as _os
 
 

@@ -67,7 +67,7 @@ def run_jobs(fn, items, jobs=1, on_progress=None):
     """fn(item) for every item, results in item order (on_progress(results) after each completed item, with None for the
     items still running: the compress CLI rewrites its CSV there).  jobs > 1: that many host threads, each with its own torch stream (and,
     through runtime.context, its own gpcc context): the files of a batch are independent, and two in flight fill what one
-    leaves idle on the GPU (the HIP runtime needs GPU_MAX_HW_QUEUES >= 3 x jobs for that, which main()
+    leaves idle on the GPU (HISTORY.md section 7; the HIP runtime needs GPU_MAX_HW_QUEUES >= 3 x jobs for that, which main()
     exports before the first GPU call)."""
     items = list(items)
     if jobs <= 1 or len(items) <= 1:

@@ -55,7 +55,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
 }
 
 // Version gpcc_encode (and the stage-level gpcc_rc_encode / gpcc_rc_decode) use for chunked containers: 4 (default: the
-// carry-propagating coder in the lanes) or 3 (torchac's coder in the lanes: what round 3 wrote).  Readers take 0-4.
+// carry-propagating coder in the lanes, HISTORY.md section 5) or 3 (torchac's coder in the lanes: what round 3 wrote).  Readers take 0-4.
 // kernel launches enqueued by the calling thread since the last reset (every launch site of the library passes LAUNCH_CHECK);
 // bench.py's `kernels per decode` and the batch's launch-count bar read it
 // the sticky device-side error word of the context (primitives.hpp: device_error_check): for callers of the stage-level entry points that

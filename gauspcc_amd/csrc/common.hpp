@@ -255,7 +255,7 @@ namespace gpcc {
 int dbg_mark(gpcc_ctx *ctx, hipStream_t st, int tag, const void *p, size_t bytes);   // api.hip (developer trace)
 int prof_event(gpcc_ctx *ctx, hipStream_t st, int *idx);   // network.hip
 // RAII bracket of one HBM-bound stage on the stream its kernels are enqueued on; bytes = the stage's ALGORITHMIC traffic
-// (what an ideal layer-by-layer implementation reads and writes), accumulated beside the time
+// (what an ideal layer-by-layer implementation reads and writes, HISTORY.md section 4), accumulated beside the time
 struct StageTimer {
     gpcc_ctx *c; hipStream_t st; int id, e0 = -1;
     StageTimer(gpcc_ctx *ctx, hipStream_t stream, int stage, double bytes) : c(ctx), st(stream), id(stage)

@@ -1,5 +1,5 @@
 // container.hpp -- reading a .bin container's header and stream directory (reference reader: HAC/utils/pcc_utils.py:271-276,
-// GausPcgc/kit/op.py:40-48; this library's chunked layouts: DESIGN.md section 5).  Everything here runs on UNTRUSTED bytes and
+// GausPcgc/kit/op.py:40-48; this library's chunked layouts: HISTORY.md section 5).  Everything here runs on UNTRUSTED bytes and
 // is plain C++ (no HIP): gpcc_decode / gpcc_decode_batch call it, and tools/asan_host.sh builds the same code with
 // AddressSanitizer + UBSan under a mutation fuzzer (tests/test_host_fuzz_cpu.py).
 #pragma once

@@ -11,7 +11,7 @@
 //                 Offsets are visited in ascending order: acc = acc + (fma chain over k from 0) per offset,
 //                 exactly the oracle's order, so results are bit-exact no matter how rows are packed into
 //                 tiles.  The asm tile loop (conv_loop_gfx950.inc) computes the product transposed; see
-//                 tools/gen_conv_loop.py and DESIGN.md section 4 for why.
+//                 tools/gen_conv_loop.py and HISTORY.md section 4 for why.
 //                 Bound: fp32 MFMA (2*32*32 flop per pair); gathers come from L2/MALL.
 // k_head          Linear-ReLU-Linear-softmax-cumsum-integerise, one node per lane, weights through
 //                 the scalar cache.  Negligible next to the convolutions.
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * SC_WAVES, CONV_MIN_WAVES(R, ASM)) void k_spars
     // with vmcnt(0) -- a batch loop that loads its residuals per batch waits for the previous batch's stores every time
     // (measured: 33 k cycles per 255-row block with a residual, 18 k without -- the short last batch went through a
     // dword-by-dword predicated path; now ~5 k / ~3 k).
-#ifdef CONV_NO_EPILOGUE   // developer ablation (WRONG results): what the copy-out costs -- one store keeps the block's work alive
+#ifdef CONV_NO_EPILOGUE   // developer ablation (WRONG results; HISTORY.md section 4, round 4): what the copy-out costs -- one store keeps the block's work alive
     if (lane == 0 && nrows > 0) J.out[(size_t)row0 * 32] = acc[ROWF];
     if (false)
 #endif

@@ -80,7 +80,7 @@ struct ConvBatch { ConvJob job[4]; int C = 0; };   // C: channels (0 = 32, the M
 // structure, no dense neighbour map), used by all 5 / 13 convolutions that run on a level.  Neighbour rows are indices
 // inside the block's own level; lv_row0 places a level in the set's feature arrays.  R is the capacity class (LDS rows per
 // wave, selects the kernel: 16 = the cooperative kernel, 255 = the wave-serial kernel at one wave per SIMD; 32 / 64 / 96 /
-// 128 remain for the variant tests), H <= R the block height (conv_pick_rows / conv_pick_height).
+// 128 remain for the variant tests), H <= R the block height (conv_pick_rows / conv_pick_height, HISTORY.md section 4).
 constexpr int CONV_R_MAX = 255;
 constexpr int CONV_HDR_PAD = 48;  // tiles a wave may read past the end of its block's list (two header batches + look-ahead)
 struct ConvTiles {

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
         ng_wave_sync();
         // the surviving Gaussians of the tile, each to its final row (:160-171).  Flags, then positions, then attributes of ALL the lane's candidates
         // (16 K / 64 <= 4) are requested together -- three round trips per tile instead of three per candidate: the kernel's emission is bound by these
-        // dependent loads, not by its stores
+        // dependent loads, not by its stores (HISTORY.md section 4)
         {
             const uint32_t *__restrict__ keepp = a.keep, *__restrict__ posp = o.pos;
             const float *__restrict__ nopap = a.nopa, *__restrict__ scalp = o.scaling, *__restrict__ anchp = a.anchor, *__restrict__ offp = o.offsets;

@@ -29,7 +29,7 @@ namespace gpcc {
 // Round 3 first built this ring in LDS, filled by LDS-DMA loads (`global_load_lds_*`, hand-counted waits), because a
 // ROLLED register ring had cost a memory round trip per trip (the compiler clusters the loads, renames the ring across the
 // back edge and waits with vmcnt(0)).  That version passed every parity test and decoded wrong symbols in 2-16 % of the
-// decodes as soon as a second scene shared the GPU (tools/inflight_check.py; DESIGN.md section 4 has the whole story):
+// decodes as soon as a second scene shared the GPU (tools/inflight_check.py; HISTORY.md section 4 has the whole story):
 // under load LDS-DMA loads do not retire in issue order, `s_waitcnt vmcnt(0)` can release a wave before the data is visible
 // to its own ds_read, the upper half of the dword a 16-bit LDS-DMA load writes is not reliably zero, and a load still in
 // flight at s_endpgm lands in LDS that may belong to another workgroup.  A three-thirds LDS ring with a whole phase between

@@ -11,7 +11,7 @@ Deliberate differences, all on the error side:
   * decompress_point_cloud(output_path=...) really writes the ASCII PLY (reference: NameError,
     `io` is never imported, :392).
 The container written by default is the chunked one (version 4: per-level chunk sizes, two coder lanes per byte-counted
-chunk, a carry-propagating range coder in the lanes, parallel decode); chunk_log2=0 writes the
+chunk, a carry-propagating range coder in the lanes, parallel decode; HISTORY.md section 5); chunk_log2=0 writes the
 reference's exact layout.  Every layout this library ever wrote (versions 1-4) and the reference's are read back transparently;
 `gauspcc_amd.pcc_utils.CONTAINER_VERSION = 3` (or GAUSPCC_CONTAINER_VERSION=3) keeps writing round 3's layout.
 """

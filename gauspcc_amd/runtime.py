@@ -20,7 +20,7 @@ _ALL_LOCK = threading.Lock()
 class _Contexts:
     """The gpcc contexts of one host thread (device index -> handle).  A context serves one call at a time, so every
     thread gets its own: two threads with their own torch streams run their calls concurrently on one GPU (two scenes in
-    flight fill what one leaves idle).  Destroyed with the thread."""
+    flight fill what one leaves idle, HISTORY.md section 7).  Destroyed with the thread."""
 
     def __init__(self):
         self.h = {}

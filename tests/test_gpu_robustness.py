@@ -4,7 +4,7 @@ aborts the process it happens in.
 * Two scenes in flight on one GPU (own context, stream and host thread each): every encode's bytes and every decode's
   points equal the scene's own solo pass.  The range coder's first row ring of round 3 lived in LDS behind LDS-DMA loads and
   hand-counted waits: wrong symbols in 2-16 % of the decodes as soon as a second scene shared the GPU, none on an idle one
-  (the rows now sit in registers behind ordinary loads).
+  (HISTORY.md section 4; the rows now sit in registers behind ordinary loads).
 * Corrupted containers at 1 M points: error or some cloud, never a fault.  The small clouds of
   test_gpu_parity.py::test_corrupted_containers_never_crash never left mapped memory; at this size unwritten rank arrays and
   an unstaged LDS slot in the tile builder did."""

@@ -158,19 +158,17 @@ def measure(n_anchors=200_000, W=1600, H=1060, coder_symbols=None, mlp_rows=None
     pt = torch.softmax(torch.randn(nt, lp_t - 1, generator=gm), dim=-1)
     cdf_t = torch.cat([torch.zeros(nt, 1), torch.cumsum(pt, dim=-1)], dim=-1).clamp(0, 1).to(dev)
     sym_t = torch.multinomial(pt, 1).view(-1).to(torch.int16).to(dev)
-    t_te, blob = timed(lambda: tac.encode_float_cdf(cdf_t, sym_t), 2)
-    t_td, sd = timed(lambda: tac.decode_float_cdf(cdf_t, blob), 2)
+    t_te, blob = timed(lambda: tac.encode_float_cdf(cdf_t, sym_t), 6)
+    t_td, sd = timed(lambda: tac.decode_float_cdf(cdf_t, blob), 6)
     # ... and with CPU tensors, torchac's own calling convention (TC-GS/utils/encodings.py:84-129 moves the table to the CPU first)
     cdf_c, sym_c = cdf_t.cpu(), sym_t.cpu()
-    t_ce, blob_c = timed(lambda: tac.encode_float_cdf(cdf_c, sym_c), 2)
-    t_cd, _ = timed(lambda: tac.decode_float_cdf(cdf_c, blob_c), 2)
+    t_ce, blob_c = timed(lambda: tac.encode_float_cdf(cdf_c, sym_c), 6)
+    t_cd, _ = timed(lambda: tac.decode_float_cdf(cdf_c, blob_c), 6)
     out["torchac_shim"] = {"symbols": nt, "encode_Msym_per_s": round(nt / t_te / 1e6, 2), "decode_Msym_per_s": round(nt / t_td / 1e6, 2),
                            "cpu_tensors_encode_Msym_per_s": round(nt / t_ce / 1e6, 2), "cpu_tensors_decode_Msym_per_s": round(nt / t_cd / 1e6, 2),
                            "coder": "host thread (csrc/hostcoder.hip): one stream is one dependent chain; int16 rows built on the tensor's device",
                            "roundtrip": bool(torch.equal(sd.to(dev), sym_t)) and blob == blob_c}
     # ... and the reference's ten-way fan-out (TC-GS/utils/encodings.py:36-82: ten chunk files, ten independent streams) on 2 M symbols: ten native threads
-    import tempfile
-
     from gauspcc_amd import torchac_encodings as te
     nf = 2_000_000
     pf_ = torch.softmax(torch.randn(nf, lp_t - 1, generator=gm), dim=-1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Developer probe: one decode of the 1 M-point bench cloud on a -DFUSED_TIMING build (tools: see DESIGN.md section 4, "small decode
+"""Developer probe: one decode of the 1 M-point bench cloud on a -DFUSED_TIMING build (tools: see HISTORY.md section 4, "small decode
 levels, round 4") -- the persistent launches print launch time, time inside grid barriers and time polling, per level.
 Usage: GAUSPCC_LIB=gauspcc_amd/variants/libgauspcc_tm512.so python tools/fused_timing.py [points]"""
 import os

@@ -2,7 +2,7 @@
 # the side-path part of tools/refresh_profiles.sh alone (attribute loops, Gaussian coder, RD loop; kernel stats; k_render counters)
 set -u
 OUT=$1
-R=${2:-r05}
+R=${2:-r06}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"

@@ -1,6 +1,6 @@
 // Is an fp32 MFMA an exact k-ordered chain of fused multiply-adds from its accumulator?  The normative conv arithmetic
 //  needs that: p = fmaf(x[k], w[k], p) for k ascending.  Checked here for the form the conv loop uses
-// (16x16x4) and for the one the "32x32x2 pair step" of DESIGN.md section 9 would use: every output element of a random
+// (16x16x4) and for the one the "32x32x2 pair step" of HISTORY.md section 9 would use: every output element of a random
 // product is compared, bit for bit, with the ascending chain, the descending chain, and "sum of exact products, then + c".
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/mfma_order.hip -o /tmp/mfma_order && /tmp/mfma_order
 #include <hip/hip_runtime.h>

@@ -41,7 +41,7 @@ GPCC_API int gpcc_version(void);
 
 GPCC_API int gpcc_ctx_create(int device, gpcc_ctx **out);
 GPCC_API void gpcc_ctx_destroy(gpcc_ctx *ctx);
-/* Chunked containers (chunk_log2 != 0) are this library's own layout (HISTORY.md section 5): version 4 (default) runs a
+/* Chunked containers (chunk_log2 != 0) are this library's own layout (the versions' history: HISTORY.md section 5): version 4 (default) runs a
  * carry-propagating range coder in the lanes of a stream -- same 16-bit CDF rows and rate as torchac's coder, a third of the
  * decoder's dependent chain --, version 3 torchac's coder (arithmetic_kernel.cu:94-163) itself.  Sets what gpcc_encode and
  * gpcc_rc_encode / gpcc_rc_decode use; gpcc_decode reads versions 0 (the reference layout, pcc_utils.py:198-203) to 4. */
@@ -114,7 +114,7 @@ typedef struct {
 /* ---- a12  compress_point_cloud (the timed span :78-189 + container :192-203)
  * xyz_dev: (N,3) int32 device, duplicate-free, any order.  chunk_log2 = 0 writes the
  * reference container layout (one range-coder stream per level and stage, decoded by
- * a single lane); 6..14 writes the chunked container (HISTORY.md section 5) whose streams are cut into
+ * a single lane); 6..14 writes the chunked container whose streams are cut into
  * chunks of at most 2^chunk_log2 symbols that decode in parallel.  A chunk must fit the staged decoder's LDS
  * window (64 KiB; 16 KiB for the 16-ary streams): should one come out larger -- possible only at chunk_log2 >= 13 with
  * a model that spends more than 8 bits per 16-ary symbol -- the cloud is coded again with chunk_log2 - 1 (the header

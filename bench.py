@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = the fastest of 8 / 16 / 32 / 64 / 128 / all cores on a short calibration run; a positive value pins the count, capped by the cores this process may use)")
     ap.add_argument("--measure-traffic", action="store_true", help="(informative) leave roofline.traffic null instead of quoting profiles/: run tools/pmc_traffic.sh for a fresh figure")
     ap.add_argument("--cpu-sample", type=int, default=1_000_000, help="points of the CPU-baseline cloud (0 = skip; default: the metric's own 1 M config)")
-    ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0 (one lane per stream: ~0.4 s)")
+    ap.add_argument("--skip-v0", action="store_true", help="do not encode the reference-layout container for bytes_v0")
     ap.add_argument("--event-steps", type=int, default=1, help="timed steps that carry the HIP-event brackets around the conv launches (-1 = all; each bracket costs its stream ~5 us, ~0.65 ms per step)")
     ap.add_argument("--scenes-in-flight", type=int, default=2, help="also report the throughput with this many independent scenes in flight on the GPU "
                     "(own context, stream and host thread each; untimed extra pass on rank 0 at N = 1; 0 = skip)")
@@ -350,7 +350,8 @@ def main():
 
     # The reference's own container layout, timed: chunk_log2 = 0 writes one torchac-compatible stream per level
     # and stage (pcc_utils.py:174-177, layout :198-203) -- the only layout the reference can read.  Every stream is ONE dependent chain, so
-    # the coder runs on one lane per stream; untimed pass behind the timed region, `value` stays the chunked container's figure.
+    # the CODER of this layout runs on the host (csrc/hostcoder.hpp: an encode's streams on a pool of native threads, a decode's -- sequentially
+    # dependent -- on one), the network on the device; untimed pass behind the timed region, `value` stays the chunked container's figure.
     # low_rate (item 3b): the same codec at a realistic rate -- (i) the bench cloud under the `peaky` model (synth.peaky_state_dict: head biases
     # = log of the stage symbols' empirical frequencies, i.e. the context-free entropy of the occupancy symbols; 3-6 bpp on this cloud needs
     # spatial context, i.e. a trained checkpoint), (ii) a SOLID cloud (synth.solid_cloud) under its own peaky model: 2.5 bits per coded node,
@@ -384,7 +385,9 @@ def main():
         reference_layout = {"container": "v0: one torchac-compatible stream per level and stage (pcc_utils.py:174-177, :198-203), chunk_log2 = 0",
                             "points": n_l, "enc_ms": round(te0 * 1e3, 3), "dec_ms": round(td0 * 1e3, 3), "value": round(n_l / (te0 + td0) / 1e6, 4),
                             "unit": "Mpoints/s", "bytes": len(blob0), "bpp": round(len(blob0) * 8 / n_l, 4), "roundtrip_bit_identical": ok0,
-                            # four symbols per coded node; a stream is one dependent chain, so the decode is bounded by what ONE lane decodes
+                            "coder": "host side (csrc/hostcoder.hip: torchac's loop; encode: the independent streams on up to 16 native threads, decode: one thread -- "
+                                     "stage s + 1 needs stage s's symbols); the network runs on the device",
+                            # four symbols per coded node; a decode's streams are ONE dependent chain: the rate is what one host thread decodes
                             "coded_symbols": int(4 * st0_.coded_nodes),
                             "decode_Msymbols_per_s": round(4 * st0_.coded_nodes / td0 / 1e6, 2), "encode_Msymbols_per_s": round(4 * st0_.coded_nodes / te0 / 1e6, 2)}
         # The chunk size trades bytes for decode latency (a lane of 2^(chunk_log2 - 1) symbols is one dependent chain; chunks cost ~2.3 bytes each):

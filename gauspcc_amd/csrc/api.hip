@@ -50,6 +50,7 @@ extern "C" void gpcc_ctx_destroy(gpcc_ctx *c)
     if (c->dbg_dev) (void)hipFree(c->dbg_dev);
     for (auto &e : c->dbg_caps) if (e.dev) (void)hipFree(e.dev);
     if (c->hstage.p) (void)hipHostFree(c->hstage.p);
+    if (c->hcoder.p) (void)hipHostFree(c->hcoder.p);
     if (c->hbatch.p) (void)hipHostFree(c->hbatch.p);
     delete c;
 }
@@ -91,7 +92,7 @@ extern "C" int gpcc_ctx_bytes(const gpcc_ctx *c, int64_t *device_bytes, int64_t 
     if (c->fused_state) d += 2 * 3456 + 128;                     // grid-barrier blocks of the persistent launches (fused.hip)
     for (const auto &e : c->dbg_caps) d += e.cap;
     if (device_bytes) *device_bytes = (int64_t)d;
-    if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap + c->hbatch.cap);
+    if (pinned_bytes) *pinned_bytes = (int64_t)(c->hbytes.cap + c->hstage.cap + c->hbatch.cap + c->hcoder.cap);
     return GPCC_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <chrono>
 
 #include <functional>
+#include "hostcoder.hpp"
 #include "codec_shared.hpp"
 #include "container.hpp"
 #include "rangecoder_dev.hpp"
@@ -195,6 +196,77 @@ int encode_body(gpcc_ctx *ctx, const gpcc_model *m, const int32_t *xyz, int64_t 
     }
     // ---- range coder over every lane of every stream
     const int nstreams = 4 * (L - 1);
+    // The reference layout (chunk_log2 = 0: ONE torchac stream per level and stage): the CODER runs on the host (hostcoder.hpp says why: a stream
+    // is one dependent chain, torchac is a CPU coder, a host core runs the chain several times faster than a GPU lane) -- the heads' packed coder
+    // words come down once, the streams (independent in an encode) are coded on a pool of native threads, the container is put together here.
+    // GAUSPCC_V0_DEVICE_CODER=1 (developer knob): the one-lane-per-stream device path below, kept as the cross-check.
+    static const bool v0_device = dev_env_int("GAUSPCC_V0_DEVICE_CODER", 0) != 0;
+    if (!chunk_log2 && !v0_device) {
+        const Level *base = &T.lv[0];
+        TAKE(base_xyz, int32_t, 3 * base->n);
+        TAKE(base_occ, uint8_t, base->n);
+        GP_TRY(level_to_raster(ctx, st, base, T.bias, base_xyz, base_occ));
+        const size_t off_w = 0, off_pairs = ((size_t)4 * (size_t)std::max<int64_t>(lohi_words, 1) + 63) & ~(size_t)63;
+        const size_t off_bx = off_pairs + 8 * (size_t)NCOUNTERS, off_bo = off_bx + 12 * (size_t)base->n;
+        GP_TRY(ctx->hcoder.reserve(off_bo + (size_t)base->n + 64));
+        uint8_t *hc = ctx->hcoder.p;
+        {
+            StageTimer tm(ctx, st, ST_CODER, (double)coded * 4 * 4);
+            if (lohi_words) HIP_TRY(hipMemcpyAsync(hc + off_w, lohi, 4 * (size_t)lohi_words, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(hc + off_pairs, pairs_dev, 8 * NCOUNTERS, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hc + off_bx, base_xyz, 12 * (size_t)base->n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hc + off_bo, base_occ, (size_t)base->n, hipMemcpyDeviceToHost, st));
+        ht.mark("enc all queued");
+        HIP_TRY(hipStreamSynchronize(st));
+        ht.mark("enc network done (sync)");
+        std::vector<const uint32_t *> sp((size_t)std::max(nstreams, 1));
+        std::vector<int64_t> sn((size_t)std::max(nstreams, 1));
+        {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(hc + off_w);
+            int64_t pre = 0; int si = 0;
+            for (int d = 1; d < L; ++d) {
+                const int64_t nc = T.lv[d].n;
+                for (int s = 0; s < 4; ++s, ++si) { sp[(size_t)si] = w + pre + (int64_t)s * nc; sn[(size_t)si] = nc; }
+                pre += 4 * nc;
+            }
+        }
+        std::vector<std::vector<uint8_t>> sb;
+        GP_TRY(host_encode_streams(sp.data(), sn.data(), nstreams, &sb, 0));
+        ht.mark("enc streams coded (host)");
+        size_t fsize = 2 + 4 + 13 * (size_t)base->n + 2;
+        for (int si = 0; si < nstreams; ++si) fsize += 4 + sb[(size_t)si].size();
+        GP_TRY(ctx->hbytes.reserve(fsize + 16));
+        uint8_t *out = ctx->hbytes.p;
+        size_t pos = 0;
+        out[0] = (uint8_t)posq; out[1] = (uint8_t)(posq >> 8); pos = 2;
+        put32(out + pos, (uint32_t)base->n); pos += 4;
+        memcpy(out + pos, hc + off_bx, 12 * (size_t)base->n); pos += 12 * (size_t)base->n;
+        memcpy(out + pos, hc + off_bo, (size_t)base->n); pos += (size_t)base->n;
+        out[pos] = (uint8_t)nstreams; out[pos + 1] = (uint8_t)(nstreams >> 8); pos += 2;
+        for (int si = 0; si < nstreams; ++si) {
+            const std::vector<uint8_t> &b = sb[(size_t)si];
+            put32(out + pos, (uint32_t)b.size()); pos += 4;
+            if (!b.empty()) memcpy(out + pos, b.data(), b.size());
+            pos += b.size();
+        }
+        if (pos != fsize) return fail(GPCC_ERR_HIP, "internal: container size mismatch (%zu vs %zu)", pos, fsize);
+        if (ctx->prof.on && ctx->prof.stages) ctx->prof.stage_bytes[ST_CODER] += 3.0 * (double)(fsize - (2 + 4 + 13 * (size_t)base->n + 2 + 4 * (size_t)nstreams));
+        const unsigned long long *hp = reinterpret_cast<const unsigned long long *>(hc + off_pairs);
+        unsigned long long set_pairs[2] = {0, 0};
+        for (int d = 0; d < L; ++d) { if (d + 1 < L) set_pairs[0] += hp[d]; if (d) set_pairs[1] += hp[d]; }
+        if (ctx->prof.on) GP_TRY(prof_collect(ctx, set_pairs, 2));
+        *bytes_out = out; *nbytes_out = (int64_t)pos;
+        if (stats) {
+            memset(stats, 0, sizeof *stats);
+            stats->num_points = n; stats->num_bytes = (int64_t)pos; stats->num_levels = L; stats->coded_nodes = coded;
+            for (int d = 0; d < L; ++d) stats->level_nodes[d] = T.lv[d].n;
+            stats->conv_pairs = (int64_t)set_pairs[0] * 5 + (int64_t)set_pairs[1] * 13;
+            const double *hb = reinterpret_cast<const double *>(hp + MAXLV);
+            for (int i = 0; i < 16; ++i) stats->ideal_bits += hb[i];
+        }
+        return GPCC_OK;
+    }
     std::vector<RcChunk> chunks;         // one descriptor per lane
     std::vector<uint32_t> gaps;          // reference layout: container bytes in front of a lane's payload that are not payload (the stream lengths);
                                          // chunked: the stream of every lane (the gaps depend on the byte counts: rc_layout_launch)
@@ -674,7 +746,21 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
             GP_TRY(dbg_mark(ctx, st, g * 100 + 13 + 5 * s, cdf, cdf_bytes));
             if (g == 0 && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_bytes, 0));
             if (g == TAB_EARLY && s == 0) HIP_TRY(hipStreamWaitEvent(st, ctx->ev_tables, 0));
-            {
+            static const bool v0_device = dev_env_int("GAUSPCC_V0_DEVICE_CODER", 0) != 0;
+            if (!v1 && !v0_device) {
+                // the reference layout: the stream is ONE chain of nc symbols -- decoded on the host by the library's torchac coder (hostcoder.hpp):
+                // the stage's compact CDF rows come down, the symbols go up; the next stage's input waits for them on the stream as it always did
+                const int lp = STAGE_M[s] + 1, rs = rc_row_stride(lp);
+                const size_t rows_b = (size_t)nc * (size_t)rs * 2, off_sym = (rows_b + 63) & ~(size_t)63;
+                GP_TRY(ctx->hcoder.reserve(off_sym + (size_t)nc + 64));
+                StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
+                HIP_TRY(hipMemcpyAsync(ctx->hcoder.p, cdf, rows_b, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                GP_TRY(host_decode_compact(reinterpret_cast<const uint16_t *>(ctx->hcoder.p), lp, in + hdr.s_off[(size_t)(4 * g + s)], s_len[(size_t)(4 * g + s)], nc,
+                                           ctx->hcoder.p + off_sym));
+                HIP_TRY(hipMemcpyAsync(sym[s], ctx->hcoder.p + off_sym, (size_t)nc, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipStreamSynchronize(st));   // (the pinned block is reused by the next stage)
+            } else {
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
                 GP_TRY(rc_decode_launch(st, cdf, STAGE_M[s] + 1, dbytes, dchunks + (size_t)s * nch, nch, win_bytes[g][s], pl.dual, sym[s], rc_coder_of_version(version)));
             }

@@ -197,6 +197,7 @@ struct gpcc_ctx {
     gpcc::Arena arena;              // device workspace
     gpcc::HostBuf<uint8_t> hbytes;  // pinned output / staging bytes
     gpcc::HostBuf<uint8_t> hstage;  // pinned small staging (counts, flags, descriptors)
+    gpcc::HostBuf<uint8_t> hcoder;  // pinned: what the host coder of the reference layout reads / writes (coder words, CDF rows, symbols; hostcoder.hpp)
     gpcc::HostBuf<uint8_t> hbatch;  // pinned staging of the batched calls (forest.hpp: per-scene tables); reserved once per call, before anything reads it asynchronously
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // second stream of the codec: octree / tile-list work of the next step runs beside the convolutions of this one

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <string>
@@ -23,6 +24,7 @@
 
 #include "../../include/gauspcc.h"
 #include "errors.hpp"
+#include "hostcoder.hpp"
 
 namespace {
 
@@ -63,19 +65,17 @@ struct RowsF32 {
     }
 };
 
-template <typename ROWS>
-int host_encode(const int16_t *sym, ROWS rows, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+// BOUNDS: bounds(i, &c_low, &c_high) -> the coded symbol's interval [c_low, c_high) in 2^-16 units (false: a bad symbol, message set)
+template <typename BOUNDS>
+int host_encode_core(BOUNDS bounds, int64_t n, uint8_t *out, int64_t cap, int64_t *nbytes_out)
 {
     BitSink w = {out, cap, 0, 0, 0};
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint64_t pending = 0;
-    const int top = lp - 2;
     for (int64_t i = 0; i < n; ++i) {
-        const int s = sym[i];
-        if (s < 0 || s > top) return gpcc::fail(GPCC_ERR_ARG, "symbol %d at %lld outside [0, %d]", s, (long long)i, top);
-        const uint16_t *row = rows.row(i);
+        uint32_t c_low, c_high;
+        if (!bounds(i, &c_low, &c_high)) return GPCC_ERR_ARG;
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
-        const uint32_t c_low = row[s], c_high = s == top ? 0x10000u : row[s + 1];
         high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
         low = low + (uint32_t)((span * c_low) >> 16);
         // E1 / E2: the n1 leading bits on which low and high agree leave at once (the first with the pending run behind it)
@@ -111,6 +111,26 @@ int host_encode(const int16_t *sym, ROWS rows, int64_t n, int lp, uint8_t *out, 
 }
 
 template <typename ROWS>
+int host_encode(const int16_t *sym, ROWS rows, int64_t n, int lp, uint8_t *out, int64_t cap, int64_t *nbytes_out)
+{
+    const int top = lp - 2;
+    return host_encode_core([&](int64_t i, uint32_t *c_low, uint32_t *c_high) -> bool {
+        const int s = sym[i];
+        if (s < 0 || s > top) { (void)gpcc::fail(GPCC_ERR_ARG, "symbol %d at %lld outside [0, %d]", s, (long long)i, top); return false; }
+        const uint16_t *row = rows.row(i);
+        *c_low = row[s]; *c_high = s == top ? 0x10000u : row[s + 1];
+        return true;
+    }, n, out, cap, nbytes_out);
+}
+
+// the device's compact CDF rows (rc_format.hpp: rc_row_stride uint16 per row, the interior values v[1 .. lp - 2] only)
+struct RowsCompact {
+    const uint16_t *rows; int lp, stride;
+    struct View { const uint16_t *r; inline uint32_t operator[](int m) const { return m ? r[m - 1] : 0u; } };   // v[0] = 0 is not stored
+    inline View row(int64_t i) { return View{rows + i * stride}; }
+};
+
+template <typename ROWS>
 int host_decode(ROWS rows, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
 {
     // bit reservoir: `value` holds the 32 bits at the read position; bits past the end read as zero (arithmetic_kernel.cu:244-262)
@@ -125,7 +145,7 @@ int host_decode(ROWS rows, const uint8_t *bytes, int64_t nbytes, int64_t n, int 
     uint32_t low = 0, high = 0xFFFFFFFFu, value = take(32);
     const int top = lp - 2;
     for (int64_t i = 0; i < n; ++i) {
-        const uint16_t *row = rows.row(i);
+        const auto row = rows.row(i);
         const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
         const uint32_t x = value - low;
         // the reference picks the largest s with row[s] <= count, count = ((x + 1) 2^16 - 1) / span; row[s] <= count  <=>
@@ -133,7 +153,7 @@ int host_decode(ROWS rows, const uint8_t *bytes, int64_t nbytes, int64_t n, int 
         int lo_i = 0, hi_i = top + 1;
         while (lo_i + 1 < hi_i) {
             const int m = (lo_i + hi_i) >> 1;
-            if ((uint32_t)((span * row[m]) >> 16) <= x) lo_i = m; else hi_i = m;
+            if ((uint32_t)((span * (uint64_t)row[m]) >> 16) <= x) lo_i = m; else hi_i = m;
         }
         const int s = lo_i;
         sym_out[i] = (int16_t)s;
@@ -187,6 +207,58 @@ extern "C" int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int6
     std::vector<uint16_t> tmp((size_t)lp);
     return host_decode(RowsF32{cdf, lp, tmp.data(), (float)(65536 - (lp - 1))}, bytes, nbytes, n, lp, sym_out);
 }
+
+// ---- the reference-layout container of gpcc_encode / gpcc_decode (chunk_log2 = 0: one torchac stream per level and stage) on this coder
+namespace gpcc {
+
+// streams[k] = the packed (c_low | (c_high - 1) << 16) words of stream k (what the heads emit), n[k] symbols; out[k] receives its bytes.
+// The streams of an encode are independent (teacher-forced): a pool of native threads takes them longest first.
+int host_encode_streams(const uint32_t *const *streams, const int64_t *n, int nstreams, std::vector<std::vector<uint8_t>> *out, int threads)
+{
+    out->assign((size_t)nstreams, {});
+    std::vector<int> order((size_t)nstreams);
+    for (int k = 0; k < nstreams; ++k) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return n[a] > n[b]; });
+    if (threads <= 0) threads = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+    threads = std::max(1, std::min(threads, nstreams));
+    std::atomic<int> next{0}, bad{0};
+    auto work = [&]() {
+        for (;;) {
+            const int t = next.fetch_add(1);
+            if (t >= nstreams) return;
+            const int k = order[(size_t)t];
+            std::vector<uint8_t> &o = (*out)[(size_t)k];
+            o.resize((size_t)(2 * n[k] + 64));          // a symbol costs at most 16 bits (counts >= 1 of 2^16), + flush
+            const uint32_t *w = streams[k];
+            int64_t nb = 0;
+            const int rc = host_encode_core([&](int64_t i, uint32_t *c_low, uint32_t *c_high) -> bool {
+                *c_low = w[i] & 0xFFFFu; *c_high = (w[i] >> 16) + 1u;
+                return *c_low < *c_high;
+            }, n[k], o.data(), (int64_t)o.size(), &nb);
+            if (rc != GPCC_OK) { bad.store(1); return; }
+            o.resize((size_t)nb);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work);
+    work();
+    for (auto &th : pool) th.join();
+    return bad.load() ? fail(GPCC_ERR_HIP, "internal: an empty coder interval in a reference-layout stream") : GPCC_OK;
+}
+
+// one stream of n symbols under compact CDF rows (lp - 1 symbols per row): torchac's decoder, symbols as bytes
+int host_decode_compact(const uint16_t *rows, int lp, const uint8_t *bytes, int64_t nbytes, int64_t n, uint8_t *sym_out)
+{
+    if (lp < 3 || lp > 17) return fail(GPCC_ERR_ARG, "internal: compact rows of %d entries", lp);
+    std::vector<int16_t> tmp((size_t)std::max<int64_t>(n, 1));
+    RowsCompact rc{rows, lp, lp == 3 ? 1 : lp == 5 ? 4 : 16};
+    const int r = host_decode(rc, bytes, nbytes, n, lp, tmp.data());
+    if (r != GPCC_OK) return r;
+    for (int64_t i = 0; i < n; ++i) sym_out[i] = (uint8_t)tmp[(size_t)i];
+    return GPCC_OK;
+}
+
+}  // namespace gpcc
 
 // ---- many small files on native threads (the per-slice `.b` files of the attribute loops: include/gauspcc.h)
 extern "C" int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads)

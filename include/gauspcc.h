@@ -113,8 +113,9 @@ typedef struct {
 
 /* ---- a12  compress_point_cloud (the timed span :78-189 + container :192-203)
  * xyz_dev: (N,3) int32 device, duplicate-free, any order.  chunk_log2 = 0 writes the
- * reference container layout (one range-coder stream per level and stage, decoded by
- * a single lane); 6..14 writes the chunked container whose streams are cut into
+ * reference container layout (one torchac range-coder stream per level and stage: a stream is ONE
+ * dependent chain, so for this layout the coder -- not the network -- runs on the host, on the library's own
+ * torchac coder, csrc/hostcoder.hpp); 6..14 writes the chunked container whose streams are cut into
  * chunks of at most 2^chunk_log2 symbols that decode in parallel.  A chunk must fit the staged decoder's LDS
  * window (64 KiB; 16 KiB for the 16-ary streams): should one come out larger -- possible only at chunk_log2 >= 13 with
  * a model that spends more than 8 bits per 16-ary symbol -- the cloud is coded again with chunk_log2 - 1 (the header

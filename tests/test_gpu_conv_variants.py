@@ -152,3 +152,36 @@ for n, seed in ((120000, 3), (7000, 4), (40000, 5)):
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")])
     assert len(out[0]) == 3 and out[0] == out[1] == out[2] == out[3]
+
+
+def test_reference_layout_device_coder_equals_host_coder():
+    """chunk_log2 = 0 (the reference's container: one torchac stream per level and stage, pcc_utils.py:174-177): since round 6 the coder of this
+    layout runs on the host (csrc/hostcoder.hpp); the one-lane-per-stream device coder stays behind GAUSPCC_V0_DEVICE_CODER=1 as the cross-check.
+    Both write the oracle's bytes and decode them to the oracle's points."""
+    snippet = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+from tests import gpu_helpers as gh
+from gauspcc_amd import runtime
+from gauspcc_amd.model import tensor_table
+from gauspcc_amd.synth import synthetic_cloud, synthetic_state_dict
+from oracle import oracle as orc
+sd = synthetic_state_dict(32, 5)
+dm = runtime.Model(sd, 32, 5, 0)
+om = orc.Model(tensor_table(sd, 32, 5), 32, 5)
+for n, seed in ((30000, 3), (700, 4)):
+    pts = synthetic_cloud(n, seed=seed)
+    data, st = gh.encode(dm, pts, 0)
+    assert data == orc.encode(om, pts, chunk_log2=0), "bitstream differs from the oracle"
+    dec, _, _ = gh.decode(dm, data)
+    assert np.array_equal(dec, orc.decode(om, data)[0])
+print("variant ok")
+""" % ROOT
+    for env in ({}, {"GAUSPCC_V0_DEVICE_CODER": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        e["GAUSPCC_DEV"] = "1"
+        r = subprocess.run([sys.executable, "-c", snippet], env=e, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

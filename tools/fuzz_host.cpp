@@ -47,6 +47,8 @@ int gsac_host_decode_f32(const float *cdf, const uint8_t *bytes, int64_t nbytes,
 int gpcc_write_files(const char *const *paths, const uint8_t *const *data, const int64_t *sizes, int n, int threads);
 int gpcc_read_files(const char *const *paths, int n, int threads, const uint8_t **blob_out, int64_t *offsets_out);
 }
+#include "../gauspcc_amd/csrc/hostcoder.hpp"   // the reference-layout container's host coder (round 6): gpcc::host_encode_streams / host_decode_compact
+
 
 using namespace gpcc;
 
@@ -302,6 +304,35 @@ int main(int argc, char **argv)
             (void)gsac_host_encode_f32(s2.data(), cdff.data(), n, lp, enc.data(), (int64_t)enc.size(), &enb2);
             // a too-small output buffer is an error, not an overflow
             (void)gsac_host_encode_u16(s2.data(), cdf.data(), n, lp, enc.data(), (int64_t)rndn(8), &enb2);
+        }
+        // the reference-layout container's host coder (csrc/hostcoder.hpp): compact rows (interior values only) against garbage bytes, and a round
+        // trip -- the packed coder words of random symbols under valid rows through host_encode_streams, back through host_decode_compact
+        if (lp == 3 || lp == 5 || lp == 17) {
+            const int rs = lp == 3 ? 1 : lp == 5 ? 4 : 16;
+            std::vector<uint16_t> comp((size_t)n * rs, 0);
+            for (int64_t i = 0; i < n; ++i) for (int j = 1; j <= lp - 2; ++j) comp[(size_t)i * rs + (j - 1)] = cdf[(size_t)i * lp + j];
+            (void)gpcc::host_decode_compact(comp.data(), lp, bytes.data(), (int64_t)nb, n, sym8.data());
+            (void)gpcc::host_decode_compact(comp.data(), lp, bytes.data(), (int64_t)(nb / 3), n, sym8.data());
+            if (style == 0) {
+                std::vector<uint32_t> words((size_t)n);
+                std::vector<uint8_t> want((size_t)n);
+                for (int64_t i = 0; i < n; ++i) {
+                    const int sy = (int)rndn((uint32_t)lp - 1u);
+                    want[(size_t)i] = (uint8_t)sy;
+                    const uint32_t lo = cdf[(size_t)i * lp + sy], hi = sy == lp - 2 ? 0x10000u : cdf[(size_t)i * lp + sy + 1];
+                    words[(size_t)i] = lo | ((hi - 1u) << 16);
+                }
+                const uint32_t *sp[2] = {words.data(), words.data()};
+                const int64_t sn[2] = {n, n / 2};
+                std::vector<std::vector<uint8_t>> outs;
+                if (gpcc::host_encode_streams(sp, sn, 2, &outs, 1 + (int)rndn(3)) != GPCC_OK) { fprintf(stderr, "fuzz_host: host_encode_streams failed on valid rows\n"); return 3; }
+                std::vector<uint8_t> back((size_t)n);
+                std::vector<uint8_t> ex = outs[0];
+                if (ex.empty()) ex.reserve(1);
+                if (gpcc::host_decode_compact(comp.data(), lp, ex.data(), (int64_t)outs[0].size(), n, back.data()) != GPCC_OK || back != want) {
+                    fprintf(stderr, "fuzz_host: reference-layout host coder round trip failed (lp %d, n %lld)\n", lp, (long long)n); return 3;
+                }
+            }
         }
         // the oracle's stream splitter (versions 0-4) and chunk-table reader on the same garbage
         if (lp == 3 || lp == 5 || lp == 17) {

@@ -123,13 +123,6 @@ int host_encode(const int16_t *sym, ROWS rows, int64_t n, int lp, uint8_t *out, 
     }, n, out, cap, nbytes_out);
 }
 
-// the device's compact CDF rows (rc_format.hpp: rc_row_stride uint16 per row, the interior values v[1 .. lp - 2] only)
-struct RowsCompact {
-    const uint16_t *rows; int lp, stride;
-    struct View { const uint16_t *r; inline uint32_t operator[](int m) const { return m ? r[m - 1] : 0u; } };   // v[0] = 0 is not stored
-    inline View row(int64_t i) { return View{rows + i * stride}; }
-};
-
 template <typename ROWS>
 int host_decode(ROWS rows, const uint8_t *bytes, int64_t nbytes, int64_t n, int lp, int16_t *sym_out)
 {
@@ -246,16 +239,62 @@ int host_encode_streams(const uint32_t *const *streams, const int64_t *n, int ns
     return bad.load() ? fail(GPCC_ERR_HIP, "internal: an empty coder interval in a reference-layout stream") : GPCC_OK;
 }
 
+// host_decode for the three alphabets of the codec (LP = 3 / 5 / 17, compact rows of RS uint16): the same decoder -- same symbol rule, same
+// renormalisation -- with the symbol search unrolled and BRANCH-FREE (the generic binary search mispredicts on every symbol of a well-coded
+// stream): the largest s with (span * v[s]) >> 16 <= x is built bit by bit from the top, v[0] = 0 always qualifies.
+template <int LP, int RS>
+static int host_decode_compact_t(const uint16_t *rows, const uint8_t *bytes, int64_t nbytes, int64_t n, uint8_t *sym_out)
+{
+    uint64_t res = 0; int nres = 0; int64_t ptr = 0;
+    auto take = [&](int k) -> uint32_t {
+        if (k == 0) return 0u;
+        while (nres < k) { const uint64_t byte = ptr < nbytes ? bytes[ptr] : 0u; ++ptr; res |= byte << (56 - nres); nres += 8; }
+        const uint32_t v = (uint32_t)(res >> (64 - k));
+        res <<= k; nres -= k;
+        return v;
+    };
+    uint32_t low = 0, high = 0xFFFFFFFFu, value = take(32);
+    constexpr int top = LP - 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const uint16_t *r = rows + i * RS;                 // r[m - 1] = v[m], m = 1 .. top
+        const uint64_t span = (uint64_t)high - (uint64_t)low + 1u;
+        const uint32_t x = value - low;
+        int s = 0;
+#pragma GCC unroll 4
+        for (int step = (top + 1) >> 1; step >= 1; step >>= 1) {
+            const int c = s + step;                         // (top + 1 is a power of two: c <= top)
+            s = (uint32_t)((span * (uint64_t)r[c - 1]) >> 16) <= x ? c : s;
+        }
+        sym_out[i] = (uint8_t)s;
+        const uint32_t c_low = s ? r[s - 1] : 0u, c_high = s == top ? 0x10000u : r[s];
+        high = (low - 1u) + (uint32_t)((span * c_high) >> 16);
+        low = low + (uint32_t)((span * c_low) >> 16);
+        const int n1 = clz32h(low ^ high);
+        if (n1) {
+            low = n1 == 32 ? 0u : low << n1;
+            high = n1 == 32 ? 0xFFFFFFFFu : (high << n1) | ((1u << n1) - 1u);
+            value = n1 == 32 ? take(32) : (value << n1) | take(n1);
+        }
+        int n2 = clz32h(~(low << 1));
+        const int h2 = clz32h(high << 1);
+        n2 = n2 < h2 ? n2 : h2;
+        n2 = n2 < 31 ? n2 : 31;
+        if (n2) {
+            low = (low << n2) & 0x7FFFFFFFu;
+            high = (high << n2) | 0x80000000u | ((1u << n2) - 1u);
+            value = ((value << n2) | take(n2)) ^ 0x80000000u;
+        }
+    }
+    return GPCC_OK;
+}
+
 // one stream of n symbols under compact CDF rows (lp - 1 symbols per row): torchac's decoder, symbols as bytes
 int host_decode_compact(const uint16_t *rows, int lp, const uint8_t *bytes, int64_t nbytes, int64_t n, uint8_t *sym_out)
 {
-    if (lp < 3 || lp > 17) return fail(GPCC_ERR_ARG, "internal: compact rows of %d entries", lp);
-    std::vector<int16_t> tmp((size_t)std::max<int64_t>(n, 1));
-    RowsCompact rc{rows, lp, lp == 3 ? 1 : lp == 5 ? 4 : 16};
-    const int r = host_decode(rc, bytes, nbytes, n, lp, tmp.data());
-    if (r != GPCC_OK) return r;
-    for (int64_t i = 0; i < n; ++i) sym_out[i] = (uint8_t)tmp[(size_t)i];
-    return GPCC_OK;
+    if (lp == 3) return host_decode_compact_t<3, 1>(rows, bytes, nbytes, n, sym_out);
+    if (lp == 5) return host_decode_compact_t<5, 4>(rows, bytes, nbytes, n, sym_out);
+    if (lp == 17) return host_decode_compact_t<17, 16>(rows, bytes, nbytes, n, sym_out);
+    return fail(GPCC_ERR_ARG, "internal: compact rows of %d entries", lp);
 }
 
 }  // namespace gpcc

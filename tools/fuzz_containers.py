@@ -18,7 +18,8 @@ iters = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # corruptions 0 .. skip - 1 are drawn but not decoded
 model = runtime.Model(synthetic_state_dict(32, 5), 32, 5, 0)
 pts = synthetic_cloud(n, seed=11)
-data, _ = gh.encode(model, pts, 11)
+clog = int(os.environ.get("FUZZ_CHUNK_LOG2", "11"))   # 0: the reference layout (its coder runs on the host: csrc/hostcoder.hpp)
+data, _ = gh.encode(model, pts, clog)
 rng = np.random.RandomState(int(sys.argv[4]) if len(sys.argv) > 4 else 0)
 out = {"decoded": 0, "error": 0}
 for it in range(iters):

@@ -406,12 +406,23 @@ def main():
             model_l = runtime.Model(sd_fn(pts_l), 32, k, local_rank)
             blob4, te4, td4, st4, ok4 = layout_point(xs_l, pts_l, model_l, args.chunk_log2, 5)
             blobv0, tev0, tdv0, _, okv0 = layout_point(xs_l, pts_l, model_l, 0, 1)
+            # the dominant kernel on THIS cloud (HIP events around the conv launches of one encode + decode, as `roofline` does for the headline):
+            # the solid cloud's levels are dense (every node has most of its 125 neighbours), its tiles nearly full
+            _lib.check(L.gpcc_profile_enable(ctx, 1))
+            _decode_bytes(bytes(_encode_view(xs_l, model_l, args.chunk_log2, 1)[0]), model_l, device)
+            torch.cuda.synchronize(device)
+            prof_l = _lib.Profile()
+            _lib.check(L.gpcc_profile_get(ctx, C.byref(prof_l)))
+            _lib.check(L.gpcc_profile_enable(ctx, 0))
+            conv_tf = 2.0 * 32 * 32 * prof_l.conv_pair_jobs / (prof_l.conv_ms * 1e-3) / 1e12 if prof_l.conv_ms > 0 else 0.0
             low_rate.append({"case": label, "points": n_l, "coded_nodes": int(st4.coded_nodes), "bpp": round(len(blob4) * 8 / n_l, 4),
                              "bits_per_coded_node": round(len(blob4) * 8 / max(1, st4.coded_nodes), 3),
                              "enc_ms": round(te4 * 1e3, 3), "dec_ms": round(td4 * 1e3, 3), "value": round(n_l / (te4 + td4) / 1e6, 4), "unit": "Mpoints/s",
                              "container_bytes": len(blob4), "bytes_v0": len(blobv0), "bpp_v0": round(len(blobv0) * 8 / n_l, 4),
                              "chunk_overhead_frac": round((len(blob4) - len(blobv0)) / len(blobv0), 5),
-                             "v0_enc_ms": round(tev0 * 1e3, 3), "v0_dec_ms": round(tdv0 * 1e3, 3), "roundtrip_bit_identical": bool(ok4 and okv0)})
+                             "v0_enc_ms": round(tev0 * 1e3, 3), "v0_dec_ms": round(tdv0 * 1e3, 3), "roundtrip_bit_identical": bool(ok4 and okv0),
+                             "conv_TFLOP_per_s": round(conv_tf, 2), "conv_frac_of_mfma_peak": round(conv_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                             "conv_pairs_per_node": round(st4.conv_pairs / 18.0 / max(1, st4.coded_nodes), 1)})
             del model_l
         data, st = _encode_view(x, model, args.chunk_log2, 1)   # `data` is a view of the context's buffer: restore it
 

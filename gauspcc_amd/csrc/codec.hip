@@ -752,7 +752,10 @@ int decode_body(gpcc_ctx *ctx, const gpcc_model *m, const uint8_t *in, int64_t n
                 // the stage's compact CDF rows come down, the symbols go up; the next stage's input waits for them on the stream as it always did
                 const int lp = STAGE_M[s] + 1, rs = rc_row_stride(lp);
                 const size_t rows_b = (size_t)nc * (size_t)rs * 2, off_sym = (rows_b + 63) & ~(size_t)63;
-                GP_TRY(ctx->hcoder.reserve(off_sym + (size_t)nc + 64));
+                {   // (the reference layout's header carries no level sizes: the block grows with the levels -- geometrically, so that a first decode re-pins it a few times, not once per level)
+                    const size_t need = off_sym + (size_t)nc + 64;
+                    if (need > ctx->hcoder.cap) GP_TRY(ctx->hcoder.reserve(std::max(need, 4 * ctx->hcoder.cap)));
+                }
                 StageTimer tm(ctx, st, ST_CODER, (double)nc * (row_bytes + 1) + (double)s_len[4 * g + s]);
                 HIP_TRY(hipMemcpyAsync(ctx->hcoder.p, cdf, rows_b, hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));

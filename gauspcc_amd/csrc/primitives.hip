@@ -1,11 +1,11 @@
 // primitives.hip -- exclusive scan + radix sort for gfx950 (wave64).
 //
 // Radix sort: 8-bit digits, three kernels per pass
-//   k_radix_hist     per 1024-key tile: LDS-atomic digit histogram -> hist[digit][tile]
+//   k_radix_hist     per 4096-key tile (256 threads): LDS-atomic digit histogram -> hist[digit][tile]
 //   exclusive scan   over the digit-major table (global digit offsets per tile)
-//   k_radix_scatter  one wave per tile; stable in-tile rank by wave ballots (8 ballots give the
-//                    lanes that hold the same digit, popcount of the lower lanes is the rank),
-//                    running per-digit counters in LDS across the 16 rounds of a tile.
+//   k_radix_scatter  one 256-thread workgroup per tile; each wave ranks its 1 024 keys stably by wave ballots (8 ballots give the
+//                    lanes that hold the same digit, popcount of the lower lanes is the rank; running per-digit counters of the wave in
+//                    LDS), the waves' counts are chained, the tile is ordered by digit in LDS and leaves in per-digit runs.
 // HBM-bound integer work: per pass it reads keys twice and writes them once.
 #include <algorithm>
 #include "primitives.hpp"
@@ -418,69 +418,127 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
 }
 
 // ------------------------------------------------------------------ radix sort
-constexpr int RS_TILE = 1024;  // keys per tile
-constexpr int RS_ROUNDS = RS_TILE / 64;
+// One 8-bit pass = digit histogram per tile -> one scan of [digit][tile] -> scatter.  Round 6: a tile is 4 096 keys on a 256-thread workgroup
+// (until then 1 024 keys on one wave, every key stored straight to its global slot: 64 unrelated 8-byte stores per instruction, 31 Gkeys/s
+// per pass -- the two sorts were 1.1 ms of the 4.5 ms RD frame).  The tile is first ordered by digit IN LDS -- each wave ranks its 1 024
+// keys with the stable ballot ranking below, the four waves' per-digit counts are chained -- and then written out slot by slot, so that the
+// keys of a digit leave as one contiguous run (16 keys = 128 bytes on average) instead of one by one.
+constexpr int RS_SMALL = 1024;                 // up to this many keys: the whole sort in one launch of one wave (k_radix_small)
+constexpr int RS_TILE = 4096;                  // keys per tile
+constexpr int RS_T = 256;                      // threads per tile
+constexpr int RS_ROUNDS = RS_TILE / RS_T;      // keys per thread; a wave owns RS_TILE / 4 consecutive keys
 
-__global__ __launch_bounds__(256) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n, int shift, uint32_t *__restrict__ hist, int64_t ntiles)
+__global__ __launch_bounds__(RS_T) void k_radix_hist(const uint64_t *__restrict__ keys, int64_t n, int shift, uint32_t *__restrict__ hist, int64_t ntiles)
 {
     __shared__ uint32_t cnt[256];
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    uint64_t k[RS_ROUNDS];
 #pragma unroll
-    for (int r = 0; r < RS_TILE / 256; ++r) {
-        int64_t i = base + r * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255], 1u);
-    }
+    for (int r = 0; r < RS_ROUNDS; ++r) { const int64_t i = base + r * RS_T + threadIdx.x; k[r] = i < n ? keys[i] : 0; }
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r)
+        if (base + r * RS_T + threadIdx.x < n) atomicAdd(&cnt[(uint32_t)(k[r] >> shift) & 255u], 1u);
     __syncthreads();
     hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];
 }
 
 template <bool HAS_VAL>
-__global__ __launch_bounds__(64) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
-                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
-                                                      int shift, const uint32_t *__restrict__ offs, int64_t ntiles)
+__global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                        uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n,
+                                                        int shift, const uint32_t *__restrict__ offs, int64_t ntiles)
 {
-    __shared__ uint32_t cnt[256];
-    const int lane = threadIdx.x;
+    __shared__ uint64_t skey[RS_TILE];
+    __shared__ uint32_t sval[HAS_VAL ? RS_TILE : 1];
+    __shared__ uint32_t cnt[4][256];     // per wave: digit counts, then the first tile slot of the wave's keys of that digit
+    __shared__ uint32_t dstart[257];     // first tile slot of every digit
+    __shared__ uint32_t wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) cnt[lane + 64 * i] = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int w = 0; w < 4; ++w) cnt[w][tid] = 0;
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (RS_TILE / 4);   // the wave's first key
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // the wave's 1 024 keys, 16 per lane, all requested before anything is ranked (key r of lane l: index base + 64 r + l)
+    uint64_t key[RS_ROUNDS];
+    uint32_t val[RS_ROUNDS];
+#pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) {
         const int64_t i = base + r * 64 + lane;
-        const bool ok = i < n;
-        uint64_t key = ok ? keys[i] : 0;
-        const uint32_t d = (uint32_t)(key >> shift) & 255u;
+        key[r] = i < n ? keys[i] : 0;
+        if (HAS_VAL) val[r] = i < n ? vals[i] : 0u;
+    }
+    __syncthreads();
+    // stable rank inside the wave: 8 ballots give the lanes that hold my digit; the wave's running count per digit lives in its own LDS
+    // row (the LDS operations of a wave execute in order: every lane has read cnt[d] before the first peer writes it)
+    uint32_t slot[RS_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const bool ok = base + r * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
         uint64_t peers = __ballot(ok);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const uint64_t bal = __ballot((d >> b) & 1u);
             peers &= ((d >> b) & 1u) ? bal : ~bal;
         }
-        // peers: valid lanes with my digit (meaningful only when ok)
         const uint32_t rank = (uint32_t)__popcll(peers & lt);
-        const uint32_t prior = cnt[d];
+        const uint32_t prior = cnt[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (ok && rank == 0) cnt[wave][d] = prior + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        slot[r] = prior + rank;
+    }
+    __syncthreads();
+    // digit d = tid: chain the four waves' counts, then an exclusive scan over the 256 digits gives every (wave, digit) its first tile slot
+    {
+        const uint32_t c0 = cnt[0][tid], c1 = cnt[1][tid], c2 = cnt[2][tid], c3 = cnt[3][tid];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        const uint32_t inc = wave_incl_scan(tot, lane);
+        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        if (ok && rank == 0) cnt[d] = prior + (uint32_t)__popcll(peers);
-        __syncthreads();
-        if (ok) {
-            const int64_t pos = (int64_t)offs[(int64_t)d * ntiles + blockIdx.x] + prior + rank;
-            keys_out[pos] = key;
-            if (HAS_VAL) vals_out[pos] = vals[i];
+        uint32_t wb = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wb += w < wave ? wsum[w] : 0u;
+        const uint32_t ex = wb + inc - tot;
+        dstart[tid] = ex;
+        cnt[0][tid] = ex; cnt[1][tid] = ex + c0; cnt[2][tid] = ex + c0 + c1; cnt[3][tid] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        if (base + r * 64 + lane < n) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t at = cnt[wave][d] + slot[r];
+            skey[at] = key[r];
+            if (HAS_VAL) sval[at] = val[r];
+        }
+    }
+    __syncthreads();
+    // out: tile slot t -> global slot offs[digit][tile] + (t - first tile slot of the digit): a digit's keys leave as one run
+    const int64_t tile0 = (int64_t)blockIdx.x * RS_TILE;
+    const int count = (int)min((int64_t)RS_TILE, n - tile0);
+#pragma unroll
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const int t = r * RS_T + tid;
+        if (t < count) {
+            const uint64_t k = skey[t];
+            const uint32_t d = (uint32_t)(k >> shift) & 255u;
+            const int64_t pos = (int64_t)offs[(int64_t)d * ntiles + blockIdx.x] + (uint32_t)t - dstart[d];
+            keys_out[pos] = k;
+            if (HAS_VAL) vals_out[pos] = sval[t];
         }
     }
 }
 
-// n <= RS_TILE: the whole sort (every 8-bit pass) in ONE launch of one wave, keys and payloads ping-ponging in LDS.
+// n <= RS_SMALL: the whole sort (every 8-bit pass) in ONE launch of one wave, keys and payloads ping-ponging in LDS.
 // Same stable ballot ranking as k_radix_scatter.  The small octree levels sort a few hundred keys at a time, where a
 // pass of the tiled sort costs five launches.
 template <bool HAS_VAL>
 __global__ __launch_bounds__(64) void k_radix_small(uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, int n, int bits)
 {
-    __shared__ uint64_t k[2][RS_TILE];
-    __shared__ uint32_t v[2][HAS_VAL ? RS_TILE : 1];
+    __shared__ uint64_t k[2][RS_SMALL];
+    __shared__ uint32_t v[2][HAS_VAL ? RS_SMALL : 1];
     __shared__ uint32_t cnt[256];
     const int lane = threadIdx.x;
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -538,7 +596,7 @@ int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t *
 {
     if (n <= 1 || bits <= 0) return GPCC_OK;
     if (bits > 64) bits = 64;
-    if (n <= RS_TILE) {   // in place: the *_io pointers keep pointing at the result
+    if (n <= RS_SMALL) {   // in place: the *_io pointers keep pointing at the result
         if (vals_io && *vals_io) k_radix_small<true><<<1, 64, 0, st>>>(*keys_io, *vals_io, (int)n, bits);
         else k_radix_small<false><<<1, 64, 0, st>>>(*keys_io, nullptr, (int)n, bits);
         LAUNCH_CHECK();
@@ -549,13 +607,13 @@ int radix_sort_u64(gpcc_ctx *ctx, hipStream_t st, uint64_t **keys_io, uint64_t *
     TAKE(hist, uint32_t, 256 * ntiles);
     const bool has_val = vals_io && *vals_io;
     for (int shift = 0; shift < bits; shift += 8) {
-        k_radix_hist<<<dim3((unsigned)ntiles), 256, 0, st>>>(*keys_io, n, shift, hist, ntiles);
+        k_radix_hist<<<dim3((unsigned)ntiles), RS_T, 0, st>>>(*keys_io, n, shift, hist, ntiles);
         LAUNCH_CHECK();
         GP_TRY(exclusive_scan_u32(ctx, st, hist, hist, 256 * ntiles, nullptr));
         if (has_val)
-            k_radix_scatter<true><<<dim3((unsigned)ntiles), 64, 0, st>>>(*keys_io, *vals_io, *keys_tmp_io, *vals_tmp_io, n, shift, hist, ntiles);
+            k_radix_scatter<true><<<dim3((unsigned)ntiles), RS_T, 0, st>>>(*keys_io, *vals_io, *keys_tmp_io, *vals_tmp_io, n, shift, hist, ntiles);
         else
-            k_radix_scatter<false><<<dim3((unsigned)ntiles), 64, 0, st>>>(*keys_io, nullptr, *keys_tmp_io, nullptr, n, shift, hist, ntiles);
+            k_radix_scatter<false><<<dim3((unsigned)ntiles), RS_T, 0, st>>>(*keys_io, nullptr, *keys_tmp_io, nullptr, n, shift, hist, ntiles);
         LAUNCH_CHECK();
         uint64_t *tk = *keys_io; *keys_io = *keys_tmp_io; *keys_tmp_io = tk;
         if (has_val) { uint32_t *tv = *vals_io; *vals_io = *vals_tmp_io; *vals_tmp_io = tv; }

@@ -65,23 +65,25 @@ __device__ __forceinline__ float cull_limit(float A, float B, float C, float op)
     return __logf(255.0f * op) + 2e-3f;
 }
 
-__global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
-                                                   const float *__restrict__ cov3d_pre, const float *__restrict__ opac, Cam cam, int *__restrict__ radii,
+constexpr uint32_t REC_BIG = 0x80000000u;
+constexpr int RECT_SLOTS = 256;
+
+// One Gaussian of k_preprocess.  Returns the tile count of its bounding square when culling (what the reference calls num_rendered is their sum), else 0;
+// *dbits: the depth's bit pattern of a visible Gaussian (visible depths are positive: the patterns order as the values do), 0xFFFFFFFF otherwise.
+__device__ __forceinline__ uint32_t preprocess_one(int i, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
+                                                   const float *__restrict__ cov3d_pre, const float *__restrict__ opac, const Cam &cam, int *__restrict__ radii,
                                                    float2 *__restrict__ xy, float *__restrict__ depth, float4 *__restrict__ conic_op,
-                                                   uint32_t *__restrict__ tiles_touched, int cull, uint32_t *__restrict__ rect_area)
+                                                   uint32_t *__restrict__ tiles_touched, int cull, uint32_t *dbits, uint32_t *cnt_out, uint4 *rec)
 {
-    const int i = blockIdx.x * TB + threadIdx.x;
-    if (i >= P) return;
     radii[i] = 0;
     if (tiles_touched) tiles_touched[i] = 0;
-    if (rect_area) rect_area[i] = 0;
     const float px = means[3 * i], py = means[3 * i + 1], pz = means[3 * i + 2];
     const float *__restrict__ V = cam.view, *__restrict__ M = cam.proj;   // wave-uniform addresses: scalar / broadcast loads
     // transformPoint4x3 / 4x4 with the row-vector (transposed) matrices the Python side passes
     const float tx0 = V[0] * px + V[4] * py + V[8] * pz + V[12];
     const float ty0 = V[1] * px + V[5] * py + V[9] * pz + V[13];
     const float tz = V[2] * px + V[6] * py + V[10] * pz + V[14];
-    if (tz <= 0.2f) return;  // in_frustum
+    if (tz <= 0.2f) return 0;  // in_frustum
     const float hx = M[0] * px + M[4] * py + M[8] * pz + M[12];
     const float hy = M[1] * px + M[5] * py + M[9] * pz + M[13];
     const float hw = M[3] * px + M[7] * py + M[11] * pz + M[15];
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restric
     const float cxy = a0x * s1x + a0y * s1y + a0z * s1z;
     const float cyy = a1x * s1x + a1y * s1y + a1z * s1z + 0.3f;
     const float det = cxx * cyy - cxy * cxy;
-    if (det == 0.0f) return;
+    if (det == 0.0f) return 0;
     const float det_inv = 1.0f / det;
     const float mid = 0.5f * (cxx + cyy);
     const float lam = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
@@ -130,32 +132,68 @@ __global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restric
     const int rx0 = min(cam.gx, max(0, (int)((ix - my_radius) / BX))), ry0 = min(cam.gy, max(0, (int)((iy - my_radius) / BY)));
     const int rx1 = min(cam.gx, max(0, (int)((ix + my_radius + BX - 1) / BX))), ry1 = min(cam.gy, max(0, (int)((iy + my_radius + BY - 1) / BY)));
     const int area = (rx1 - rx0) * (ry1 - ry0);
-    if (area == 0) return;
+    if (area == 0) return 0;
     radii[i] = (int)my_radius;
-    if (tiles_touched) {
-        const float4 co = make_float4(cyy * det_inv, -cxy * det_inv, cxx * det_inv, opac[i]);
-        uint32_t cnt = (uint32_t)area;
-        if (cull) {
-            const float lim = cull_limit(co.x, co.y, co.z, co.w);
-            cnt = 0;
-            for (int y = ry0; y < ry1; ++y)
-                for (int x = rx0; x < rx1; ++x) cnt += tile_touches(ix, iy, co.x, co.y, co.z, lim, x, y) ? 1u : 0u;
-            rect_area[i] = (uint32_t)area;   // summed by k_sum_u32: what the reference calls num_rendered
-        }
-        tiles_touched[i] = cnt;
-        xy[i] = make_float2(ix, iy);
-        depth[i] = tz;
-        conic_op[i] = co;
+    if ((int)my_radius > 0) *dbits = __float_as_uint(tz);
+    if (!tiles_touched) return 0;
+    const float4 co = make_float4(cyy * det_inv, -cxy * det_inv, cxx * det_inv, opac[i]);
+    uint32_t cnt = (uint32_t)area;
+    const int w = rx1 - rx0;
+    uint64_t m = area >= 64 ? ~0ull : (1ull << area) - 1ull;   // bit (y - ry0) * w + (x - rx0): the tiles of the square that take the Gaussian
+    if (cull) {
+        const float lim = cull_limit(co.x, co.y, co.z, co.w);
+        cnt = 0; m = 0;
+        int b = 0;
+        for (int y = ry0; y < ry1; ++y)
+            for (int x = rx0; x < rx1; ++x, ++b)
+                if (tile_touches(ix, iy, co.x, co.y, co.z, lim, x, y)) { ++cnt; m |= 1ull << (b & 63); }
+    }
+    tiles_touched[i] = cnt;
+    *cnt_out = cnt;
+    *rec = make_uint4((uint32_t)m, (uint32_t)(m >> 32), (uint32_t)rx0 | ((uint32_t)ry0 << 16), area > 64 ? REC_BIG : (uint32_t)w);
+    xy[i] = make_float2(ix, iy);
+    depth[i] = tz;
+    conic_op[i] = co;
+    return cull ? (uint32_t)area : 0u;
+}
+
+// dkeys / dvals / recs (optional, together): the (depth, index) pairs of the two-level sort's first level, written here instead of by a pass of their
+// own.  The key's upper word carries the Gaussian's tile count (the sort looks at the lower 32 bits only and moves whole keys), so the counts come out
+// of the sort in depth order; recs[i] is what k_duplicate_sorted needs of Gaussian i in ONE 16-byte gather: the square's origin and width and the
+// mask of its tiles that take the Gaussian (squares of more than 64 tiles: REC_BIG, that kernel walks the square again).
+// rect_total (optional, zeroed by the caller): one atomic add per wave of the bounding squares' tile counts.
+__global__ __launch_bounds__(TB) void k_preprocess(int P, const float *__restrict__ means, const float *__restrict__ scales, const float *__restrict__ rots,
+                                                   const float *__restrict__ cov3d_pre, const float *__restrict__ opac, Cam cam, int *__restrict__ radii,
+                                                   float2 *__restrict__ xy, float *__restrict__ depth, float4 *__restrict__ conic_op,
+                                                   uint32_t *__restrict__ tiles_touched, int cull, unsigned long long *__restrict__ rect_total,
+                                                   uint64_t *__restrict__ dkeys, uint32_t *__restrict__ dvals, uint4 *__restrict__ recs)
+{
+    const int i = blockIdx.x * TB + threadIdx.x;
+    uint32_t dbits = 0xFFFFFFFFu, area = 0, cnt = 0;
+    uint4 rec = make_uint4(0u, 0u, 0u, 0u);
+    if (i < P) {
+        area = preprocess_one(i, means, scales, rots, cov3d_pre, opac, cam, radii, xy, depth, conic_op, tiles_touched, cull, &dbits, &cnt, &rec);
+        if (dkeys) { dkeys[i] = ((uint64_t)cnt << 32) | dbits; dvals[i] = (uint32_t)i; recs[i] = rec; }
+    }
+    if (rect_total) {   // RECT_SLOTS partial sums: 73 k wave atomics on ONE address serialise at ~10 ns each (0.7 ms at 4.66 M Gaussians, measured)
+        for (int d = 32; d; d >>= 1) area += __shfl_xor(area, d);
+        if ((threadIdx.x & 63) == 0 && area) atomicAdd(rect_total + ((blockIdx.x * (TB / 64) + (threadIdx.x >> 6)) & (RECT_SLOTS - 1)), (unsigned long long)area);
     }
 }
 
-__global__ __launch_bounds__(TB) void k_sum_u32(const uint32_t *__restrict__ v, int n, unsigned long long *__restrict__ total)
+__global__ __launch_bounds__(RECT_SLOTS) void k_sum_slots(const unsigned long long *__restrict__ slots, unsigned long long *__restrict__ total)
 {
-    unsigned long long acc = 0;
-    for (int i = blockIdx.x * TB + threadIdx.x; i < n; i += gridDim.x * TB) acc += v[i];
+    __shared__ unsigned long long part[RECT_SLOTS / 64];
+    unsigned long long acc = slots[threadIdx.x];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) acc += (unsigned long long)__shfl_xor((long long)acc, d, 64);
-    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(total, acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int k = 0; k < RECT_SLOTS / 64; ++k) t += part[k];
+        *total = t;
+    }
 }
 
 __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restrict__ xy, const float *__restrict__ depth, const uint32_t *__restrict__ offs,
@@ -184,30 +222,35 @@ __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restric
 // Two-level form of the (tile | depth) sort (round 5).  The reference sorts the L duplicated (tile << 32 | depth) keys in one radix sort
 // (six 8-bit passes over 18 M pairs at 1 M anchors: the largest part of a frame).  A stable sort by depth of the P Gaussians (four passes over
 // 5.4 M), the duplicates emitted in THAT order, and a stable sort of the duplicates by tile alone (two passes) give the same permutation:
-// within a tile, depth ascending, equal depths in Gaussian order -- exactly what the stable sort of the combined key produces.
-__global__ __launch_bounds__(TB) void k_depth_keys(int P, const float *__restrict__ depth, const int *__restrict__ radii, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+// within a tile, depth ascending, equal depths in Gaussian order -- exactly what the stable sort of the combined key produces.  (The first
+// level's (depth, index) pairs come out of k_preprocess.)
+__global__ __launch_bounds__(TB) void k_sorted_counts(int P, const uint64_t *__restrict__ keys, uint32_t *__restrict__ out)
 {
     const int i = blockIdx.x * TB + threadIdx.x;
-    if (i >= P) return;
-    keys[i] = radii[i] > 0 ? (uint64_t)__float_as_uint(depth[i]) : 0xFFFFFFFFull;   // visible depths are positive: their bit patterns order as the values do
-    vals[i] = (uint32_t)i;
+    if (i < P) out[i] = (uint32_t)(keys[i] >> 32);
 }
 
-__global__ __launch_bounds__(TB) void k_gather_touched(int P, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ touched, uint32_t *__restrict__ out)
-{
-    const int i = blockIdx.x * TB + threadIdx.x;
-    if (i < P) out[i] = touched[perm[i]];
-}
-
-__global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *__restrict__ perm, const float2 *__restrict__ xy, const uint32_t *__restrict__ offs,
-                                                         const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-                                                         const float4 *__restrict__ conic_op, int cull)
+__global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *__restrict__ perm, const uint4 *__restrict__ recs, const float2 *__restrict__ xy,
+                                                         const uint32_t *__restrict__ offs, const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys,
+                                                         uint32_t *__restrict__ vals, const float4 *__restrict__ conic_op, int cull)
 {
     const int s = blockIdx.x * TB + threadIdx.x;
     if (s >= P) return;
     const uint32_t i = perm[s];
-    if (radii[i] <= 0) return;
+    const uint4 rec = recs[i];
     uint32_t off = offs[s];
+    if (!(rec.w & REC_BIG)) {     // invisible Gaussians have an empty mask
+        uint64_t m = (uint64_t)rec.x | ((uint64_t)rec.y << 32);
+        const uint32_t w = rec.w;
+        const uint64_t row_mask = w >= 64u ? ~0ull : (1ull << w) - 1ull;
+        for (uint32_t row = (rec.z >> 16) * (uint32_t)gx + (rec.z & 0xFFFFu); m; m = w >= 64u ? 0ull : m >> w, row += (uint32_t)gx)
+            for (uint64_t bits = m & row_mask; bits; bits &= bits - 1ull) {
+                keys[off] = (uint64_t)(row + (uint32_t)__builtin_ctzll(bits));
+                vals[off] = i;
+                ++off;
+            }
+        return;
+    }
     const float r = (float)radii[i];
     const float2 p = xy[i];
     const int rx0 = min(gx, max(0, (int)((p.x - r) / BX))), ry0 = min(gy, max(0, (int)((p.y - r) / BY)));
@@ -258,13 +301,13 @@ __device__ __forceinline__ void blend_one(float power, float op, float r, float 
 }
 
 // dispatch order of the tiles: longest list first (the lists of a frame differ by two orders of magnitude; a long tile that starts last is the
-// frame's tail)
+// frame's tail).  The order is a schedule, not a result: lengths in steps of 64 entries, saturating at 16 k, make it ONE radix pass (20-bit keys: three).
 __global__ __launch_bounds__(TB) void k_tile_order_keys(const uint2 *__restrict__ ranges, int ntiles, uint64_t *__restrict__ key, uint32_t *__restrict__ idx)
 {
     const int t = blockIdx.x * TB + threadIdx.x;
     if (t >= ntiles) return;
     const uint32_t c = ranges[t].y - ranges[t].x;
-    key[t] = 0xFFFFFull - (uint64_t)min(c, 0xFFFFFu);
+    key[t] = 255ull - (uint64_t)min(c >> 6, 255u);
     idx[t] = (uint32_t)t;
 }
 
@@ -361,7 +404,7 @@ extern "C" int gsr_visible_filter(gpcc_ctx *ctx, int P, int W, int H, const floa
     hipStream_t st = (hipStream_t)stream;
     Cam cam;
     GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
-    k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, nullptr, cam, radii, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr);
     LAUNCH_CHECK();
     return GPCC_OK;
 }
@@ -381,7 +424,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
     Cam cam;
     GP_TRY(make_cam(&cam, W, H, viewmatrix, projmatrix, tan_fovx, tan_fovy, scale_modifier));
     const int ntiles = cam.gx * cam.gy;
-    size_t want = (size_t)std::max(P, 1) * 100 + (size_t)ntiles * 8 + ((size_t)8 << 20);
+    size_t want = (size_t)std::max(P, 1) * 112 + (size_t)ntiles * 8 + ((size_t)8 << 20);
     uint32_t L = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         GP_TRY(ctx->arena.reserve(want + (size_t)L * 40));
@@ -391,22 +434,27 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
         HIP_TRY(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)ntiles, st));
         static const bool two_level = dev_env_int("GAUSPCC_RASTER_SORT2", 1) != 0;
         static const int cull = dev_env_int("GAUSPCC_RASTER_CULL", 1) != 0 ? 1 : 0;   // exact tile culling (tile_touches); 0: the reference's lists
-        TAKE(rect_total, unsigned long long, 1); TAKE(rect_area, uint32_t, std::max(P, 1));
-        HIP_TRY(hipMemsetAsync(rect_total, 0, 8, st));
+        TAKE(rect_total, unsigned long long, RECT_SLOTS + 1);      // the slots of k_preprocess, then their sum
+        HIP_TRY(hipMemsetAsync(rect_total, 0, 8 * (RECT_SLOTS + 1), st));
         unsigned long long rect_host = 0;
         const uint32_t *perm = nullptr;          // Gaussians in depth order (two-level sort)
         const uint32_t *offs = touched;
+        uint4 *recs = nullptr;
         if (P > 0) {
-            k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched, cull, cull ? rect_area : nullptr);
-            LAUNCH_CHECK();
-            if (cull) { k_sum_u32<<<256, TB, 0, st>>>(rect_area, P, rect_total); LAUNCH_CHECK(); }
+            uint64_t *dka = nullptr, *dkb = nullptr; uint32_t *dva = nullptr, *dvb = nullptr, *ts = nullptr;
             if (two_level) {
-                TAKE(dka, uint64_t, P); TAKE(dkb, uint64_t, P); TAKE(dva, uint32_t, P); TAKE(dvb, uint32_t, P); TAKE(ts, uint32_t, P + 1);
-                k_depth_keys<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, depth, radii, dka, dva);
-                LAUNCH_CHECK();
+                dka = ctx->arena.take<uint64_t>(P); dkb = ctx->arena.take<uint64_t>(P); dva = ctx->arena.take<uint32_t>(P); dvb = ctx->arena.take<uint32_t>(P);
+                ts = ctx->arena.take<uint32_t>((size_t)P + 1); recs = ctx->arena.take<uint4>(P);
+                if (!dka || !dkb || !dva || !dvb || !ts || !recs) return fail(GPCC_ERR_NOMEM, "rasteriser workspace");
+            }
+            k_preprocess<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, means3D, scales, rotations, cov3D_precomp, opacities, cam, radii, xy, depth, conic_op, touched, cull,
+                                                               cull ? rect_total : nullptr, dka, dva, recs);
+            LAUNCH_CHECK();
+            if (cull) { k_sum_slots<<<1, RECT_SLOTS, 0, st>>>(rect_total, rect_total + RECT_SLOTS); LAUNCH_CHECK(); }
+            if (two_level) {
                 uint64_t *k0 = dka, *k1 = dkb; uint32_t *v0 = dva, *v1 = dvb;
                 GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, P, 32));
-                k_gather_touched<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, v0, touched, ts);
+                k_sorted_counts<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, k0, ts);
                 LAUNCH_CHECK();
                 GP_TRY(exclusive_scan_u32(ctx, st, ts, ts, P, ts + P));
                 HIP_TRY(hipMemcpyAsync(&L, ts + P, 4, hipMemcpyDeviceToHost, st));
@@ -415,7 +463,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
                 GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
                 HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
             }
-            if (cull) HIP_TRY(hipMemcpyAsync(&rect_host, rect_total, 8, hipMemcpyDeviceToHost, st));
+            if (cull) HIP_TRY(hipMemcpyAsync(&rect_host, rect_total + RECT_SLOTS, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
         static const bool stats = dev_env_int("GAUSPCC_RASTER_STATS", 0) != 0;
@@ -430,7 +478,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             while ((1 << tbits) < ntiles) ++tbits;
             uint64_t *k0 = ka, *k1 = kb; uint32_t *v0 = va, *v1 = vb;
             if (perm) {
-                k_duplicate_sorted<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, perm, xy, offs, radii, cam.gx, cam.gy, ka, va, conic_op, cull);
+                k_duplicate_sorted<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, perm, recs, xy, offs, radii, cam.gx, cam.gy, ka, va, conic_op, cull);
                 LAUNCH_CHECK();
                 GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, L, tbits));
                 k_tile_ranges<<<(unsigned)cdiv(L, TB), TB, 0, st>>>((int)L, k0, 0, ranges);
@@ -451,7 +499,7 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
             k_tile_order_keys<<<(unsigned)cdiv(ntiles, TB), TB, 0, st>>>(ranges, ntiles, oka, ova);
             LAUNCH_CHECK();
             uint64_t *k0 = oka, *k1 = okb; uint32_t *v0 = ova, *v1 = ovb;
-            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, ntiles, 20));
+            GP_TRY(radix_sort_u64(ctx, st, &k0, &k1, &v0, &v1, ntiles, 8));
             tile_order = v0;
         }
         k_render<<<(unsigned)ntiles, RT, 0, st>>>(ranges, tile_order, vals_sorted, W, H, cam.gx, xy, colors_precomp, conic_op, background, out_color);

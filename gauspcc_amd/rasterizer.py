@@ -44,7 +44,7 @@ class GaussianRasterizer(nn.Module):
         rs = self.raster_settings
         means3D, scales, rotations, cov3D_precomp = _f32(means3D), _f32(scales), _f32(rotations), _f32(cov3D_precomp)
         P = means3D.shape[0]
-        radii = torch.zeros(P, dtype=torch.int32, device=means3D.device)
+        radii = torch.empty(P, dtype=torch.int32, device=means3D.device)       # k_preprocess writes every entry
         view, proj = _f32(rs.viewmatrix), _f32(rs.projmatrix)
         _lib.check(_lib.lib().gsr_visible_filter(
             runtime.context(means3D.device), P, int(rs.image_width), int(rs.image_height), means3D.data_ptr(),
@@ -68,7 +68,7 @@ class GaussianRasterizer(nn.Module):
         dev = means3D.device
         H, W = int(rs.image_height), int(rs.image_width)
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-        radii = torch.zeros(P, dtype=torch.int32, device=dev)
+        radii = torch.empty(P, dtype=torch.int32, device=dev)       # k_preprocess writes every entry
         view, proj, bg = _f32(rs.viewmatrix), _f32(rs.projmatrix), _f32(rs.bg)
         n = C.c_int64()
         _lib.check(_lib.lib().gsr_forward(

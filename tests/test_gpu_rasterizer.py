@@ -95,10 +95,12 @@ def test_empty_and_background():
     assert torch.allclose(img, torch.tensor(bg).cuda().view(3, 1, 1).expand(3, H, W))
 
 
-def test_two_level_sort_equals_combined_key_sort():
+@pytest.mark.parametrize("boost", [0.0, 1.2])
+def test_two_level_sort_equals_combined_key_sort(boost):
     """The (tile | depth) order through a depth sort of the Gaussians + a tile sort of the duplicates (csrc/rasterizer.hip, round 5) against
     the reference's single sort of the combined key (GAUSPCC_RASTER_SORT2=0, developer knob): the same image bit for bit, on a scene where a
-    third of the Gaussians share their depth with others (equal keys: the stable order by Gaussian index decides)."""
+    third of the Gaussians share their depth with others (equal keys: the stable order by Gaussian index decides).  boost 1.2: splats of ~50 pixels
+    radius, their bounding squares on either side of 64 tiles -- both forms of k_duplicate_sorted's record (tile mask / REC_BIG walk)."""
     import hashlib
     import os
     import subprocess
@@ -116,11 +118,12 @@ W, H, n = 400, 300, 60000
 sc = _scene(n, 11, W, H)
 sc["means"][::3, 2] = np.float32(0.5)          # shared depth
 sc["means"][1::7, 2] = np.float32(-1.25)
+sc["scales"] *= np.float32(np.exp(%r))
 rast = GaussianRasterizer(_settings(torch, sc, W, H, np.array([0.1, 0.2, 0.3], np.float32)))
 t = {k: torch.tensor(v).cuda() for k, v in sc.items() if isinstance(v, np.ndarray)}
 img, radii = rast(means3D=t["means"], means2D=None, shs=None, colors_precomp=t["colors"], opacities=t["opac"], scales=t["scales"], rotations=t["rots"])
-print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), rast.num_rendered)
-""" % root
+print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), int((radii > 64).sum()), rast.num_rendered)
+""" % (root, boost)
     out = []
     for v, cull in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
         e = dict(os.environ)
@@ -131,6 +134,7 @@ print("digest", hashlib.sha256(img.cpu().numpy().tobytes()).hexdigest(), rast.nu
         assert r.returncode == 0, r.stderr[-3000:]
         out.append([ln for ln in r.stdout.splitlines() if ln.startswith("digest")][0])
     assert out[0] == out[1] == out[2] == out[3] and int(out[0].split()[-1]) > 100000
+    assert boost == 0.0 or int(out[0].split()[-2]) > 1000       # squares wider than 8 tiles are there
 
 
 def test_needle_splats_survive_exact_culling():

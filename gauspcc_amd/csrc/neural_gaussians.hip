@@ -170,8 +170,22 @@ __device__ __forceinline__ MlpLds ng_stage(float *&sm, const Mlp &m, int din, in
     using M = NGM<F>;
     float *W1s = sm, *W2s = W1s + M::NT1 * 16 * p1, *B1s = W2s + nt2 * 16 * M::P2, *B2s = B1s + M::NT1 * 16;
     sm = B2s + nt2 * 16;
-    for (int i = tid; i < M::NT1 * 16 * dinp; i += nthreads) { const int c = i / dinp, k = i - c * dinp; W1s[c * p1 + k] = (c < F && k < din) ? m.w1[c * din + k] : 0.0f; }
-    for (int i = tid; i < nt2 * 16 * M::DHP; i += nthreads) { const int c = i / M::DHP, k = i - c * M::DHP; W2s[c * M::P2 + k] = (c < dout && k < F) ? m.w2[c * F + k] : 0.0f; }
+    // (four loads in flight per trip: written as a plain loop, hipcc 7.2 waits for every element's load before it issues the next -- one HBM / L2 round trip
+    //  per element, ~15 us at the head of every workgroup)
+    for (int i0 = tid; i0 < M::NT1 * 16 * dinp; i0 += 4 * nthreads) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / dinp, k = i - c * dinp; v[u] = (i < M::NT1 * 16 * dinp && c < F && k < din) ? m.w1[c * din + k] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / dinp, k = i - c * dinp; if (i < M::NT1 * 16 * dinp) W1s[c * p1 + k] = v[u]; }
+    }
+    for (int i0 = tid; i0 < nt2 * 16 * M::DHP; i0 += 4 * nthreads) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / M::DHP, k = i - c * M::DHP; v[u] = (i < nt2 * 16 * M::DHP && c < dout && k < F) ? m.w2[c * F + k] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / M::DHP, k = i - c * M::DHP; if (i < nt2 * 16 * M::DHP) W2s[c * M::P2 + k] = v[u]; }
+    }
     for (int i = tid; i < M::NT1 * 16; i += nthreads) B1s[i] = i < F ? m.b1[i] : 0.0f;
     for (int i = tid; i < nt2 * 16; i += nthreads) B2s[i] = i < dout ? m.b2[i] : 0.0f;
     return MlpLds{W1s, B1s, W2s, B2s};
@@ -256,20 +270,39 @@ __device__ __forceinline__ void ng_layer2(const float (&a)[NGM<F>::DHP / 4], con
 // partial EXEC of the feature-load loop and branched on it again inside the divergent emission loop -- lanes that were inactive at the first place read
 // rows[] through the null pointer (found by tests/test_gpu_hac_plus_codec.py on an un-decoded model: a memory fault that depended on which Gaussians survive)
 template <int F, bool ROWS>
-__device__ __forceinline__ void ng_build_x(const NGArgs &a, int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane)
+__device__ __forceinline__ void ng_build_x(const NGArgs &a, const float (&cam)[3], int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane)
 {
     using M = NGM<F>;
     const int e = lane & 15, g = lane >> 4;
-    for (int i = lane; i < 16 * (F / 2); i += 64) {
-        const int r = i / (F / 2), c2 = i - r * (F / 2);
-        int64_t row = row0 + r < a.n ? row0 + r : a.n - 1;
-        if (ROWS) row = a.rows[row];
-        *reinterpret_cast<float2 *>(xs + r * px + 2 * c2) = *reinterpret_cast<const float2 *>(a.feat + row * F + 2 * c2);
+    // every load of the tile is requested before the first one is used: as a run-time loop (`for (i = lane; i < 16 * F / 2; i += 64)`) the compiler
+    // waited for each float2 before asking for the next -- seven dependent round trips per tile, 5 of the 7.8 us a wave spent on a tile of k_ng_opacity
+    constexpr int NLD = (16 * (F / 2) + 63) / 64;
+    float2 fv[NLD];
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    {
+        int64_t rws[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = lane + 64 * it, r = i / (F / 2);
+            rws[it] = row0 + r < a.n ? row0 + r : a.n - 1;
+            if (ROWS) rws[it] = i < 16 * (F / 2) ? (int64_t)a.rows[rws[it]] : 0;
+        }
+        int64_t arow = row0 + lane < a.n ? row0 + lane : a.n - 1;
+        if (ROWS) arow = lane < 16 ? (int64_t)a.rows[arow] : 0;
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int i = lane + 64 * it, r = i / (F / 2), c2 = i - r * (F / 2);
+            fv[it] = i < 16 * (F / 2) ? *reinterpret_cast<const float2 *>(a.feat + rws[it] * F + 2 * c2) : make_float2(0.0f, 0.0f);
+        }
+        if (lane < 16) { ax = a.anchor[3 * arow]; ay = a.anchor[3 * arow + 1]; az = a.anchor[3 * arow + 2]; }
+    }
+#pragma unroll
+    for (int it = 0; it < NLD; ++it) {
+        const int i = lane + 64 * it, r = i / (F / 2), c2 = i - r * (F / 2);
+        if (i < 16 * (F / 2)) *reinterpret_cast<float2 *>(xs + r * px + 2 * c2) = fv[it];
     }
     if (lane < 16) {   // ob_view / ob_dist (:116-118)
-        int64_t row = row0 + lane < a.n ? row0 + lane : a.n - 1;
-        if (ROWS) row = a.rows[row];
-        const float vx = a.anchor[3 * row] - a.cam[0], vy = a.anchor[3 * row + 1] - a.cam[1], vz = a.anchor[3 * row + 2] - a.cam[2];
+        const float vx = ax - cam[0], vy = ay - cam[1], vz = az - cam[2];
         const float dist = sqrtf(vx * vx + vy * vy + vz * vz);
         float *x = xs + lane * px + F;
         x[0] = vx / dist; x[1] = vy / dist; x[2] = vz / dist; x[3] = dist;
@@ -336,6 +369,7 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
     constexpr int PX = M::P1;
     float *xs = sm + wave * 16 * (PX + M::P2), *hs = xs + 16 * PX;
     const int64_t ntiles = (a.n + 15) / 16;
+    const float cam[3] = {a.cam[0], a.cam[1], a.cam[2]};     // read once: inside the tile loop it was a round trip of its own per tile
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
         // the grid masks of this lane's four outputs: requested now, used after the MLP (their round trip is off the tile's chain)
@@ -346,7 +380,7 @@ __global__ __launch_bounds__(512) void k_ng_opacity(NGArgs a)
             mk[i] = 0.0f;
             if (e < a.K && row < a.n) mk[i] = a.mask[(ROWS ? (int64_t)a.rows[row] : row) * a.K + e];
         }
-        ng_build_x<F, ROWS>(a, row0, xs, PX, hs, bank, bk, lane);
+        ng_build_x<F, ROWS>(a, cam, row0, xs, PX, hs, bank, bk, lane);
         float a1[M::DINP / 4];
 #pragma unroll
         for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
@@ -396,9 +430,10 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
     __syncthreads();
     float *xs = sm + wave * 16 * (PX + M::P2), *hs = xs + 16 * PX;
     const int64_t ntiles = (a.n + 15) / 16;
+    const float cam[3] = {a.cam[0], a.cam[1], a.cam[2]};     // read once: inside the tile loop it was a round trip of its own per tile
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
-        ng_build_x<F, ROWS>(a, row0, xs, PX, hs, bank, bk, lane);
+        ng_build_x<F, ROWS>(a, cam, row0, xs, PX, hs, bank, bk, lane);
         float a1[M::DINP / 4];
 #pragma unroll
         for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
@@ -429,9 +464,8 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
             }
         });
         ng_wave_sync();
-        // the surviving Gaussians of the tile, each to its final row (:160-171).  Flags, then positions, then attributes of ALL the lane's candidates
-        // (16 K / 64 <= 4) are requested together -- three round trips per tile instead of three per candidate: the kernel's emission is bound by these
-        // dependent loads, not by its stores (HISTORY.md section 4)
+        // the surviving Gaussians of the tile, each to its final row (:160-171); the emission is bound by its loads' round trips, not by its stores
+        // (HISTORY.md section 4)
         {
             const uint32_t *__restrict__ keepp = a.keep, *__restrict__ posp = o.pos;
             const float *__restrict__ nopap = a.nopa, *__restrict__ scalp = o.scaling, *__restrict__ anchp = a.anchor, *__restrict__ offp = o.offsets;
@@ -446,27 +480,24 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
                 gis[it] = (row0 + rr[it]) * K + jj[it];
                 kp[it] = idx < 16 * K && row0 + rr[it] < a.n;
             }
-            uint32_t kf[NIT];
+            // ONE batch: flag, position and attributes of every candidate are requested together, the dropped candidates' too (their offsets are the only
+            // bytes that would not have been fetched anyway) -- the flag -> position -> attributes chain was three dependent round trips per tile
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) kf[it] = kp[it] ? keepp[gis[it]] : 0u;
-            uint32_t pp[NIT];
+            for (int it = 0; it < NIT; ++it) srcs[it] = ROWS ? (kp[it] ? (int64_t)a.rows[row0 + rr[it]] : 0) : (kp[it] ? row0 + rr[it] : 0);
+            uint32_t kf[NIT], pp[NIT];
             float no[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                kp[it] = kf[it] != 0u;
-                pp[it] = kp[it] ? posp[gis[it]] : 0u;
-                no[it] = kp[it] ? nopap[gis[it]] : 0.0f;
-                srcs[it] = ROWS ? (kp[it] ? (int64_t)a.rows[row0 + rr[it]] : 0) : row0 + rr[it];
-            }
             float sc[NIT][6], an[NIT][3], of[NIT][3];
 #pragma unroll
-            for (int it = 0; it < NIT; ++it)
-                if (kp[it]) {
+            for (int it = 0; it < NIT; ++it) {
+                const int64_t gi = kp[it] ? gis[it] : 0;
+                kf[it] = keepp[gi]; pp[it] = posp[gi]; no[it] = nopap[gi];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) sc[it][k] = scalp[srcs[it] * 6 + k];
+                for (int k = 0; k < 6; ++k) sc[it][k] = scalp[srcs[it] * 6 + k];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { an[it][k] = anchp[3 * srcs[it] + k]; of[it][k] = offp[(srcs[it] * K + jj[it]) * 3 + k]; }
-                }
+                for (int k = 0; k < 3; ++k) { an[it][k] = anchp[3 * srcs[it] + k]; of[it][k] = offp[(srcs[it] * K + (kp[it] ? jj[it] : 0)) * 3 + k]; }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) kp[it] = kp[it] && kf[it] != 0u;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (kp[it]) {

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(TB) void k_assemble(AsmArgs a)
 // x is rebuilt rather than kept: 200 MB of feature reads against 430 MB of x written and read back.  n_offsets <= 16 (the
 // reference's configurations use 10: HAC/arguments/__init__.py:55); wider models stay on k_anchor_mlps.
 typedef float f32x4n __attribute__((ext_vector_type(4)));
+constexpr int NG_AUX = 9;     // anchor (3) + scaling (6) per row of a tile, k_ng_emit's LDS copy
 #define NG_MF(c, a, b) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0)
 
 template <int F> struct NGM {
@@ -270,7 +271,7 @@ __device__ __forceinline__ void ng_layer2(const float (&a)[NGM<F>::DHP / 4], con
 // partial EXEC of the feature-load loop and branched on it again inside the divergent emission loop -- lanes that were inactive at the first place read
 // rows[] through the null pointer (found by tests/test_gpu_hac_plus_codec.py on an un-decoded model: a memory fault that depended on which Gaussians survive)
 template <int F, bool ROWS>
-__device__ __forceinline__ void ng_build_x(const NGArgs &a, const float (&cam)[3], int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane)
+__device__ __forceinline__ void ng_build_x(const NGArgs &a, const float (&cam)[3], int64_t row0, float *xs, int px, float *hs, bool bank, const MlpLds &bk, int lane, float *aux = nullptr)
 {
     using M = NGM<F>;
     const int e = lane & 15, g = lane >> 4;
@@ -278,7 +279,7 @@ __device__ __forceinline__ void ng_build_x(const NGArgs &a, const float (&cam)[3
     // waited for each float2 before asking for the next -- seven dependent round trips per tile, 5 of the 7.8 us a wave spent on a tile of k_ng_opacity
     constexpr int NLD = (16 * (F / 2) + 63) / 64;
     float2 fv[NLD];
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, sv[6] = {};
     {
         int64_t rws[NLD];
 #pragma unroll
@@ -295,6 +296,16 @@ __device__ __forceinline__ void ng_build_x(const NGArgs &a, const float (&cam)[3
             fv[it] = i < 16 * (F / 2) ? *reinterpret_cast<const float2 *>(a.feat + rws[it] * F + 2 * c2) : make_float2(0.0f, 0.0f);
         }
         if (lane < 16) { ax = a.anchor[3 * arow]; ay = a.anchor[3 * arow + 1]; az = a.anchor[3 * arow + 2]; }
+        if (aux && lane < 16) {   // k_ng_emit: the tile's anchors and scalings, kept in LDS for the emission (aux[16][NG_AUX])
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sv[k] = a.scaling[arow * 6 + k];
+        }
+    }
+    if (aux && lane < 16) {
+        float *q = aux + lane * NG_AUX;
+        q[0] = ax; q[1] = ay; q[2] = az;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[3 + k] = sv[k];
     }
 #pragma unroll
     for (int it = 0; it < NLD; ++it) {
@@ -414,6 +425,9 @@ struct EmitArgs {
 };
 
 // NIT = candidates per lane in the emission = ceil(16 K / 64): a template parameter so that their attributes stay in registers
+#ifndef NG_EMIT_LOADS_AT
+#define NG_EMIT_LOADS_AT 1
+#endif
 template <int F, bool ROWS, int NIT>
 __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
 {
@@ -428,12 +442,43 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
     const MlpLds col = ng_stage<F>(sm, a.color, F + 4, M::DINP, M::P1, 3 * K, ntc, tid, blockDim.x);
     const MlpLds cov = ng_stage<F>(sm, a.cov, F + 4, M::DINP, M::P1, 7 * K, ntv, tid, blockDim.x);
     __syncthreads();
-    float *xs = sm + wave * 16 * (PX + M::P2), *hs = xs + 16 * PX;
+    float *xs = sm + wave * 16 * (PX + M::P2 + NG_AUX), *hs = xs + 16 * PX, *aux = hs + 16 * M::P2;
     const int64_t ntiles = (a.n + 15) / 16;
     const float cam[3] = {a.cam[0], a.cam[1], a.cam[2]};     // read once: inside the tile loop it was a round trip of its own per tile
     for (int64_t tile = (int64_t)blockIdx.x * waves + wave; tile < ntiles; tile += (int64_t)gridDim.x * waves) {
         const int64_t row0 = tile * 16;
-        ng_build_x<F, ROWS>(a, cam, row0, xs, PX, hs, bank, bk, lane);
+        ng_build_x<F, ROWS>(a, cam, row0, xs, PX, hs, bank, bk, lane, aux);
+        // the emission's inputs (flag, position, attributes of the lane's NIT candidates): requested at NG_EMIT_LOADS_AT -- 0: where they are used, behind the
+        // covariance MLP; 1: in front of it; 2: in front of both MLPs -- so that their round trip runs beside the matrix work
+        const uint32_t *__restrict__ keepp = a.keep, *__restrict__ posp = o.pos;
+        const float *__restrict__ nopap = a.nopa, *__restrict__ offp = o.offsets;
+        bool kp[NIT];
+        int64_t gis[NIT], srcs[NIT];
+        int rr[NIT], jj[NIT];
+        uint32_t kf[NIT], pp[NIT];
+        float no[NIT];
+        float of[NIT][3];
+        auto emission_loads = [&]() {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = lane + 64 * it;
+                rr[it] = idx / K; jj[it] = idx - rr[it] * K;
+                gis[it] = (row0 + rr[it]) * K + jj[it];
+                kp[it] = idx < 16 * K && row0 + rr[it] < a.n;
+            }
+            // ONE batch: flag, position and offset of every candidate are requested together, the dropped candidates' too (anchor and scaling of the tile's
+            // rows sit in LDS since ng_build_x) -- the flag -> position -> attributes chain was three dependent round trips per tile
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) srcs[it] = ROWS ? (kp[it] ? (int64_t)a.rows[row0 + rr[it]] : 0) : (kp[it] ? row0 + rr[it] : 0);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int64_t gi = kp[it] ? gis[it] : 0;
+                kf[it] = keepp[gi]; pp[it] = posp[gi]; no[it] = nopap[gi];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) of[it][k] = offp[(srcs[it] * K + (kp[it] ? jj[it] : 0)) * 3 + k];
+            }
+        };
+        if (NG_EMIT_LOADS_AT == 2) emission_loads();
         float a1[M::DINP / 4];
 #pragma unroll
         for (int kk = 0; kk < M::DINP / 4; ++kk) a1[kk] = xs[e * PX + 4 * kk + g];
@@ -451,6 +496,7 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
             }
         });
         ng_wave_sync();
+        if (NG_EMIT_LOADS_AT == 1) emission_loads();
         // covariance: linear head, 7 per Gaussian (:151-152) -> columns 3 K .. 10 K - 1
         ng_hidden<F, M::DINP / 4>(a1, cov.w1, M::P1, cov.b1, hs, e, g);
         ng_wave_sync();
@@ -467,51 +513,24 @@ __global__ __launch_bounds__(512) void k_ng_emit(NGArgs a, EmitArgs o)
         // the surviving Gaussians of the tile, each to its final row (:160-171); the emission is bound by its loads' round trips, not by its stores
         // (HISTORY.md section 4)
         {
-            const uint32_t *__restrict__ keepp = a.keep, *__restrict__ posp = o.pos;
-            const float *__restrict__ nopap = a.nopa, *__restrict__ scalp = o.scaling, *__restrict__ anchp = a.anchor, *__restrict__ offp = o.offsets;
             float *__restrict__ oop = o.opacity, *__restrict__ ocol = o.color, *__restrict__ osc = o.scale, *__restrict__ orot = o.rot, *__restrict__ oxyz = o.xyz;
-            bool kp[NIT];
-            int64_t gis[NIT], srcs[NIT];
-            int rr[NIT], jj[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int idx = lane + 64 * it;
-                rr[it] = idx / K; jj[it] = idx - rr[it] * K;
-                gis[it] = (row0 + rr[it]) * K + jj[it];
-                kp[it] = idx < 16 * K && row0 + rr[it] < a.n;
-            }
-            // ONE batch: flag, position and attributes of every candidate are requested together, the dropped candidates' too (their offsets are the only
-            // bytes that would not have been fetched anyway) -- the flag -> position -> attributes chain was three dependent round trips per tile
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) srcs[it] = ROWS ? (kp[it] ? (int64_t)a.rows[row0 + rr[it]] : 0) : (kp[it] ? row0 + rr[it] : 0);
-            uint32_t kf[NIT], pp[NIT];
-            float no[NIT];
-            float sc[NIT][6], an[NIT][3], of[NIT][3];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int64_t gi = kp[it] ? gis[it] : 0;
-                kf[it] = keepp[gi]; pp[it] = posp[gi]; no[it] = nopap[gi];
-#pragma unroll
-                for (int k = 0; k < 6; ++k) sc[it][k] = scalp[srcs[it] * 6 + k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { an[it][k] = anchp[3 * srcs[it] + k]; of[it][k] = offp[(srcs[it] * K + (kp[it] ? jj[it] : 0)) * 3 + k]; }
-            }
+            if (NG_EMIT_LOADS_AT == 0) emission_loads();
 #pragma unroll
             for (int it = 0; it < NIT; ++it) kp[it] = kp[it] && kf[it] != 0u;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (kp[it]) {
                     const uint32_t p = pp[it];
-                    const float *c3 = xs + rr[it] * PX + 3 * jj[it], *d = xs + rr[it] * PX + 3 * K + 7 * jj[it];
+                    const float *c3 = xs + rr[it] * PX + 3 * jj[it], *d = xs + rr[it] * PX + 3 * K + 7 * jj[it], *ar = aux + rr[it] * NG_AUX;
                     oop[p] = no[it];
                     ocol[3 * p] = c3[0]; ocol[3 * p + 1] = c3[1]; ocol[3 * p + 2] = c3[2];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) osc[3 * p + k] = sc[it][3 + k] * (1.0f / (1.0f + expf(-d[k])));
+                    for (int k = 0; k < 3; ++k) osc[3 * p + k] = ar[6 + k] * (1.0f / (1.0f + expf(-d[k])));
                     const float q0 = d[3], q1 = d[4], q2 = d[5], q3 = d[6];
                     const float nrm = fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f);
                     orot[4 * p] = q0 / nrm; orot[4 * p + 1] = q1 / nrm; orot[4 * p + 2] = q2 / nrm; orot[4 * p + 3] = q3 / nrm;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) oxyz[3 * p + k] = an[it][k] + of[it][k] * sc[it][k];
+                    for (int k = 0; k < 3; ++k) oxyz[3 * p + k] = ar[k] + of[it][k] * ar[3 + k];
                 }
         }
         ng_wave_sync();
@@ -530,7 +549,7 @@ template <int F> static size_t ng_lds_emit(bool bank, int K, int waves)
 {
     using M = NGM<F>;
     return 4 * ((size_t)(bank ? ng_mlp_floats<F>(M::PB, 1) : 0) + ng_mlp_floats<F>(M::P1, (3 * K + 15) / 16) + ng_mlp_floats<F>(M::P1, (7 * K + 15) / 16) +
-                (size_t)waves * 16 * (ng_emit_pitch<F>(K) + M::P2));
+                (size_t)waves * 16 * (ng_emit_pitch<F>(K) + M::P2 + NG_AUX));
 }
 
 // number of waves per workgroup for the two launches, 0 when the model does not fit the matrix-pipe path

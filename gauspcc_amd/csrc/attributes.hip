@@ -669,8 +669,20 @@ __global__ __launch_bounds__(64 * MLPM_WAVES_MAX) void k_mlp2_mfma(const float *
     float *W1s = sm, *W2s = W1s + DH * P1, *B1s = W2s + DOUT * P2, *B2s = B1s + NT1 * 16, *XS = B2s + NT2 * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, MLPM_WAVES = nthreads >> 6;
     const int e = lane & 15, g = lane >> 4;
-    for (int i = tid; i < DH * DIN; i += nthreads) { const int c = i / DIN, k = i - c * DIN; W1s[c * P1 + k] = (c < dh && k < din) ? w1[(size_t)c * din + k] : 0.0f; }
-    for (int i = tid; i < DOUT * DH; i += nthreads) { const int c = i / DH, k = i - c * DH; W2s[c * P2 + k] = (c < dout && k < dh) ? w2[(size_t)c * dh + k] : 0.0f; }
+    for (int i0 = tid; i0 < DH * DIN; i0 += 4 * nthreads) {     // (four loads in flight per trip, see the tile loads below)
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / DIN, k = i - c * DIN; v[u] = (i < DH * DIN && c < dh && k < din) ? w1[(size_t)c * din + k] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / DIN, k = i - c * DIN; if (i < DH * DIN) W1s[c * P1 + k] = v[u]; }
+    }
+    for (int i0 = tid; i0 < DOUT * DH; i0 += 4 * nthreads) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / DH, k = i - c * DH; v[u] = (i < DOUT * DH && c < dout && k < dh) ? w2[(size_t)c * dh + k] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * nthreads, c = i / DH, k = i - c * DH; if (i < DOUT * DH) W2s[c * P2 + k] = v[u]; }
+    }
     for (int i = tid; i < NT1 * 16; i += nthreads) B1s[i] = i < dh ? b1[i] : 0.0f;
     for (int i = tid; i < NT2 * 16; i += nthreads) B2s[i] = i < dout ? b2[i] : 0.0f;
     __syncthreads();
@@ -679,16 +691,37 @@ __global__ __launch_bounds__(64 * MLPM_WAVES_MAX) void k_mlp2_mfma(const float *
     for (int64_t tile = (int64_t)blockIdx.x * MLPM_WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * MLPM_WAVES) {
         const int64_t row0 = tile * 16;
         // the tile's rows: coalesced float2 loads (rows past n: the last row again), the wave's own LDS slice
+        // (loads in batches that are in flight together: as one run-time loop hipcc 7.2 waited for every element before it requested the next --
+        //  12 dependent round trips per tile of the 96-column class)
         if (din == DIN) {
-            for (int i = lane; i < 16 * DIN / 2; i += 64) {
-                const int r = i / (DIN / 2), c2 = i - r * (DIN / 2);
-                const float2 v = *reinterpret_cast<const float2 *>(x + (size_t)min(row0 + r, n - 1) * DIN + 2 * c2);
-                *reinterpret_cast<float2 *>(xs + r * PX + 2 * c2) = v;
+            static_assert((16 * DIN / 2) % 64 == 0, "whole trips");
+            constexpr int NLD = 16 * DIN / 2 / 64, NB = NLD % 6 == 0 ? 6 : (NLD % 4 == 0 ? 4 : NLD);
+            const float *xt = x + (size_t)row0 * DIN;                        // wave-uniform base, 32-bit offsets
+            const int last = (int)min((int64_t)15, n - 1 - row0);
+#pragma unroll
+            for (int b0 = 0; b0 < NLD; b0 += NB) {
+                float2 v[NB];
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int i = lane + 64 * (b0 + u), r = i / (DIN / 2), c2 = i - r * (DIN / 2);
+                    v[u] = *reinterpret_cast<const float2 *>(xt + min(r, last) * DIN + 2 * c2);
+                }
+#pragma unroll
+                for (int u = 0; u < NB; ++u) {
+                    const int i = lane + 64 * (b0 + u), r = i / (DIN / 2), c2 = i - r * (DIN / 2);
+                    *reinterpret_cast<float2 *>(xs + r * PX + 2 * c2) = v[u];
+                }
             }
         } else {   // a narrower layer in this class: column by column, zeros beyond din
-            for (int i = lane; i < 16 * DIN; i += 64) {
-                const int r = i / DIN, c = i - r * DIN;
-                xs[r * PX + c] = c < din ? x[(size_t)min(row0 + r, n - 1) * din + c] : 0.0f;
+            const float *xn = x + (size_t)row0 * din;
+            const int lastn = (int)min((int64_t)15, n - 1 - row0);
+            static_assert((16 * DIN / 64) % 4 == 0, "whole batches");
+            for (int i0 = lane; i0 < 16 * DIN; i0 += 4 * 64) {      // unconditional loads (column clamped), four in flight
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u, r = i / DIN, c = i - r * DIN; v[u] = xn[min(r, lastn) * din + min(c, din - 1)]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u, r = i / DIN, c = i - r * DIN; xs[r * PX + c] = c < din ? v[u] : 0.0f; }
             }
         }
         float a[DIN / 4 > DH / 4 ? DIN / 4 : DH / 4];

@@ -452,11 +452,14 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint64_t *__restri
     __shared__ uint64_t skey[RS_TILE];
     __shared__ uint32_t sval[HAS_VAL ? RS_TILE : 1];
     __shared__ uint32_t cnt[4][256];     // per wave: digit counts, then the first tile slot of the wave's keys of that digit
-    __shared__ uint32_t dstart[257];     // first tile slot of every digit
+    __shared__ uint32_t dstart[256];     // per digit: its first global slot for this tile minus its first tile slot
     __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < 4; ++w) cnt[w][tid] = 0;
+    // digit tid's first global slot for this tile: requested now, used by the copy-out at the end through LDS (fetched inside the copy-out loop it was a
+    // dependent round trip in front of every one of a thread's 16 stores)
+    const uint32_t my_off = offs[(int64_t)tid * ntiles + blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * (RS_TILE / 4);   // the wave's first key
     const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
     // the wave's 1 024 keys, 16 per lane, all requested before anything is ranked (key r of lane l: index base + 64 r + l)
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint64_t *__restri
 #pragma unroll
         for (int w = 0; w < 4; ++w) wb += w < wave ? wsum[w] : 0u;
         const uint32_t ex = wb + inc - tot;
-        dstart[tid] = ex;
+        dstart[tid] = my_off - ex;       // global slot of tile slot t of digit tid: dstart[tid] + t (mod 2^32)
         cnt[0][tid] = ex; cnt[1][tid] = ex + c0; cnt[2][tid] = ex + c0 + c1; cnt[3][tid] = ex + c0 + c1 + c2;
     }
     __syncthreads();
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(RS_T) void k_radix_scatter(const uint64_t *__restri
         if (t < count) {
             const uint64_t k = skey[t];
             const uint32_t d = (uint32_t)(k >> shift) & 255u;
-            const int64_t pos = (int64_t)offs[(int64_t)d * ntiles + blockIdx.x] + (uint32_t)t - dstart[d];
+            const int64_t pos = (int64_t)(uint32_t)(dstart[d] + (uint32_t)t);
             keys_out[pos] = k;
             if (HAS_VAL) vals_out[pos] = sval[t];
         }

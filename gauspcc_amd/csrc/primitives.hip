@@ -437,9 +437,18 @@ __global__ __launch_bounds__(RS_T) void k_radix_hist(const uint64_t *__restrict_
     uint64_t k[RS_ROUNDS];
 #pragma unroll
     for (int r = 0; r < RS_ROUNDS; ++r) { const int64_t i = base + r * RS_T + threadIdx.x; k[r] = i < n ? keys[i] : 0; }
+    // (a wave whose 64 keys share the digit -- the upper bytes of depths, tile ids, Morton codes of one region -- adds its count once: 64 atomics on one
+    //  LDS word serialise, which made the last pass of a 32-bit sort twice as slow as the first)
 #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; ++r)
-        if (base + r * RS_T + threadIdx.x < n) atomicAdd(&cnt[(uint32_t)(k[r] >> shift) & 255u], 1u);
+    for (int r = 0; r < RS_ROUNDS; ++r) {
+        const bool ok = base + r * RS_T + threadIdx.x < n;
+        const uint32_t d = (uint32_t)(k[r] >> shift) & 255u;
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);     // lane 0's key: in range whenever any key of the wave is
+        const uint64_t act = __ballot(ok), same = __ballot(ok && d == d0);
+        if (same == act) {
+            if ((threadIdx.x & 63) == 0 && act) atomicAdd(&cnt[d0], (uint32_t)__popcll(act));
+        } else if (ok) atomicAdd(&cnt[d], 1u);
+    }
     __syncthreads();
     hist[(int64_t)threadIdx.x * ntiles + blockIdx.x] = cnt[threadIdx.x];
 }

@@ -1,7 +1,8 @@
 """The scan kernels on their own (csrc/primitives.hip): one-wave tiles without an LDS allocation for arrays up to 16 k elements, the
 decoupled look-back scan above that -- against numpy's cumsum at the sizes where a tile, a row or the launch path changes, in place
 and out of place, on aligned and unaligned arrays (the unaligned ones take the 256-thread kernels), the pair form, and many launches
-back to back on one stream (the look-back state is reused with an epoch)."""
+back to back on one stream (the look-back state is reused with an epoch).  And the radix sort (round 6: tiles ordered in LDS) through
+gpcc_sort_zyx: stable, equal to np.lexsort at the sizes where its path or tiling changes, on keys whose upper digits are constant."""
 import ctypes as C
 
 import numpy as np
@@ -69,3 +70,34 @@ def test_many_lookback_scans_back_to_back_reuse_their_state():
         x = rng.randint(0, 3, size=n).astype(np.uint32)
         out, total = _scan(x)
         assert total == int(x.sum()) and out[-1] == total - int(x[-1]) and out[n // 2] == int(x[: n // 2].sum()), (it, n)
+
+
+# ---------------------------------------------------------------- radix sort (through gpcc_sort_zyx: 63-bit keys with a payload, eight 8-bit passes)
+SORT_SIZES = [1, 63, 64, 1023, 1024, 1025, 4095, 4096, 4097, 8193, 12289, 300_001]
+
+
+def _cloud(kind, n, rng):
+    if kind == "random":
+        return rng.randint(-(1 << 20), 1 << 20, (n, 3)).astype(np.int32)
+    if kind == "x_only":        # y, z constant: the upper six passes see ONE digit per wave (k_radix_hist's one-add path), the payload order must survive them
+        p = np.zeros((n, 3), np.int32)
+        p[:, 0] = rng.randint(-30000, 30000, n)
+        p[:, 1] = 77; p[:, 2] = -5
+        return p
+    if kind == "dups":          # a few distinct points, each many times: stability (equal keys keep their input order) is the whole result
+        base = rng.randint(-100, 100, (7, 3)).astype(np.int32)
+        return base[rng.randint(0, 7, n)]
+    return np.full((n, 3), 12345, np.int32)     # "constant"
+
+
+@pytest.mark.parametrize("kind", ["random", "x_only", "dups", "constant"])
+@pytest.mark.parametrize("n", SORT_SIZES)
+def test_radix_sort_is_stable_and_matches_lexsort(kind, n):
+    """csrc/primitives.hip: k_radix_small (n <= 1024, one wave), k_radix_hist / k_radix_scatter (4 096-key tiles ordered in LDS) at the sizes where
+    the path, a tile or a wave's share of a tile changes; np.lexsort is stable, so equality of the permutations checks stability too."""
+    from tests import gpu_helpers as gh
+
+    rng = np.random.RandomState(n % 9973 + len(kind))
+    p = _cloud(kind, n, rng)
+    perm = gh.sort_zyx(p)
+    assert np.array_equal(perm, np.lexsort((p[:, 0], p[:, 1], p[:, 2])))

@@ -635,12 +635,16 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int 
     a.cov = Mlp{mlp[8], mlp[9], mlp[10], mlp[11]};
     a.color = Mlp{mlp[12], mlp[13], mlp[14], mlp[15]};
     a.nopa = nopa; a.keep = keep;
-    uint32_t total = 0;
+    // the survivor count lands in pinned memory: a copy into the stack variable is staged by the runtime and holds the host until it is done -- the emission
+    // was enqueued ~18 us after the scan ended
+    GP_TRY(ctx->hstage.reserve(64));
+    volatile uint32_t *htotal = reinterpret_cast<volatile uint32_t *>(ctx->hstage.p);
+    *htotal = 0;
     if (waves) {   // matrix pipe: flags -> scan -> colour / covariance and the surviving rows in one launch
         if (rows) { if (feat_dim == 32) GP_TRY((ng_mfma_opacity<32, true>(ctx, a, waves, st))); else GP_TRY((ng_mfma_opacity<50, true>(ctx, a, waves, st))); }
         else { if (feat_dim == 32) GP_TRY((ng_mfma_opacity<32, false>(ctx, a, waves, st))); else GP_TRY((ng_mfma_opacity<50, false>(ctx, a, waves, st))); }
         GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
-        HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(htotal), pos + nk, 4, hipMemcpyDeviceToHost, st));
         EmitArgs o = {offsets, scaling, pos, 0, xyz_out, color_out, opacity_out, scale_out, rot_out};
         if (rows) { if (feat_dim == 32) GP_TRY((ng_mfma_emit<32, true>(ctx, a, o, waves, st))); else GP_TRY((ng_mfma_emit<50, true>(ctx, a, o, waves, st))); }
         else { if (feat_dim == 32) GP_TRY((ng_mfma_emit<32, false>(ctx, a, o, waves, st))); else GP_TRY((ng_mfma_emit<50, false>(ctx, a, o, waves, st))); }
@@ -651,13 +655,13 @@ extern "C" int gsnn_generate(gpcc_ctx *ctx, int64_t n, const int32_t *rows, int 
         else k_anchor_mlps<50><<<(unsigned)cdiv(n, TB), TB, 0, st>>>(a);
         LAUNCH_CHECK();
         GP_TRY(exclusive_scan_u32(ctx, st, keep, pos, nk, pos + nk));
-        HIP_TRY(hipMemcpyAsync(&total, pos + nk, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(htotal), pos + nk, 4, hipMemcpyDeviceToHost, st));
         AsmArgs b = {anchor, offsets, scaling, nopa, dense, rows, keep, pos, nk, n_offsets, xyz_out, color_out, opacity_out, scale_out, rot_out};
         k_assemble<<<(unsigned)cdiv(nk, TB), TB, 0, st>>>(b);
         LAUNCH_CHECK();
     }
     HIP_TRY(hipStreamSynchronize(st));
     GP_TRY(device_error_check(ctx));
-    *count_out = (int64_t)total;
+    *count_out = (int64_t)*htotal;
     return GPCC_OK;
 }

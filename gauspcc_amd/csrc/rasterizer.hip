@@ -426,6 +426,10 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
     const int ntiles = cam.gx * cam.gy;
     size_t want = (size_t)std::max(P, 1) * 112 + (size_t)ntiles * 8 + ((size_t)8 << 20);
     uint32_t L = 0;
+    // the two counts a frame reads back mid-way land in pinned memory (copies into stack variables are staged by the runtime, one blocking hop each)
+    GP_TRY(ctx->hstage.reserve(64));
+    volatile uint32_t *hL = reinterpret_cast<volatile uint32_t *>(ctx->hstage.p);
+    volatile unsigned long long *hrect = reinterpret_cast<volatile unsigned long long *>(ctx->hstage.p + 8);
     for (int attempt = 0; attempt < 2; ++attempt) {
         GP_TRY(ctx->arena.reserve(want + (size_t)L * 40));
         ctx->arena.reset();
@@ -457,14 +461,16 @@ extern "C" int gsr_forward(gpcc_ctx *ctx, int P, const float *background, int W,
                 k_sorted_counts<<<(unsigned)cdiv(P, TB), TB, 0, st>>>(P, k0, ts);
                 LAUNCH_CHECK();
                 GP_TRY(exclusive_scan_u32(ctx, st, ts, ts, P, ts + P));
-                HIP_TRY(hipMemcpyAsync(&L, ts + P, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(hL), ts + P, 4, hipMemcpyDeviceToHost, st));
                 perm = v0; offs = ts;
             } else {
                 GP_TRY(exclusive_scan_u32(ctx, st, touched, touched, P, touched + P));
-                HIP_TRY(hipMemcpyAsync(&L, touched + P, 4, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(const_cast<uint32_t *>(hL), touched + P, 4, hipMemcpyDeviceToHost, st));
             }
-            if (cull) HIP_TRY(hipMemcpyAsync(&rect_host, rect_total + RECT_SLOTS, 8, hipMemcpyDeviceToHost, st));
+            if (cull) HIP_TRY(hipMemcpyAsync(const_cast<unsigned long long *>(hrect), rect_total + RECT_SLOTS, 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
+            L = *hL;
+            if (cull) rect_host = *hrect;
         }
         static const bool stats = dev_env_int("GAUSPCC_RASTER_STATS", 0) != 0;
         if (stats) fprintf(stderr, "[gauspcc] rasteriser: %u (Gaussian, tile) pairs sorted and blended, %llu in the bounding squares\n", L, cull ? rect_host : (unsigned long long)L);

@@ -228,12 +228,14 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_single2(const uint32_t *in0, ui
 // ------------------------------------------------------------------ single-pass scan (decoupled look-back)
 // Round 3 scanned every array above 16 k elements with three launches (reduce, scan of the block sums, apply): 1080 scan launches
 // and 5.6 ms of stream time per encode + decode step, at ~300 GB/s.  Here ONE launch: a workgroup draws a tile (4096 elements:
-// four 16-byte loads per thread) from a ticket counter -- tiles are therefore started in order, so a tile only ever waits for tiles
+// four 16-byte loads per thread) from a ticket counter (round 6: one of eight, see the kernel) -- tiles are started in order, so a tile only ever waits for tiles
 // that are running or done --, scans it, publishes (epoch | AGGREGATE | sum) as ONE 8-byte agent-scope word (the value is the
 // flag: no fence), looks back over its predecessors' words 64 at a time until it meets an INCLUSIVE prefix, publishes its own
 // inclusive prefix and writes the tile.  The status words carry the launch's epoch: no reset between launches.
 constexpr int LB_T = 64, LB_TILE = WT_TILE;    // one wave per tile: no LDS allocation (see "one-wave tiles" above)
 constexpr int64_t LB_MAX_TILES = 65536;
+constexpr int LB_SHARDS = 8, LB_SHARD_STRIDE = 32;      // ticket counters per scan state, 128 bytes apart
+constexpr size_t LB_TAIL = (size_t)LB_SHARDS * LB_SHARD_STRIDE * 4;
 constexpr unsigned long long LB_AGG = 1ull << 32, LB_INC = 2ull << 32;
 __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag, uint32_t v) { return ((unsigned long long)epoch << 34) | flag | v; }
 
@@ -243,8 +245,17 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
     const int lane = threadIdx.x;
     uint32_t t = 0;
     if (lane == 0) {
-        t = atomicAdd(ticket, 1u);
-        if (t == gridDim.x - 1u) atomicExch(ticket, 0u);     // every ticket of this launch is taken: ready for the next launch on this stream
+        // LB_SHARDS ticket counters, workgroup b draws from counter b mod LB_SHARDS and becomes tile LB_SHARDS x ticket + (b mod LB_SHARDS): device-scope
+        // atomics on ONE word serialise at ~10 ns each (measured: 24 of the 52 us of a 2 442-tile launch were the tiles queueing for their ticket).
+        // Within a shard tiles start in id order; across shards a started tile can meet a predecessor whose workgroup has not started only while the
+        // dispatcher is about to start it (workgroups leave the dispatcher in blockIdx order, so the shards' counts differ by at most one) -- and should
+        // that ever not hold, the bounded wait below ends the launch with the context's error word instead of a hang.
+        const uint32_t c = blockIdx.x % (uint32_t)LB_SHARDS;
+        const uint32_t mine = (gridDim.x - c + (uint32_t)LB_SHARDS - 1u) / (uint32_t)LB_SHARDS;      // tickets of this shard in this launch
+        uint32_t *tk = ticket + c * LB_SHARD_STRIDE;
+        const uint32_t k = atomicAdd(tk, 1u);
+        if (k == mine - 1u) atomicExch(tk, 0u);              // every ticket of the shard is taken: ready for the next launch on this stream
+        t = k * (uint32_t)LB_SHARDS + c;
     }
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     const int64_t base = (int64_t)tile * LB_TILE;
@@ -297,7 +308,7 @@ int device_error_check(gpcc_ctx *ctx)
     *static_cast<volatile uint32_t *>(ctx->dev_err) = 0u;
     for (auto &ss : ctx->scan_states) {   // tickets and status words of an abandoned launch are undefined: start every stream's state over
         (void)hipStreamSynchronize(ss.st);
-        (void)hipMemsetAsync(ss.status, 0, 8 * (size_t)LB_MAX_TILES + 256, ss.st);
+        (void)hipMemsetAsync(ss.status, 0, 8 * (size_t)LB_MAX_TILES + LB_TAIL, ss.st);
         ss.epoch = 0u;
     }
     (void)hipGetLastError();
@@ -343,11 +354,11 @@ static int scan_state(gpcc_ctx *ctx, hipStream_t st, gpcc_ctx::ScanState **out)
     }
     gpcc_ctx::ScanState ns = {st, nullptr, nullptr, 0u};
     void *p = recycled;
-    if (!p) HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + 256));
+    if (!p) HIP_TRY(hipMalloc(&p, 8 * (size_t)LB_MAX_TILES + LB_TAIL));
     // ON THE STREAM that will use it: a hipMemset on the null stream is not ordered with a non-blocking stream, and may return before it
     // has run -- it then zeroed the ticket word under a running scan (found with tools/inflight_side.py: tiles drawn twice, others
     // never, their successors spinning for ever)
-    HIP_TRY(hipMemsetAsync(p, 0, 8 * (size_t)LB_MAX_TILES + 256, st));
+    HIP_TRY(hipMemsetAsync(p, 0, 8 * (size_t)LB_MAX_TILES + LB_TAIL, st));
     ns.status = static_cast<unsigned long long *>(p);
     ns.ticket = reinterpret_cast<uint32_t *>(ns.status + LB_MAX_TILES);
     ctx->scan_states.push_back(ns);

@@ -236,11 +236,12 @@ constexpr int LB_T = 64, LB_TILE = WT_TILE;    // one wave per tile: no LDS allo
 constexpr int64_t LB_MAX_TILES = 65536;
 constexpr int LB_SHARDS = 8, LB_SHARD_STRIDE = 32;      // ticket counters per scan state, 128 bytes apart
 constexpr size_t LB_TAIL = (size_t)LB_SHARDS * LB_SHARD_STRIDE * 4;
+constexpr int64_t LB_SHARD_MIN_TILES = 1024;            // launches of at least this many tiles (4 M elements) draw from all the counters
 constexpr unsigned long long LB_AGG = 1ull << 32, LB_INC = 2ull << 32;
 __device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag, uint32_t v) { return ((unsigned long long)epoch << 34) | flag | v; }
 
 __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, int64_t n, unsigned long long *status, uint32_t *ticket,
-                                                        uint32_t epoch, uint32_t *__restrict__ total_out, uint32_t *err, uint32_t spin_limit, uint32_t skip_tile)
+                                                        uint32_t epoch, uint32_t *__restrict__ total_out, uint32_t *err, uint32_t spin_limit, uint32_t skip_tile, uint32_t shards)
 {
     const int lane = threadIdx.x;
     uint32_t t = 0;
@@ -250,12 +251,14 @@ __global__ __launch_bounds__(LB_T) void k_scan_lookback(const uint32_t *__restri
         // Within a shard tiles start in id order; across shards a started tile can meet a predecessor whose workgroup has not started only while the
         // dispatcher is about to start it (workgroups leave the dispatcher in blockIdx order, so the shards' counts differ by at most one) -- and should
         // that ever not hold, the bounded wait below ends the launch with the context's error word instead of a hang.
-        const uint32_t c = blockIdx.x % (uint32_t)LB_SHARDS;
-        const uint32_t mine = (gridDim.x - c + (uint32_t)LB_SHARDS - 1u) / (uint32_t)LB_SHARDS;      // tickets of this shard in this launch
+        // (shards = 1 below LB_SHARD_MIN_TILES: the scans of the codec -- a few hundred tiles, beside a convolution on the other stream -- keep the strict
+        // start order of ONE counter, where a tile never waits for a workgroup that has not started; their tickets cost 2-6 us)
+        const uint32_t c = blockIdx.x % shards;
+        const uint32_t mine = (gridDim.x - c + shards - 1u) / shards;      // tickets of this shard in this launch
         uint32_t *tk = ticket + c * LB_SHARD_STRIDE;
         const uint32_t k = atomicAdd(tk, 1u);
         if (k == mine - 1u) atomicExch(tk, 0u);              // every ticket of the shard is taken: ready for the next launch on this stream
-        t = k * (uint32_t)LB_SHARDS + c;
+        t = k * shards + c;
     }
     const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     const int64_t base = (int64_t)tile * LB_TILE;
@@ -413,7 +416,8 @@ int exclusive_scan_u32(gpcc_ctx *ctx, hipStream_t st, const uint32_t *in, uint32
         static std::atomic<int> launches{0};
         uint32_t limit = 1u << 24, skip = 0xFFFFFFFFu;
         if (fault_at > 0 && ++launches == fault_at) { limit = 1u << 12; skip = 0u; }
-        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev, ctx->dev_err_dev, limit, skip);
+        k_scan_lookback<<<(unsigned)tiles, LB_T, 0, st>>>(in, out, n, ss->status, ss->ticket, ss->epoch, total_dev, ctx->dev_err_dev, limit, skip,
+                                                                 tiles >= LB_SHARD_MIN_TILES ? (uint32_t)LB_SHARDS : 1u);
         LAUNCH_CHECK();
         return GPCC_OK;
     }

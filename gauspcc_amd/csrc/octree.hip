@@ -117,12 +117,15 @@ __global__ __launch_bounds__(TB) void k_level_build(const uint64_t *__restrict__
 // Levels of at most LEVEL_SINGLE_MAX children: head flags, their scan and the build in ONE single-workgroup launch (the upper
 // half of a tree is launch-latency-bound: four launches per level otherwise).  The workgroup walks the children in tiles of
 // 1024 with the running count in a register.
-constexpr int LS_T = 256, LS_E = 4, LS_TILE = LS_T * LS_E;
-constexpr int64_t LEVEL_SINGLE_MAX = 8 * LS_TILE;   // (one workgroup builds 8 k children in 44 us, 16 k in 81; the five-launch path takes ~40 at either size)
+// (round 6: 1 024 threads -- sixteen waves' partial counts chained through LDS -- so that 8 k children are two tiles, not eight: a tile is a chain of
+// dependent round trips, ~4 us whatever its width; the four levels of S1M that take this path 30 + 21 + 24 + 17 us -> see profiles/r06_timeline.txt)
+constexpr int LS_T = 1024, LS_E = 4, LS_TILE = LS_T * LS_E;
+constexpr int64_t LEVEL_SINGLE_MAX = 2 * LS_TILE;   // (8 k children, as before; above: the flags / scan / build launches)
 __global__ __launch_bounds__(LS_T) void k_level_up_single(const uint64_t *__restrict__ key, int64_t n, uint64_t *__restrict__ key_up, uint64_t *__restrict__ rkey_up,
                                                          uint32_t *__restrict__ cstart_up, uint8_t *__restrict__ occ_up, uint32_t *__restrict__ parent_lo)
 {
-    __shared__ uint32_t lds[4];
+    constexpr int NWV = LS_T / 64;
+    __shared__ uint32_t lds[NWV];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (int64_t b0 = 0; b0 < n; b0 += LS_TILE) {
@@ -143,14 +146,16 @@ __global__ __launch_bounds__(LS_T) void k_level_up_single(const uint64_t *__rest
         __syncthreads();
         if (lane == 63) lds[wave] = inc;
         __syncthreads();
-        const uint32_t w0 = lds[0], w1 = lds[1], w2 = lds[2], w3 = lds[3];
-        uint32_t ex = carry + (wave == 0 ? 0u : wave == 1 ? w0 : wave == 2 ? w0 + w1 : w0 + w1 + w2) + inc - s;
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { const uint32_t v = lds[w]; before += w < wave ? v : 0u; all += v; }
+        uint32_t ex = carry + before + inc - s;
 #pragma unroll
         for (int e = 0; e < LS_E; ++e) {
             if (base + e < n) level_build_at(key, n, base + e, ex, key_up, rkey_up, cstart_up, occ_up, parent_lo);
             ex += f[e];
         }
-        carry += w0 + w1 + w2 + w3;
+        carry += all;
     }
 }
 

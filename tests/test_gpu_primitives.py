@@ -72,6 +72,41 @@ def test_many_lookback_scans_back_to_back_reuse_their_state():
         assert total == int(x.sum()) and out[-1] == total - int(x[-1]) and out[n // 2] == int(x[: n // 2].sum()), (it, n)
 
 
+def test_large_scans_on_three_streams_at_once():
+    """Launches of 1 024 tiles and more draw their tile ids from eight ticket counters (csrc/primitives.hip: LB_SHARD_MIN_TILES) -- a tile may then meet
+    a predecessor whose workgroup has not started yet.  Three streams of one context scan 4.3 M / 5 M / 6.1 M elements (1 050 - 1 490 tiles, every one
+    with its own scan state) twelve times each, interleaved with small single-counter scans on the same streams, all in flight together; every
+    result against numpy."""
+    from gauspcc_amd import _lib, runtime
+
+    dev = torch.device("cuda", 0)
+    ctx = runtime.context(dev)
+    L = _lib.lib()
+    rng = np.random.RandomState(11)
+    sizes = [4_300_001, 5_000_000, 6_100_003]
+    streams = [torch.cuda.Stream(device=dev) for _ in sizes]
+    xs = [rng.randint(0, 4, size=n).astype(np.uint32) for n in sizes]
+    refs = [(np.concatenate([np.zeros(1, np.uint64), np.cumsum(x[:-1], dtype=np.uint64)]) & np.uint64(0xFFFFFFFF)).astype(np.uint32) for x in xs]
+    small = rng.randint(0, 4, size=70_000).astype(np.uint32)
+    small_ref = np.concatenate([np.zeros(1, np.uint64), np.cumsum(small[:-1], dtype=np.uint64)]).astype(np.uint32)
+    ins = [torch.from_numpy(x.view(np.int32)).to(dev) for x in xs]
+    sm_in = torch.from_numpy(small.view(np.int32)).to(dev)
+    outs = [[torch.empty_like(i) for _ in range(12)] for i in ins]
+    sm_outs = [[torch.empty_like(sm_in) for _ in range(12)] for _ in sizes]
+    totals = [torch.zeros(12, dtype=torch.int32, device=dev) for _ in sizes]
+    torch.cuda.synchronize()
+    for rep in range(12):
+        for k, st in enumerate(streams):
+            _lib.check(L.gpcc_debug_exclusive_scan(ctx, ins[k].data_ptr(), outs[k][rep].data_ptr(), None, None, sizes[k], totals[k][rep:].data_ptr(), st.cuda_stream))
+            _lib.check(L.gpcc_debug_exclusive_scan(ctx, sm_in.data_ptr(), sm_outs[k][rep].data_ptr(), None, None, small.size, None, st.cuda_stream))
+    torch.cuda.synchronize()
+    for k in range(len(sizes)):
+        assert (totals[k].cpu().numpy().view(np.uint32) == np.uint32(int(xs[k].sum(dtype=np.uint64)) & 0xFFFFFFFF)).all(), k
+        for rep in range(12):
+            assert np.array_equal(outs[k][rep].cpu().numpy().view(np.uint32), refs[k]), (k, rep)
+            assert np.array_equal(sm_outs[k][rep].cpu().numpy().view(np.uint32), small_ref), (k, rep)
+
+
 # ---------------------------------------------------------------- radix sort (through gpcc_sort_zyx: 63-bit keys with a payload, eight 8-bit passes)
 SORT_SIZES = [1, 63, 64, 1023, 1024, 1025, 4095, 4096, 4097, 8193, 12289, 300_001]
 

@@ -39,21 +39,23 @@ __device__ __forceinline__ float ndc2pix(float v, int S) { return ((v + 1.0f) * 
 // twice k_render's own pre-test) and, since round 6, a part that SCALES WITH THE TERMS: for a long thin splat far from its centre each of the
 // three terms of q is ~1e6 and they cancel down to q ~ 5, so the fp32 edge minimum here and the per-pixel power of k_render (another order of
 // the same operations) may differ by several ulp of 1e6 -- far more than 2e-3.  8 eps x (|term| summed) bounds both sides' error.
-__device__ __forceinline__ float edge_min(float c, float lo, float hi, float Ac, float Bm, float Cv)
-{   // min over v in [lo, hi] of 0.5 Ac c^2 + Bm c v + 0.5 Cv v^2, less the rounding slack of its evaluation (Ac, Cv > 0)
-    const float v = fminf(hi, fmaxf(lo, -Bm * c / Cv));
+__device__ __forceinline__ float edge_min(float c, float lo, float hi, float Ac, float Bm, float Cv, float inv_Cv)
+{   // min over v in [lo, hi] of 0.5 Ac c^2 + Bm c v + 0.5 Cv v^2, less the rounding slack of its evaluation (Ac, Cv > 0).  The minimiser through the
+    // reciprocal the caller computed once per Gaussian (four correctly rounded divisions per tile were 40 of this test's ~90 instructions): any v in
+    // [lo, hi] gives a value >= the minimum, and an error of an ulp in v moves the value by its square
+    const float v = fminf(hi, fmaxf(lo, -Bm * c * inv_Cv));
     const float t0 = 0.5f * Ac * c * c, t1 = Bm * c * v, t2 = 0.5f * Cv * v * v;
     return (t0 + t1 + t2) - 9.6e-7f * (t0 + fabsf(t1) + t2);
 }
-__device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, float B, float C, float lim, int tx, int ty)
+__device__ __forceinline__ bool tile_touches(float gx_, float gy_, float A, float B, float C, float inv_A, float inv_C, float lim, int tx, int ty)
 {
     // d = centre - pixel, pixels tx*16 .. tx*16 + 15 (the last tiles' pixels beyond the image only make the rectangle larger)
     const float dx_hi = gx_ - (float)(tx * BX), dx_lo = dx_hi - (float)(BX - 1);
     const float dy_hi = gy_ - (float)(ty * BY), dy_lo = dy_hi - (float)(BY - 1);
     if (!(lim < __builtin_inff())) return true;     // conics outside the argument (cull_limit): the reference's lists
     if (dx_lo <= 0.0f && dx_hi >= 0.0f && dy_lo <= 0.0f && dy_hi >= 0.0f) return true;
-    const float m = fminf(fminf(edge_min(dx_lo, dy_lo, dy_hi, A, B, C), edge_min(dx_hi, dy_lo, dy_hi, A, B, C)),
-                          fminf(edge_min(dy_lo, dx_lo, dx_hi, C, B, A), edge_min(dy_hi, dx_lo, dx_hi, C, B, A)));
+    const float m = fminf(fminf(edge_min(dx_lo, dy_lo, dy_hi, A, B, C, inv_C), edge_min(dx_hi, dy_lo, dy_hi, A, B, C, inv_C)),
+                          fminf(edge_min(dy_lo, dx_lo, dx_hi, C, B, A, inv_A), edge_min(dy_hi, dx_lo, dx_hi, C, B, A, inv_A)));
     return !(m > lim);                              // (a NaN anywhere keeps the pair)
 }
 // the bound on q for a Gaussian of opacity op: +inf for conics the argument above does not cover (never culled), -1 when op < 1 / 255 (never blended)
@@ -142,11 +144,12 @@ __device__ __forceinline__ uint32_t preprocess_one(int i, const float *__restric
     uint64_t m = area >= 64 ? ~0ull : (1ull << area) - 1ull;   // bit (y - ry0) * w + (x - rx0): the tiles of the square that take the Gaussian
     if (cull) {
         const float lim = cull_limit(co.x, co.y, co.z, co.w);
+        const float inv_a = 1.0f / co.x, inv_c = 1.0f / co.z;       // (used only when lim is finite: co.x, co.z > 0 then)
         cnt = 0; m = 0;
         int b = 0;
         for (int y = ry0; y < ry1; ++y)
             for (int x = rx0; x < rx1; ++x, ++b)
-                if (tile_touches(ix, iy, co.x, co.y, co.z, lim, x, y)) { ++cnt; m |= 1ull << (b & 63); }
+                if (tile_touches(ix, iy, co.x, co.y, co.z, inv_a, inv_c, lim, x, y)) { ++cnt; m |= 1ull << (b & 63); }
     }
     tiles_touched[i] = cnt;
     *cnt_out = cnt;
@@ -210,9 +213,10 @@ __global__ __launch_bounds__(TB) void k_duplicate(int P, const float2 *__restric
     const uint32_t dbits = __float_as_uint(depth[i]);
     const float4 co = conic_op[i];
     const float lim = cull ? cull_limit(co.x, co.y, co.z, co.w) : 0.0f;
+    const float inv_a = 1.0f / co.x, inv_c = 1.0f / co.z;       // as in k_preprocess: the count there and the pairs here come from the same test
     for (int y = ry0; y < ry1; ++y)
         for (int x = rx0; x < rx1; ++x) {
-            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, lim, x, y)) continue;
+            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, inv_a, inv_c, lim, x, y)) continue;
             keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
             vals[off] = (uint32_t)i;
             ++off;
@@ -257,9 +261,10 @@ __global__ __launch_bounds__(TB) void k_duplicate_sorted(int P, const uint32_t *
     const int rx1 = min(gx, max(0, (int)((p.x + r + BX - 1) / BX))), ry1 = min(gy, max(0, (int)((p.y + r + BY - 1) / BY)));
     const float4 co = conic_op[i];
     const float lim = cull ? cull_limit(co.x, co.y, co.z, co.w) : 0.0f;
+    const float inv_a = 1.0f / co.x, inv_c = 1.0f / co.z;       // as in k_preprocess: the count there and the pairs here come from the same test
     for (int y = ry0; y < ry1; ++y)
         for (int x = rx0; x < rx1; ++x) {
-            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, lim, x, y)) continue;
+            if (cull && !tile_touches(p.x, p.y, co.x, co.y, co.z, inv_a, inv_c, lim, x, y)) continue;
             keys[off] = (uint64_t)(uint32_t)(y * gx + x);
             vals[off] = i;
             ++off;
